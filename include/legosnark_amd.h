@@ -1,0 +1,105 @@
+/* include/legosnark_amd.h -- C-ABI of the MI355X (gfx950) implementation of LegoSNARK's
+ * elliptic-curve hot path: alt_bn128 G1/G2 multi-scalar multiplication, fixed-base
+ * batch exponentiation, and batched Miller-loop / final-exponentiation.
+ *
+ * The reference has no FFI layer: its gadgets call libff's C++ templates directly
+ * (SURVEY.md section 8b).  This header is the boundary a libff-compatible shim binds
+ * (legosnark_amd/shim/libff/...; INTEGRATION.md shows the forwarding wrappers).  Every
+ * entry point names the reference interface it replaces (file:line under
+ * /root/reference).
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; all buffers caller-owned.
+ *  - Byte layout = libff's in-memory layout: Fr/Fq = 32 B, 4 x u64 little-endian limbs in
+ *    Montgomery form (R = 2^256); G1 = {X,Y,Z} Jacobian 96 B (Z == 0 <=> infinity);
+ *    Fq2 = {c0,c1} 64 B; G2 = 192 B; GT = Fq12 = {c0:{c0,c1,c2}, c1:{..}} 384 B.
+ *  - Return 0 on success, negative lsa_status on failure; lsa_last_error() gives text.
+ *    No exceptions cross the boundary.  There is NO CPU fallback: without a usable
+ *    gfx950 device every compute entry point fails with LSA_ERR_NO_DEVICE.
+ *  - One process drives one GPU (lsa_init(device)); calls are issued from one host
+ *    thread at a time, matching the reference (single caller thread).
+ *  - Results are the same group / field elements libff computes.  Jacobian outputs are
+ *    valid representatives (compare with libff operator== or after
+ *    to_affine_coordinates()); field outputs (GT) are canonical, hence bit-identical.
+ */
+#ifndef LEGOSNARK_AMD_H
+#define LEGOSNARK_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    LSA_OK = 0,
+    LSA_ERR_NO_DEVICE = -1,   /* no HIP device / wrong arch / lsa_init not called */
+    LSA_ERR_INVALID = -2,     /* bad argument */
+    LSA_ERR_HIP = -3,         /* HIP runtime error, see lsa_last_error() */
+    LSA_ERR_NOMEM = -4
+} lsa_status;
+
+/* ---- lifecycle -------------------------------------------------------------------- */
+/* Replaces default_ec_pp::init_public_params() as the one-time setup call
+ * (src/examples/cplink.cc:81).  Selects `device`, creates the library's HIP stream. */
+int lsa_init(int device);
+void lsa_shutdown(void);
+int lsa_device_count(void);
+const char *lsa_last_error(void);
+/* hipStream_t on which every kernel of this library is launched (for HIP-event timing). */
+void *lsa_stream(void);
+/* Block until all work queued on lsa_stream() has finished. */
+int lsa_synchronize(void);
+
+/* ---- variable-base MSM from host buffers ------------------------------------------- */
+/* out = sum_i scalars[i] * bases[i], i < n.
+ * Replaces libff::multi_exp_with_mixed_addition<G1<pp>,Fr<pp>,multi_exp_method_BDLO12>
+ * (src/utils/globl.h:74-77, multiExpMA) and libff::multi_exp<..BDLO12>
+ * (src/utils/sparsemexp.h:58,89).  `chunks` is libff's CPU work split
+ * (src/utils/globl.h:67-71); it does not change the result and is accepted for
+ * signature compatibility only.  bases: n x 96 B (G1) / 192 B (G2); scalars: n x 32 B;
+ * out: one Jacobian point. */
+int lsa_g1_msm(const void *bases_jac, const void *scalars_mont, size_t n, size_t chunks, void *out_jac);
+int lsa_g2_msm(const void *bases_jac, const void *scalars_mont, size_t n, size_t chunks, void *out_jac);
+
+/* ---- device-resident bases (CRS) ---------------------------------------------------- */
+/* The CRS vectors passed to multiExpMA are fixed per key (crs->P at
+ * src/gadgets/subspace.cc:82, g1s/g2s at src/prototools/commit.h:154-155), so they are
+ * uploaded once, batch-normalised to affine in HBM (64 B / 128 B per point) and reused.
+ * `bases_jac` may be a host pointer or (src_on_device != 0) a device pointer. */
+typedef struct lsa_bases lsa_bases;
+int lsa_g1_bases_create(const void *bases_jac, size_t n, int src_on_device, lsa_bases **out);
+int lsa_g2_bases_create(const void *bases_jac, size_t n, int src_on_device, lsa_bases **out);
+void lsa_bases_destroy(lsa_bases *b);
+size_t lsa_bases_size(const lsa_bases *b);
+/* Device pointer to the normalised affine array (n x 64 B / 128 B), for inspection. */
+const void *lsa_bases_device_ptr(const lsa_bases *b);
+
+/* MSM over bases[first .. first+n) with scalars already resident in HBM
+ * (d_scalars_mont: device pointer, n x 32 B, Montgomery Fr).  out_jac is a HOST buffer
+ * (96 B / 192 B); the call returns after the result has landed there. */
+int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars_mont, size_t n, void *out_jac);
+/* Same, asynchronous: result is written to the DEVICE buffer d_out_jac on lsa_stream(). */
+int lsa_msm_run_async(const lsa_bases *bases, size_t first, const void *d_scalars_mont, size_t n, void *d_out_jac);
+
+/* Window width (bits) the MSM uses for n pairs -- exposed for DESIGN.md / tests. */
+unsigned lsa_msm_window_bits(size_t n);
+
+/* ---- per-stage timing (HIP events on lsa_stream()) ----------------------------------- */
+#define LSA_MSM_STAGES 8
+/* 0 digits+histogram, 1 scan, 2 scatter, 3 bucket accumulate (dominant), 4 bucket
+ * reduce, 5 window fold, 6 reserved, 7 total */
+int lsa_profile_enable(int on);
+/* Milliseconds per stage of the LAST lsa_msm_run* call made with profiling enabled. */
+int lsa_profile_last_msm(float ms[LSA_MSM_STAGES]);
+
+/* ---- point helpers ------------------------------------------------------------------- */
+/* Jacobian -> libff "special" form (affine with Z = 1, or (0,1,0)), n points, host
+ * buffers; replaces G::to_affine_coordinates()/batch_to_special on result vectors. */
+int lsa_g1_normalize(const void *in_jac, size_t n, void *out_jac);
+int lsa_g2_normalize(const void *in_jac, size_t n, void *out_jac);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,192 @@
+"""legosnark_amd -- MI355X (gfx950) implementation of LegoSNARK's elliptic-curve hot path.
+
+This package is plumbing around the C-ABI shared library (include/legosnark_amd.h):
+it loads ``liblegosnark_amd.so`` with ctypes and exposes thin helpers that take numpy
+buffers in libff's byte layout or torch CUDA tensors (device pointers).  There is no
+CPU fallback: if the library or a gfx950 device is missing every compute call raises.
+
+Host-side C++ users bind the same C-ABI through the libff-compatible header shim in
+``legosnark_amd/shim``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "liblegosnark_amd.so")
+_lib = None
+
+MSM_STAGES = 8
+STAGE_NAMES = ("digits", "scan", "scatter", "accumulate", "reduce", "fold", "reserved", "total")
+
+
+class LsaError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_PKG, "csrc"), "-j4"]
+    if not verbose:
+        cmd.append("-s")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LsaError("%s is missing: run legosnark_amd.build() / __graft_entry__.build() "
+                           "(there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.lsa_last_error.restype = C.c_char_p
+        L.lsa_stream.restype = C.c_void_p
+        L.lsa_bases_size.restype = C.c_size_t
+        L.lsa_bases_size.argtypes = [C.c_void_p]
+        L.lsa_bases_device_ptr.restype = C.c_void_p
+        L.lsa_bases_device_ptr.argtypes = [C.c_void_p]
+        L.lsa_bases_destroy.argtypes = [C.c_void_p]
+        L.lsa_bases_destroy.restype = None
+        L.lsa_msm_window_bits.restype = C.c_uint
+        L.lsa_msm_window_bits.argtypes = [C.c_size_t]
+        for name in ("lsa_g1_bases_create", "lsa_g2_bases_create"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
+        for name in ("lsa_g1_msm", "lsa_g2_msm"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+        for name in ("lsa_msm_run", "lsa_msm_run_async"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        for name in ("lsa_g1_normalize", "lsa_g2_normalize"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise LsaError("legosnark_amd error %d: %s" % (rc, lib().lsa_last_error().decode()))
+
+
+def init(device=0):
+    _check(lib().lsa_init(int(device)))
+
+
+def shutdown():
+    lib().lsa_shutdown()
+
+
+def device_count():
+    return lib().lsa_device_count()
+
+
+def stream_handle():
+    """Raw hipStream_t (int) on which the library launches all kernels."""
+    return lib().lsa_stream()
+
+
+def synchronize():
+    _check(lib().lsa_synchronize())
+
+
+def _host_ptr(a):
+    assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _ptr(x):
+    """numpy array -> host pointer, torch tensor -> data_ptr, int -> as is."""
+    if isinstance(x, np.ndarray):
+        return _host_ptr(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    return C.c_void_p(int(x))
+
+
+def _group_width(group):
+    if group not in ("g1", "g2"):
+        raise ValueError(group)
+    return 12 if group == "g1" else 24
+
+
+def msm(group, bases, scalars, chunks=1):
+    """multiExpMA drop-in on host buffers (uint64 arrays, libff layout)."""
+    w = _group_width(group)
+    bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, w)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    n = min(len(bases), len(scalars))   # src/utils/globl.h:66
+    out = np.zeros(w, dtype=np.uint64)
+    fn = lib().lsa_g1_msm if group == "g1" else lib().lsa_g2_msm
+    _check(fn(_host_ptr(bases), _host_ptr(scalars), n, chunks, _host_ptr(out)))
+    return out
+
+
+class Bases:
+    """Device-resident, affine-normalised CRS vector (lsa_bases handle)."""
+
+    def __init__(self, group, bases, on_device=False):
+        self.group = group
+        self.w = _group_width(group)
+        h = C.c_void_p()
+        if on_device:
+            n = bases.numel() * bases.element_size() // (self.w * 8)
+            ptr = C.c_void_p(bases.data_ptr())
+        else:
+            bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, self.w)
+            n = len(bases)
+            ptr = _host_ptr(bases)
+        fn = lib().lsa_g1_bases_create if group == "g1" else lib().lsa_g2_bases_create
+        _check(fn(ptr, n, 1 if on_device else 0, C.byref(h)))
+        self.handle = h
+        self.n = n
+
+    def msm(self, d_scalars, n=None, first=0):
+        """d_scalars: torch CUDA tensor (n x 32 B Montgomery Fr).  Returns host Jacobian point."""
+        if n is None:
+            n = self.n - first
+        out = np.zeros(self.w, dtype=np.uint64)
+        _check(lib().lsa_msm_run(self.handle, first, _ptr(d_scalars), n, _host_ptr(out)))
+        return out
+
+    def msm_async(self, d_scalars, d_out, n=None, first=0):
+        if n is None:
+            n = self.n - first
+        _check(lib().lsa_msm_run_async(self.handle, first, _ptr(d_scalars), n, _ptr(d_out)))
+
+    def device_ptr(self):
+        return lib().lsa_bases_device_ptr(self.handle)
+
+    def close(self):
+        if self.handle:
+            lib().lsa_bases_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def normalize(group, pts):
+    w = _group_width(group)
+    pts = np.ascontiguousarray(pts, dtype=np.uint64).reshape(-1, w)
+    out = np.zeros_like(pts)
+    fn = lib().lsa_g1_normalize if group == "g1" else lib().lsa_g2_normalize
+    _check(fn(_host_ptr(pts), len(pts), _host_ptr(out)))
+    return out
+
+
+def profile_enable(on=True):
+    lib().lsa_profile_enable(1 if on else 0)
+
+
+def profile_last_msm():
+    ms = (C.c_float * MSM_STAGES)()
+    lib().lsa_profile_last_msm(ms)
+    return dict(zip(STAGE_NAMES, [float(x) for x in ms]))
+
+
+def msm_window_bits(n):
+    return lib().lsa_msm_window_bits(n)

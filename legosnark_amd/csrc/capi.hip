@@ -1,0 +1,263 @@
+// legosnark_amd/csrc/capi.hip -- implementation of the C-ABI in include/legosnark_amd.h.
+// No CPU fallback: every compute entry point requires lsa_init() to have found a gfx950
+// device and fails with LSA_ERR_NO_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "msm.h"
+
+namespace lsa {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+struct State {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    void *d_result = nullptr;      // 192-byte device slot for MSM results
+    void *h_result = nullptr;      // pinned host mirror
+};
+static State g;
+
+#define HIPCHK(x)                                                                      \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return LSA_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+static int require_ready() {
+    if (!g.ready) {
+        set_error("legosnark_amd: no initialised gfx950 device (call lsa_init first; there is no CPU fallback)");
+        return LSA_ERR_NO_DEVICE;
+    }
+    return LSA_OK;
+}
+
+}  // namespace lsa
+
+using namespace lsa;
+
+struct lsa_bases {
+    void *d_aff = nullptr;   // Aff<Fq> or Aff<Fq2> array
+    size_t n = 0;
+    int group = 1;           // 1 = G1, 2 = G2
+};
+
+extern "C" {
+
+int lsa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *lsa_last_error(void) { return g_err; }
+
+int lsa_init(int device) {
+    if (g.ready && g.device == device) return LSA_OK;
+    if (g.ready) lsa_shutdown();
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        set_error("lsa_init: no HIP device visible (there is no CPU fallback)");
+        return LSA_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) {
+        set_error("lsa_init: device %d out of range (%d visible)", device, n);
+        return LSA_ERR_INVALID;
+    }
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("lsa_init: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        return LSA_ERR_NO_DEVICE;
+    }
+    HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&g.d_result, 256));
+    HIPCHK(hipHostMalloc(&g.h_result, 256, hipHostMallocDefault));
+    g.device = device;
+    g.ready = true;
+    return LSA_OK;
+}
+
+void lsa_shutdown(void) {
+    if (!g.ready) return;
+    (void)hipStreamSynchronize(g.stream);
+    msm_release_workspace();
+    (void)hipFree(g.d_result);
+    (void)hipHostFree(g.h_result);
+    (void)hipStreamDestroy(g.stream);
+    g = State();
+}
+
+void *lsa_stream(void) { return g.ready ? (void *)g.stream : nullptr; }
+
+int lsa_synchronize(void) {
+    int rc = require_ready();
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return LSA_OK;
+}
+
+unsigned lsa_msm_window_bits(size_t n) { return msm_window_bits(n); }
+
+int lsa_profile_enable(int on) { msm_profile_enable(on != 0); return LSA_OK; }
+int lsa_profile_last_msm(float ms[LSA_MSM_STAGES]) { msm_profile_last(ms); return LSA_OK; }
+
+// ---------------------------------------------------------------- bases
+}  // extern "C"
+template <class F>
+static int bases_create(const void *bases_jac, size_t n, int src_on_device, int group, lsa_bases **out) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (!out || (n && !bases_jac)) { set_error("bases_create: null argument"); return LSA_ERR_INVALID; }
+    lsa_bases *b = new lsa_bases();
+    b->n = n;
+    b->group = group;
+    if (n) {
+        const Jac<F> *d_in = nullptr;
+        void *tmp = nullptr;
+        if (hipMalloc(&b->d_aff, n * sizeof(Aff<F>)) != hipSuccess) {
+            delete b;
+            set_error("bases_create: hipMalloc of %zu bytes failed", n * sizeof(Aff<F>));
+            return LSA_ERR_NOMEM;
+        }
+        if (src_on_device) {
+            d_in = (const Jac<F> *)bases_jac;
+        } else {
+            if (hipMalloc(&tmp, n * sizeof(Jac<F>)) != hipSuccess) {
+                (void)hipFree(b->d_aff); delete b;
+                set_error("bases_create: hipMalloc of %zu bytes failed", n * sizeof(Jac<F>));
+                return LSA_ERR_NOMEM;
+            }
+            hipError_t e = hipMemcpyAsync(tmp, bases_jac, n * sizeof(Jac<F>), hipMemcpyHostToDevice, g.stream);
+            if (e != hipSuccess) { (void)hipFree(tmp); (void)hipFree(b->d_aff); delete b; set_error("bases_create: H2D failed: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
+            d_in = (const Jac<F> *)tmp;
+        }
+        rc = normalize_to_affine<F>(d_in, (Aff<F> *)b->d_aff, n, g.stream);
+        hipError_t e = hipStreamSynchronize(g.stream);
+        if (tmp) (void)hipFree(tmp);
+        if (rc || e != hipSuccess) {
+            if (!rc) { set_error("bases_create: kernel failed: %s", hipGetErrorString(e)); rc = LSA_ERR_HIP; }
+            (void)hipFree(b->d_aff); delete b;
+            return rc;
+        }
+    }
+    *out = b;
+    return LSA_OK;
+}
+
+extern "C" {
+int lsa_g1_bases_create(const void *bases_jac, size_t n, int src_on_device, lsa_bases **out) {
+    return bases_create<Fq>(bases_jac, n, src_on_device, 1, out);
+}
+int lsa_g2_bases_create(const void *bases_jac, size_t n, int src_on_device, lsa_bases **out) {
+    return bases_create<Fq2>(bases_jac, n, src_on_device, 2, out);
+}
+void lsa_bases_destroy(lsa_bases *b) {
+    if (!b) return;
+    if (b->d_aff) (void)hipFree(b->d_aff);
+    delete b;
+}
+size_t lsa_bases_size(const lsa_bases *b) { return b ? b->n : 0; }
+const void *lsa_bases_device_ptr(const lsa_bases *b) { return b ? b->d_aff : nullptr; }
+
+// ---------------------------------------------------------------- MSM
+int lsa_msm_run_async(const lsa_bases *bases, size_t first, const void *d_scalars, size_t n, void *d_out_jac) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (!bases || !d_out_jac || (n && !d_scalars)) { set_error("msm_run: null argument"); return LSA_ERR_INVALID; }
+    if (first > bases->n || n > bases->n - first) { set_error("msm_run: range [%zu,%zu) exceeds %zu bases", first, first + n, bases->n); return LSA_ERR_INVALID; }
+    if (bases->group == 1)
+        return msm_device<Fq>((const Aff<Fq> *)bases->d_aff + first, (const Fr *)d_scalars, n, (Jac<Fq> *)d_out_jac, g.stream);
+    return msm_device<Fq2>((const Aff<Fq2> *)bases->d_aff + first, (const Fr *)d_scalars, n, (Jac<Fq2> *)d_out_jac, g.stream);
+}
+
+int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars, size_t n, void *out_jac) {
+    int rc = lsa_msm_run_async(bases, first, d_scalars, n, g.d_result);
+    if (rc) return rc;
+    size_t bytes = bases->group == 1 ? sizeof(Jac<Fq>) : sizeof(Jac<Fq2>);
+    HIPCHK(hipMemcpyAsync(g.h_result, g.d_result, bytes, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    memcpy(out_jac, g.h_result, bytes);
+    return LSA_OK;
+}
+
+}  // extern "C"
+template <class F>
+static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *out_jac, int group) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (!out_jac || (n && (!bases_jac || !scalars))) { set_error("msm: null argument"); return LSA_ERR_INVALID; }
+    lsa_bases *b = nullptr;
+    rc = bases_create<F>(bases_jac, n, 0, group, &b);
+    if (rc) return rc;
+    void *d_sc = nullptr;
+    if (n) {
+        if (hipMalloc(&d_sc, n * sizeof(Fr)) != hipSuccess) { lsa_bases_destroy(b); set_error("msm: hipMalloc scalars failed"); return LSA_ERR_NOMEM; }
+        hipError_t e = hipMemcpyAsync(d_sc, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream);
+        if (e != hipSuccess) { (void)hipFree(d_sc); lsa_bases_destroy(b); set_error("msm: H2D failed: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
+    }
+    rc = lsa_msm_run(b, 0, d_sc, n, out_jac);
+    if (d_sc) (void)hipFree(d_sc);
+    lsa_bases_destroy(b);
+    return rc;
+}
+
+extern "C" {
+int lsa_g1_msm(const void *bases_jac, const void *scalars, size_t n, size_t chunks, void *out_jac) {
+    (void)chunks;
+    return msm_host<Fq>(bases_jac, scalars, n, out_jac, 1);
+}
+int lsa_g2_msm(const void *bases_jac, const void *scalars, size_t n, size_t chunks, void *out_jac) {
+    (void)chunks;
+    return msm_host<Fq2>(bases_jac, scalars, n, out_jac, 2);
+}
+
+// ---------------------------------------------------------------- normalisation
+}  // extern "C"
+template <class F>
+static int normalize_host(const void *in_jac, size_t n, void *out_jac) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (n == 0) return LSA_OK;
+    if (!in_jac || !out_jac) { set_error("normalize: null argument"); return LSA_ERR_INVALID; }
+    void *d_in = nullptr, *d_aff = nullptr;
+    if (hipMalloc(&d_in, n * sizeof(Jac<F>)) != hipSuccess || hipMalloc(&d_aff, n * sizeof(Aff<F>)) != hipSuccess) {
+        if (d_in) (void)hipFree(d_in);
+        set_error("normalize: hipMalloc failed");
+        return LSA_ERR_NOMEM;
+    }
+    hipError_t e = hipMemcpyAsync(d_in, in_jac, n * sizeof(Jac<F>), hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess) rc = normalize_to_affine<F>((const Jac<F> *)d_in, (Aff<F> *)d_aff, n, g.stream);
+    std::vector<Aff<F>> host(n);
+    if (e == hipSuccess && !rc) e = hipMemcpyAsync(host.data(), d_aff, n * sizeof(Aff<F>), hipMemcpyDeviceToHost, g.stream);
+    if (e == hipSuccess && !rc) e = hipStreamSynchronize(g.stream);
+    (void)hipFree(d_in);
+    (void)hipFree(d_aff);
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error("normalize: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
+    Jac<F> *o = (Jac<F> *)out_jac;
+    for (size_t i = 0; i < n; i++) {
+        if (host[i].is_inf()) o[i] = Jac<F>::inf();
+        else o[i] = Jac<F>{host[i].x, host[i].y, F::one()};
+    }
+    return LSA_OK;
+}
+extern "C" {
+int lsa_g1_normalize(const void *in_jac, size_t n, void *out_jac) { return normalize_host<Fq>(in_jac, n, out_jac); }
+int lsa_g2_normalize(const void *in_jac, size_t n, void *out_jac) { return normalize_host<Fq2>(in_jac, n, out_jac); }
+
+}  // extern "C"

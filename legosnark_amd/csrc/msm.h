@@ -1,0 +1,28 @@
+// legosnark_amd/csrc/msm.h -- internal interface between the C-ABI (capi.hip) and the
+// MSM / normalisation kernels (msm.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include "../../include/legosnark_amd.h"
+#include "ec.h"
+
+namespace lsa {
+
+// printf-style error text retrievable through lsa_last_error()
+void set_error(const char *fmt, ...);
+
+unsigned msm_window_bits(size_t n);
+
+// Jacobian (libff layout, device) -> affine (device), batch inversion per lane.
+template <class F>
+int normalize_to_affine(const Jac<F> *d_in, Aff<F> *d_out, size_t n, hipStream_t st);
+
+// out = sum scalars[i] * bases[i]; everything device-resident; asynchronous on `st`.
+template <class F>
+int msm_device(const Aff<F> *d_bases, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st);
+
+void msm_release_workspace();
+void msm_profile_enable(bool on);
+void msm_profile_last(float ms[LSA_MSM_STAGES]);
+
+}  // namespace lsa

@@ -1,0 +1,490 @@
+// legosnark_amd/csrc/msm.hip -- variable-base multi-scalar multiplication on gfx950.
+//
+// Replaces libff::multi_exp_with_mixed_addition / multi_exp<BDLO12> as called by
+// multiExpMA (/root/reference/src/utils/globl.h:63-78) and sparsemexp
+// (/root/reference/src/utils/sparsemexp.h:58,89).  Same sum, different schedule:
+//
+//   1 digits     scalars (Montgomery Fr, 32 B, read once, coalesced) -> canonical ->
+//                signed c-bit digits; per (window,bucket) population counted with one
+//                returning atomic per non-zero digit (the return value is the slot of
+//                the entry inside its bucket).
+//   2 scan       exclusive prefix sum over the nwin*2^(c-1) counters.
+//   3 scatter    entry (point index | sign) written to offsets[bucket] + slot.
+//   4 accumulate one lane per bucket walks its entry list, gathers 64-B affine points
+//                and accumulates in XYZZ (8M+2S mixed add) -- the dominant kernel.
+//                Buckets above a population threshold are split across a whole
+//                workgroup (skewed scalars, e.g. the u[i]=i inputs of
+//                /root/reference/src/examples/hadamard.cc:130-135).
+//   5 reduce     sum_b (b+1)*S_b per window: per-lane running sums over L buckets,
+//                then wavefront suffix-scan + tree reductions with cross-lane shuffles.
+//   6 fold       Horner over the windows (c doublings + 1 add each) -> one Jacobian point.
+//
+// Signed digits halve the bucket count (2^(c-1)); the zero/one filter of libff's
+// multi_exp_with_mixed_addition needs no special case (0 contributes nothing, 1 lands in
+// bucket 1 of window 0) and gives the same group element.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#include "ec.h"
+#include "msm.h"
+
+namespace lsa {
+
+// ------------------------------------------------------------------------------------
+// window choice
+// ------------------------------------------------------------------------------------
+unsigned msm_window_bits(size_t n) {
+    unsigned lg = 0;
+    while ((size_t(1) << (lg + 1)) <= n) lg++;   // floor(log2 n), 0 for n <= 1
+    int c = (int)lg - 4;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    return (unsigned)c;
+}
+
+static inline unsigned num_windows(unsigned c) { return (255 + c - 1) / c; }
+
+// ------------------------------------------------------------------------------------
+// kernel 0: Jacobian (libff layout) -> affine, per-lane Montgomery batch inversion
+// ------------------------------------------------------------------------------------
+template <class F, int K>
+__global__ __launch_bounds__(256) void k_normalize(const Jac<F> *__restrict__ in, Aff<F> *__restrict__ out, size_t n) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t base = t * K;
+    if (base >= n) return;
+    F prod[K];
+    F acc = F::one();
+    const F one = F::one();
+    bool need_inv = false;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        if (base + i < n) {
+            F z = in[base + i].Z;
+            if (!z.is_zero() && z != one) { acc = acc * z; need_inv = true; }
+        }
+        prod[i] = acc;
+    }
+    F inv = need_inv ? acc.inverse() : one;
+#pragma unroll
+    for (int i = K - 1; i >= 0; i--) {
+        if (base + i < n) {
+            Jac<F> p = in[base + i];
+            Aff<F> a;
+            if (p.Z.is_zero()) {
+                a = Aff<F>::inf();
+            } else if (p.Z == one) {
+                a.x = p.X; a.y = p.Y;
+            } else {
+                F before = (i == 0) ? one : prod[i - 1];
+                F zi = inv * before;          // 1 / Z_i
+                inv = inv * p.Z;
+                F zi2 = zi.sqr();
+                a.x = p.X * zi2;
+                a.y = p.Y * (zi2 * zi);
+            }
+            out[base + i] = a;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// kernel 1: digits + histogram
+// ------------------------------------------------------------------------------------
+// digits[k*n + i] : signed digit of scalar i in window k
+// slot  [k*n + i] : arrival order of entry inside its bucket (valid when digit != 0)
+__global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, size_t n, unsigned c, unsigned nwin,
+                                                int16_t *__restrict__ digits, uint32_t *__restrict__ slot,
+                                                uint32_t *__restrict__ hist) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[8];
+    scalars[i].to_canonical(s);
+    const uint32_t B = 1u << (c - 1);
+    uint32_t carry = 0;
+    for (unsigned k = 0; k < nwin; k++) {
+        unsigned bit = k * c;
+        unsigned w = bit >> 5, sh = bit & 31;
+        uint64_t two = (uint64_t)(w < 8 ? s[w] : 0) | ((uint64_t)(w + 1 < 8 ? s[w + 1] : 0) << 32);
+        uint32_t d = (uint32_t)(two >> sh) & ((1u << c) - 1);
+        d += carry;
+        int32_t sd;
+        if (k + 1 < nwin && d >= B) { sd = (int32_t)d - (int32_t)(1u << c); carry = 1; }
+        else { sd = (int32_t)d; carry = 0; }
+        digits[(size_t)k * n + i] = (int16_t)sd;
+        if (sd != 0) {
+            uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
+            slot[(size_t)k * n + i] = atomicAdd(&hist[k * B + b], 1u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// kernel 2: exclusive scan of `count` counters (single workgroup, count <= 2^20)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ hist, uint32_t *__restrict__ offs, uint32_t count) {
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (count + 1023) / 1024;
+    const uint32_t lo = tid * per;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; j++) {
+        uint32_t idx = lo + j;
+        if (idx < count) sum += hist[idx];
+    }
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = (tid >= d) ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - sum;
+    for (uint32_t j = 0; j < per; j++) {
+        uint32_t idx = lo + j;
+        if (idx < count) { offs[idx] = run; run += hist[idx]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// kernel 3: scatter (point index | sign<<31) into bucket-sorted order
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter(const int16_t *__restrict__ digits, const uint32_t *__restrict__ slot,
+                                                 const uint32_t *__restrict__ offs, size_t n, unsigned c, unsigned nwin,
+                                                 uint32_t *__restrict__ entries) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n * nwin) return;
+    unsigned k = (unsigned)(g / n);
+    uint32_t i = (uint32_t)(g - (size_t)k * n);
+    int32_t sd = digits[g];
+    if (sd == 0) return;
+    const uint32_t B = 1u << (c - 1);
+    uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
+    uint32_t pos = offs[k * B + b] + slot[g];
+    entries[pos] = i | (sd < 0 ? 0x80000000u : 0u);
+}
+
+// ------------------------------------------------------------------------------------
+// kernel 4: bucket accumulation (one lane per bucket); heavy buckets deferred
+// ------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(256) void k_accumulate(const Aff<F> *__restrict__ bases, const uint32_t *__restrict__ entries,
+                                                    const uint32_t *__restrict__ offs, const uint32_t *__restrict__ hist,
+                                                    uint32_t nbuckets_total, uint32_t heavy_threshold,
+                                                    uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count,
+                                                    XYZZ<F> *__restrict__ buckets) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nbuckets_total) return;
+    uint32_t cnt = hist[g];
+    if (cnt > heavy_threshold) {
+        heavy_list[atomicAdd(heavy_count, 1u)] = g;
+        return;
+    }
+    const uint32_t *e = entries + offs[g];
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint32_t j = 0; j < cnt; j++) {
+        uint32_t v = e[j];
+        Aff<F> p = bases[v & 0x7fffffffu];
+        if (v >> 31) p.y = p.y.neg();
+        acc = xyzz_madd(acc, p);
+    }
+    buckets[g] = acc;
+}
+
+template <class F>
+__device__ __forceinline__ XYZZ<F> shfl_down_xyzz(const XYZZ<F> &p, unsigned delta) {
+    XYZZ<F> r;
+    constexpr int NW = sizeof(XYZZ<F>) / 4;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(&p);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+    for (int i = 0; i < NW; i++) dst[i] = __shfl_down(src[i], delta, 64);
+    return r;
+}
+
+// wavefront tree sum: result valid in lane 0
+template <class F>
+__device__ __forceinline__ XYZZ<F> wave_sum(XYZZ<F> v, unsigned lane) {
+    for (unsigned d = 32; d >= 1; d >>= 1) {
+        XYZZ<F> t = shfl_down_xyzz(v, d);
+        if (lane + d < 64) v = xyzz_add(v, t);
+    }
+    return v;
+}
+
+// Heavy buckets (population > threshold): a fixed grid of 256-lane workgroups loops over
+// (heavy bucket, slice) work items; the per-slice partials are summed by k_heavy_finish.
+// With uniformly random scalars heavy_count == 0 and both kernels exit at once.
+template <class F>
+__global__ __launch_bounds__(256) void k_accumulate_heavy(const Aff<F> *__restrict__ bases, const uint32_t *__restrict__ entries,
+                                                          const uint32_t *__restrict__ offs, const uint32_t *__restrict__ hist,
+                                                          const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ heavy_count,
+                                                          uint32_t slices, XYZZ<F> *__restrict__ partials) {
+    __shared__ XYZZ<F> wsum[4];
+    const uint32_t items = *heavy_count * slices;
+    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
+        uint32_t h = item / slices, sl = item % slices;
+        uint32_t g = heavy_list[h];
+        uint32_t cnt = hist[g];
+        const uint32_t *e = entries + offs[g];
+        uint32_t stride = slices * 256;
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (uint32_t j = sl * 256 + threadIdx.x; j < cnt; j += stride) {
+            uint32_t v = e[j];
+            Aff<F> p = bases[v & 0x7fffffffu];
+            if (v >> 31) p.y = p.y.neg();
+            acc = xyzz_madd(acc, p);
+        }
+        unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        acc = wave_sum(acc, lane);
+        if (lane == 0) wsum[wv] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            XYZZ<F> s = wsum[0];
+            for (int w = 1; w < 4; w++) s = xyzz_add(s, wsum[w]);
+            partials[(size_t)h * slices + sl] = s;
+        }
+        __syncthreads();
+    }
+}
+
+template <class F>
+__global__ __launch_bounds__(64) void k_heavy_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ heavy_count,
+                                                     uint32_t slices, const XYZZ<F> *__restrict__ partials,
+                                                     XYZZ<F> *__restrict__ buckets) {
+    const uint32_t nh = *heavy_count;
+    unsigned lane = threadIdx.x;
+    for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
+        XYZZ<F> acc = XYZZ<F>::inf();
+        for (uint32_t j = lane; j < slices; j += 64) acc = xyzz_add(acc, partials[(size_t)h * slices + j]);
+        acc = wave_sum(acc, lane);
+        if (lane == 0) buckets[heavy_list[h]] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// kernel 5: bucket reduction.  For lanes j = 0..63 holding (acc_j, run_j) returns in lane 0
+//   ACC = sum_j acc_j + 2^log_mult * sum_j j*run_j      RUN = sum_j run_j
+// using an inclusive suffix scan of run (6 shuffle steps), then two tree sums.
+// ------------------------------------------------------------------------------------
+template <class F>
+__device__ __forceinline__ void wave_weighted(XYZZ<F> &acc, XYZZ<F> &run, unsigned log_mult, unsigned lane) {
+    // suffix scan: run_j <- sum_{i >= j} run_i
+    for (unsigned d = 1; d < 64; d <<= 1) {
+        XYZZ<F> t = shfl_down_xyzz(run, d);
+        if (lane + d < 64) run = xyzz_add(run, t);
+    }
+    // sum_{k=1..63} Suf_k = sum_j j*run_j
+    XYZZ<F> s = (lane == 0) ? XYZZ<F>::inf() : run;
+    s = wave_sum(s, lane);
+    acc = wave_sum(acc, lane);
+    if (lane == 0) {
+        for (unsigned i = 0; i < log_mult; i++) s = xyzz_dbl(s);
+        acc = xyzz_add(acc, s);
+    }
+}
+
+// Level 1: T = B/L lanes per window (padded to a multiple of 64); lane t owns buckets
+// [t*L, (t+1)*L).  Writes one (ACC,RUN) pair per wavefront.
+template <class F>
+__global__ __launch_bounds__(64) void k_reduce1(const XYZZ<F> *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t logL,
+                                                uint32_t waves_per_window, XYZZ<F> *__restrict__ wave_out) {
+    uint32_t wave = blockIdx.x;                 // global wave id = k*waves_per_window + w
+    uint32_t k = wave / waves_per_window, w = wave % waves_per_window;
+    unsigned lane = threadIdx.x;
+    uint32_t t = w * 64 + lane;
+    XYZZ<F> acc = XYZZ<F>::inf(), run = XYZZ<F>::inf();
+    if ((uint64_t)t * L < B) {
+        const XYZZ<F> *bk = buckets + (size_t)k * B + (size_t)t * L;
+        for (int i = (int)L - 1; i >= 0; i--) {
+            run = xyzz_add(run, bk[i]);
+            acc = xyzz_add(acc, run);
+        }
+    }
+    wave_weighted(acc, run, logL, lane);
+    if (lane == 0) {
+        wave_out[2 * (size_t)wave] = acc;
+        wave_out[2 * (size_t)wave + 1] = run;
+    }
+}
+
+// Level 2: one wavefront per window folds the <= 64 wave pairs of level 1.
+template <class F>
+__global__ __launch_bounds__(64) void k_reduce2(const XYZZ<F> *__restrict__ wave_in, uint32_t waves_per_window, uint32_t log_mult,
+                                                XYZZ<F> *__restrict__ window_sums) {
+    uint32_t k = blockIdx.x;
+    unsigned lane = threadIdx.x;
+    XYZZ<F> acc = XYZZ<F>::inf(), run = XYZZ<F>::inf();
+    if (lane < waves_per_window) {
+        acc = wave_in[2 * ((size_t)k * waves_per_window + lane)];
+        run = wave_in[2 * ((size_t)k * waves_per_window + lane) + 1];
+    }
+    wave_weighted(acc, run, log_mult, lane);
+    if (lane == 0) window_sums[k] = acc;
+}
+
+// ------------------------------------------------------------------------------------
+// kernel 6: Horner fold over windows -> Jacobian (libff layout)
+// ------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(64) void k_fold(const XYZZ<F> *__restrict__ window_sums, unsigned nwin, unsigned c, Jac<F> *__restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Jac<F> r = xyzz_to_jac(window_sums[nwin - 1]);
+    for (int k = (int)nwin - 2; k >= 0; k--) {
+        for (unsigned i = 0; i < c; i++) r = jac_dbl(r);
+        r = jac_add(r, xyzz_to_jac(window_sums[k]));
+    }
+    *out = r;
+}
+
+// ------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------
+#define HIPCHK(x)                                                                      \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return LSA_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+struct Workspace {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; cap = 0;
+        size_t want = bytes + bytes / 8;
+        if (hipMalloc(&ptr, want) != hipSuccess) {
+            if (hipMalloc(&ptr, bytes) != hipSuccess) { ptr = nullptr; return -1; }
+            want = bytes;
+        }
+        cap = want;
+        return 0;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+};
+
+static Workspace g_ws;
+static hipEvent_t g_ev[LSA_MSM_STAGES + 1];
+static bool g_ev_ready = false;
+static bool g_profile = false;
+static float g_last_ms[LSA_MSM_STAGES] = {0};
+
+void msm_release_workspace() {
+    g_ws.release();
+    if (g_ev_ready) { for (auto &e : g_ev) (void)hipEventDestroy(e); g_ev_ready = false; }
+}
+void msm_profile_enable(bool on) { g_profile = on; }
+void msm_profile_last(float ms[LSA_MSM_STAGES]) { memcpy(ms, g_last_ms, sizeof g_last_ms); }
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+template <class F>
+int normalize_to_affine(const Jac<F> *d_in, Aff<F> *d_out, size_t n, hipStream_t st) {
+    if (n == 0) return LSA_OK;
+    constexpr int K = 8;
+    size_t threads = (n + K - 1) / K;
+    unsigned blocks = (unsigned)((threads + 255) / 256);
+    hipLaunchKernelGGL((k_normalize<F, K>), dim3(blocks), dim3(256), 0, st, d_in, d_out, n);
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
+template int normalize_to_affine<Fq>(const Jac<Fq> *, Aff<Fq> *, size_t, hipStream_t);
+template int normalize_to_affine<Fq2>(const Jac<Fq2> *, Aff<Fq2> *, size_t, hipStream_t);
+
+template <class F>
+int msm_device(const Aff<F> *d_bases, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st) {
+    if (n == 0) {
+        Jac<F> inf = Jac<F>::inf();
+        HIPCHK(hipMemcpyAsync(d_out, &inf, sizeof inf, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return LSA_OK;
+    }
+    if (n >= (size_t(1) << 27)) { set_error("msm: n too large (%zu)", n); return LSA_ERR_INVALID; }
+    const unsigned c = msm_window_bits(n);
+    const unsigned nwin = num_windows(c);
+    const uint32_t B = 1u << (c - 1);
+    const uint32_t nb = nwin * B;
+    const size_t ne = n * nwin;
+    const uint32_t L = B > 4096 ? B / 4096 : 1;
+    uint32_t logL = 0;
+    while ((1u << logL) < L) logL++;
+    const uint32_t T = B / L;
+    const uint32_t wpw = (T + 63) / 64;              // wavefronts per window, <= 64
+    const uint32_t heavy_threshold = 1024;
+    const uint32_t max_heavy = (uint32_t)std::min<size_t>(nb, ne / heavy_threshold + 1);
+    const uint32_t slices = 64;
+
+    // workspace carve-up
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    size_t o_hist = carve((size_t)nb * 4 + 256);     // + heavy_count word
+    size_t o_offs = carve((size_t)nb * 4);
+    size_t o_digits = carve(ne * 2);
+    size_t o_slot = carve(ne * 4);
+    size_t o_entries = carve(ne * 4);
+    size_t o_buckets = carve((size_t)nb * sizeof(XYZZ<F>));
+    size_t o_heavy = carve((size_t)max_heavy * 4);
+    size_t o_hpart = carve((size_t)max_heavy * slices * sizeof(XYZZ<F>));
+    size_t o_wave = carve((size_t)nwin * wpw * 2 * sizeof(XYZZ<F>));
+    size_t o_win = carve((size_t)nwin * sizeof(XYZZ<F>));
+    if (g_ws.ensure(off) != 0) { set_error("msm: workspace allocation of %zu bytes failed", off); return LSA_ERR_NOMEM; }
+    char *ws = (char *)g_ws.ptr;
+    uint32_t *hist = (uint32_t *)(ws + o_hist);
+    uint32_t *heavy_count = hist + nb;
+    uint32_t *offs = (uint32_t *)(ws + o_offs);
+    int16_t *digits = (int16_t *)(ws + o_digits);
+    uint32_t *slot = (uint32_t *)(ws + o_slot);
+    uint32_t *entries = (uint32_t *)(ws + o_entries);
+    XYZZ<F> *buckets = (XYZZ<F> *)(ws + o_buckets);
+    uint32_t *heavy_list = (uint32_t *)(ws + o_heavy);
+    XYZZ<F> *hpart = (XYZZ<F> *)(ws + o_hpart);
+    XYZZ<F> *wave_out = (XYZZ<F> *)(ws + o_wave);
+    XYZZ<F> *window_sums = (XYZZ<F> *)(ws + o_win);
+
+    if (g_profile && !g_ev_ready) {
+        for (auto &e : g_ev) HIPCHK(hipEventCreate(&e));
+        g_ev_ready = true;
+    }
+    int evi = 0;
+    auto mark = [&]() { if (g_profile) (void)hipEventRecord(g_ev[evi++], st); };
+
+    mark();  // 0
+    HIPCHK(hipMemsetAsync(hist, 0, (size_t)nb * 4 + 4, st));
+    hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, c, nwin, digits, slot, hist);
+    mark();  // 1
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, hist, offs, nb);
+    mark();  // 2
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, digits, slot, offs, n, c, nwin, entries);
+    mark();  // 3
+    hipLaunchKernelGGL((k_accumulate<F>), dim3((nb + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, nb,
+                       heavy_threshold, heavy_list, heavy_count, buckets);
+    hipLaunchKernelGGL((k_accumulate_heavy<F>), dim3(1024), dim3(256), 0, st, d_bases, entries, offs, hist,
+                       heavy_list, heavy_count, slices, hpart);
+    hipLaunchKernelGGL((k_heavy_finish<F>), dim3(256), dim3(64), 0, st, heavy_list, heavy_count, slices, hpart, buckets);
+    mark();  // 4
+    hipLaunchKernelGGL((k_reduce1<F>), dim3(nwin * wpw), dim3(64), 0, st, buckets, B, L, logL, wpw, wave_out);
+    hipLaunchKernelGGL((k_reduce2<F>), dim3(nwin), dim3(64), 0, st, wave_out, wpw, logL + 6, window_sums);
+    mark();  // 5
+    hipLaunchKernelGGL((k_fold<F>), dim3(1), dim3(64), 0, st, window_sums, nwin, c, d_out);
+    mark();  // 6
+    HIPCHK(hipGetLastError());
+    if (g_profile) {
+        HIPCHK(hipEventSynchronize(g_ev[6]));
+        for (int s = 0; s < 6; s++) (void)hipEventElapsedTime(&g_last_ms[s], g_ev[s], g_ev[s + 1]);
+        g_last_ms[6] = 0.f;
+        (void)hipEventElapsedTime(&g_last_ms[7], g_ev[0], g_ev[6]);
+    }
+    return LSA_OK;
+}
+template int msm_device<Fq>(const Aff<Fq> *, const Fr *, size_t, Jac<Fq> *, hipStream_t);
+template int msm_device<Fq2>(const Aff<Fq2> *, const Fr *, size_t, Jac<Fq2> *, hipStream_t);
+
+}  // namespace lsa

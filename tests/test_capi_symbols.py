@@ -1,0 +1,62 @@
+"""CPU suite: the C-ABI shared library loads and exports every symbol that
+include/*.h declares (no compute calls -- there is no GPU here), and the product
+code does not reach into oracle/."""
+import ctypes
+import glob
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    syms = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = open(h).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        syms |= set(re.findall(r"\b(lsa_[a-z0-9_]+)\s*\(", text))
+    return sorted(syms)
+
+
+def test_header_declares_entry_points():
+    syms = declared_symbols()
+    for must in ("lsa_init", "lsa_g1_msm", "lsa_g2_msm", "lsa_msm_run", "lsa_g1_bases_create"):
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol():
+    import legosnark_amd
+    if not os.path.exists(legosnark_amd.LIB_PATH):
+        legosnark_amd.build()
+    lib = ctypes.CDLL(legosnark_amd.LIB_PATH)
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_no_cpu_fallback_without_device():
+    """Without a GPU every compute entry point must fail loudly (never fall back)."""
+    import legosnark_amd
+    if not os.path.exists(legosnark_amd.LIB_PATH):
+        legosnark_amd.build()
+    if legosnark_amd.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(legosnark_amd.LsaError):
+        legosnark_amd.init(0)
+    import numpy as np
+    with pytest.raises(legosnark_amd.LsaError):
+        legosnark_amd.msm("g1", np.zeros((1, 12), dtype=np.uint64), np.zeros((1, 4), dtype=np.uint64))
+
+
+def test_product_does_not_touch_oracle():
+    bad = []
+    for base in ("legosnark_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".so", ".o", ".pyc")):
+                    continue
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"oracle[/_.]|liboracle|oracle_lib", text):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad

@@ -1,0 +1,156 @@
+"""GPU parity tests for the MSM path, through the C-ABI (ctypes), bit-exact after
+affine normalisation against (i) the committed golden vectors, (ii) the oracle on
+seeded inputs at sizes it finishes in seconds, (iii) the known-discrete-log identity at
+BASELINE.json's full size n = 2^20."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from conftest import g1_dec, g2_dec
+
+pytestmark = pytest.mark.gpu
+P, R = o.P, o.R
+
+
+def canon(group, pt):
+    return o.g1_canonical_affine(pt) if group == "g1" else o.g2_canonical_affine(pt)
+
+
+def rand_z(group, rng):
+    return rng.randrange(2, P) if group == "g1" else (rng.randrange(2, P), rng.randrange(P))
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_msm_golden_vectors(lsa, golden, group):
+    dec = g1_dec if group == "g1" else g2_dec
+    arr = o.g1_array if group == "g1" else o.g2_array
+    rng = random.Random(21)
+    for e in golden[group + "_msm"]:
+        pts = [dec(p) for p in e["bases"]]
+        sc = o.fr_mont_array([int(s, 16) for s in e["scalars"]])
+        want = dec(e["result"])
+        # normalised (Z=1) and un-normalised (random Z) libff inputs
+        for zs in (None, [rand_z(group, rng) for _ in pts]):
+            got = lsa.msm(group, arr(pts, zs), sc)
+            assert canon(group, got) == want, e["name"]
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 64, 65, 1000, 1026, 4097])
+def test_msm_vs_oracle_seeded(lsa, group, n):
+    a, b = 0xA5A5A5A5A5A5 << 40 | 3, 0x5A5A5A5A << 90 | 7
+    bases = o.arith_bases(group, a, b, n)        # un-normalised Jacobian
+    sc, ints = o.random_scalars(n, seed=1000 + n)
+    want = canon(group, o.multi_exp(group, bases, sc, chunks=1, mode="mixed"))
+    got = canon(group, lsa.msm(group, bases, sc))
+    assert got == want
+    k = sum(s * (a + i * b) for i, s in enumerate(ints)) % R
+    mul = o.g1_mul if group == "g1" else o.g2_mul
+    assert got == canon(group, mul(o.generator(group), o.fr_mont(k)))
+
+
+def test_msm_empty_and_truncation(lsa):
+    z = np.zeros((0, 12), dtype=np.uint64)
+    assert canon("g1", lsa.msm("g1", z, np.zeros((0, 4), dtype=np.uint64))) is None
+    # multiExpMA truncates to min(|gs|,|xs|)  (src/utils/globl.h:66)
+    bases = o.arith_bases("g1", 5, 9, 10)
+    sc, _ = o.random_scalars(6, seed=2)
+    want = canon("g1", o.multi_exp("g1", bases[:6], sc, mode="mixed"))
+    assert canon("g1", lsa.msm("g1", bases, sc)) == want
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_msm_degenerate_inputs(lsa, group):
+    """All-equal bases (CommScheme: n copies of the generator, commit.h:134-138),
+    all-equal scalars, zeros/ones, infinity bases, small scalars (hadamard.cc:130-135)."""
+    n = 3000
+    g = o.generator(group)
+    w = 12 if group == "g1" else 24
+    same = np.tile(g, (n, 1))
+    sc, ints = o.random_scalars(n, seed=77)
+    mul = o.g1_mul if group == "g1" else o.g2_mul
+    # n copies of the generator
+    got = canon(group, lsa.msm(group, same, sc))
+    assert got == canon(group, mul(g, o.fr_mont(sum(ints) % R)))
+    # u[i] = i and i^2
+    small = o.fr_mont_array([i for i in range(n)])
+    assert canon(group, lsa.msm(group, same, small)) == canon(group, mul(g, o.fr_mont(n * (n - 1) // 2)))
+    sq = o.fr_mont_array([i * i for i in range(n)])
+    assert canon(group, lsa.msm(group, same, sq)) == canon(group, mul(g, o.fr_mont(sum(i * i for i in range(n)) % R)))
+    # all scalars equal (one heavy bucket per window)
+    bases = o.arith_bases(group, 11, 13, n)
+    eq = np.tile(o.fr_mont(0xABCDEF0123456789ABCDEF), (n, 1))
+    assert canon(group, lsa.msm(group, bases, eq)) == canon(group, o.multi_exp(group, bases, eq, mode="mixed"))
+    # zeros, ones, r-1 and infinity bases mixed in
+    sc2 = sc.copy()
+    sc2[::7] = o.fr_mont(0)
+    sc2[1::7] = o.fr_mont(1)
+    sc2[2::7] = o.fr_mont(R - 1)
+    b2 = bases.copy()
+    inf = np.zeros(w, dtype=np.uint64)
+    inf[w // 3: w // 3 + 4] = o.fq_mont(1)
+    b2[3::11] = inf
+    assert canon(group, lsa.msm(group, b2, sc2)) == canon(group, o.multi_exp(group, b2, sc2, mode="mixed"))
+    # all-zero scalars -> O
+    assert canon(group, lsa.msm(group, bases, np.zeros((n, 4), dtype=np.uint64))) is None
+
+
+def test_msm_cplink_prover_shape(lsa):
+    """SubspaceSnark::prove (subspace.cc:78-85): P has 2N+2 entries (trailing N are O),
+    w = (0, rF, u) has N+2 entries -> MSM over min() = N+2 pairs, w[0] = 0."""
+    N = 1 << 10
+    P_ = np.zeros((2 * N + 2, 12), dtype=np.uint64)
+    P_[:N + 2] = o.arith_bases("g1", 99, 1234567, N + 2)
+    P_[N + 2:, 4:8] = o.fq_mont(1)   # libff zero() = (0,1,0)
+    w, _ = o.random_scalars(N + 2, seed=9)
+    w[0] = o.fr_mont(0)
+    want = canon("g1", o.multi_exp("g1", P_, w, mode="mixed"))
+    assert canon("g1", lsa.msm("g1", P_, w)) == want
+
+
+def test_msm_resident_api_and_linearity_full_size(lsa):
+    """n = 2^20 (BASELINE.json config 2): device-resident bases + scalars, checked by the
+    known-discrete-log identity and by linearity MSM(s) + MSM(t) == MSM(s + t)."""
+    import torch
+    n = 1 << 20
+    a, b = 0x1F2E3D4C5B6A7988 << 64 | 0x123, 0x0FEDCBA987654321 << 32 | 0x77
+    bases = o.arith_bases("g1", a, b, n)
+    B = lsa.Bases("g1", bases)
+    rng = np.random.default_rng(123)
+    raw = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)   # canonical < 2^254 .. reduce below
+    raw[:, 3] &= np.uint64((1 << 60) - 1)                           # < 2^252 < r: canonical as is
+    raw_t = np.roll(raw, 1, axis=0).copy()
+
+    def to_ints(arr):
+        return [int(arr[i, 0]) | int(arr[i, 1]) << 64 | int(arr[i, 2]) << 128 | int(arr[i, 3]) << 192 for i in range(n)]
+    si, ti = to_ints(raw), to_ints(raw_t)
+    mont_s = o.fr_mont_array(si)
+    mont_t = o.fr_mont_array(ti)
+    mont_st = o.fr_mont_array([(x + y) % R for x, y in zip(si, ti)])
+    dev = torch.device("cuda:0")
+    d_s = torch.from_numpy(mont_s.view(np.int64)).to(dev)
+    d_t = torch.from_numpy(mont_t.view(np.int64)).to(dev)
+    d_st = torch.from_numpy(mont_st.view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    r_s, r_t, r_st = B.msm(d_s), B.msm(d_t), B.msm(d_st)
+    k = sum(s * (a + i * b) for i, s in enumerate(si)) % R
+    assert canon("g1", r_s) == canon("g1", o.g1_mul(o.generator("g1"), o.fr_mont(k)))
+    assert canon("g1", o.g1_add(r_s, r_t)) == canon("g1", r_st)
+    # sub-range run
+    r_half = B.msm(d_s[: n // 2], n=n // 2)
+    k2 = sum(s * (a + i * b) for i, s in enumerate(si[: n // 2])) % R
+    assert canon("g1", r_half) == canon("g1", o.g1_mul(o.generator("g1"), o.fr_mont(k2)))
+    B.close()
+
+
+def test_normalize(lsa):
+    pts = o.arith_bases("g1", 3, 5, 100)
+    pts[7] = 0
+    pts[7, 4:8] = o.fq_mont(1)
+    out = lsa.normalize("g1", pts)
+    for i in range(100):
+        assert canon("g1", out[i]) == canon("g1", pts[i])
+        if i != 7:
+            assert np.array_equal(out[i, 8:12], o.fq_mont(1))

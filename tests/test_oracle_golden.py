@@ -1,0 +1,188 @@
+"""CPU suite: pins the C restatement (oracle/) against the golden vectors produced by
+the independent big-int model, the public alt_bn128 known answers and algebraic
+identities.  No GPU needed."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from conftest import f12_dec, g1_dec, g2_dec
+
+P, R = o.P, o.R
+
+
+def test_field_montgomery_roundtrip(golden):
+    import ctypes as C
+    for e in golden["field"]:
+        which = 0 if e["field"] == "fq" else 1
+        x = int(e["x"], 16)
+        lim = o.int_to_limbs(x)
+        out = np.zeros(4, dtype=np.uint64)
+        o.lib().ofp_from_canonical(o._p(out), o._p(lim), C.c_int(which))
+        assert o.limbs_to_int(out) == int(e["mont"], 16)
+        back = np.zeros(4, dtype=np.uint64)
+        o.lib().ofp_to_canonical(o._p(back), o._p(out), C.c_int(which))
+        assert o.limbs_to_int(back) == x
+
+
+def test_field_mul_inv(golden):
+    import ctypes as C
+    for e in golden["field_mul"]:
+        which = 0 if e["field"] == "fq" else 1
+        m = P if which == 0 else R
+        a, b = int(e["a"], 16), int(e["b"], 16)
+        am = o.int_to_limbs(a * o.MONT % m)
+        bm = o.int_to_limbs(b * o.MONT % m)
+        r = np.zeros(4, dtype=np.uint64)
+        o.lib().ofp_mul(o._p(r), o._p(am), o._p(bm), C.c_int(which))
+        assert o.limbs_to_int(r) == int(e["ab"], 16) * o.MONT % m
+        o.lib().ofp_inv(o._p(r), o._p(am), C.c_int(which))
+        assert o.limbs_to_int(r) == int(e["a_inv"], 16) * o.MONT % m
+
+
+def test_public_known_answers(golden):
+    # 2*G1 (EIP-196 test vector, quoted in SURVEY.md section 4)
+    two = (1368015179489954701390400359078579693043519447331113978918064868415326638035,
+           9918110051302171585080402603319702774565515993150576347155970296011118125764)
+    assert g1_dec(golden["kat"]["g1_two"]) == two
+    g = o.generator("g1")
+    assert o.g1_canonical_affine(o.g1_dbl(g)) == two
+    assert o.g1_canonical_affine(o.g1_add(g, g)) == two
+    # r*G = O in both groups (r = 0 mod r, so multiply by r-1 and add G)
+    rm1 = o.fr_mont(R - 1)
+    assert o.g1_canonical_affine(o.g1_add(o.g1_mul(g, rm1), g)) is None
+    g2 = o.generator("g2")
+    assert o.g2_canonical_affine(g2) == g2_dec(golden["kat"]["g2_gen"])
+    assert o.g2_canonical_affine(o.g2_add(o.g2_mul(g2, rm1), g2)) is None
+    assert o.lib().og1_is_well_formed(o._p(g)) == 1
+    assert o.lib().og2_is_well_formed(o._p(g2)) == 1
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_group_law_cases(golden, group):
+    dec = g1_dec if group == "g1" else g2_dec
+    mk = o.g1_from_affine if group == "g1" else o.g2_from_affine
+    add = o.g1_add if group == "g1" else o.g2_add
+    madd = o.g1_mixed_add if group == "g1" else o.g2_mixed_add
+    canon = o.g1_canonical_affine if group == "g1" else o.g2_canonical_affine
+    rng = random.Random(7)
+    for e in golden[group + "_add"]:
+        a, b, s = dec(e["a"]), dec(e["b"]), dec(e["sum"])
+        za = rng.randrange(2, P) if group == "g1" else (rng.randrange(2, P), rng.randrange(P))
+        zb = rng.randrange(2, P) if group == "g1" else (rng.randrange(2, P), rng.randrange(P))
+        assert canon(add(mk(a), mk(b))) == s, e["name"]
+        assert canon(add(mk(a, za) if a else mk(a), mk(b, zb) if b else mk(b))) == s, e["name"]
+        assert canon(madd(mk(a, za) if a else mk(a), mk(b))) == s, e["name"]
+
+
+def test_scalar_mul(golden):
+    g1, g2 = o.generator("g1"), o.generator("g2")
+    for e in golden["scalar_mul"]:
+        k = o.fr_mont(int(e["k"], 16))
+        assert o.g1_canonical_affine(o.g1_mul(g1, k)) == g1_dec(e["g1"])
+        assert o.g2_canonical_affine(o.g2_mul(g2, k)) == g2_dec(e["g2"])
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_msm_golden(golden, group):
+    dec = g1_dec if group == "g1" else g2_dec
+    arr = o.g1_array if group == "g1" else o.g2_array
+    canon = o.g1_canonical_affine if group == "g1" else o.g2_canonical_affine
+    rng = random.Random(11)
+    for e in golden[group + "_msm"]:
+        pts = [dec(p) for p in e["bases"]]
+        sc = o.fr_mont_array([int(s, 16) for s in e["scalars"]])
+        want = dec(e["result"])
+        if group == "g1":
+            zs = [rng.randrange(1, P) for _ in pts]
+        else:
+            zs = [(rng.randrange(1, P), rng.randrange(P)) for _ in pts]
+        bases = arr(pts, zs)
+        for mode, chunks, threads in (("inner", 1, 0), ("multi_exp", 1, 0), ("multi_exp", 3, 0),
+                                      ("mixed", 1, 0), ("mixed", 4, 2)):
+            got = canon(o.multi_exp(group, bases, sc, chunks=chunks, threads=threads, mode=mode))
+            assert got == want, (e["name"], mode, chunks)
+
+
+def test_bdlo12_window_rule(golden):
+    for n, c in golden["bdlo12_window"]:
+        assert o.lib().oracle_bdlo12_window(n) == c
+    # values quoted in SURVEY.md section 7 step 1
+    for n, c in ((1, 2), (2, 3), (3, 4), (8, 4), (1 << 10, 9), (1025, 10), (1 << 20, 16), (1 << 24, 18)):
+        assert o.lib().oracle_bdlo12_window(n) == c
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_batch_exp_matches_scalar_mul(group):
+    g = o.generator(group)
+    sc, ints = o.random_scalars(9, seed=5)
+    sc[0] = o.fr_mont(0)
+    sc[1] = o.fr_mont(1)
+    mul = o.g1_mul if group == "g1" else o.g2_mul
+    canon = o.g1_canonical_affine if group == "g1" else o.g2_canonical_affine
+    for window in (None, 1, 5):
+        out = o.batch_exp(group, g, sc, window=window)
+        for i in range(len(sc)):
+            assert canon(out[i]) == canon(mul(g, sc[i]))
+
+
+def test_msm_known_discrete_log_medium():
+    """n = 4096 with bases (a + i b) G: result must be (sum s_i (a + i b)) G."""
+    n = 4096
+    a, b = 0x1234567 << 100 | 5, 0xDEADBEEF << 64 | 9
+    sc, ints = o.random_scalars(n, seed=3)
+    for group in ("g1", "g2"):
+        bases = o.arith_bases(group, a, b, n)
+        got = o.multi_exp(group, bases, sc, chunks=8, threads=4, mode="mixed")
+        k = sum(s * (a + i * b) for i, s in enumerate(ints)) % R
+        mul = o.g1_mul if group == "g1" else o.g2_mul
+        canon = o.g1_canonical_affine if group == "g1" else o.g2_canonical_affine
+        assert canon(got) == canon(mul(o.generator(group), o.fr_mont(k)))
+
+
+def test_pairing_golden(golden):
+    pr = golden["pairing"]
+    g1, g2 = o.generator("g1"), o.generator("g2")
+    e = o.reduced_pairing(g1, g2)
+    assert o.fq12_to_model(e) == f12_dec(pr["e_g1_g2"])
+    one = o.fq12_one()
+    assert o.fq12_to_model(o.final_exponentiation(one)) == f12_dec(pr["final_exp_of_one"])
+    assert np.array_equal(o.final_exponentiation(one), one)
+    rng = random.Random(5)
+    for t in pr["bilinear"]:
+        Pp = o.g1_from_affine(g1_dec(t["P"]), rng.randrange(2, P))
+        Qq = o.g2_from_affine(g2_dec(t["Q"]), (rng.randrange(2, P), rng.randrange(P)))
+        assert o.fq12_to_model(o.reduced_pairing(Pp, Qq)) == f12_dec(t["e"])
+    pp = pr["planted_product"]
+    Ps = o.g1_array([g1_dec(x) for x in pp["P"]])
+    Qs = o.g2_array([g2_dec(x) for x in pp["Q"]])
+    assert np.array_equal(o.pairing_product(Ps, Qs), one)
+    p2 = pr["product2"]
+    Ps = o.g1_array([g1_dec(x) for x in p2["P"]])
+    Qs = o.g2_array([g2_dec(x) for x in p2["Q"]])
+    assert o.fq12_to_model(o.pairing_product(Ps, Qs)) == f12_dec(p2["result"])
+
+
+def test_pairing_identities():
+    import ctypes as C
+    g1, g2 = o.generator("g1"), o.generator("g2")
+    a, b = 123456789, 987654321
+    ea = o.reduced_pairing(o.g1_mul(g1, o.fr_mont(a)), o.g2_mul(g2, o.fr_mont(b)))
+    eb = o.reduced_pairing(o.g1_mul(g1, o.fr_mont(a * b % R)), g2)
+    assert np.array_equal(ea, eb)
+    # e(P,Q) * e(-P,Q) == 1
+    neg = np.zeros(12, dtype=np.uint64)
+    o.lib().og1_neg(o._p(neg), o._p(g1))
+    prod = o.pairing_product(np.stack([g1, neg]), np.stack([g2, g2]))
+    assert np.array_equal(prod, o.fq12_one())
+    # Frobenius == generic p-th power; double_miller_loop == product of miller loops
+    f = o.miller_loop_batch(g1.reshape(1, 12), g2.reshape(1, 24))[0]
+    fr = np.zeros(48, dtype=np.uint64)
+    fp = np.zeros(48, dtype=np.uint64)
+    o.lib().ofq12_frobenius(o._p(fr), o._p(f), C.c_uint(1))
+    o.lib().ofq12_pow_p(o._p(fp), o._p(f))
+    assert np.array_equal(fr, fp)
+    inv = np.zeros(48, dtype=np.uint64)
+    o.lib().ofq12_inverse(o._p(inv), o._p(f))
+    assert np.array_equal(o.fq12_mul(f, inv), o.fq12_one())
