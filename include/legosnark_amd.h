@@ -89,9 +89,26 @@ unsigned lsa_msm_window_bits(size_t n);
 #define LSA_MSM_STAGES 8
 /* 0 digits+histogram, 1 scan, 2 scatter, 3 bucket accumulate (dominant), 4 bucket
  * reduce, 5 window fold, 6 reserved, 7 total */
-int lsa_profile_enable(int on);
-/* Milliseconds per stage of the LAST lsa_msm_run* call made with profiling enabled. */
+int lsa_profile_enable(int on);   /* also resets the recorded-call counter */
+/* Average milliseconds per stage over the MSM calls (at most 64) recorded since
+ * lsa_profile_enable(1); synchronises on their events; returns the number of calls. */
 int lsa_profile_last_msm(float ms[LSA_MSM_STAGES]);
+
+/* ---- fixed-base batch exponentiation ------------------------------------------------ */
+/* out[i] = scalars[i] * base, i < n.  Replaces libff get_window_table + batch_exp as used
+ * by cputil::simpleBatchExp (src/utils/util.h:119-134) and Interpolator::mkG1Exp/mkG2Exp
+ * (src/prototools/interp.h:36-59).  base: one HOST Jacobian point; scalars: n x 32 B
+ * Montgomery Fr; out: n Jacobian points (valid representatives, not normalised).
+ * `on_device` != 0: scalars and out are device pointers, else host pointers. */
+int lsa_g1_batch_exp(const void *base_jac, const void *scalars_mont, size_t n, void *out_jac, int on_device);
+int lsa_g2_batch_exp(const void *base_jac, const void *scalars_mont, size_t n, void *out_jac, int on_device);
+
+/* ---- sum of points --------------------------------------------------------------------- */
+/* out = sum_i pts[i]; pts: n Jacobian points on the DEVICE, d_out_jac: DEVICE (async on
+ * lsa_stream()).  Folds the per-GPU MSM partials after the RCCL all-gather that replaces
+ * libff's `final = final + partial[i]` loop over chunks (multi_exp). */
+int lsa_g1_sum_async(const void *d_pts_jac, size_t n, void *d_out_jac);
+int lsa_g2_sum_async(const void *d_pts_jac, size_t n, void *d_out_jac);
 
 /* ---- point helpers ------------------------------------------------------------------- */
 /* Jacobian -> libff "special" form (affine with Z = 1, or (0,1,0)), n points, host

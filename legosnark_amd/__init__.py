@@ -60,6 +60,10 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         for name in ("lsa_g1_normalize", "lsa_g2_normalize"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        for name in ("lsa_g1_batch_exp", "lsa_g2_batch_exp"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        for name in ("lsa_g1_sum_async", "lsa_g2_sum_async"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         _lib = L
     return _lib
 
@@ -178,14 +182,45 @@ def normalize(group, pts):
     return out
 
 
+def batch_exp(group, base, scalars, out=None):
+    """simpleBatchExp drop-in: out[i] = scalars[i] * base.
+
+    base: host Jacobian point (uint64 limbs).  scalars: numpy (host) or torch CUDA tensor
+    (device); `out` must live on the same side (allocated here for the host case)."""
+    w = _group_width(group)
+    base = np.ascontiguousarray(base, dtype=np.uint64).reshape(w)
+    fn = lib().lsa_g1_batch_exp if group == "g1" else lib().lsa_g2_batch_exp
+    if isinstance(scalars, np.ndarray):
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        n = len(scalars)
+        out = np.zeros((n, w), dtype=np.uint64)
+        _check(fn(_host_ptr(base), _host_ptr(scalars), n, _host_ptr(out), 0))
+        return out
+    n = scalars.numel() * scalars.element_size() // 32
+    if out is None:
+        import torch
+        out = torch.empty((n, w), dtype=torch.int64, device=scalars.device)
+    _check(fn(_host_ptr(base), _ptr(scalars), n, _ptr(out), 1))
+    return out
+
+
+def sum_async(group, d_pts, n, d_out):
+    """d_out = sum of n device-resident Jacobian points (async on the library stream)."""
+    fn = lib().lsa_g1_sum_async if group == "g1" else lib().lsa_g2_sum_async
+    _check(fn(_ptr(d_pts), n, _ptr(d_out)))
+
+
 def profile_enable(on=True):
     lib().lsa_profile_enable(1 if on else 0)
 
 
 def profile_last_msm():
+    """Average per-stage milliseconds over the MSM calls recorded since profile_enable()."""
     ms = (C.c_float * MSM_STAGES)()
-    lib().lsa_profile_last_msm(ms)
-    return dict(zip(STAGE_NAMES, [float(x) for x in ms]))
+    cnt = lib().lsa_profile_last_msm(ms)
+    d = dict(zip(STAGE_NAMES, [float(x) for x in ms]))
+    d["calls"] = int(cnt)
+    return d
 
 
 def msm_window_bits(n):

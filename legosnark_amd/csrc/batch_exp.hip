@@ -1,0 +1,139 @@
+// legosnark_amd/csrc/batch_exp.hip -- fixed-base batch scalar multiplication on gfx950.
+//
+// Replaces libff get_window_table + batch_exp as used by cputil::simpleBatchExp
+// (/root/reference/src/utils/util.h:119-134) and Interpolator::mkG1Exp/mkG2Exp
+// (/root/reference/src/prototools/interp.h:36-59):  out[i] = scalars[i] * base.
+//
+//   1 powers   pw[j] = 2^(w*j) * base                       (one lane, nwin*w doublings)
+//   2 table    T[j][d] = d * pw[j], d < 2^w                 (one lane per entry, w steps)
+//   3 affine   batch-normalise the table (k_normalize, msm.hip)  -> 64/128 B entries, L2-resident
+//   4 main     one lane per scalar: Montgomery -> canonical, nwin table lookups,
+//              XYZZ mixed adds, Jacobian result (96/192 B) written coalesced.
+// HBM traffic per scalar: 32 B in + 96 B (G1) / 192 B (G2) out; table reads hit L2.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ec.h"
+#include "msm.h"
+
+namespace lsa {
+
+template <class F>
+__global__ __launch_bounds__(64) void k_bexp_powers(Jac<F> base, Jac<F> *__restrict__ pw, unsigned w, unsigned nwin) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Jac<F> cur = base;
+    for (unsigned j = 0; j < nwin; j++) {
+        pw[j] = cur;
+        for (unsigned i = 0; i < w; i++) cur = jac_dbl(cur);
+    }
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void k_bexp_table(const Jac<F> *__restrict__ pw, Jac<F> *__restrict__ tbl, unsigned w, unsigned nwin) {
+    unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned per = 1u << w;
+    if (g >= nwin * per) return;
+    unsigned j = g >> w, d = g & (per - 1);
+    Jac<F> p = pw[j];
+    Jac<F> r = Jac<F>::inf();
+    for (int b = (int)w - 1; b >= 0; b--) {
+        r = jac_dbl(r);
+        if ((d >> b) & 1) r = jac_add(r, p);
+    }
+    tbl[g] = r;
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void k_bexp_main(const Aff<F> *__restrict__ tbl, const Fr *__restrict__ scalars, size_t n,
+                                                   unsigned w, unsigned nwin, Jac<F> *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[8];
+    scalars[i].to_canonical(s);
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (unsigned j = 0; j < nwin; j++) {
+        unsigned bit = j * w;
+        unsigned wd = bit >> 5, sh = bit & 31;
+        uint64_t two = (uint64_t)(wd < 8 ? s[wd] : 0) | ((uint64_t)(wd + 1 < 8 ? s[wd + 1] : 0) << 32);
+        uint32_t d = (uint32_t)(two >> sh) & ((1u << w) - 1);
+        if (d) acc = xyzz_madd(acc, tbl[((size_t)j << w) + d]);
+    }
+    out[i] = xyzz_to_jac(acc);
+}
+
+#define HIPCHK(x)                                                                      \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return LSA_ERR_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+unsigned batch_exp_window_bits(size_t n) { return n >= (size_t(1) << 16) ? 12 : 8; }
+
+// base: host value; d_scalars / d_out: device.  Asynchronous on `st` except for the
+// temporary table, which is freed after a stream sync.
+template <class F>
+int batch_exp_device(const Jac<F> &base, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st) {
+    if (n == 0) return LSA_OK;
+    const unsigned w = batch_exp_window_bits(n);
+    const unsigned nwin = (254 + w - 1) / w;
+    const size_t entries = (size_t)nwin << w;
+    Jac<F> *d_pw = nullptr, *d_tbl = nullptr;
+    Aff<F> *d_aff = nullptr;
+    if (hipMalloc(&d_pw, nwin * sizeof(Jac<F>)) != hipSuccess || hipMalloc(&d_tbl, entries * sizeof(Jac<F>)) != hipSuccess ||
+        hipMalloc(&d_aff, entries * sizeof(Aff<F>)) != hipSuccess) {
+        if (d_pw) (void)hipFree(d_pw);
+        if (d_tbl) (void)hipFree(d_tbl);
+        set_error("batch_exp: table allocation failed");
+        return LSA_ERR_NOMEM;
+    }
+    hipLaunchKernelGGL((k_bexp_powers<F>), dim3(1), dim3(64), 0, st, base, d_pw, w, nwin);
+    hipLaunchKernelGGL((k_bexp_table<F>), dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st, d_pw, d_tbl, w, nwin);
+    int rc = normalize_to_affine<F>(d_tbl, d_aff, entries, st);
+    if (!rc) {
+        hipLaunchKernelGGL((k_bexp_main<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_aff, d_scalars, n, w, nwin, d_out);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(d_pw);
+    (void)hipFree(d_tbl);
+    (void)hipFree(d_aff);
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error("batch_exp: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
+    return LSA_OK;
+}
+template int batch_exp_device<Fq>(const Jac<Fq> &, const Fr *, size_t, Jac<Fq> *, hipStream_t);
+template int batch_exp_device<Fq2>(const Jac<Fq2> &, const Fr *, size_t, Jac<Fq2> *, hipStream_t);
+
+// ------------------------------------------------------------------------------------
+// sum of n Jacobian points (device) -> one Jacobian point: used to fold the per-GPU MSM
+// partials after the RCCL all-gather and small result vectors.
+// ------------------------------------------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(64) void k_sum_points(const Jac<F> *__restrict__ in, size_t n, Jac<F> *__restrict__ out) {
+    unsigned lane = threadIdx.x;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (size_t i = lane; i < n; i += 64) acc = xyzz_add(acc, jac_to_xyzz(in[i]));
+    for (unsigned d = 32; d >= 1; d >>= 1) {
+        XYZZ<F> t;
+        constexpr int NW = sizeof(XYZZ<F>) / 4;
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&acc);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&t);
+#pragma unroll
+        for (int i = 0; i < NW; i++) dst[i] = __shfl_down(src[i], d, 64);
+        if (lane + d < 64) acc = xyzz_add(acc, t);
+    }
+    if (lane == 0) *out = xyzz_to_jac(acc);
+}
+
+template <class F>
+int sum_points_device(const Jac<F> *d_in, size_t n, Jac<F> *d_out, hipStream_t st) {
+    hipLaunchKernelGGL((k_sum_points<F>), dim3(1), dim3(64), 0, st, d_in, n, d_out);
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
+template int sum_points_device<Fq>(const Jac<Fq> *, size_t, Jac<Fq> *, hipStream_t);
+template int sum_points_device<Fq2>(const Jac<Fq2> *, size_t, Jac<Fq2> *, hipStream_t);
+
+}  // namespace lsa

@@ -114,7 +114,7 @@ int lsa_synchronize(void) {
 unsigned lsa_msm_window_bits(size_t n) { return msm_window_bits(n); }
 
 int lsa_profile_enable(int on) { msm_profile_enable(on != 0); return LSA_OK; }
-int lsa_profile_last_msm(float ms[LSA_MSM_STAGES]) { msm_profile_last(ms); return LSA_OK; }
+int lsa_profile_last_msm(float ms[LSA_MSM_STAGES]) { return msm_profile_last(ms); }
 
 // ---------------------------------------------------------------- bases
 }  // extern "C"
@@ -260,4 +260,51 @@ extern "C" {
 int lsa_g1_normalize(const void *in_jac, size_t n, void *out_jac) { return normalize_host<Fq>(in_jac, n, out_jac); }
 int lsa_g2_normalize(const void *in_jac, size_t n, void *out_jac) { return normalize_host<Fq2>(in_jac, n, out_jac); }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------- batch_exp / sum
+template <class F>
+static int batch_exp_any(const void *base_jac, const void *scalars, size_t n, void *out_jac, int on_device) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (n == 0) return LSA_OK;
+    if (!base_jac || !scalars || !out_jac) { set_error("batch_exp: null argument"); return LSA_ERR_INVALID; }
+    Jac<F> base;
+    memcpy(&base, base_jac, sizeof base);
+    if (on_device) return batch_exp_device<F>(base, (const Fr *)scalars, n, (Jac<F> *)out_jac, g.stream);
+    void *d_sc = nullptr, *d_out = nullptr;
+    if (hipMalloc(&d_sc, n * sizeof(Fr)) != hipSuccess || hipMalloc(&d_out, n * sizeof(Jac<F>)) != hipSuccess) {
+        if (d_sc) (void)hipFree(d_sc);
+        set_error("batch_exp: hipMalloc failed");
+        return LSA_ERR_NOMEM;
+    }
+    hipError_t e = hipMemcpyAsync(d_sc, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream);
+    if (e == hipSuccess) rc = batch_exp_device<F>(base, (const Fr *)d_sc, n, (Jac<F> *)d_out, g.stream);
+    if (e == hipSuccess && !rc) e = hipMemcpy(out_jac, d_out, n * sizeof(Jac<F>), hipMemcpyDeviceToHost);
+    (void)hipFree(d_sc);
+    (void)hipFree(d_out);
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error("batch_exp: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
+    return LSA_OK;
+}
+
+extern "C" {
+int lsa_g1_batch_exp(const void *base_jac, const void *scalars, size_t n, void *out_jac, int on_device) {
+    return batch_exp_any<Fq>(base_jac, scalars, n, out_jac, on_device);
+}
+int lsa_g2_batch_exp(const void *base_jac, const void *scalars, size_t n, void *out_jac, int on_device) {
+    return batch_exp_any<Fq2>(base_jac, scalars, n, out_jac, on_device);
+}
+int lsa_g1_sum_async(const void *d_pts, size_t n, void *d_out) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (!d_out || (n && !d_pts)) { set_error("sum: null argument"); return LSA_ERR_INVALID; }
+    return sum_points_device<Fq>((const Jac<Fq> *)d_pts, n, (Jac<Fq> *)d_out, g.stream);
+}
+int lsa_g2_sum_async(const void *d_pts, size_t n, void *d_out) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (!d_out || (n && !d_pts)) { set_error("sum: null argument"); return LSA_ERR_INVALID; }
+    return sum_points_device<Fq2>((const Jac<Fq2> *)d_pts, n, (Jac<Fq2> *)d_out, g.stream);
+}
 }  // extern "C"

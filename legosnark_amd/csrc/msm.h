@@ -21,8 +21,17 @@ int normalize_to_affine(const Jac<F> *d_in, Aff<F> *d_out, size_t n, hipStream_t
 template <class F>
 int msm_device(const Aff<F> *d_bases, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st);
 
+// out[i] = scalars[i] * base (fixed base); d_scalars/d_out device-resident.
+template <class F>
+int batch_exp_device(const Jac<F> &base, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st);
+unsigned batch_exp_window_bits(size_t n);
+
+// d_out = sum of n Jacobian points in d_in (device-resident).
+template <class F>
+int sum_points_device(const Jac<F> *d_in, size_t n, Jac<F> *d_out, hipStream_t st);
+
 void msm_release_workspace();
 void msm_profile_enable(bool on);
-void msm_profile_last(float ms[LSA_MSM_STAGES]);
+int msm_profile_last(float ms[LSA_MSM_STAGES]);
 
 }  // namespace lsa

@@ -372,17 +372,34 @@ struct Workspace {
 };
 
 static Workspace g_ws;
-static hipEvent_t g_ev[LSA_MSM_STAGES + 1];
+// Per-stage HIP events on the library stream.  A ring of EV_POOL call slots so that
+// profiling never synchronises inside the timed loop; msm_profile_last() harvests.
+static constexpr int EV_POOL = 64;
+static constexpr int EV_MARKS = 7;
+static hipEvent_t g_ev[EV_POOL][EV_MARKS];
 static bool g_ev_ready = false;
 static bool g_profile = false;
-static float g_last_ms[LSA_MSM_STAGES] = {0};
+static int g_ev_calls = 0;
 
 void msm_release_workspace() {
     g_ws.release();
-    if (g_ev_ready) { for (auto &e : g_ev) (void)hipEventDestroy(e); g_ev_ready = false; }
+    if (g_ev_ready) { for (auto &row : g_ev) for (auto &e : row) (void)hipEventDestroy(e); g_ev_ready = false; }
 }
-void msm_profile_enable(bool on) { g_profile = on; }
-void msm_profile_last(float ms[LSA_MSM_STAGES]) { memcpy(ms, g_last_ms, sizeof g_last_ms); }
+void msm_profile_enable(bool on) { g_profile = on; g_ev_calls = 0; }
+// Average per-stage milliseconds over the (up to EV_POOL) MSM calls recorded since
+// profiling was enabled; returns the number of calls averaged.
+int msm_profile_last(float ms[LSA_MSM_STAGES]) {
+    for (int s = 0; s < LSA_MSM_STAGES; s++) ms[s] = 0.f;
+    int cnt = g_ev_calls < EV_POOL ? g_ev_calls : EV_POOL;
+    if (!g_ev_ready || cnt == 0) return 0;
+    for (int c = 0; c < cnt; c++) {
+        if (hipEventSynchronize(g_ev[c][EV_MARKS - 1]) != hipSuccess) return 0;
+        for (int s = 0; s < 6; s++) { float t = 0.f; (void)hipEventElapsedTime(&t, g_ev[c][s], g_ev[c][s + 1]); ms[s] += t; }
+        float t = 0.f; (void)hipEventElapsedTime(&t, g_ev[c][0], g_ev[c][EV_MARKS - 1]); ms[7] += t;
+    }
+    for (int s = 0; s < LSA_MSM_STAGES; s++) ms[s] /= (float)cnt;
+    return cnt;
+}
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -450,11 +467,12 @@ int msm_device(const Aff<F> *d_bases, const Fr *d_scalars, size_t n, Jac<F> *d_o
     XYZZ<F> *window_sums = (XYZZ<F> *)(ws + o_win);
 
     if (g_profile && !g_ev_ready) {
-        for (auto &e : g_ev) HIPCHK(hipEventCreate(&e));
+        for (auto &row : g_ev) for (auto &e : row) HIPCHK(hipEventCreate(&e));
         g_ev_ready = true;
     }
     int evi = 0;
-    auto mark = [&]() { if (g_profile) (void)hipEventRecord(g_ev[evi++], st); };
+    const int evslot = g_ev_calls % EV_POOL;
+    auto mark = [&]() { if (g_profile) (void)hipEventRecord(g_ev[evslot][evi++], st); };
 
     mark();  // 0
     HIPCHK(hipMemsetAsync(hist, 0, (size_t)nb * 4 + 4, st));
@@ -476,12 +494,7 @@ int msm_device(const Aff<F> *d_bases, const Fr *d_scalars, size_t n, Jac<F> *d_o
     hipLaunchKernelGGL((k_fold<F>), dim3(1), dim3(64), 0, st, window_sums, nwin, c, d_out);
     mark();  // 6
     HIPCHK(hipGetLastError());
-    if (g_profile) {
-        HIPCHK(hipEventSynchronize(g_ev[6]));
-        for (int s = 0; s < 6; s++) (void)hipEventElapsedTime(&g_last_ms[s], g_ev[s], g_ev[s + 1]);
-        g_last_ms[6] = 0.f;
-        (void)hipEventElapsedTime(&g_last_ms[7], g_ev[0], g_ev[6]);
-    }
+    if (g_profile) g_ev_calls++;
     return LSA_OK;
 }
 template int msm_device<Fq>(const Aff<Fq> *, const Fr *, size_t, Jac<Fq> *, hipStream_t);

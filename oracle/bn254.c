@@ -36,7 +36,7 @@ static inline uint64_t limbs_add(uint64_t r[4], const uint64_t a[4], const uint6
 }
 
 /* CIOS Montgomery product: r = a*b*R^-1 mod m, inputs/outputs in [0,m). */
-static void mont_mul(uint64_t r[4], const uint64_t a[4], const uint64_t b[4], int which) {
+static inline __attribute__((always_inline)) void mont_mul(uint64_t r[4], const uint64_t a[4], const uint64_t b[4], const int which) {
     const uint64_t *m = modulus(which);
     const uint64_t inv = mod_inv(which);
     uint64_t t[6] = {0, 0, 0, 0, 0, 0};
@@ -106,8 +106,8 @@ static inline int fq_is_zero(const ofp_t *a) { return (a->l[0] | a->l[1] | a->l[
 static inline int fq_eq(const ofp_t *a, const ofp_t *b) { return memcmp(a, b, 32) == 0; }
 static inline void fq_add(ofp_t *r, const ofp_t *a, const ofp_t *b) { ofp_add(r, a, b, 0); }
 static inline void fq_sub(ofp_t *r, const ofp_t *a, const ofp_t *b) { ofp_sub(r, a, b, 0); }
-static inline void fq_mul(ofp_t *r, const ofp_t *a, const ofp_t *b) { ofp_mul(r, a, b, 0); }
-static inline void fq_sqr(ofp_t *r, const ofp_t *a) { ofp_mul(r, a, a, 0); }
+static inline void fq_mul(ofp_t *r, const ofp_t *a, const ofp_t *b) { mont_mul(r->l, a->l, b->l, 0); }
+static inline void fq_sqr(ofp_t *r, const ofp_t *a) { mont_mul(r->l, a->l, a->l, 0); }
 static inline void fq_neg(ofp_t *r, const ofp_t *a) { ofp_t z; fq_zero(&z); ofp_sub(r, &z, a, 0); }
 static inline void fq_inv(ofp_t *r, const ofp_t *a) { ofp_inv(r, a, 0); }
 
