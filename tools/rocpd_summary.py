@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 (ROCm 7.2, rocpd sqlite output) runs into small text files that
+can be committed under profiles/.
+
+  python tools/rocpd_summary.py trace  <trace_results.db>            -> per-kernel stats
+  python tools/rocpd_summary.py pmc    <pmc_results.db> [more.db...] -> per-kernel counter means
+  python tools/rocpd_summary.py hbm    <fetch.db> <write.db> <kernel-substring> <out.json>
+        -> per-launch HBM bytes for one kernel, corrected as MI355X_MICROARCH.md
+           prescribes (FETCH_SIZE is KiB and reads 1/2 of wide coalesced reads on gfx950:
+           bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024)
+"""
+import json
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = name.split("(")[0]
+    name = re.sub(r"lsa::Fp<lsa::FqParams>\s*", "Fq", name)
+    name = re.sub(r"lsa::Fp<lsa::FrParams>\s*", "Fr", name)
+    name = name.replace("lsa::", "")
+    if len(name) > 70:
+        name = name[:67] + "..."
+    return name
+
+
+def trace(db_path):
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+    print("%-72s %7s %12s %12s %7s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
+    for name, calls, total, avg, pct in rows:
+        print("%-72s %7d %12.1f %12.3f %6.2f%%" % (short(name), calls, total, avg, pct))
+
+
+def pmc_means(db_path):
+    db = sqlite3.connect(db_path)
+    q = ("select kernel_name, counter_name, count(*), avg(value), avg(duration), max(vgpr_count), max(sgpr_count), "
+         "max(lds_block_size), max(scratch_size) from counters_collection group by kernel_name, counter_name")
+    return db.execute(q).fetchall()
+
+
+def pmc(paths):
+    print("%-60s %-18s %6s %16s %12s %5s %5s %7s %7s" % ("kernel", "counter", "calls", "mean_value", "avg_us", "vgpr", "sgpr", "lds", "scratch"))
+    for p in paths:
+        for name, ctr, cnt, val, dur, vg, sg, lds, scr in pmc_means(p):
+            if "lsa::" not in name:
+                continue
+            print("%-60s %-18s %6d %16.3f %12.3f %5d %5d %7d %7d" % (short(name)[:60], ctr, cnt, val, dur / 1e3, vg, sg, lds, scr))
+
+
+def hbm(fetch_db, write_db, needle, out):
+    def mean(dbp, ctr):
+        for name, c, cnt, val, dur, *_ in pmc_means(dbp):
+            if needle in name and c == ctr:
+                return val, cnt, dur
+        raise SystemExit("kernel %r / counter %s not found in %s" % (needle, ctr, dbp))
+    f, fc, fd = mean(fetch_db, "FETCH_SIZE")
+    w, wc, wd = mean(write_db, "WRITE_SIZE")
+    res = {
+        "kernel": needle, "fetch_size_kib_mean": f, "write_size_kib_mean": w, "launches": [fc, wc],
+        "kernel_us_under_pmc": [fd / 1e3, wd / 1e3],
+        "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024,
+        "note": "2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE half-count correction, MI355X_MICROARCH.md HBM section); "
+                "inputs fit the 256 MiB Infinity Cache, so memory-side counters can under-report re-reads",
+    }
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    mode = sys.argv[1]
+    if mode == "trace":
+        trace(sys.argv[2])
+    elif mode == "pmc":
+        pmc(sys.argv[2:])
+    elif mode == "hbm":
+        hbm(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])
