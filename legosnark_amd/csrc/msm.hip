@@ -123,31 +123,65 @@ __global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, 
 }
 
 // ------------------------------------------------------------------------------------
-// kernel 2: exclusive scan of `count` counters (single workgroup, count <= 2^20)
+// kernel 2: exclusive scan of `count` counters in three small launches:
+//   a) per-block sums (2048 counters per 256-lane block, LDS-free wave shuffles)
+//   b) one block scans the <= 1024 block sums
+//   c) per-block exclusive scan seeded with the block offset
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ hist, uint32_t *__restrict__ offs, uint32_t count) {
-    __shared__ uint32_t part[1024];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (count + 1023) / 1024;
-    const uint32_t lo = tid * per;
-    uint32_t sum = 0;
-    for (uint32_t j = 0; j < per; j++) {
-        uint32_t idx = lo + j;
-        if (idx < count) sum += hist[idx];
+#define SCAN_PER_BLOCK 2048
+__device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t *lds, uint32_t *total) {
+    // 256 lanes; wave-level shuffles then 4 wave totals through LDS
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += t;
     }
-    part[tid] = sum;
+    if (lane == 63) lds[wv] = incl;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024; d <<= 1) {
-        uint32_t v = (tid >= d) ? part[tid - d] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[tid] - sum;
-    for (uint32_t j = 0; j < per; j++) {
-        uint32_t idx = lo + j;
-        if (idx < count) { offs[idx] = run; run += hist[idx]; }
-    }
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (unsigned w = 0; w < 4; w++) { uint32_t x = lds[w]; if (w < wv) base += x; tot += x; }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_sums(const uint32_t *__restrict__ hist, uint32_t count, uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t lds[4];
+    const uint32_t base = blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * 8;
+    uint32_t s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (base + j < count) s += hist[base + j];
+    uint32_t tot;
+    (void)block_exclusive_scan_256(s, lds, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_scan_blocks(uint32_t *__restrict__ block_sums, uint32_t nblocks) {
+    __shared__ uint32_t lds[4];
+    // nblocks <= 1024: 4 per lane
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { uint32_t idx = threadIdx.x * 4 + j; v[j] = idx < nblocks ? block_sums[idx] : 0; s += v[j]; }
+    uint32_t tot;
+    uint32_t run = block_exclusive_scan_256(s, lds, &tot);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { uint32_t idx = threadIdx.x * 4 + j; if (idx < nblocks) block_sums[idx] = run; run += v[j]; }
+}
+
+__global__ __launch_bounds__(256) void k_scan_final(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ block_sums,
+                                                    uint32_t count, uint32_t *__restrict__ offs) {
+    __shared__ uint32_t lds[4];
+    const uint32_t base = blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * 8;
+    uint32_t v[8], s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { v[j] = (base + j < count) ? hist[base + j] : 0; s += v[j]; }
+    uint32_t tot;
+    uint32_t run = block_sums[blockIdx.x] + block_exclusive_scan_256(s, lds, &tot);
+#pragma unroll
+    for (int j = 0; j < 8; j++) { if (base + j < count) offs[base + j] = run; run += v[j]; }
 }
 
 // ------------------------------------------------------------------------------------
@@ -444,6 +478,8 @@ int msm_device(const Aff<F> *d_bases, const Fr *d_scalars, size_t n, Jac<F> *d_o
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     size_t o_hist = carve((size_t)nb * 4 + 256);     // + heavy_count word
     size_t o_offs = carve((size_t)nb * 4);
+    const uint32_t scan_blocks = (nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;   // <= 1024 since nb <= 2^20
+    size_t o_bsum = carve((size_t)scan_blocks * 4);
     size_t o_digits = carve(ne * 2);
     size_t o_slot = carve(ne * 4);
     size_t o_entries = carve(ne * 4);
@@ -457,6 +493,7 @@ int msm_device(const Aff<F> *d_bases, const Fr *d_scalars, size_t n, Jac<F> *d_o
     uint32_t *hist = (uint32_t *)(ws + o_hist);
     uint32_t *heavy_count = hist + nb;
     uint32_t *offs = (uint32_t *)(ws + o_offs);
+    uint32_t *bsum = (uint32_t *)(ws + o_bsum);
     int16_t *digits = (int16_t *)(ws + o_digits);
     uint32_t *slot = (uint32_t *)(ws + o_slot);
     uint32_t *entries = (uint32_t *)(ws + o_entries);
@@ -478,7 +515,9 @@ int msm_device(const Aff<F> *d_bases, const Fr *d_scalars, size_t n, Jac<F> *d_o
     HIPCHK(hipMemsetAsync(hist, 0, (size_t)nb * 4 + 4, st));
     hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, c, nwin, digits, slot, hist);
     mark();  // 1
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, st, hist, offs, nb);
+    hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(256), 0, st, hist, nb, bsum);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bsum, scan_blocks);
+    hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, hist, bsum, nb, offs);
     mark();  // 2
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, digits, slot, offs, n, c, nwin, entries);
     mark();  // 3
