@@ -110,6 +110,24 @@ int lsa_g2_batch_exp(const void *base_jac, const void *scalars_mont, size_t n, v
 int lsa_g1_sum_async(const void *d_pts_jac, size_t n, void *d_out_jac);
 int lsa_g2_sum_async(const void *d_pts_jac, size_t n, void *d_out_jac);
 
+/* ---- pairing ---------------------------------------------------------------------------- */
+/* out[i] = miller_loop(precompute_G1(P_i), precompute_G2(Q_i)), i < n: replaces libff
+ * alt_bn128_pp::precompute_G1 / precompute_G2 / miller_loop (src/utils/globl.h:96-102,
+ * src/gadgets/subspace.cc:142-160, src/gadgets/poly.h:105-119).  P_i: libff G1 (96 B),
+ * Q_i: libff G2 (192 B), out: n x Fq12 (384 B).  on_device != 0: all three are device
+ * pointers, else host pointers. */
+int lsa_miller_loop(const void *g1_jac, const void *g2_jac, size_t n, void *out_fq12, int on_device);
+/* out = prod_i miller_loop(P_i, Q_i) (one Fq12, HOST): n = 2 is libff double_miller_loop
+ * (src/gadgets/subspace.cc:147-163, src/gadgets/lipmaa.cc:187-207). Host pointers. */
+int lsa_miller_loop_product(const void *g1_jac, const void *g2_jac, size_t n, void *out_fq12);
+/* out[i] = final_exponentiation(in[i]): replaces alt_bn128_pp::final_exponentiation
+ * (src/utils/globl.h:103, src/gadgets/subspace.cc:166, src/gadgets/poly.h:110,122). */
+int lsa_final_exponentiation(const void *in_fq12, size_t n, void *out_fq12, int on_device);
+/* out = final_exponentiation(prod_i miller_loop(P_i, Q_i)) (one GT element, HOST).  n = 1 is
+ * reduced_pairing (src/gadgets/subspace.cc:88-102,123-124); the batched form is the CPhad /
+ * CPsc verifier shape (BASELINE.json configs[4]).  Host pointers. */
+int lsa_pairing_product(const void *g1_jac, const void *g2_jac, size_t n, void *out_gt);
+
 /* ---- point helpers ------------------------------------------------------------------- */
 /* Jacobian -> libff "special" form (affine with Z = 1, or (0,1,0)), n points, host
  * buffers; replaces G::to_affine_coordinates()/batch_to_special on result vectors. */

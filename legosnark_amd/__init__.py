@@ -64,6 +64,10 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         for name in ("lsa_g1_sum_async", "lsa_g2_sum_async"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.lsa_miller_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.lsa_miller_loop_product.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.lsa_pairing_product.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.lsa_final_exponentiation.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         _lib = L
     return _lib
 
@@ -208,6 +212,45 @@ def sum_async(group, d_pts, n, d_out):
     """d_out = sum of n device-resident Jacobian points (async on the library stream)."""
     fn = lib().lsa_g1_sum_async if group == "g1" else lib().lsa_g2_sum_async
     _check(fn(_ptr(d_pts), n, _ptr(d_out)))
+
+
+def _pairs(g1, g2):
+    g1 = np.ascontiguousarray(g1, dtype=np.uint64).reshape(-1, 12)
+    g2 = np.ascontiguousarray(g2, dtype=np.uint64).reshape(-1, 24)
+    if len(g1) != len(g2):
+        raise ValueError("need as many G1 as G2 points")
+    return g1, g2
+
+
+def miller_loop(g1, g2):
+    """out[i] = miller_loop(precompute_G1(P_i), precompute_G2(Q_i)) -> (n, 48) uint64 (Fq12)."""
+    g1, g2 = _pairs(g1, g2)
+    out = np.zeros((len(g1), 48), dtype=np.uint64)
+    _check(lib().lsa_miller_loop(_host_ptr(g1), _host_ptr(g2), len(g1), _host_ptr(out), 0))
+    return out
+
+
+def miller_loop_product(g1, g2):
+    """prod_i miller_loop(P_i, Q_i) (n = 2: double_miller_loop) -> (48,) uint64."""
+    g1, g2 = _pairs(g1, g2)
+    out = np.zeros(48, dtype=np.uint64)
+    _check(lib().lsa_miller_loop_product(_host_ptr(g1), _host_ptr(g2), len(g1), _host_ptr(out)))
+    return out
+
+
+def pairing_product(g1, g2):
+    """final_exponentiation(prod_i miller_loop(P_i, Q_i)) (n = 1: reduced_pairing) -> (48,) uint64."""
+    g1, g2 = _pairs(g1, g2)
+    out = np.zeros(48, dtype=np.uint64)
+    _check(lib().lsa_pairing_product(_host_ptr(g1), _host_ptr(g2), len(g1), _host_ptr(out)))
+    return out
+
+
+def final_exponentiation(f):
+    f = np.ascontiguousarray(f, dtype=np.uint64).reshape(-1, 48)
+    out = np.zeros_like(f)
+    _check(lib().lsa_final_exponentiation(_host_ptr(f), len(f), _host_ptr(out), 0))
+    return out
 
 
 def profile_enable(on=True):

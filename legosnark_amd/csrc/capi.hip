@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "msm.h"
+#include "tower.h"
 
 namespace lsa {
 
@@ -306,5 +307,93 @@ int lsa_g2_sum_async(const void *d_pts, size_t n, void *d_out) {
     if (rc) return rc;
     if (!d_out || (n && !d_pts)) { set_error("sum: null argument"); return LSA_ERR_INVALID; }
     return sum_points_device<Fq2>((const Jac<Fq2> *)d_pts, n, (Jac<Fq2> *)d_out, g.stream);
+}
+}  // extern "C"
+
+// ---------------------------------------------------------------- pairing
+namespace {
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? 0 : -1; }
+};
+
+// uploads n (P,Q) pairs, runs the Miller loops; d_f receives n Fq12 values
+int miller_upload_run(const void *g1, const void *g2, size_t n, DevBuf &d_f) {
+    DevBuf d_p, d_q;
+    if (d_p.alloc(n * sizeof(Jac<Fq>)) || d_q.alloc(n * sizeof(Jac<Fq2>)) || d_f.alloc(n * fq12_bytes())) {
+        set_error("pairing: hipMalloc failed");
+        return LSA_ERR_NOMEM;
+    }
+    HIPCHK(hipMemcpyAsync(d_p.p, g1, n * sizeof(Jac<Fq>), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(d_q.p, g2, n * sizeof(Jac<Fq2>), hipMemcpyHostToDevice, g.stream));
+    int rc = miller_device(d_p.p, d_q.p, n, d_f.p, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return LSA_OK;
+}
+
+int miller_product_host(const void *g1, const void *g2, size_t n, void *out, bool final_exp) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (!out || (n && (!g1 || !g2))) { set_error("pairing: null argument"); return LSA_ERR_INVALID; }
+    DevBuf d_f, d_s, d_o;
+    void *res = nullptr;
+    if (n == 0) {
+        // empty product = 1; final_exponentiation(1) = 1
+        Fq12 one = Fq12::one();
+        memcpy(out, &one, sizeof one);
+        return LSA_OK;
+    }
+    rc = miller_upload_run(g1, g2, n, d_f);
+    if (rc) return rc;
+    if (d_s.alloc(((n + 7) / 8) * fq12_bytes()) || d_o.alloc(fq12_bytes())) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    rc = fq12_product_device(d_f.p, d_s.p, n, &res, g.stream);
+    if (rc) return rc;
+    if (final_exp) {
+        rc = final_exp_device(res, 1, d_o.p, g.stream);
+        if (rc) return rc;
+        res = d_o.p;
+    }
+    HIPCHK(hipMemcpyAsync(g.h_result, res, fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    memcpy(out, g.h_result, fq12_bytes());
+    return LSA_OK;
+}
+}  // namespace
+
+extern "C" {
+int lsa_miller_loop(const void *g1, const void *g2, size_t n, void *out, int on_device) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (n == 0) return LSA_OK;
+    if (!g1 || !g2 || !out) { set_error("miller_loop: null argument"); return LSA_ERR_INVALID; }
+    if (on_device) return miller_device(g1, g2, n, out, g.stream);
+    DevBuf d_f;
+    rc = miller_upload_run(g1, g2, n, d_f);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out, d_f.p, n * fq12_bytes(), hipMemcpyDeviceToHost));
+    return LSA_OK;
+}
+int lsa_miller_loop_product(const void *g1, const void *g2, size_t n, void *out) {
+    return miller_product_host(g1, g2, n, out, false);
+}
+int lsa_pairing_product(const void *g1, const void *g2, size_t n, void *out) {
+    return miller_product_host(g1, g2, n, out, true);
+}
+int lsa_final_exponentiation(const void *in, size_t n, void *out, int on_device) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (n == 0) return LSA_OK;
+    if (!in || !out) { set_error("final_exponentiation: null argument"); return LSA_ERR_INVALID; }
+    if (on_device) return final_exp_device(in, n, out, g.stream);
+    DevBuf d_i, d_o;
+    if (d_i.alloc(n * fq12_bytes()) || d_o.alloc(n * fq12_bytes())) { set_error("final_exponentiation: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    HIPCHK(hipMemcpyAsync(d_i.p, in, n * fq12_bytes(), hipMemcpyHostToDevice, g.stream));
+    rc = final_exp_device(d_i.p, n, d_o.p, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(out, d_o.p, n * fq12_bytes(), hipMemcpyDeviceToHost));
+    return LSA_OK;
 }
 }  // extern "C"

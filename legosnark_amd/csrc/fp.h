@@ -14,10 +14,10 @@
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define LSA_HD __host__ __device__ __forceinline__
-#define LSA_HD_NOINLINE __host__ __device__ __noinline__
+#define LSA_HD_NOINLINE inline __host__ __device__ __noinline__
 #else
 #define LSA_HD inline
-#define LSA_HD_NOINLINE
+#define LSA_HD_NOINLINE inline
 #endif
 
 namespace lsa {

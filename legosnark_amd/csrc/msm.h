@@ -30,6 +30,12 @@ unsigned batch_exp_window_bits(size_t n);
 template <class F>
 int sum_points_device(const Jac<F> *d_in, size_t n, Jac<F> *d_out, hipStream_t st);
 
+// pairing (pairing.hip): all pointers device-resident, asynchronous on `st`.
+int miller_device(const void *d_g1_jac, const void *d_g2_jac, size_t n, void *d_out_fq12, hipStream_t st);
+int final_exp_device(const void *d_in_fq12, size_t n, void *d_out_fq12, hipStream_t st);
+int fq12_product_device(void *d_buf, void *d_scratch, size_t n, void **result, hipStream_t st);
+size_t fq12_bytes();
+
 void msm_release_workspace();
 void msm_profile_enable(bool on);
 int msm_profile_last(float ms[LSA_MSM_STAGES]);

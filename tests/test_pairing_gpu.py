@@ -1,0 +1,89 @@
+"""GPU parity tests for the pairing path (C-ABI): Miller-loop values and GT values are
+canonical Fq12 elements, so they are compared byte-for-byte with the oracle and with the
+golden vectors of the independent model."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from conftest import f12_dec, g1_dec, g2_dec
+
+pytestmark = pytest.mark.gpu
+P, R = o.P, o.R
+
+
+def test_pairing_golden(lsa, golden):
+    pr = golden["pairing"]
+    g1, g2 = o.generator("g1"), o.generator("g2")
+    e = lsa.pairing_product(g1, g2)
+    assert o.fq12_to_model(e) == f12_dec(pr["e_g1_g2"])
+    rng = random.Random(15)
+    for t in pr["bilinear"]:
+        Pp = o.g1_from_affine(g1_dec(t["P"]), rng.randrange(2, P))                         # un-normalised inputs
+        Qq = o.g2_from_affine(g2_dec(t["Q"]), (rng.randrange(2, P), rng.randrange(P)))
+        assert o.fq12_to_model(lsa.pairing_product(Pp, Qq)) == f12_dec(t["e"])
+    pp = pr["planted_product"]
+    Ps = o.g1_array([g1_dec(x) for x in pp["P"]])
+    Qs = o.g2_array([g2_dec(x) for x in pp["Q"]])
+    assert np.array_equal(lsa.pairing_product(Ps, Qs), o.fq12_one())
+    p2 = pr["product2"]
+    Ps = o.g1_array([g1_dec(x) for x in p2["P"]])
+    Qs = o.g2_array([g2_dec(x) for x in p2["Q"]])
+    assert o.fq12_to_model(lsa.pairing_product(Ps, Qs)) == f12_dec(p2["result"])
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 9, 70])
+def test_miller_and_final_exp_vs_oracle(lsa, n):
+    ps = o.arith_bases("g1", 1000 + n, 77, n)          # un-normalised Jacobian
+    qs = o.arith_bases("g2", 31337, 5 + n, n)
+    f_gpu = lsa.miller_loop(ps, qs)
+    f_cpu = o.miller_loop_batch(ps, qs)
+    assert np.array_equal(f_gpu, f_cpu)                 # libff miller_loop values, bit-exact
+    e_gpu = lsa.final_exponentiation(f_gpu)
+    for i in range(0, n, max(1, n // 5)):
+        assert np.array_equal(e_gpu[i], o.final_exponentiation(f_cpu[i]))
+    assert np.array_equal(lsa.pairing_product(ps, qs), o.pairing_product(ps, qs))
+    # double_miller_loop shape: product of Miller loops without the final exponentiation
+    prod = f_cpu[0]
+    for i in range(1, n):
+        prod = o.fq12_mul(prod, f_cpu[i])
+    assert np.array_equal(lsa.miller_loop_product(ps, qs), prod)
+
+
+def test_pairing_identities_and_edge_cases(lsa):
+    g1, g2 = o.generator("g1"), o.generator("g2")
+    one = o.fq12_one()
+    # empty product, final_exp(1) = 1
+    assert np.array_equal(lsa.pairing_product(np.zeros((0, 12), np.uint64), np.zeros((0, 24), np.uint64)), one)
+    assert np.array_equal(lsa.final_exponentiation(one)[0], one)
+    # e(P,Q) e(-P,Q) = 1  (simple_pairing_check shape, globl.h:94-105)
+    import ctypes as C
+    neg = np.zeros(12, dtype=np.uint64)
+    o.lib().og1_neg(o._p(neg), o._p(g1))
+    assert np.array_equal(lsa.pairing_product(np.stack([g1, neg]), np.stack([g2, g2])), one)
+    # bilinearity through the GPU only: e(aP, bQ) == e(abP, Q)
+    a, b = 0x1234567890ABCDEF, 0xFEDCBA0987654321
+    lhs = lsa.pairing_product(o.g1_mul(g1, o.fr_mont(a)), o.g2_mul(g2, o.fr_mont(b)))
+    rhs = lsa.pairing_product(o.g1_mul(g1, o.fr_mont(a * b % R)), g2)
+    assert np.array_equal(lhs, rhs)
+    # points at infinity follow libff's (unguarded) to_affine_coordinates() convention
+    inf1 = np.zeros(12, dtype=np.uint64); inf1[4:8] = o.fq_mont(1)
+    assert np.array_equal(lsa.miller_loop(inf1, g2)[0], o.miller_loop_batch(inf1.reshape(1, 12), g2.reshape(1, 24))[0])
+
+
+def test_batched_planted_product_256(lsa):
+    """BASELINE.json configs[4] shape at a size the oracle checks in seconds: a planted
+    relation sum alpha_j beta_j = 0 mod r makes prod e(P_j, Q_j) = 1."""
+    n = 256
+    rng = random.Random(99)
+    al = [rng.randrange(1, R) for _ in range(n)]
+    be = [rng.randrange(1, R) for _ in range(n - 1)]
+    s = sum(x * y for x, y in zip(al, be)) % R
+    be.append((-s) * pow(al[-1], -1, R) % R)
+    ps = o.batch_exp("g1", o.generator("g1"), o.fr_mont_array(al))
+    qs = o.batch_exp("g2", o.generator("g2"), o.fr_mont_array(be))
+    assert np.array_equal(lsa.pairing_product(ps, qs), o.fq12_one())
+    # break the relation -> not one
+    qs2 = qs.copy(); qs2[0] = qs[1]
+    assert not np.array_equal(lsa.pairing_product(ps, qs2), o.fq12_one())
