@@ -86,8 +86,8 @@ int lsa_init(int device) {
         return LSA_ERR_NO_DEVICE;
     }
     HIPCHK(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc(&g.d_result, 256));
-    HIPCHK(hipHostMalloc(&g.h_result, 256, hipHostMallocDefault));
+    HIPCHK(hipMalloc(&g.d_result, 512));
+    HIPCHK(hipHostMalloc(&g.h_result, 512, hipHostMallocDefault));
     g.device = device;
     g.ready = true;
     return LSA_OK;
