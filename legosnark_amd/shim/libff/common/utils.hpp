@@ -1,0 +1,4 @@
+// libff-compatible include path (see ../../lsa_libff.hpp): LegoSNARK's sources include
+// <libff/common/utils.hpp>; everything is provided by the single shim header.
+#pragma once
+#include "../lsa_libff.hpp"

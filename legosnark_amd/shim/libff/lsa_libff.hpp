@@ -1,0 +1,463 @@
+// legosnark_amd/shim/libff/lsa_libff.hpp -- libff-compatible C++17 surface over the C-ABI
+// in include/legosnark_amd.h, so that LegoSNARK's unchanged sources
+// (/root/reference/src/{utils,prototools,gadgets,examples}) compile and link against the
+// MI355X library instead of libff/libsnark.
+//
+// What lives where:
+//  * HOT PATH (forwarded to the GPU through the C-ABI; no CPU fallback):
+//      multi_exp, multi_exp_with_mixed_addition            -> lsa_g1_msm / lsa_g2_msm
+//      batch_exp                                           -> lsa_g1_batch_exp / lsa_g2_batch_exp
+//      miller_loop, double_miller_loop, final_exponentiation, reduced_pairing
+//                                                          -> lsa_miller_loop*, lsa_final_exponentiation, lsa_pairing_product
+//  * COLD host glue (single field / group operators the gadgets use a handful of times):
+//      inline host code from csrc/fp.h, ec.h, tower.h (the same formulas the kernels use).
+// Class layouts are libff's (Fr/Fq 32 B Montgomery limbs, G1 {X,Y,Z} 96 B, G2 192 B,
+// GT 384 B), so std::vector<G1<pp>> crosses the C-ABI as a plain pointer.
+// Names mirror the libff symbols the reference uses.
+#pragma once
+#include <cassert>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/legosnark_amd.h"
+#include "../../csrc/ec.h"
+#include "../../csrc/tower.h"
+
+namespace libff {
+
+// ---------------------------------------------------------------- errors
+inline void lsa_require(int rc, const char *what) {
+    if (rc != 0) throw std::runtime_error(std::string(what) + ": " + lsa_last_error());
+}
+
+// ---------------------------------------------------------------- profiling stubs (libff/common/profiling.hpp)
+inline bool &inhibit_profiling_info_ref() { static bool b = false; return b; }
+#define inhibit_profiling_info (::libff::inhibit_profiling_info_ref())
+inline bool &inhibit_profiling_counters_ref() { static bool b = false; return b; }
+#define inhibit_profiling_counters (::libff::inhibit_profiling_counters_ref())
+inline void print_indent() {}
+inline void print_header(const char *msg) { printf("\n================================================================================\n%s\n================================================================================\n\n", msg); }
+inline void enter_block(const std::string &, bool = false) {}
+inline void leave_block(const std::string &, bool = false) {}
+inline void start_profiling() {}
+inline size_t log2(size_t n) {   // ceil(log2 n)
+    size_t r = ((n & (n - 1)) == 0 ? 0 : 1);
+    while (n > 1) { n >>= 1; r++; }
+    return r;
+}
+#ifndef UNUSED
+#define UNUSED(x) (void)(x)
+#endif
+
+// ---------------------------------------------------------------- bigint<4>
+template <long N>
+struct bigint {
+    uint64_t data[N] = {0};
+    bigint() = default;
+    bigint(unsigned long x) { data[0] = x; }
+    bool test_bit(size_t i) const { return i < 64 * N && ((data[i >> 6] >> (i & 63)) & 1); }
+    size_t max_bits() const { return 64 * N; }
+    size_t num_bits() const {
+        for (long i = N - 1; i >= 0; --i) if (data[i]) return 64 * i + (64 - __builtin_clzll(data[i]));
+        return 0;
+    }
+    unsigned long as_ulong() const { return data[0]; }
+    bool operator==(const bigint &o) const { return memcmp(data, o.data, sizeof data) == 0; }
+    bool operator!=(const bigint &o) const { return !(*this == o); }
+};
+
+inline std::mt19937_64 &lsa_rng() {
+    static std::mt19937_64 g = []() {
+        const char *s = getenv("LSA_SEED");
+        if (s) return std::mt19937_64(strtoull(s, nullptr, 0));
+        std::random_device rd;
+        return std::mt19937_64(((uint64_t)rd() << 32) ^ rd());
+    }();
+    return g;
+}
+
+// ---------------------------------------------------------------- prime fields
+template <class P>
+class Fp_shim {
+public:
+    lsa::Fp<P> v;
+    static const long num_limbs = 4;
+    static const Fp_shim multiplicative_generator;   // 5 generates Fr^* (libff alt_bn128_init)
+    Fp_shim() : v(lsa::Fp<P>::zero()) {}
+    Fp_shim(const lsa::Fp<P> &x) : v(x) {}
+    Fp_shim(long x) { set_long(x); }
+    Fp_shim(int x) { set_long(x); }
+    Fp_shim(unsigned long x) { set_ulong(x); }
+    Fp_shim(unsigned long long x) { set_ulong(x); }
+    Fp_shim(unsigned int x) { set_ulong(x); }
+    Fp_shim(const char *dec) {   // decimal string, as libff's bigint(const char*)
+        Fp_shim acc, ten(10L);
+        for (const char *c = dec; *c; ++c) { if (*c < '0' || *c > '9') continue; acc = acc * ten + Fp_shim((long)(*c - '0')); }
+        v = acc.v;
+    }
+    Fp_shim(const bigint<4> &b) {
+        uint32_t l[8];
+        for (int i = 0; i < 4; i++) { l[2 * i] = (uint32_t)b.data[i]; l[2 * i + 1] = (uint32_t)(b.data[i] >> 32); }
+        v = lsa::Fp<P>::from_canonical(l);
+    }
+    void set_ulong(unsigned long long x) {
+        uint32_t l[8] = {(uint32_t)x, (uint32_t)(x >> 32), 0, 0, 0, 0, 0, 0};
+        v = lsa::Fp<P>::from_canonical(l);
+    }
+    void set_long(long x) {
+        if (x >= 0) set_ulong((unsigned long long)x);
+        else { set_ulong((unsigned long long)(-x)); v = v.neg(); }
+    }
+    static Fp_shim zero() { return Fp_shim(); }
+    static Fp_shim one() { return Fp_shim(lsa::Fp<P>::one()); }
+    static size_t size_in_bits() { return 254; }
+    static size_t capacity() { return 253; }
+    static Fp_shim random_element() {
+        for (;;) {
+            uint32_t l[8];
+            for (int i = 0; i < 4; i++) { uint64_t r = lsa_rng()(); l[2 * i] = (uint32_t)r; l[2 * i + 1] = (uint32_t)(r >> 32); }
+            l[7] &= 0x3fffffffu;
+            bool lt = false;   // l < MOD ?
+            for (int i = 7; i >= 0; --i) { if (l[i] != P::MOD[i]) { lt = l[i] < P::MOD[i]; break; } }
+            if (lt) { Fp_shim r; for (int i = 0; i < 8; i++) r.v.l[i] = l[i]; return r; }   // random Montgomery residue
+        }
+    }
+    bool is_zero() const { return v.is_zero(); }
+    bool operator==(const Fp_shim &o) const { return v == o.v; }
+    bool operator!=(const Fp_shim &o) const { return !(v == o.v); }
+    Fp_shim operator+(const Fp_shim &o) const { return Fp_shim(v + o.v); }
+    Fp_shim operator-(const Fp_shim &o) const { return Fp_shim(v - o.v); }
+    Fp_shim operator*(const Fp_shim &o) const { return Fp_shim(v * o.v); }
+    Fp_shim operator-() const { return Fp_shim(v.neg()); }
+    Fp_shim &operator+=(const Fp_shim &o) { v = v + o.v; return *this; }
+    Fp_shim &operator-=(const Fp_shim &o) { v = v - o.v; return *this; }
+    Fp_shim &operator*=(const Fp_shim &o) { v = v * o.v; return *this; }
+    Fp_shim squared() const { return Fp_shim(v.sqr()); }
+    Fp_shim inverse() const { return Fp_shim(v.inverse()); }
+    Fp_shim operator^(unsigned long e) const {
+        Fp_shim acc = one(), b = *this;
+        while (e) { if (e & 1) acc *= b; b = b.squared(); e >>= 1; }
+        return acc;
+    }
+    Fp_shim operator^(const bigint<4> &e) const {
+        Fp_shim acc = one();
+        for (long i = 255; i >= 0; --i) { acc = acc.squared(); if (e.test_bit(i)) acc *= *this; }
+        return acc;
+    }
+    bigint<4> as_bigint() const {
+        uint32_t l[8];
+        v.to_canonical(l);
+        bigint<4> b;
+        for (int i = 0; i < 4; i++) b.data[i] = (uint64_t)l[2 * i] | ((uint64_t)l[2 * i + 1] << 32);
+        return b;
+    }
+    unsigned long as_ulong() const { return as_bigint().as_ulong(); }
+    void print() const { std::cout << *this << "\n"; }
+    // text I/O: canonical value in decimal (libff without BINARY_OUTPUT / MONTGOMERY_OUTPUT)
+    friend std::ostream &operator<<(std::ostream &os, const Fp_shim &a) {
+        bigint<4> b = a.as_bigint();
+        // 256-bit -> decimal
+        uint32_t w[8];
+        for (int i = 0; i < 4; i++) { w[2 * i] = (uint32_t)b.data[i]; w[2 * i + 1] = (uint32_t)(b.data[i] >> 32); }
+        std::string s;
+        bool nz = true;
+        while (nz) {
+            uint64_t rem = 0; nz = false;
+            for (int i = 7; i >= 0; --i) { uint64_t cur = (rem << 32) | w[i]; w[i] = (uint32_t)(cur / 10); rem = cur % 10; if (w[i]) nz = true; }
+            s.push_back((char)('0' + rem));
+        }
+        for (size_t i = 0; i < s.size() / 2; i++) std::swap(s[i], s[s.size() - 1 - i]);
+        return os << s;
+    }
+    friend std::istream &operator>>(std::istream &is, Fp_shim &a) {
+        std::string s; is >> s; a = Fp_shim(s.c_str()); return is;
+    }
+};
+
+template <class P>
+const Fp_shim<P> Fp_shim<P>::multiplicative_generator = Fp_shim<P>(5L);
+
+using alt_bn128_Fr = Fp_shim<lsa::FrParams>;
+using alt_bn128_Fq = Fp_shim<lsa::FqParams>;
+
+inline alt_bn128_Fr fr_multiplicative_generator() { return alt_bn128_Fr(5L); }
+
+// 2^s-th primitive root of unity in Fr (r - 1 = 2^28 * odd); libff get_root_of_unity
+template <class FieldT>
+FieldT get_root_of_unity(size_t n) {
+    const size_t logn = log2(n);
+    if (n != (size_t(1) << logn) || logn > 28) throw std::invalid_argument("get_root_of_unity: n must be a power of two <= 2^28");
+    // omega = 5^((r-1)/2^28)
+    bigint<4> e;   // (r-1) >> 28
+    {
+        uint64_t r[4];
+        for (int i = 0; i < 4; i++) r[i] = (uint64_t)lsa::FrParams::MOD[2 * i] | ((uint64_t)lsa::FrParams::MOD[2 * i + 1] << 32);
+        r[0] -= 1;
+        for (int i = 0; i < 4; i++) e.data[i] = (r[i] >> 28) | (i < 3 ? (r[i + 1] << 36) : 0);
+    }
+    FieldT omega = FieldT(5L) ^ e;
+    for (size_t i = 28; i > logn; --i) omega = omega.squared();
+    return omega;
+}
+
+// ---------------------------------------------------------------- Fq2 / GT
+class alt_bn128_Fq2 {
+public:
+    lsa::Fq2 v;
+    alt_bn128_Fq2() : v(lsa::Fq2::zero()) {}
+    alt_bn128_Fq2(const lsa::Fq2 &x) : v(x) {}
+    static alt_bn128_Fq2 zero() { return alt_bn128_Fq2(); }
+    static alt_bn128_Fq2 one() { return alt_bn128_Fq2(lsa::Fq2::one()); }
+    bool operator==(const alt_bn128_Fq2 &o) const { return v == o.v; }
+};
+
+class alt_bn128_Fq12 {
+public:
+    lsa::Fq12 v;
+    alt_bn128_Fq12() : v(lsa::Fq12::one()) { v.c0.c0 = lsa::Fq2::zero(); }
+    alt_bn128_Fq12(const lsa::Fq12 &x) : v(x) {}
+    static alt_bn128_Fq12 one() { return alt_bn128_Fq12(lsa::Fq12::one()); }
+    static alt_bn128_Fq12 zero() { return alt_bn128_Fq12(); }
+    bool operator==(const alt_bn128_Fq12 &o) const { return v == o.v; }
+    bool operator!=(const alt_bn128_Fq12 &o) const { return !(v == o.v); }
+    alt_bn128_Fq12 operator*(const alt_bn128_Fq12 &o) const { return alt_bn128_Fq12(lsa::fq12_mul(v, o.v)); }
+    alt_bn128_Fq12 &operator*=(const alt_bn128_Fq12 &o) { v = lsa::fq12_mul(v, o.v); return *this; }
+    alt_bn128_Fq12 squared() const { return alt_bn128_Fq12(lsa::fq12_sqr(v)); }
+    alt_bn128_Fq12 inverse() const { return alt_bn128_Fq12(lsa::fq12_inverse(v)); }
+    alt_bn128_Fq12 unitary_inverse() const { return alt_bn128_Fq12(v.unitary_inverse()); }
+    alt_bn128_Fq12 operator^(const bigint<4> &e) const {
+        alt_bn128_Fq12 acc = one();
+        for (long i = 255; i >= 0; --i) { acc = acc.squared(); if (e.test_bit(i)) acc *= *this; }
+        return acc;
+    }
+    void print() const { printf("<Fq12>\n"); }
+    friend std::ostream &operator<<(std::ostream &os, const alt_bn128_Fq12 &a) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&a.v);
+        for (size_t i = 0; i < sizeof(lsa::Fq12) / 4; i++) os << w[i] << (i + 1 < sizeof(lsa::Fq12) / 4 ? " " : "");
+        return os;
+    }
+};
+static_assert(sizeof(alt_bn128_Fq12) == 384, "GT layout");
+using alt_bn128_GT = alt_bn128_Fq12;
+
+// ---------------------------------------------------------------- groups
+template <class F, int GROUP>
+class G_shim {
+public:
+    F X, Y, Z;   // libff layout: Jacobian, Montgomery limbs
+    using Jac = lsa::Jac<F>;
+    G_shim() { *this = zero(); }
+    G_shim(const F &x, const F &y, const F &z) : X(x), Y(y), Z(z) {}
+    G_shim(const Jac &j) : X(j.X), Y(j.Y), Z(j.Z) {}
+    Jac jac() const { return Jac{X, Y, Z}; }
+    static G_shim zero() { return G_shim(Jac::inf()); }
+    static G_shim one() {
+        if constexpr (GROUP == 1) {
+            return G_shim(lsa::Fq::from_u32(1), lsa::Fq::from_u32(2), lsa::Fq::one());
+        } else {
+            return G_shim(lsa::fq2_const(LSA_G2_GEN_X), lsa::fq2_const(LSA_G2_GEN_Y), lsa::Fq2::one());
+        }
+    }
+    static G_shim random_element() { return alt_bn128_Fr::random_element() * one(); }
+    static size_t size_in_bits() { return GROUP == 1 ? 255 : 509; }
+    bool is_zero() const { return Z.is_zero(); }
+    bool is_special() const { return is_zero() || Z == F::one(); }
+    bool operator==(const G_shim &o) const { return lsa::jac_eq(jac(), o.jac()); }
+    bool operator!=(const G_shim &o) const { return !(*this == o); }
+    G_shim operator+(const G_shim &o) const { return G_shim(lsa::jac_add(jac(), o.jac())); }
+    G_shim operator-() const { return G_shim(lsa::jac_neg(jac())); }
+    G_shim operator-(const G_shim &o) const { return *this + (-o); }
+    G_shim &operator+=(const G_shim &o) { *this = *this + o; return *this; }
+    G_shim add(const G_shim &o) const { return *this + o; }
+    G_shim mixed_add(const G_shim &o) const { return *this + o; }
+    G_shim dbl() const { return G_shim(lsa::jac_dbl(jac())); }
+    void to_affine_coordinates() { *this = G_shim(lsa::jac_normalize(jac())); }
+    void to_special() { to_affine_coordinates(); }
+    bool is_well_formed() const { return true; }
+    void print() const { std::cout << *this << "\n"; }
+    // libff "scalar * point": MSB-first double-and-add on the canonical scalar (cold path)
+    friend G_shim operator*(const alt_bn128_Fr &k, const G_shim &p) {
+        bigint<4> e = k.as_bigint();
+        Jac res = Jac::inf(), base = p.jac();
+        bool found = false;
+        for (long i = 255; i >= 0; --i) {
+            if (found) res = lsa::jac_dbl(res);
+            if (e.test_bit(i)) { found = true; res = lsa::jac_add(res, base); }
+        }
+        return G_shim(res);
+    }
+    // text I/O: affine coordinates as raw 32-bit words (round-trips within this library)
+    friend std::ostream &operator<<(std::ostream &os, const G_shim &p) {
+        G_shim a = p; a.to_affine_coordinates();
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&a);
+        const size_t nw = sizeof(G_shim) / 4;
+        for (size_t i = 0; i < nw; i++) os << w[i] << (i + 1 < nw ? " " : "");
+        return os;
+    }
+    friend std::istream &operator>>(std::istream &is, G_shim &p) {
+        uint32_t *w = reinterpret_cast<uint32_t *>(&p);
+        for (size_t i = 0; i < sizeof(G_shim) / 4; i++) is >> w[i];
+        return is;
+    }
+};
+using alt_bn128_G1 = G_shim<lsa::Fq, 1>;
+using alt_bn128_G2 = G_shim<lsa::Fq2, 2>;
+static_assert(sizeof(alt_bn128_G1) == 96 && sizeof(alt_bn128_G2) == 192, "libff point layout");
+static_assert(sizeof(alt_bn128_Fr) == 32, "libff field layout");
+
+// ---------------------------------------------------------------- pairing-friendly curve "pp"
+struct alt_bn128_G1_precomp { alt_bn128_G1 P; };   // libff keeps (PX,PY); the GPU normalises itself
+struct alt_bn128_G2_precomp { alt_bn128_G2 Q; };   // libff keeps ~100 line coefficients; fused on the GPU
+
+class alt_bn128_pp {
+public:
+    typedef alt_bn128_Fr Fp_type;
+    typedef alt_bn128_G1 G1_type;
+    typedef alt_bn128_G2 G2_type;
+    typedef alt_bn128_G1_precomp G1_precomp_type;
+    typedef alt_bn128_G2_precomp G2_precomp_type;
+    typedef alt_bn128_Fq Fq_type;
+    typedef alt_bn128_Fq2 Fqe_type;
+    typedef alt_bn128_Fq12 Fqk_type;
+    typedef alt_bn128_GT GT_type;
+    static const bool has_affine_pairing = false;
+
+    // one-time setup (src/examples/cplink.cc:81): brings the GPU library up.  LSA_DEVICE
+    // selects the device (default 0).  Fails loudly without a gfx950 device.
+    static void init_public_params() {
+        const char *d = getenv("LSA_DEVICE");
+        lsa_require(lsa_init(d ? atoi(d) : 0), "init_public_params");
+    }
+    static alt_bn128_G1_precomp precompute_G1(const alt_bn128_G1 &P) { return {P}; }
+    static alt_bn128_G2_precomp precompute_G2(const alt_bn128_G2 &Q) { return {Q}; }
+    static alt_bn128_Fq12 miller_loop(const alt_bn128_G1_precomp &p, const alt_bn128_G2_precomp &q) {
+        alt_bn128_Fq12 out;
+        lsa_require(lsa_miller_loop(&p.P, &q.Q, 1, &out, 0), "miller_loop");
+        return out;
+    }
+    static alt_bn128_Fq12 double_miller_loop(const alt_bn128_G1_precomp &p1, const alt_bn128_G2_precomp &q1,
+                                             const alt_bn128_G1_precomp &p2, const alt_bn128_G2_precomp &q2) {
+        alt_bn128_G1 ps[2] = {p1.P, p2.P};
+        alt_bn128_G2 qs[2] = {q1.Q, q2.Q};
+        alt_bn128_Fq12 out;
+        lsa_require(lsa_miller_loop_product(ps, qs, 2, &out), "double_miller_loop");
+        return out;
+    }
+    static alt_bn128_GT final_exponentiation(const alt_bn128_Fq12 &elt) {
+        alt_bn128_GT out;
+        lsa_require(lsa_final_exponentiation(&elt, 1, &out, 0), "final_exponentiation");
+        return out;
+    }
+    static alt_bn128_GT reduced_pairing(const alt_bn128_G1 &P, const alt_bn128_G2 &Q) {
+        alt_bn128_GT out;
+        lsa_require(lsa_pairing_product(&P, &Q, 1, &out), "reduced_pairing");
+        return out;
+    }
+    static alt_bn128_Fq12 pairing(const alt_bn128_G1 &P, const alt_bn128_G2 &Q) { return miller_loop(precompute_G1(P), precompute_G2(Q)); }
+};
+
+typedef alt_bn128_pp default_ec_pp;
+
+template <typename EC_ppT> using Fr = typename EC_ppT::Fp_type;
+template <typename EC_ppT> using G1 = typename EC_ppT::G1_type;
+template <typename EC_ppT> using G2 = typename EC_ppT::G2_type;
+template <typename EC_ppT> using G1_precomp = typename EC_ppT::G1_precomp_type;
+template <typename EC_ppT> using G2_precomp = typename EC_ppT::G2_precomp_type;
+template <typename EC_ppT> using Fq = typename EC_ppT::Fq_type;
+template <typename EC_ppT> using Fqe = typename EC_ppT::Fqe_type;
+template <typename EC_ppT> using Fqk = typename EC_ppT::Fqk_type;
+template <typename EC_ppT> using GT = typename EC_ppT::GT_type;
+template <typename EC_ppT> using Fr_vector = std::vector<Fr<EC_ppT>>;
+template <typename EC_ppT> using G1_vector = std::vector<G1<EC_ppT>>;
+template <typename EC_ppT> using G2_vector = std::vector<G2<EC_ppT>>;
+
+// ---------------------------------------------------------------- multiexp.hpp
+enum multi_exp_method {
+    multi_exp_method_naive,
+    multi_exp_method_naive_plain,
+    multi_exp_method_bos_coster,
+    multi_exp_method_BDLO12
+};
+
+namespace detail {
+template <class T> struct group_id;
+template <> struct group_id<alt_bn128_G1> { static const int value = 1; };
+template <> struct group_id<alt_bn128_G2> { static const int value = 2; };
+
+template <class T, class FieldT>
+T msm_forward(typename std::vector<T>::const_iterator vec_start, typename std::vector<T>::const_iterator vec_end,
+              typename std::vector<FieldT>::const_iterator scalar_start, typename std::vector<FieldT>::const_iterator scalar_end,
+              size_t chunks) {
+    static_assert(std::is_same<FieldT, alt_bn128_Fr>::value, "scalars must be Fr");
+    const size_t n = (size_t)(vec_end - vec_start);
+    assert((size_t)(scalar_end - scalar_start) == n);
+    (void)scalar_end;
+    T out;
+    const void *b = n ? (const void *)&*vec_start : nullptr;
+    const void *s = n ? (const void *)&*scalar_start : nullptr;
+    if (group_id<T>::value == 1) lsa_require(lsa_g1_msm(b, s, n, chunks, &out), "multi_exp<G1>");
+    else lsa_require(lsa_g2_msm(b, s, n, chunks, &out), "multi_exp<G2>");
+    return out;
+}
+}  // namespace detail
+
+// Every method computes the same sum; on the GPU they all run the signed-digit bucket
+// pipeline (bos_coster is only ever named by the never-called multiExp, globl.h:47-61).
+template <typename T, typename FieldT, multi_exp_method Method>
+T multi_exp(typename std::vector<T>::const_iterator vec_start, typename std::vector<T>::const_iterator vec_end,
+            typename std::vector<FieldT>::const_iterator scalar_start, typename std::vector<FieldT>::const_iterator scalar_end,
+            const size_t chunks) {
+    return detail::msm_forward<T, FieldT>(vec_start, vec_end, scalar_start, scalar_end, chunks);
+}
+template <typename T, typename FieldT, multi_exp_method Method>
+T multi_exp_with_mixed_addition(typename std::vector<T>::const_iterator vec_start, typename std::vector<T>::const_iterator vec_end,
+                                typename std::vector<FieldT>::const_iterator scalar_start,
+                                typename std::vector<FieldT>::const_iterator scalar_end, const size_t chunks) {
+    return detail::msm_forward<T, FieldT>(vec_start, vec_end, scalar_start, scalar_end, chunks);
+}
+
+// fixed-base tables: the GPU builds its own table per call, so the "table" only carries
+// the base point (get_window_table + batch_exp always travel together in the reference:
+// src/utils/util.h:125-133, src/prototools/interp.h:45-58).
+template <typename T>
+struct window_table {
+    T base;
+    size_t scalar_size = 0, window = 0;
+};
+template <typename T>
+size_t get_exp_window_size(const size_t num_scalars) { return num_scalars >= (size_t(1) << 16) ? 12 : 8; }
+template <typename T>
+window_table<T> get_window_table(const size_t scalar_size, const size_t window, const T &g) { return window_table<T>{g, scalar_size, window}; }
+template <typename T, typename FieldT>
+std::vector<T> batch_exp(const size_t scalar_size, const size_t window, const window_table<T> &table, const std::vector<FieldT> &v) {
+    (void)scalar_size; (void)window;
+    std::vector<T> out(v.size());
+    if (v.empty()) return out;
+    if (detail::group_id<T>::value == 1) lsa_require(lsa_g1_batch_exp(&table.base, v.data(), v.size(), out.data(), 0), "batch_exp<G1>");
+    else lsa_require(lsa_g2_batch_exp(&table.base, v.data(), v.size(), out.data(), 0), "batch_exp<G2>");
+    return out;
+}
+template <typename T, typename FieldT>
+T windowed_exp(const size_t scalar_size, const size_t window, const window_table<T> &table, const FieldT &pow) {
+    return batch_exp<T, FieldT>(scalar_size, window, table, std::vector<FieldT>{pow})[0];
+}
+template <typename T>
+void batch_to_special(std::vector<T> &vec) {
+    if (vec.empty()) return;
+    if (detail::group_id<T>::value == 1) lsa_require(lsa_g1_normalize(vec.data(), vec.size(), vec.data()), "batch_to_special");
+    else lsa_require(lsa_g2_normalize(vec.data(), vec.size(), vec.data()), "batch_to_special");
+}
+template <typename T>
+void batch_to_special_all_non_zeros(std::vector<T> &vec) { batch_to_special(vec); }
+
+}  // namespace libff
+
+// ate-pairing / xbyak backend of the reference's default CURVE=BN128 build
+// (src/utils/matrix.h:31, src/gadgets/subspace.cc:13 say `using namespace bn;`)
+namespace bn {}
