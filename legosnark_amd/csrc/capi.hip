@@ -130,9 +130,9 @@ static int bases_create(const void *bases_jac, size_t n, int src_on_device, int 
     if (n) {
         const Jac<F> *d_in = nullptr;
         void *tmp = nullptr;
-        if (hipMalloc(&b->d_aff, n * sizeof(Aff<F>)) != hipSuccess) {
+        if (hipMalloc(&b->d_aff, n * msm_base_bytes(group)) != hipSuccess) {
             delete b;
-            set_error("bases_create: hipMalloc of %zu bytes failed", n * sizeof(Aff<F>));
+            set_error("bases_create: hipMalloc of %zu bytes failed", n * msm_base_bytes(group));
             return LSA_ERR_NOMEM;
         }
         if (src_on_device) {
@@ -147,7 +147,7 @@ static int bases_create(const void *bases_jac, size_t n, int src_on_device, int 
             if (e != hipSuccess) { (void)hipFree(tmp); (void)hipFree(b->d_aff); delete b; set_error("bases_create: H2D failed: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
             d_in = (const Jac<F> *)tmp;
         }
-        rc = normalize_to_affine<F>(d_in, (Aff<F> *)b->d_aff, n, g.stream);
+        rc = prepare_bases<F>(d_in, b->d_aff, n, g.stream);
         hipError_t e = hipStreamSynchronize(g.stream);
         if (tmp) (void)hipFree(tmp);
         if (rc || e != hipSuccess) {
@@ -182,8 +182,8 @@ int lsa_msm_run_async(const lsa_bases *bases, size_t first, const void *d_scalar
     if (!bases || !d_out_jac || (n && !d_scalars)) { set_error("msm_run: null argument"); return LSA_ERR_INVALID; }
     if (first > bases->n || n > bases->n - first) { set_error("msm_run: range [%zu,%zu) exceeds %zu bases", first, first + n, bases->n); return LSA_ERR_INVALID; }
     if (bases->group == 1)
-        return msm_device<Fq>((const Aff<Fq> *)bases->d_aff + first, (const Fr *)d_scalars, n, (Jac<Fq> *)d_out_jac, g.stream);
-    return msm_device<Fq2>((const Aff<Fq2> *)bases->d_aff + first, (const Fr *)d_scalars, n, (Jac<Fq2> *)d_out_jac, g.stream);
+        return msm_device<Fq>(bases->d_aff, first, (const Fr *)d_scalars, n, (Jac<Fq> *)d_out_jac, g.stream);
+    return msm_device<Fq2>(bases->d_aff, first, (const Fr *)d_scalars, n, (Jac<Fq2> *)d_out_jac, g.stream);
 }
 
 int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars, size_t n, void *out_jac) {

@@ -17,9 +17,16 @@ unsigned msm_window_bits(size_t n);
 template <class F>
 int normalize_to_affine(const Jac<F> *d_in, Aff<F> *d_out, size_t n, hipStream_t st);
 
-// out = sum scalars[i] * bases[i]; everything device-resident; asynchronous on `st`.
+// Jacobian (libff layout, device) -> the MSM pipeline's device-resident base format
+// (G1: 64-B packed 29-bit-limb Montgomery affine; G2: 128-B affine), msm_base_bytes(group)
+// per point.
 template <class F>
-int msm_device(const Aff<F> *d_bases, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st);
+int prepare_bases(const Jac<F> *d_in, void *d_out, size_t n, hipStream_t st);
+size_t msm_base_bytes(int group);
+
+// out = sum scalars[i] * bases[first + i]; everything device-resident; asynchronous on `st`.
+template <class F>
+int msm_device(const void *d_bases, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st);
 
 // out[i] = scalars[i] * base (fixed base); d_scalars/d_out device-resident.
 template <class F>

@@ -27,9 +27,11 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "ec.h"
+#include "fp29.h"
 #include "msm.h"
 
 namespace lsa {
@@ -47,6 +49,55 @@ unsigned msm_window_bits(size_t n) {
 }
 
 static inline unsigned num_windows(unsigned c) { return (255 + c - 1) / c; }
+
+// ------------------------------------------------------------------------------------
+// curve traits: which representation the bucket pipeline computes in
+// ------------------------------------------------------------------------------------
+// Generic: XYZZ over F with canonical saturated limbs (used for G2 = curve over Fq2).
+template <class F>
+struct CurveGeneric {
+    using Field = F;
+    using Base = Aff<F>;
+    using Acc = XYZZ<F>;
+    static __device__ __forceinline__ Acc inf() { return Acc::inf(); }
+    static __device__ __forceinline__ Acc madd(const Acc &a, const Base &b, bool negate) {
+        Aff<F> q = b;
+        if (negate) q.y = q.y.neg();
+        return xyzz_madd(a, q);
+    }
+    static __device__ __forceinline__ Acc add(const Acc &a, const Acc &b) { return xyzz_add(a, b); }
+    static __device__ __forceinline__ Acc dbl(const Acc &a) { return xyzz_dbl(a); }
+    static __device__ __forceinline__ Jac<F> to_jac(const Acc &a) { return xyzz_to_jac(a); }
+    static __device__ __forceinline__ Base from_affine(const Aff<F> &a) { return a; }
+};
+// G1 on 9 x 29-bit unsaturated limbs (fp29.h); bases packed to 64 B.
+struct CurveG1 {
+    using Field = Fq;
+    using Base = AffPacked;
+    using Acc = XYZZ29;
+    static __device__ __forceinline__ Acc inf() { return Acc::inf(); }
+    static __device__ __forceinline__ Acc madd(const Acc &a, const Base &b, bool negate) {
+        Aff29 q = unpack_affine(b);
+        if (negate && !q.is_inf()) q.y = sub_k<1>(F29::zero(), q.y);   // p - y
+        return xyzz29_madd(a, q);
+    }
+    static __device__ __forceinline__ Acc add(const Acc &a, const Acc &b) { return xyzz29_add(a, b); }
+    static __device__ __forceinline__ Acc dbl(const Acc &a) { return xyzz29_dbl(a); }
+    static __device__ __forceinline__ Jac<Fq> to_jac(const Acc &a) { return xyzz29_to_jac(a); }
+    static __device__ __forceinline__ Base from_affine(const Aff<Fq> &a) {
+        Base r;
+        if (a.is_inf()) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { r.x[i] = 0; r.y[i] = 0; }
+        } else {
+            F29::from_mont256(a.x).canonical().pack256(r.x);
+            F29::from_mont256(a.y).canonical().pack256(r.y);
+        }
+        return r;
+    }
+};
+template <class F> struct CurveOf { using type = CurveGeneric<F>; };
+template <> struct CurveOf<Fq> { using type = CurveG1; };
 
 // ------------------------------------------------------------------------------------
 // kernel 0: Jacobian (libff layout) -> affine, per-lane Montgomery batch inversion
@@ -89,6 +140,13 @@ __global__ __launch_bounds__(256) void k_normalize(const Jac<F> *__restrict__ in
             out[base + i] = a;
         }
     }
+}
+
+// affine (libff Montgomery limbs) -> the curve's device-resident base format
+template <class C>
+__global__ __launch_bounds__(256) void k_convert_bases(const Aff<typename C::Field> *__restrict__ in, typename C::Base *__restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = C::from_affine(in[i]);
 }
 
 // ------------------------------------------------------------------------------------
@@ -203,14 +261,17 @@ __global__ __launch_bounds__(256) void k_scatter(const int16_t *__restrict__ dig
 }
 
 // ------------------------------------------------------------------------------------
-// kernel 4: bucket accumulation (one lane per bucket); heavy buckets deferred
+// kernel 4: bucket accumulation (one lane per bucket); heavy buckets deferred.
+// C = curve traits (CurveG1: 29-bit limbs, 64-B packed bases; CurveGeneric<Fq2>: G2).
+// The next entry's point is fetched before the current mixed add is issued, so the
+// ~2 us gather latency hides under ~2300 VALU instructions of arithmetic.
 // ------------------------------------------------------------------------------------
-template <class F>
-__global__ __launch_bounds__(256) void k_accumulate(const Aff<F> *__restrict__ bases, const uint32_t *__restrict__ entries,
+template <class C>
+__global__ __launch_bounds__(256) void k_accumulate(const typename C::Base *__restrict__ bases, const uint32_t *__restrict__ entries,
                                                     const uint32_t *__restrict__ offs, const uint32_t *__restrict__ hist,
                                                     uint32_t nbuckets_total, uint32_t heavy_threshold,
                                                     uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count,
-                                                    XYZZ<F> *__restrict__ buckets) {
+                                                    typename C::Acc *__restrict__ buckets) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nbuckets_total) return;
     uint32_t cnt = hist[g];
@@ -219,20 +280,26 @@ __global__ __launch_bounds__(256) void k_accumulate(const Aff<F> *__restrict__ b
         return;
     }
     const uint32_t *e = entries + offs[g];
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (uint32_t j = 0; j < cnt; j++) {
-        uint32_t v = e[j];
-        Aff<F> p = bases[v & 0x7fffffffu];
-        if (v >> 31) p.y = p.y.neg();
-        acc = xyzz_madd(acc, p);
+    typename C::Acc acc = C::inf();
+    if (cnt) {
+        uint32_t v = e[0];
+        typename C::Base cur = bases[v & 0x7fffffffu];
+        for (uint32_t j = 0; j < cnt; j++) {
+            uint32_t vn = v;
+            typename C::Base nxt = cur;
+            if (j + 1 < cnt) { vn = e[j + 1]; nxt = bases[vn & 0x7fffffffu]; }
+            acc = C::madd(acc, cur, (v >> 31) != 0);
+            v = vn;
+            cur = nxt;
+        }
     }
     buckets[g] = acc;
 }
 
-template <class F>
-__device__ __forceinline__ XYZZ<F> shfl_down_xyzz(const XYZZ<F> &p, unsigned delta) {
-    XYZZ<F> r;
-    constexpr int NW = sizeof(XYZZ<F>) / 4;
+template <class A>
+__device__ __forceinline__ A shfl_down_acc(const A &p, unsigned delta) {
+    A r;
+    constexpr int NW = sizeof(A) / 4;
     const uint32_t *src = reinterpret_cast<const uint32_t *>(&p);
     uint32_t *dst = reinterpret_cast<uint32_t *>(&r);
 #pragma unroll
@@ -241,11 +308,11 @@ __device__ __forceinline__ XYZZ<F> shfl_down_xyzz(const XYZZ<F> &p, unsigned del
 }
 
 // wavefront tree sum: result valid in lane 0
-template <class F>
-__device__ __forceinline__ XYZZ<F> wave_sum(XYZZ<F> v, unsigned lane) {
+template <class C>
+__device__ __forceinline__ typename C::Acc wave_sum(typename C::Acc v, unsigned lane) {
     for (unsigned d = 32; d >= 1; d >>= 1) {
-        XYZZ<F> t = shfl_down_xyzz(v, d);
-        if (lane + d < 64) v = xyzz_add(v, t);
+        typename C::Acc t = shfl_down_acc(v, d);
+        if (lane + d < 64) v = C::add(v, t);
     }
     return v;
 }
@@ -253,12 +320,12 @@ __device__ __forceinline__ XYZZ<F> wave_sum(XYZZ<F> v, unsigned lane) {
 // Heavy buckets (population > threshold): a fixed grid of 256-lane workgroups loops over
 // (heavy bucket, slice) work items; the per-slice partials are summed by k_heavy_finish.
 // With uniformly random scalars heavy_count == 0 and both kernels exit at once.
-template <class F>
-__global__ __launch_bounds__(256) void k_accumulate_heavy(const Aff<F> *__restrict__ bases, const uint32_t *__restrict__ entries,
+template <class C>
+__global__ __launch_bounds__(256) void k_accumulate_heavy(const typename C::Base *__restrict__ bases, const uint32_t *__restrict__ entries,
                                                           const uint32_t *__restrict__ offs, const uint32_t *__restrict__ hist,
                                                           const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ heavy_count,
-                                                          uint32_t slices, XYZZ<F> *__restrict__ partials) {
-    __shared__ XYZZ<F> wsum[4];
+                                                          uint32_t slices, typename C::Acc *__restrict__ partials) {
+    __shared__ typename C::Acc wsum[4];
     const uint32_t items = *heavy_count * slices;
     for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
         uint32_t h = item / slices, sl = item % slices;
@@ -266,36 +333,34 @@ __global__ __launch_bounds__(256) void k_accumulate_heavy(const Aff<F> *__restri
         uint32_t cnt = hist[g];
         const uint32_t *e = entries + offs[g];
         uint32_t stride = slices * 256;
-        XYZZ<F> acc = XYZZ<F>::inf();
+        typename C::Acc acc = C::inf();
         for (uint32_t j = sl * 256 + threadIdx.x; j < cnt; j += stride) {
             uint32_t v = e[j];
-            Aff<F> p = bases[v & 0x7fffffffu];
-            if (v >> 31) p.y = p.y.neg();
-            acc = xyzz_madd(acc, p);
+            acc = C::madd(acc, bases[v & 0x7fffffffu], (v >> 31) != 0);
         }
         unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        acc = wave_sum(acc, lane);
+        acc = wave_sum<C>(acc, lane);
         if (lane == 0) wsum[wv] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
-            XYZZ<F> s = wsum[0];
-            for (int w = 1; w < 4; w++) s = xyzz_add(s, wsum[w]);
+            typename C::Acc s = wsum[0];
+            for (int w = 1; w < 4; w++) s = C::add(s, wsum[w]);
             partials[(size_t)h * slices + sl] = s;
         }
         __syncthreads();
     }
 }
 
-template <class F>
+template <class C>
 __global__ __launch_bounds__(64) void k_heavy_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ heavy_count,
-                                                     uint32_t slices, const XYZZ<F> *__restrict__ partials,
-                                                     XYZZ<F> *__restrict__ buckets) {
+                                                     uint32_t slices, const typename C::Acc *__restrict__ partials,
+                                                     typename C::Acc *__restrict__ buckets) {
     const uint32_t nh = *heavy_count;
     unsigned lane = threadIdx.x;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
-        XYZZ<F> acc = XYZZ<F>::inf();
-        for (uint32_t j = lane; j < slices; j += 64) acc = xyzz_add(acc, partials[(size_t)h * slices + j]);
-        acc = wave_sum(acc, lane);
+        typename C::Acc acc = C::inf();
+        for (uint32_t j = lane; j < slices; j += 64) acc = C::add(acc, partials[(size_t)h * slices + j]);
+        acc = wave_sum<C>(acc, lane);
         if (lane == 0) buckets[heavy_list[h]] = acc;
     }
 }
@@ -305,41 +370,41 @@ __global__ __launch_bounds__(64) void k_heavy_finish(const uint32_t *__restrict_
 //   ACC = sum_j acc_j + 2^log_mult * sum_j j*run_j      RUN = sum_j run_j
 // using an inclusive suffix scan of run (6 shuffle steps), then two tree sums.
 // ------------------------------------------------------------------------------------
-template <class F>
-__device__ __forceinline__ void wave_weighted(XYZZ<F> &acc, XYZZ<F> &run, unsigned log_mult, unsigned lane) {
-    // suffix scan: run_j <- sum_{i >= j} run_i
-    for (unsigned d = 1; d < 64; d <<= 1) {
-        XYZZ<F> t = shfl_down_xyzz(run, d);
-        if (lane + d < 64) run = xyzz_add(run, t);
+template <class C>
+__device__ __forceinline__ void wave_weighted(typename C::Acc &acc, typename C::Acc &run, unsigned log_mult, unsigned lane) {
+    using A = typename C::Acc;
+    for (unsigned d = 1; d < 64; d <<= 1) {          // suffix scan: run_j <- sum_{i >= j} run_i
+        A t = shfl_down_acc(run, d);
+        if (lane + d < 64) run = C::add(run, t);
     }
-    // sum_{k=1..63} Suf_k = sum_j j*run_j
-    XYZZ<F> s = (lane == 0) ? XYZZ<F>::inf() : run;
-    s = wave_sum(s, lane);
-    acc = wave_sum(acc, lane);
+    A s = (lane == 0) ? C::inf() : run;              // sum_{k=1..63} Suf_k = sum_j j*run_j
+    s = wave_sum<C>(s, lane);
+    acc = wave_sum<C>(acc, lane);
     if (lane == 0) {
-        for (unsigned i = 0; i < log_mult; i++) s = xyzz_dbl(s);
-        acc = xyzz_add(acc, s);
+        for (unsigned i = 0; i < log_mult; i++) s = C::dbl(s);
+        acc = C::add(acc, s);
     }
 }
 
 // Level 1: T = B/L lanes per window (padded to a multiple of 64); lane t owns buckets
 // [t*L, (t+1)*L).  Writes one (ACC,RUN) pair per wavefront.
-template <class F>
-__global__ __launch_bounds__(64) void k_reduce1(const XYZZ<F> *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t logL,
-                                                uint32_t waves_per_window, XYZZ<F> *__restrict__ wave_out) {
+template <class C>
+__global__ __launch_bounds__(64) void k_reduce1(const typename C::Acc *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t logL,
+                                                uint32_t waves_per_window, typename C::Acc *__restrict__ wave_out) {
+    using A = typename C::Acc;
     uint32_t wave = blockIdx.x;                 // global wave id = k*waves_per_window + w
     uint32_t k = wave / waves_per_window, w = wave % waves_per_window;
     unsigned lane = threadIdx.x;
     uint32_t t = w * 64 + lane;
-    XYZZ<F> acc = XYZZ<F>::inf(), run = XYZZ<F>::inf();
+    A acc = C::inf(), run = C::inf();
     if ((uint64_t)t * L < B) {
-        const XYZZ<F> *bk = buckets + (size_t)k * B + (size_t)t * L;
+        const A *bk = buckets + (size_t)k * B + (size_t)t * L;
         for (int i = (int)L - 1; i >= 0; i--) {
-            run = xyzz_add(run, bk[i]);
-            acc = xyzz_add(acc, run);
+            run = C::add(run, bk[i]);
+            acc = C::add(acc, run);
         }
     }
-    wave_weighted(acc, run, logL, lane);
+    wave_weighted<C>(acc, run, logL, lane);
     if (lane == 0) {
         wave_out[2 * (size_t)wave] = acc;
         wave_out[2 * (size_t)wave + 1] = run;
@@ -347,32 +412,34 @@ __global__ __launch_bounds__(64) void k_reduce1(const XYZZ<F> *__restrict__ buck
 }
 
 // Level 2: one wavefront per window folds the <= 64 wave pairs of level 1.
-template <class F>
-__global__ __launch_bounds__(64) void k_reduce2(const XYZZ<F> *__restrict__ wave_in, uint32_t waves_per_window, uint32_t log_mult,
-                                                XYZZ<F> *__restrict__ window_sums) {
+template <class C>
+__global__ __launch_bounds__(64) void k_reduce2(const typename C::Acc *__restrict__ wave_in, uint32_t waves_per_window, uint32_t log_mult,
+                                                typename C::Acc *__restrict__ window_sums) {
+    using A = typename C::Acc;
     uint32_t k = blockIdx.x;
     unsigned lane = threadIdx.x;
-    XYZZ<F> acc = XYZZ<F>::inf(), run = XYZZ<F>::inf();
+    A acc = C::inf(), run = C::inf();
     if (lane < waves_per_window) {
         acc = wave_in[2 * ((size_t)k * waves_per_window + lane)];
         run = wave_in[2 * ((size_t)k * waves_per_window + lane) + 1];
     }
-    wave_weighted(acc, run, log_mult, lane);
+    wave_weighted<C>(acc, run, log_mult, lane);
     if (lane == 0) window_sums[k] = acc;
 }
 
 // ------------------------------------------------------------------------------------
 // kernel 6: Horner fold over windows -> Jacobian (libff layout)
 // ------------------------------------------------------------------------------------
-template <class F>
-__global__ __launch_bounds__(64) void k_fold(const XYZZ<F> *__restrict__ window_sums, unsigned nwin, unsigned c, Jac<F> *__restrict__ out) {
+template <class C>
+__global__ __launch_bounds__(64) void k_fold(const typename C::Acc *__restrict__ window_sums, unsigned nwin, unsigned c,
+                                             Jac<typename C::Field> *__restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Jac<F> r = xyzz_to_jac(window_sums[nwin - 1]);
+    typename C::Acc r = window_sums[nwin - 1];
     for (int k = (int)nwin - 2; k >= 0; k--) {
-        for (unsigned i = 0; i < c; i++) r = jac_dbl(r);
-        r = jac_add(r, xyzz_to_jac(window_sums[k]));
+        for (unsigned i = 0; i < c; i++) r = C::dbl(r);
+        r = C::add(r, window_sums[k]);
     }
-    *out = r;
+    *out = C::to_jac(r);
 }
 
 // ------------------------------------------------------------------------------------
@@ -437,6 +504,34 @@ int msm_profile_last(float ms[LSA_MSM_STAGES]) {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+size_t msm_base_bytes(int group) { return group == 1 ? sizeof(CurveG1::Base) : sizeof(CurveGeneric<Fq2>::Base); }
+
+// Jacobian (libff layout, device) -> device-resident bases of the curve's pipeline:
+// batch-normalise to affine, then convert to the curve's base format.
+template <class F>
+int prepare_bases(const Jac<F> *d_in, void *d_out, size_t n, hipStream_t st) {
+    using C = typename CurveOf<F>::type;
+    if (n == 0) return LSA_OK;
+    constexpr int K = 8;
+    size_t threads = (n + K - 1) / K;
+    unsigned blocks = (unsigned)((threads + 255) / 256);
+    if (std::is_same<typename C::Base, Aff<F>>::value) {
+        hipLaunchKernelGGL((k_normalize<F, K>), dim3(blocks), dim3(256), 0, st, d_in, (Aff<F> *)d_out, n);
+        HIPCHK(hipGetLastError());
+        return LSA_OK;
+    }
+    Aff<F> *tmp = nullptr;
+    if (hipMalloc(&tmp, n * sizeof(Aff<F>)) != hipSuccess) { set_error("prepare_bases: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    hipLaunchKernelGGL((k_normalize<F, K>), dim3(blocks), dim3(256), 0, st, d_in, tmp, n);
+    hipLaunchKernelGGL((k_convert_bases<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tmp, (typename C::Base *)d_out, n);
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) { set_error("prepare_bases: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
+    return LSA_OK;
+}
+template int prepare_bases<Fq>(const Jac<Fq> *, void *, size_t, hipStream_t);
+template int prepare_bases<Fq2>(const Jac<Fq2> *, void *, size_t, hipStream_t);
+
 template <class F>
 int normalize_to_affine(const Jac<F> *d_in, Aff<F> *d_out, size_t n, hipStream_t st) {
     if (n == 0) return LSA_OK;
@@ -451,7 +546,10 @@ template int normalize_to_affine<Fq>(const Jac<Fq> *, Aff<Fq> *, size_t, hipStre
 template int normalize_to_affine<Fq2>(const Jac<Fq2> *, Aff<Fq2> *, size_t, hipStream_t);
 
 template <class F>
-int msm_device(const Aff<F> *d_bases, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st) {
+int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st) {
+    using C = typename CurveOf<F>::type;
+    using A = typename C::Acc;
+    const typename C::Base *d_bases = (const typename C::Base *)d_bases_v + first;
     if (n == 0) {
         Jac<F> inf = Jac<F>::inf();
         HIPCHK(hipMemcpyAsync(d_out, &inf, sizeof inf, hipMemcpyHostToDevice, st));
@@ -483,11 +581,11 @@ int msm_device(const Aff<F> *d_bases, const Fr *d_scalars, size_t n, Jac<F> *d_o
     size_t o_digits = carve(ne * 2);
     size_t o_slot = carve(ne * 4);
     size_t o_entries = carve(ne * 4);
-    size_t o_buckets = carve((size_t)nb * sizeof(XYZZ<F>));
+    size_t o_buckets = carve((size_t)nb * sizeof(A));
     size_t o_heavy = carve((size_t)max_heavy * 4);
-    size_t o_hpart = carve((size_t)max_heavy * slices * sizeof(XYZZ<F>));
-    size_t o_wave = carve((size_t)nwin * wpw * 2 * sizeof(XYZZ<F>));
-    size_t o_win = carve((size_t)nwin * sizeof(XYZZ<F>));
+    size_t o_hpart = carve((size_t)max_heavy * slices * sizeof(A));
+    size_t o_wave = carve((size_t)nwin * wpw * 2 * sizeof(A));
+    size_t o_win = carve((size_t)nwin * sizeof(A));
     if (g_ws.ensure(off) != 0) { set_error("msm: workspace allocation of %zu bytes failed", off); return LSA_ERR_NOMEM; }
     char *ws = (char *)g_ws.ptr;
     uint32_t *hist = (uint32_t *)(ws + o_hist);
@@ -497,11 +595,11 @@ int msm_device(const Aff<F> *d_bases, const Fr *d_scalars, size_t n, Jac<F> *d_o
     int16_t *digits = (int16_t *)(ws + o_digits);
     uint32_t *slot = (uint32_t *)(ws + o_slot);
     uint32_t *entries = (uint32_t *)(ws + o_entries);
-    XYZZ<F> *buckets = (XYZZ<F> *)(ws + o_buckets);
+    A *buckets = (A *)(ws + o_buckets);
     uint32_t *heavy_list = (uint32_t *)(ws + o_heavy);
-    XYZZ<F> *hpart = (XYZZ<F> *)(ws + o_hpart);
-    XYZZ<F> *wave_out = (XYZZ<F> *)(ws + o_wave);
-    XYZZ<F> *window_sums = (XYZZ<F> *)(ws + o_win);
+    A *hpart = (A *)(ws + o_hpart);
+    A *wave_out = (A *)(ws + o_wave);
+    A *window_sums = (A *)(ws + o_win);
 
     if (g_profile && !g_ev_ready) {
         for (auto &row : g_ev) for (auto &e : row) HIPCHK(hipEventCreate(&e));
@@ -521,22 +619,22 @@ int msm_device(const Aff<F> *d_bases, const Fr *d_scalars, size_t n, Jac<F> *d_o
     mark();  // 2
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, digits, slot, offs, n, c, nwin, entries);
     mark();  // 3
-    hipLaunchKernelGGL((k_accumulate<F>), dim3((nb + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, nb,
+    hipLaunchKernelGGL((k_accumulate<C>), dim3((nb + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, nb,
                        heavy_threshold, heavy_list, heavy_count, buckets);
-    hipLaunchKernelGGL((k_accumulate_heavy<F>), dim3(1024), dim3(256), 0, st, d_bases, entries, offs, hist,
+    hipLaunchKernelGGL((k_accumulate_heavy<C>), dim3(1024), dim3(256), 0, st, d_bases, entries, offs, hist,
                        heavy_list, heavy_count, slices, hpart);
-    hipLaunchKernelGGL((k_heavy_finish<F>), dim3(256), dim3(64), 0, st, heavy_list, heavy_count, slices, hpart, buckets);
+    hipLaunchKernelGGL((k_heavy_finish<C>), dim3(256), dim3(64), 0, st, heavy_list, heavy_count, slices, hpart, buckets);
     mark();  // 4
-    hipLaunchKernelGGL((k_reduce1<F>), dim3(nwin * wpw), dim3(64), 0, st, buckets, B, L, logL, wpw, wave_out);
-    hipLaunchKernelGGL((k_reduce2<F>), dim3(nwin), dim3(64), 0, st, wave_out, wpw, logL + 6, window_sums);
+    hipLaunchKernelGGL((k_reduce1<C>), dim3(nwin * wpw), dim3(64), 0, st, buckets, B, L, logL, wpw, wave_out);
+    hipLaunchKernelGGL((k_reduce2<C>), dim3(nwin), dim3(64), 0, st, wave_out, wpw, logL + 6, window_sums);
     mark();  // 5
-    hipLaunchKernelGGL((k_fold<F>), dim3(1), dim3(64), 0, st, window_sums, nwin, c, d_out);
+    hipLaunchKernelGGL((k_fold<C>), dim3(1), dim3(64), 0, st, window_sums, nwin, c, d_out);
     mark();  // 6
     HIPCHK(hipGetLastError());
     if (g_profile) g_ev_calls++;
     return LSA_OK;
 }
-template int msm_device<Fq>(const Aff<Fq> *, const Fr *, size_t, Jac<Fq> *, hipStream_t);
-template int msm_device<Fq2>(const Aff<Fq2> *, const Fr *, size_t, Jac<Fq2> *, hipStream_t);
+template int msm_device<Fq>(const void *, size_t, const Fr *, size_t, Jac<Fq> *, hipStream_t);
+template int msm_device<Fq2>(const void *, size_t, const Fr *, size_t, Jac<Fq2> *, hipStream_t);
 
 }  // namespace lsa
