@@ -17,7 +17,7 @@
 // Device-resident bases and buckets use this form; conversion from/to libff's layout
 // (8 x 32-bit limbs, R = 2^256) happens once at the boundary (from_mont256 / to_mont256).
 #pragma once
-#include "fp.h"
+#include "ec.h"
 
 namespace lsa {
 
@@ -241,7 +241,7 @@ struct XYZZ29 {
 LSA_HD Aff29 unpack_affine(const AffPacked &q) { return {F29::unpack256(q.x), F29::unpack256(q.y)}; }
 
 // 2*(x,y), affine input (mdbl-2008-s-1).  Output within the accumulator invariants.
-LSA_HD_NOINLINE XYZZ29 xyzz29_dbl_affine(const Aff29 &b) {
+LSA_HD XYZZ29 xyzz29_dbl_affine(const Aff29 &b) {
     F29 U = add_lazy(b.y, b.y);                    // [2p; loose]
     F29 V = sqr(U);                                // [<2p]
     F29 W = mul(U, V);
@@ -254,7 +254,7 @@ LSA_HD_NOINLINE XYZZ29 xyzz29_dbl_affine(const Aff29 &b) {
 }
 
 // 2*P (dbl-2008-s-1)
-LSA_HD_NOINLINE XYZZ29 xyzz29_dbl(const XYZZ29 &a) {
+LSA_HD XYZZ29 xyzz29_dbl(const XYZZ29 &a) {
     if (a.is_inf()) return a;
     F29 U = add_lazy(a.Y, a.Y);                    // [<8p; loose]
     F29 V = sqr(U);
@@ -288,7 +288,7 @@ LSA_HD XYZZ29 xyzz29_madd(const XYZZ29 &a, const Aff29 &b) {
 }
 
 // a + b, complete (add-2008-s).  Inputs and output within the accumulator invariants.
-LSA_HD_NOINLINE XYZZ29 xyzz29_add(const XYZZ29 &a, const XYZZ29 &b) {
+LSA_HD XYZZ29 xyzz29_add(const XYZZ29 &a, const XYZZ29 &b) {
     if (b.is_inf()) return a;
     if (a.is_inf()) return b;
     F29 U1 = mul(a.X, b.ZZ);
@@ -316,7 +316,7 @@ LSA_HD XYZZ29 xyzz29_neg(const XYZZ29 &a) {
 
 // XYZZ29 -> libff Jacobian (Montgomery R = 2^256, canonical limbs): Z = ZZZ, X' = X*ZZ^2,
 // Y' = Y*ZZZ^2.
-LSA_HD_NOINLINE Jac<Fq> xyzz29_to_jac(const XYZZ29 &a) {
+LSA_HD Jac<Fq> xyzz29_to_jac(const XYZZ29 &a) {
     if (a.is_inf()) return Jac<Fq>::inf();
     F29 Xj = mul(a.X, sqr(a.ZZ));
     F29 Yj = mul(a.Y, sqr(a.ZZZ));

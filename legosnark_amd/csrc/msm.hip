@@ -430,14 +430,26 @@ __global__ __launch_bounds__(64) void k_reduce2(const typename C::Acc *__restric
 // ------------------------------------------------------------------------------------
 // kernel 6: Horner fold over windows -> Jacobian (libff layout)
 // ------------------------------------------------------------------------------------
+// Keep a value in VGPRs: without this the compiler proves the single active lane's data
+// wave-uniform and moves the whole fold onto the scalar ALU (3x slower).
+template <class A>
+__device__ __forceinline__ void pin_vgpr(A &a) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(&a);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(A) / 4); i++) asm volatile("" : "+v"(w[i]));
+}
+
 template <class C>
 __global__ __launch_bounds__(64) void k_fold(const typename C::Acc *__restrict__ window_sums, unsigned nwin, unsigned c,
                                              Jac<typename C::Field> *__restrict__ out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     typename C::Acc r = window_sums[nwin - 1];
+    pin_vgpr(r);
     for (int k = (int)nwin - 2; k >= 0; k--) {
         for (unsigned i = 0; i < c; i++) r = C::dbl(r);
-        r = C::add(r, window_sums[k]);
+        typename C::Acc w = window_sums[k];
+        pin_vgpr(w);
+        r = C::add(r, w);
     }
     *out = C::to_jac(r);
 }

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <vector>
 #include "fp.h"
+#include "fp29.h"
 
 using namespace lsa;
 
@@ -59,6 +60,22 @@ __global__ __launch_bounds__(256) void k_fqmul(Fq *out, const Fq *in, int iters)
     out[tid] = x + y;
 }
 
+template <int ILP>
+__global__ __launch_bounds__(256) void k_mul29(F29 *out, const F29 *in, int iters) {
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    F29 x[ILP], y = in[tid + 1];
+#pragma unroll
+    for (int j = 0; j < ILP; j++) { x[j] = in[tid]; x[j].l[0] ^= j; }
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int j = 0; j < ILP; j++) x[j] = mul(x[j], y);      // ILP independent dependent-chains
+    }
+    F29 r = x[0];
+#pragma unroll
+    for (int j = 1; j < ILP; j++) r = add_lazy(r, x[j]);
+    out[tid] = r;
+}
+
 template <class Fn>
 static float time_ms(Fn fn, int reps = 3) {
     hipEvent_t e0, e1;
@@ -105,6 +122,24 @@ int main() {
             float ms1 = time_ms([&] { hipLaunchKernelGGL((k_fqmul<true>), dim3(bl), dim3(threads), 0, 0, d_o, d_in, fi); });
             float ms2 = time_ms([&] { hipLaunchKernelGGL((k_fqmul<false>), dim3(bl), dim3(threads), 0, 0, d_o, d_in, fi); });
             printf("Fq mul, %d blocks/CU: inline %8.3f ms = %7.2f Gmul/s | call %8.3f ms = %7.2f Gmul/s\n", occ, ms1, muls / ms1 * 1e-6, ms2, muls / ms2 * 1e-6);
+        }
+    }
+    // 29-bit-limb multiplication: throughput vs occupancy and per-lane ILP
+    {
+        size_t n = (size_t)prop.multiProcessorCount * 8 * 256;
+        std::vector<F29> h(n + 1);
+        for (size_t i = 0; i <= n; i++) for (int j = 0; j < 9; j++) h[i].l[j] = (uint32_t)(i * 2654435761u + j * 40503u + 12345u) & (j == 8 ? 0x3fffffu : 0x1fffffffu);
+        F29 *d_in, *d_o;
+        hipMalloc(&d_in, (n + 1) * sizeof(F29)); hipMalloc(&d_o, n * sizeof(F29));
+        hipMemcpy(d_in, h.data(), (n + 1) * sizeof(F29), hipMemcpyHostToDevice);
+        const int fi = 512;
+        for (int occ = 1; occ <= 8; occ *= 2) {
+            int bl = prop.multiProcessorCount * occ;
+            double muls = (double)bl * threads * fi;
+            float m1 = time_ms([&] { hipLaunchKernelGGL((k_mul29<1>), dim3(bl), dim3(threads), 0, 0, d_o, d_in, fi); });
+            float m2 = time_ms([&] { hipLaunchKernelGGL((k_mul29<2>), dim3(bl), dim3(threads), 0, 0, d_o, d_in, fi); });
+            float m4 = time_ms([&] { hipLaunchKernelGGL((k_mul29<4>), dim3(bl), dim3(threads), 0, 0, d_o, d_in, fi); });
+            printf("F29 mul, %d waves/SIMD: ILP1 %7.2f Gmul/s | ILP2 %7.2f Gmul/s | ILP4 %7.2f Gmul/s\n", occ, muls / m1 * 1e-6, 2 * muls / m2 * 1e-6, 4 * muls / m4 * 1e-6);
         }
     }
     return 0;
