@@ -261,6 +261,84 @@ __global__ __launch_bounds__(256) void k_scatter(const int16_t *__restrict__ dig
 }
 
 // ------------------------------------------------------------------------------------
+// kernel 3b: order buckets by population, largest first, so that the 64 lanes of a
+// wavefront walk equally long entry lists (bucket sizes are ~Poisson(n/2^(c-1)); unsorted,
+// a wavefront waits for its longest lane: ~1.45x the mean at n=2^20, c=16).
+// Counting sort on min(count, SIZE_BINS-1) with LDS-aggregated histograms; empty buckets
+// get their identity written here, over-threshold ones go to the heavy list.
+// ------------------------------------------------------------------------------------
+#define SIZE_BINS 1025          // counts 0..1024 (heavy_threshold == 1024)
+template <class C>
+__global__ __launch_bounds__(256) void k_size_hist(const uint32_t *__restrict__ hist, uint32_t nb, uint32_t *__restrict__ bin_count) {
+    __shared__ uint32_t lcnt[SIZE_BINS];
+    for (uint32_t t = threadIdx.x; t < SIZE_BINS; t += 256) lcnt[t] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * 2048 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint32_t g = base + j * 256;
+        if (g < nb) { uint32_t cnt = hist[g]; if (cnt > 0 && cnt < SIZE_BINS) atomicAdd(&lcnt[cnt], 1u); }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < SIZE_BINS; t += 256) if (lcnt[t]) atomicAdd(&bin_count[t], lcnt[t]);
+}
+// bin_start[b] = number of buckets with a larger population (descending order); total in bin_start[0]
+__global__ __launch_bounds__(256) void k_size_scan(const uint32_t *__restrict__ bin_count, uint32_t *__restrict__ bin_start) {
+    __shared__ uint32_t lds[4];
+    // lane t owns bins [SIZE_BINS-1-4t-3 .. SIZE_BINS-1-4t], visited from large to small
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int bin = (int)SIZE_BINS - 1 - (int)(threadIdx.x * 4 + j);
+        v[j] = (bin >= 1) ? bin_count[bin] : 0;
+        s += v[j];
+    }
+    uint32_t tot;
+    uint32_t run = block_exclusive_scan_256(s, lds, &tot);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int bin = (int)SIZE_BINS - 1 - (int)(threadIdx.x * 4 + j);
+        if (bin >= 1) bin_start[bin] = run;
+        run += v[j];
+    }
+    if (threadIdx.x == 0) bin_start[0] = tot;     // number of buckets in the permutation
+}
+template <class C>
+__global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict__ hist, uint32_t nb, const uint32_t *__restrict__ bin_start,
+                                                      uint32_t *__restrict__ bin_cursor, uint32_t *__restrict__ perm,
+                                                      uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count,
+                                                      typename C::Acc *__restrict__ buckets) {
+    __shared__ uint32_t lcnt[SIZE_BINS];
+    for (uint32_t t = threadIdx.x; t < SIZE_BINS; t += 256) lcnt[t] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * 2048 + threadIdx.x;
+    uint32_t cnt[8], rank[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint32_t g = base + j * 256;
+        cnt[j] = 0; rank[j] = 0;
+        if (g < nb) {
+            cnt[j] = hist[g];
+            if (cnt[j] == 0) buckets[g] = C::inf();
+            else if (cnt[j] >= SIZE_BINS) heavy_list[atomicAdd(heavy_count, 1u)] = g;
+            else rank[j] = atomicAdd(&lcnt[cnt[j]], 1u);
+        }
+    }
+    __syncthreads();
+    // reserve this block's slice of every bin it touched (reuse lcnt as the slice base)
+    for (uint32_t t = threadIdx.x; t < SIZE_BINS; t += 256) {
+        uint32_t c = lcnt[t];
+        lcnt[t] = c ? atomicAdd(&bin_cursor[t], c) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint32_t g = base + j * 256;
+        if (g < nb && cnt[j] > 0 && cnt[j] < SIZE_BINS) perm[bin_start[cnt[j]] + lcnt[cnt[j]] + rank[j]] = g;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // kernel 4: bucket accumulation (one lane per bucket); heavy buckets deferred.
 // C = curve traits (CurveG1: 29-bit limbs, 64-B packed bases; CurveGeneric<Fq2>: G2).
 // The next entry's point is fetched before the current mixed add is issued, so the
@@ -269,29 +347,23 @@ __global__ __launch_bounds__(256) void k_scatter(const int16_t *__restrict__ dig
 template <class C>
 __global__ __launch_bounds__(256) void k_accumulate(const typename C::Base *__restrict__ bases, const uint32_t *__restrict__ entries,
                                                     const uint32_t *__restrict__ offs, const uint32_t *__restrict__ hist,
-                                                    uint32_t nbuckets_total, uint32_t heavy_threshold,
-                                                    uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count,
+                                                    const uint32_t *__restrict__ perm, const uint32_t *__restrict__ nperm,
                                                     typename C::Acc *__restrict__ buckets) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= nbuckets_total) return;
-    uint32_t cnt = hist[g];
-    if (cnt > heavy_threshold) {
-        heavy_list[atomicAdd(heavy_count, 1u)] = g;
-        return;
-    }
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *nperm) return;
+    const uint32_t g = perm[t];
+    const uint32_t cnt = hist[g];           // 1 .. heavy_threshold
     const uint32_t *e = entries + offs[g];
     typename C::Acc acc = C::inf();
-    if (cnt) {
-        uint32_t v = e[0];
-        typename C::Base cur = bases[v & 0x7fffffffu];
-        for (uint32_t j = 0; j < cnt; j++) {
-            uint32_t vn = v;
-            typename C::Base nxt = cur;
-            if (j + 1 < cnt) { vn = e[j + 1]; nxt = bases[vn & 0x7fffffffu]; }
-            acc = C::madd(acc, cur, (v >> 31) != 0);
-            v = vn;
-            cur = nxt;
-        }
+    uint32_t v = e[0];
+    typename C::Base cur = bases[v & 0x7fffffffu];
+    for (uint32_t j = 0; j < cnt; j++) {
+        uint32_t vn = v;
+        typename C::Base nxt = cur;
+        if (j + 1 < cnt) { vn = e[j + 1]; nxt = bases[vn & 0x7fffffffu]; }
+        acc = C::madd(acc, cur, (v >> 31) != 0);
+        v = vn;
+        cur = nxt;
     }
     buckets[g] = acc;
 }
@@ -579,7 +651,7 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     while ((1u << logL) < L) logL++;
     const uint32_t T = B / L;
     const uint32_t wpw = (T + 63) / 64;              // wavefronts per window, <= 64
-    const uint32_t heavy_threshold = 1024;
+    const uint32_t heavy_threshold = SIZE_BINS - 1;   // populations above this are split across workgroups
     const uint32_t max_heavy = (uint32_t)std::min<size_t>(nb, ne / heavy_threshold + 1);
     const uint32_t slices = 64;
 
@@ -590,6 +662,8 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     size_t o_offs = carve((size_t)nb * 4);
     const uint32_t scan_blocks = (nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;   // <= 1024 since nb <= 2^20
     size_t o_bsum = carve((size_t)scan_blocks * 4);
+    size_t o_bins = carve((size_t)3 * SIZE_BINS * 4);   // bin_count | bin_start | bin_cursor
+    size_t o_perm = carve((size_t)nb * 4);
     size_t o_digits = carve(ne * 2);
     size_t o_slot = carve(ne * 4);
     size_t o_entries = carve(ne * 4);
@@ -604,6 +678,8 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     uint32_t *heavy_count = hist + nb;
     uint32_t *offs = (uint32_t *)(ws + o_offs);
     uint32_t *bsum = (uint32_t *)(ws + o_bsum);
+    uint32_t *bin_count = (uint32_t *)(ws + o_bins), *bin_start = bin_count + SIZE_BINS, *bin_cursor = bin_start + SIZE_BINS;
+    uint32_t *perm = (uint32_t *)(ws + o_perm);
     int16_t *digits = (int16_t *)(ws + o_digits);
     uint32_t *slot = (uint32_t *)(ws + o_slot);
     uint32_t *entries = (uint32_t *)(ws + o_entries);
@@ -623,6 +699,7 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
 
     mark();  // 0
     HIPCHK(hipMemsetAsync(hist, 0, (size_t)nb * 4 + 4, st));
+    HIPCHK(hipMemsetAsync(bin_count, 0, (size_t)3 * SIZE_BINS * 4, st));
     hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, c, nwin, digits, slot, hist);
     mark();  // 1
     hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(256), 0, st, hist, nb, bsum);
@@ -631,8 +708,13 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     mark();  // 2
     hipLaunchKernelGGL(k_scatter, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, digits, slot, offs, n, c, nwin, entries);
     mark();  // 3
-    hipLaunchKernelGGL((k_accumulate<C>), dim3((nb + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, nb,
-                       heavy_threshold, heavy_list, heavy_count, buckets);
+    {
+        const unsigned sb = (nb + 2047) / 2048;
+        hipLaunchKernelGGL((k_size_hist<C>), dim3(sb), dim3(256), 0, st, hist, nb, bin_count);
+        hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(256), 0, st, bin_count, bin_start);
+        hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, st, hist, nb, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets);
+    }
+    hipLaunchKernelGGL((k_accumulate<C>), dim3((nb + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
     hipLaunchKernelGGL((k_accumulate_heavy<C>), dim3(1024), dim3(256), 0, st, d_bases, entries, offs, hist,
                        heavy_list, heavy_count, slices, hpart);
     hipLaunchKernelGGL((k_heavy_finish<C>), dim3(256), dim3(64), 0, st, heavy_list, heavy_count, slices, hpart, buckets);
