@@ -41,6 +41,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise LsaError("%s is missing: run legosnark_amd.build() / __graft_entry__.build() "
                            "(there is no CPU fallback)" % LIB_PATH)
+        # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP runtimes
+        # in one process cannot both own the GPU, so when torch is installed it must be loaded
+        # FIRST: our library's libamdhip64.so.7 dependency then resolves to torch's copy.
+        if not os.environ.get("LSA_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         L.lsa_last_error.restype = C.c_char_p
         L.lsa_stream.restype = C.c_void_p

@@ -44,14 +44,17 @@ class ShardedMSM:
         self.total = torch.zeros(self.w, dtype=torch.int64, device=device)
 
     def run(self, d_scalars):
-        """Asynchronous on the library stream; returns the device tensor holding the sum
-        (identical on every rank)."""
+        """Asynchronous; returns the device tensor holding the sum (identical on every rank).
+        The local MSM and the fold run on the library's HIP stream, the all-gather on
+        torch's current stream; the two are ordered with stream waits (no host sync)."""
         self.local_msm(d_scalars, self.partial)
         if self.world == 1:
             return self.partial
         if self.stream is not None:
-            with self.torch.cuda.stream(self.stream):
-                self.dist.all_gather_into_tensor(self.gathered.view(-1), self.partial)
+            cur = self.torch.cuda.current_stream()
+            cur.wait_stream(self.stream)            # partial is ready
+            self.dist.all_gather_into_tensor(self.gathered.view(-1), self.partial)
+            self.stream.wait_stream(cur)            # gathered is ready
         else:
             self.dist.all_gather_into_tensor(self.gathered.view(-1), self.partial)
         self.fold(self.gathered, self.world, self.total)

@@ -154,3 +154,35 @@ def test_normalize(lsa):
         assert canon("g1", out[i]) == canon("g1", pts[i])
         if i != 7:
             assert np.array_equal(out[i, 8:12], o.fq_mont(1))
+
+
+def test_sharded_path_on_one_gpu_with_virtual_peer(lsa):
+    """Exercises the multi-GPU step (library stream <-> torch stream hand-offs, gather buffer,
+    lsa_g1_sum fold) on one GPU: the collective is replaced by a stand-in that supplies the
+    peer's partial, computed beforehand by the same library on the other index range."""
+    import torch
+    from legosnark_amd import sharded
+    n = 5000
+    bases = o.arith_bases("g1", 424242, 31, n)
+    sc, _ = o.random_scalars(n, seed=8)
+    lo0, hi0 = sharded.shard_range(n, 2, 0)
+    lo1, hi1 = sharded.shard_range(n, 2, 1)
+    assert (lo0, hi0, hi1) == (0, n // 2, n) and lo1 == hi0
+    peer = lsa.msm("g1", bases[lo1:hi1], sc[lo1:hi1])
+    d_peer = torch.from_numpy(peer.view(np.int64)).to("cuda:0")
+
+    class FakeDist:
+        def all_gather_into_tensor(self, out, inp):
+            out.view(2, 12)[0].copy_(inp)
+            out.view(2, 12)[1].copy_(d_peer)
+
+    B = lsa.Bases("g1", bases[lo0:hi0])
+    job = sharded.make_gpu_sharded(lsa, "g1", B, 2, 0, dist=FakeDist())
+    d_s = torch.from_numpy(sc[lo0:hi0].view(np.int64)).to("cuda:0")
+    torch.cuda.synchronize()
+    for _ in range(3):
+        res = job.run(d_s)
+    got = job.result_host(res)
+    want = o.multi_exp("g1", bases, sc, chunks=2, mode="multi_exp")     # libff chunked sum
+    assert canon("g1", got) == canon("g1", want)
+    B.close()
