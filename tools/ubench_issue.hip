@@ -39,6 +39,23 @@ KERNEL(k_fma_f32, "v_fma_f32 %0, %0, %1, %0", "+v"(f0), "v"(f1))
 KERNEL(k_mul_u24, "v_mul_u32_u24 %0, %0, %1", "+v"(a0), "v"(a1))
 KERNEL(k_mul_hi_u24, "v_mul_hi_u32_u24 %0, %0, %1", "+v"(a0), "v"(a1))
 KERNEL(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc", "+v"(a0), "v"(a1) : "vcc")
+// v_cndmask variants: VCC written once before the loop / SGPR-pair mask (VOP3)
+__global__ __launch_bounds__(256) void k_cndmask_vcc_set(uint32_t *out, int iters) {
+    uint32_t a0 = threadIdx.x + 1, a1 = threadIdx.x * 3 + 7;
+    asm volatile("v_cmp_lt_u32 vcc, %0, %1" :: "v"(a0), "v"(a1) : "vcc");
+    for (int it = 0; it < iters; it++) { asm volatile(REP32("v_cndmask_b32 %0, %0, %1, vcc\n") : "+v"(a0) : "v"(a1) : "vcc"); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0;
+}
+__global__ __launch_bounds__(256) void k_cndmask_e64(uint32_t *out, int iters) {
+    uint32_t a0 = threadIdx.x + 1, a1 = threadIdx.x * 3 + 7;
+    unsigned long long m = __ballot(a0 & 1);
+    for (int it = 0; it < iters; it++) { asm volatile(REP32("v_cndmask_b32_e64 %0, %0, %1, %2\n") : "+v"(a0) : "v"(a1), "s"(m)); }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0;
+}
+KERNEL(k_xor, "v_xor_b32 %0, %0, %1", "+v"(a0), "v"(a1))
+KERNEL(k_and_or, "v_and_or_b32 %0, %0, %1, %1", "+v"(a0), "v"(a1))
+KERNEL(k_bfi, "v_bfi_b32 %0, %1, %0, %1", "+v"(a0), "v"(a1))
+KERNEL(k_mov_dpp, "v_mov_b32_dpp %0, %1 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf", "+v"(a0), "v"(a1))
 KERNEL(k_add3, "v_add3_u32 %0, %0, %1, %1", "+v"(a0), "v"(a1))
 KERNEL(k_lshl_add, "v_lshl_add_u32 %0, %0, 3, %1", "+v"(a0), "v"(a1))
 KERNEL(k_bfe, "v_bfe_u32 %0, %0, 3, 29", "+v"(a0), "v"(a1))
@@ -74,6 +91,7 @@ int main() {
     (void)hipMalloc(&d_out, (size_t)cus * 8 * 256 * 4);
 #define R(k) run(#k, k, d_out, cus, ghz);
     R(k_add_u32) R(k_mov) R(k_and) R(k_add_co) R(k_addc_co) R(k_add3) R(k_lshl_add) R(k_bfe) R(k_cndmask) R(k_alignbit)
+    R(k_cndmask_vcc_set) R(k_cndmask_e64) R(k_xor) R(k_and_or) R(k_bfi) R(k_mov_dpp)
     R(k_mul_lo) R(k_mul_hi) R(k_mul_u24) R(k_mul_hi_u24) R(k_mad_u32_u24) R(k_mad_u64)
     R(k_lshl_add_u64) R(k_lshrrev_b64) R(k_fma_f32) R(k_fma_f64)
     return 0;
