@@ -5,19 +5,23 @@
 // (/root/reference/src/utils/sparsemexp.h:58,89).  Same sum, different schedule:
 //
 //   1 digits     scalars (Montgomery Fr, 32 B, read once, coalesced) -> canonical ->
-//                signed c-bit digits; per (window,bucket) population counted with one
-//                returning atomic per non-zero digit (the return value is the slot of
-//                the entry inside its bucket).
-//   2 scan       exclusive prefix sum over the nwin*2^(c-1) counters.
-//   3 scatter    entry (point index | sign) written to offsets[bucket] + slot.
+//                signed c-bit digits.  Then per (tile of 32768 scalars, window) a bucket
+//                histogram in LDS ranks every entry inside (tile, bucket) with one LDS
+//                atomic; a per-bucket prefix over tiles gives populations.  No global atomics.
+//   2 scan       exclusive prefix sum over the nwin*2^(c-1) bucket populations.
+//   3 scatter    entry (point index | sign) written to offs[bucket] + tile_base + rank,
+//                the base table of the (tile, window) held in LDS.
+//   3b order     buckets ordered by population (largest first) so a wavefront's 64 lanes
+//                walk equally long lists.
 //   4 accumulate one lane per bucket walks its entry list, gathers 64-B affine points
-//                and accumulates in XYZZ (8M+2S mixed add) -- the dominant kernel.
-//                Buckets above a population threshold are split across a whole
-//                workgroup (skewed scalars, e.g. the u[i]=i inputs of
+//                and accumulates in XYZZ (8M+2S mixed add, 29-bit limbs for G1) -- the
+//                dominant kernel.  Buckets above a population threshold are split across
+//                workgroups (skewed scalars, e.g. the u[i]=i inputs of
 //                /root/reference/src/examples/hadamard.cc:130-135).
 //   5 reduce     sum_b (b+1)*S_b per window: per-lane running sums over L buckets,
 //                then wavefront suffix-scan + tree reductions with cross-lane shuffles.
-//   6 fold       Horner over the windows (c doublings + 1 add each) -> one Jacobian point.
+//   6 fold       Horner over the windows (c doublings + 1 add each) -> one Jacobian point;
+//                for G1 each point is shared by a quad of lanes (quad29.h).
 //
 // Signed digits halve the bucket count (2^(c-1)); the zero/one filter of libff's
 // multi_exp_with_mixed_addition needs no special case (0 contributes nothing, 1 lands in
@@ -151,13 +155,19 @@ __global__ __launch_bounds__(256) void k_convert_bases(const Aff<typename C::Fie
 }
 
 // ------------------------------------------------------------------------------------
-// kernel 1: digits + histogram
+// kernels 1a-1c: digits, LDS ranking, tile prefix.  No global atomics.
+//   1a k_digits     scalars (Montgomery Fr, read once, coalesced) -> canonical -> signed
+//                   c-bit digits, digits[k][i] (int16).
+//   1b k_rank       one workgroup per (tile of TILE scalars, window): a bucket histogram of
+//                   the tile lives in LDS (u16 counters packed in pairs, <= 64 KiB); each
+//                   non-zero digit takes its rank inside (tile, bucket) with ONE returning
+//                   LDS atomic.  rank[k][i] (u16) and the tile histogram go to HBM.
+//   1c k_tile_scan  per (window, bucket): exclusive prefix over the tiles (u32) and the
+//                   bucket population hist[k][b].
 // ------------------------------------------------------------------------------------
-// digits[k*n + i] : signed digit of scalar i in window k
-// slot  [k*n + i] : arrival order of entry inside its bucket (valid when digit != 0)
+#define SORT_TILE 32768u
 __global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, size_t n, unsigned c, unsigned nwin,
-                                                int16_t *__restrict__ digits, uint32_t *__restrict__ slot,
-                                                uint32_t *__restrict__ hist) {
+                                                int16_t *__restrict__ digits) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t s[8];
@@ -174,11 +184,45 @@ __global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, 
         if (k + 1 < nwin && d >= B) { sd = (int32_t)d - (int32_t)(1u << c); carry = 1; }
         else { sd = (int32_t)d; carry = 0; }
         digits[(size_t)k * n + i] = (int16_t)sd;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_rank(const int16_t *__restrict__ digits, size_t n, uint32_t B, uint32_t ntiles,
+                                               uint16_t *__restrict__ rank, uint16_t *__restrict__ tile_hist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cnt2[];   // B/2 words: two u16 counters each
+    const uint32_t t = blockIdx.x, k = blockIdx.y;
+    for (uint32_t x = threadIdx.x; x < B / 2; x += 1024) cnt2[x] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)t * SORT_TILE;
+    const size_t hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
+    const int16_t *dg = digits + (size_t)k * n;
+    uint16_t *rk = rank + (size_t)k * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        int32_t sd = dg[i];
         if (sd != 0) {
             uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
-            slot[(size_t)k * n + i] = atomicAdd(&hist[k * B + b], 1u);
+            uint32_t sh = (b & 1) * 16;
+            uint32_t old = atomicAdd(&cnt2[b >> 1], 1u << sh);      // ds_add_rtn_u32
+            rk[i] = (uint16_t)(old >> sh);
         }
     }
+    __syncthreads();
+    uint32_t *th = reinterpret_cast<uint32_t *>(tile_hist + ((size_t)k * ntiles + t) * B);
+    for (uint32_t x = threadIdx.x; x < B / 2; x += 1024) th[x] = cnt2[x];
+}
+
+__global__ __launch_bounds__(256) void k_tile_scan(const uint16_t *__restrict__ tile_hist, uint32_t B, uint32_t ntiles, uint32_t nb,
+                                                   uint32_t *__restrict__ tile_base, uint32_t *__restrict__ hist) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;      // g = k*B + b
+    if (g >= nb) return;
+    uint32_t k = g / B, b = g - k * B;
+    uint32_t run = 0;
+    for (uint32_t t = 0; t < ntiles; t++) {
+        size_t idx = ((size_t)k * ntiles + t) * B + b;
+        tile_base[idx] = run;
+        run += tile_hist[idx];
+    }
+    hist[g] = run;
 }
 
 // ------------------------------------------------------------------------------------
@@ -244,21 +288,30 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t *__restrict__
 }
 
 // ------------------------------------------------------------------------------------
-// kernel 3: scatter (point index | sign<<31) into bucket-sorted order
+// kernel 3: scatter.  One workgroup per (tile, window) loads base[b] = offs[k][b] +
+// tile_base[k][t][b] into LDS (<= 128 KiB) and writes entry (point index | sign<<31) at
+// base[b] + rank.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scatter(const int16_t *__restrict__ digits, const uint32_t *__restrict__ slot,
-                                                 const uint32_t *__restrict__ offs, size_t n, unsigned c, unsigned nwin,
-                                                 uint32_t *__restrict__ entries) {
-    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n * nwin) return;
-    unsigned k = (unsigned)(g / n);
-    uint32_t i = (uint32_t)(g - (size_t)k * n);
-    int32_t sd = digits[g];
-    if (sd == 0) return;
-    const uint32_t B = 1u << (c - 1);
-    uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
-    uint32_t pos = offs[k * B + b] + slot[g];
-    entries[pos] = i | (sd < 0 ? 0x80000000u : 0u);
+__global__ __launch_bounds__(1024) void k_scatter(const int16_t *__restrict__ digits, const uint16_t *__restrict__ rank,
+                                                  const uint32_t *__restrict__ offs, const uint32_t *__restrict__ tile_base,
+                                                  size_t n, uint32_t B, uint32_t ntiles, uint32_t *__restrict__ entries) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t base[];   // B words
+    const uint32_t t = blockIdx.x, k = blockIdx.y;
+    const uint32_t *of = offs + (size_t)k * B;
+    const uint32_t *tb = tile_base + ((size_t)k * ntiles + t) * B;
+    for (uint32_t x = threadIdx.x; x < B; x += 1024) base[x] = of[x] + tb[x];
+    __syncthreads();
+    const size_t lo = (size_t)t * SORT_TILE;
+    const size_t hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
+    const int16_t *dg = digits + (size_t)k * n;
+    const uint16_t *rk = rank + (size_t)k * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        int32_t sd = dg[i];
+        if (sd != 0) {
+            uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
+            entries[base[b] + rk[i]] = (uint32_t)i | (sd < 0 ? 0x80000000u : 0u);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -686,8 +739,11 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     size_t o_bsum = carve((size_t)scan_blocks * 4);
     size_t o_bins = carve((size_t)3 * SIZE_BINS * 4);   // bin_count | bin_start | bin_cursor
     size_t o_perm = carve((size_t)nb * 4);
+    const uint32_t ntiles = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
     size_t o_digits = carve(ne * 2);
-    size_t o_slot = carve(ne * 4);
+    size_t o_rank = carve(ne * 2);
+    size_t o_thist = carve((size_t)nb * ntiles * 2);
+    size_t o_tbase = carve((size_t)nb * ntiles * 4);
     size_t o_entries = carve(ne * 4);
     size_t o_buckets = carve((size_t)nb * sizeof(A));
     size_t o_heavy = carve((size_t)max_heavy * 4);
@@ -703,7 +759,9 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     uint32_t *bin_count = (uint32_t *)(ws + o_bins), *bin_start = bin_count + SIZE_BINS, *bin_cursor = bin_start + SIZE_BINS;
     uint32_t *perm = (uint32_t *)(ws + o_perm);
     int16_t *digits = (int16_t *)(ws + o_digits);
-    uint32_t *slot = (uint32_t *)(ws + o_slot);
+    uint16_t *rank = (uint16_t *)(ws + o_rank);
+    uint16_t *tile_hist = (uint16_t *)(ws + o_thist);
+    uint32_t *tile_base = (uint32_t *)(ws + o_tbase);
     uint32_t *entries = (uint32_t *)(ws + o_entries);
     A *buckets = (A *)(ws + o_buckets);
     uint32_t *heavy_list = (uint32_t *)(ws + o_heavy);
@@ -720,15 +778,23 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     auto mark = [&]() { if (g_profile) (void)hipEventRecord(g_ev[evslot][evi++], st); };
 
     mark();  // 0
-    HIPCHK(hipMemsetAsync(hist, 0, (size_t)nb * 4 + 4, st));
+    HIPCHK(hipMemsetAsync(heavy_count, 0, 4, st));
     HIPCHK(hipMemsetAsync(bin_count, 0, (size_t)3 * SIZE_BINS * 4, st));
-    hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, c, nwin, digits, slot, hist);
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {   // > 64 KiB of dynamic LDS needs an explicit opt-in
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        lds_attr_set = true;
+    }
+    hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, c, nwin, digits);
+    hipLaunchKernelGGL(k_rank, dim3(ntiles, nwin), dim3(1024), (size_t)B * 2, st, digits, n, B, ntiles, rank, tile_hist);
+    hipLaunchKernelGGL(k_tile_scan, dim3((nb + 255) / 256), dim3(256), 0, st, tile_hist, B, ntiles, nb, tile_base, hist);
     mark();  // 1
     hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(256), 0, st, hist, nb, bsum);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bsum, scan_blocks);
     hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, hist, bsum, nb, offs);
     mark();  // 2
-    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, digits, slot, offs, n, c, nwin, entries);
+    hipLaunchKernelGGL(k_scatter, dim3(ntiles, nwin), dim3(1024), (size_t)B * 4, st, digits, rank, offs, tile_base, n, B, ntiles, entries);
     mark();  // 3
     {
         const unsigned sb = (nb + 2047) / 2048;
