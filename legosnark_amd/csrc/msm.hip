@@ -36,6 +36,7 @@
 
 #include "ec.h"
 #include "fp29.h"
+#include "glv.h"
 #include "quad29.h"
 #include "msm.h"
 
@@ -64,8 +65,9 @@ struct CurveGeneric {
     using Field = F;
     using Base = Aff<F>;
     using Acc = XYZZ<F>;
+    static constexpr bool GLV = false;
     static __device__ __forceinline__ Acc inf() { return Acc::inf(); }
-    static __device__ __forceinline__ Acc madd(const Acc &a, const Base &b, bool negate) {
+    static __device__ __forceinline__ Acc madd(const Acc &a, const Base &b, bool negate, bool /*endo*/) {
         Aff<F> q = b;
         if (negate) q.y = q.y.neg();
         return xyzz_madd(a, q);
@@ -80,10 +82,17 @@ struct CurveG1 {
     using Field = Fq;
     using Base = AffPacked;
     using Acc = XYZZ29;
+    static constexpr bool GLV = true;     // scalars split as k1 + k2*lambda (glv.h)
     static __device__ __forceinline__ Acc inf() { return Acc::inf(); }
-    static __device__ __forceinline__ Acc madd(const Acc &a, const Base &b, bool negate) {
+    static __device__ __forceinline__ Acc madd(const Acc &a, const Base &b, bool negate, bool endo) {
         Aff29 q = unpack_affine(b);
-        if (negate && !q.is_inf()) q.y = sub_k<1>(F29::zero(), q.y);   // p - y
+        if (q.is_inf()) return a;
+        if (negate) q.y = sub_k<1>(F29::zero(), q.y);                  // p - y
+        if (endo) {                                                     // phi(x,y) = (beta*x, y)
+            constexpr uint32_t BETA29[9] = {0x0a337995u, 0x158d1d23u, 0x189c9b98u, 0x12fa4e45u, 0x185faadcu,
+                                            0x0176f16du, 0x0eed93bau, 0x14291140u, 0x000c0afeu};
+            q.x = mul(q.x, F29::from_limbs(BETA29));                    // [<2p; tight]
+        }
         return xyzz29_madd(a, q);
     }
     static __device__ __forceinline__ Acc add(const Acc &a, const Acc &b) { return xyzz29_add(a, b); }
@@ -166,28 +175,41 @@ __global__ __launch_bounds__(256) void k_convert_bases(const Aff<typename C::Fie
 //                   bucket population hist[k][b].
 // ------------------------------------------------------------------------------------
 #define SORT_TILE 32768u
-__global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, size_t n, unsigned c, unsigned nwin,
-                                                int16_t *__restrict__ digits) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t s[8];
-    scalars[i].to_canonical(s);
+__device__ __forceinline__ void write_digits(const uint32_t *s, int nlimbs, bool negate, size_t col, size_t nv, unsigned c,
+                                             unsigned nwin, int32_t *__restrict__ digits) {
     const uint32_t B = 1u << (c - 1);
     uint32_t carry = 0;
     for (unsigned k = 0; k < nwin; k++) {
         unsigned bit = k * c;
-        unsigned w = bit >> 5, sh = bit & 31;
-        uint64_t two = (uint64_t)(w < 8 ? s[w] : 0) | ((uint64_t)(w + 1 < 8 ? s[w + 1] : 0) << 32);
+        int w = (int)(bit >> 5);
+        unsigned sh = bit & 31;
+        uint64_t two = (uint64_t)(w < nlimbs ? s[w] : 0) | ((uint64_t)(w + 1 < nlimbs ? s[w + 1] : 0) << 32);
         uint32_t d = (uint32_t)(two >> sh) & ((1u << c) - 1);
         d += carry;
         int32_t sd;
         if (k + 1 < nwin && d >= B) { sd = (int32_t)d - (int32_t)(1u << c); carry = 1; }
         else { sd = (int32_t)d; carry = 0; }
-        digits[(size_t)k * n + i] = (int16_t)sd;
+        digits[(size_t)k * nv + col] = negate ? -sd : sd;
+    }
+}
+// GLV: scalar i yields two virtual scalars, columns i (k1, point i) and n+i (k2, phi(point i)).
+template <bool GLV>
+__global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, size_t n, unsigned c, unsigned nwin,
+                                                int32_t *__restrict__ digits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[8];
+    scalars[i].to_canonical(s);
+    if (GLV) {
+        GlvSplit g = glv_decompose(s);
+        write_digits(g.k1, 4, g.neg1, i, 2 * n, c, nwin, digits);
+        write_digits(g.k2, 4, g.neg2, n + i, 2 * n, c, nwin, digits);
+    } else {
+        write_digits(s, 8, false, i, n, c, nwin, digits);
     }
 }
 
-__global__ __launch_bounds__(1024) void k_rank(const int16_t *__restrict__ digits, size_t n, uint32_t B, uint32_t ntiles,
+__global__ __launch_bounds__(1024) void k_rank(const int32_t *__restrict__ digits, size_t n, uint32_t B, uint32_t ntiles,
                                                uint16_t *__restrict__ rank, uint16_t *__restrict__ tile_hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cnt2[];   // B/2 words: two u16 counters each
     const uint32_t t = blockIdx.x, k = blockIdx.y;
@@ -195,7 +217,7 @@ __global__ __launch_bounds__(1024) void k_rank(const int16_t *__restrict__ digit
     __syncthreads();
     const size_t lo = (size_t)t * SORT_TILE;
     const size_t hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
-    const int16_t *dg = digits + (size_t)k * n;
+    const int32_t *dg = digits + (size_t)k * n;
     uint16_t *rk = rank + (size_t)k * n;
     for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
         int32_t sd = dg[i];
@@ -292,9 +314,9 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t *__restrict__
 // tile_base[k][t][b] into LDS (<= 128 KiB) and writes entry (point index | sign<<31) at
 // base[b] + rank.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scatter(const int16_t *__restrict__ digits, const uint16_t *__restrict__ rank,
+__global__ __launch_bounds__(1024) void k_scatter(const int32_t *__restrict__ digits, const uint16_t *__restrict__ rank,
                                                   const uint32_t *__restrict__ offs, const uint32_t *__restrict__ tile_base,
-                                                  size_t n, uint32_t B, uint32_t ntiles, uint32_t *__restrict__ entries) {
+                                                  size_t n, size_t npoints, uint32_t B, uint32_t ntiles, uint32_t *__restrict__ entries) {
     extern __shared__ __attribute__((aligned(16))) uint32_t base[];   // B words
     const uint32_t t = blockIdx.x, k = blockIdx.y;
     const uint32_t *of = offs + (size_t)k * B;
@@ -303,13 +325,15 @@ __global__ __launch_bounds__(1024) void k_scatter(const int16_t *__restrict__ di
     __syncthreads();
     const size_t lo = (size_t)t * SORT_TILE;
     const size_t hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
-    const int16_t *dg = digits + (size_t)k * n;
+    const int32_t *dg = digits + (size_t)k * n;
     const uint16_t *rk = rank + (size_t)k * n;
     for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
         int32_t sd = dg[i];
         if (sd != 0) {
             uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
-            entries[base[b] + rk[i]] = (uint32_t)i | (sd < 0 ? 0x80000000u : 0u);
+            // entry = point index | endo << 30 | sign << 31   (virtual scalar i >= npoints: phi(point))
+            uint32_t pt = i < npoints ? (uint32_t)i : ((uint32_t)(i - npoints) | 0x40000000u);
+            entries[base[b] + rk[i]] = pt | (sd < 0 ? 0x80000000u : 0u);
         }
     }
 }
@@ -410,12 +434,12 @@ __global__ __launch_bounds__(256) void k_accumulate(const typename C::Base *__re
     const uint32_t *e = entries + offs[g];
     typename C::Acc acc = C::inf();
     uint32_t v = e[0];
-    typename C::Base cur = bases[v & 0x7fffffffu];
+    typename C::Base cur = bases[v & 0x3fffffffu];
     for (uint32_t j = 0; j < cnt; j++) {
         uint32_t vn = v;
         typename C::Base nxt = cur;
-        if (j + 1 < cnt) { vn = e[j + 1]; nxt = bases[vn & 0x7fffffffu]; }
-        acc = C::madd(acc, cur, (v >> 31) != 0);
+        if (j + 1 < cnt) { vn = e[j + 1]; nxt = bases[vn & 0x3fffffffu]; }
+        acc = C::madd(acc, cur, (v >> 31) != 0, ((v >> 30) & 1) != 0);
         v = vn;
         cur = nxt;
     }
@@ -462,7 +486,7 @@ __global__ __launch_bounds__(256) void k_accumulate_heavy(const typename C::Base
         typename C::Acc acc = C::inf();
         for (uint32_t j = sl * 256 + threadIdx.x; j < cnt; j += stride) {
             uint32_t v = e[j];
-            acc = C::madd(acc, bases[v & 0x7fffffffu], (v >> 31) != 0);
+            acc = C::madd(acc, bases[v & 0x3fffffffu], (v >> 31) != 0, ((v >> 30) & 1) != 0);
         }
         unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         acc = wave_sum<C>(acc, lane);
@@ -717,10 +741,11 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     }
     if (n >= (size_t(1) << 27)) { set_error("msm: n too large (%zu)", n); return LSA_ERR_INVALID; }
     const unsigned c = msm_window_bits(n);
-    const unsigned nwin = num_windows(c);
+    const unsigned nwin = C::GLV ? (128 + c - 1) / c : num_windows(c);   // |k1|,|k2| < 2^127 (glv.h)
+    const size_t nv = C::GLV ? 2 * n : n;                                  // virtual scalars
     const uint32_t B = 1u << (c - 1);
     const uint32_t nb = nwin * B;
-    const size_t ne = n * nwin;
+    const size_t ne = nv * nwin;
     const uint32_t L = B > 4096 ? B / 4096 : 1;
     uint32_t logL = 0;
     while ((1u << logL) < L) logL++;
@@ -739,8 +764,8 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     size_t o_bsum = carve((size_t)scan_blocks * 4);
     size_t o_bins = carve((size_t)3 * SIZE_BINS * 4);   // bin_count | bin_start | bin_cursor
     size_t o_perm = carve((size_t)nb * 4);
-    const uint32_t ntiles = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
-    size_t o_digits = carve(ne * 2);
+    const uint32_t ntiles = (uint32_t)((nv + SORT_TILE - 1) / SORT_TILE);
+    size_t o_digits = carve(ne * 4);
     size_t o_rank = carve(ne * 2);
     size_t o_thist = carve((size_t)nb * ntiles * 2);
     size_t o_tbase = carve((size_t)nb * ntiles * 4);
@@ -758,7 +783,7 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     uint32_t *bsum = (uint32_t *)(ws + o_bsum);
     uint32_t *bin_count = (uint32_t *)(ws + o_bins), *bin_start = bin_count + SIZE_BINS, *bin_cursor = bin_start + SIZE_BINS;
     uint32_t *perm = (uint32_t *)(ws + o_perm);
-    int16_t *digits = (int16_t *)(ws + o_digits);
+    int32_t *digits = (int32_t *)(ws + o_digits);
     uint16_t *rank = (uint16_t *)(ws + o_rank);
     uint16_t *tile_hist = (uint16_t *)(ws + o_thist);
     uint32_t *tile_base = (uint32_t *)(ws + o_tbase);
@@ -786,15 +811,15 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         lds_attr_set = true;
     }
-    hipLaunchKernelGGL(k_digits, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, c, nwin, digits);
-    hipLaunchKernelGGL(k_rank, dim3(ntiles, nwin), dim3(1024), (size_t)B * 2, st, digits, n, B, ntiles, rank, tile_hist);
+    hipLaunchKernelGGL((k_digits<C::GLV>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, c, nwin, digits);
+    hipLaunchKernelGGL(k_rank, dim3(ntiles, nwin), dim3(1024), (size_t)B * 2, st, digits, nv, B, ntiles, rank, tile_hist);
     hipLaunchKernelGGL(k_tile_scan, dim3((nb + 255) / 256), dim3(256), 0, st, tile_hist, B, ntiles, nb, tile_base, hist);
     mark();  // 1
     hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(256), 0, st, hist, nb, bsum);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bsum, scan_blocks);
     hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, hist, bsum, nb, offs);
     mark();  // 2
-    hipLaunchKernelGGL(k_scatter, dim3(ntiles, nwin), dim3(1024), (size_t)B * 4, st, digits, rank, offs, tile_base, n, B, ntiles, entries);
+    hipLaunchKernelGGL(k_scatter, dim3(ntiles, nwin), dim3(1024), (size_t)B * 4, st, digits, rank, offs, tile_base, nv, n, B, ntiles, entries);
     mark();  // 3
     {
         const unsigned sb = (nb + 2047) / 2048;
