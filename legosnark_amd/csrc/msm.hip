@@ -345,6 +345,7 @@ __global__ __launch_bounds__(1024) void k_scatter(const int32_t *__restrict__ di
 // Counting sort on min(count, SIZE_BINS-1) with LDS-aggregated histograms; empty buckets
 // get their identity written here, over-threshold ones go to the heavy list.
 // ------------------------------------------------------------------------------------
+#define ACC_SPLIT 2u            // lanes per bucket in k_accumulate
 #define SIZE_BINS 1025          // counts 0..1024 (heavy_threshold == 1024)
 template <class C>
 __global__ __launch_bounds__(256) void k_size_hist(const uint32_t *__restrict__ hist, uint32_t nb, uint32_t *__restrict__ bin_count) {
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict
         cnt[j] = 0; rank[j] = 0;
         if (g < nb) {
             cnt[j] = hist[g];
-            if (cnt[j] == 0) buckets[g] = C::inf();
+            if (cnt[j] == 0) { for (uint32_t h = 0; h < ACC_SPLIT; h++) buckets[(size_t)g * ACC_SPLIT + h] = C::inf(); }
             else if (cnt[j] >= SIZE_BINS) heavy_list[atomicAdd(heavy_count, 1u)] = g;
             else rank[j] = atomicAdd(&lcnt[cnt[j]], 1u);
         }
@@ -427,23 +428,28 @@ __global__ __launch_bounds__(256) void k_accumulate(const typename C::Base *__re
                                                     const uint32_t *__restrict__ offs, const uint32_t *__restrict__ hist,
                                                     const uint32_t *__restrict__ perm, const uint32_t *__restrict__ nperm,
                                                     typename C::Acc *__restrict__ buckets) {
+    // SPLIT lanes per bucket (interleaved halves of its entry list) keep >= 2.5 wavefronts
+    // per SIMD slot in flight even when GLV halves the bucket count; the halves are summed
+    // when the bucket reduction loads them.
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= *nperm) return;
-    const uint32_t g = perm[t];
+    if (t >= *nperm * ACC_SPLIT) return;
+    const uint32_t g = perm[t / ACC_SPLIT], part = t % ACC_SPLIT;
     const uint32_t cnt = hist[g];           // 1 .. heavy_threshold
     const uint32_t *e = entries + offs[g];
     typename C::Acc acc = C::inf();
-    uint32_t v = e[0];
-    typename C::Base cur = bases[v & 0x3fffffffu];
-    for (uint32_t j = 0; j < cnt; j++) {
-        uint32_t vn = v;
-        typename C::Base nxt = cur;
-        if (j + 1 < cnt) { vn = e[j + 1]; nxt = bases[vn & 0x3fffffffu]; }
-        acc = C::madd(acc, cur, (v >> 31) != 0, ((v >> 30) & 1) != 0);
-        v = vn;
-        cur = nxt;
+    if (part < cnt) {
+        uint32_t v = e[part];
+        typename C::Base cur = bases[v & 0x3fffffffu];
+        for (uint32_t j = part; j < cnt; j += ACC_SPLIT) {
+            uint32_t vn = v;
+            typename C::Base nxt = cur;
+            if (j + ACC_SPLIT < cnt) { vn = e[j + ACC_SPLIT]; nxt = bases[vn & 0x3fffffffu]; }
+            acc = C::madd(acc, cur, (v >> 31) != 0, ((v >> 30) & 1) != 0);
+            v = vn;
+            cur = nxt;
+        }
     }
-    buckets[g] = acc;
+    buckets[(size_t)g * ACC_SPLIT + part] = acc;
 }
 
 template <class A>
@@ -511,7 +517,10 @@ __global__ __launch_bounds__(64) void k_heavy_finish(const uint32_t *__restrict_
         typename C::Acc acc = C::inf();
         for (uint32_t j = lane; j < slices; j += 64) acc = C::add(acc, partials[(size_t)h * slices + j]);
         acc = wave_sum<C>(acc, lane);
-        if (lane == 0) buckets[heavy_list[h]] = acc;
+        if (lane == 0) {
+            buckets[(size_t)heavy_list[h] * ACC_SPLIT] = acc;
+            for (uint32_t x = 1; x < ACC_SPLIT; x++) buckets[(size_t)heavy_list[h] * ACC_SPLIT + x] = C::inf();
+        }
     }
 }
 
@@ -548,9 +557,9 @@ __global__ __launch_bounds__(64) void k_reduce1(const typename C::Acc *__restric
     uint32_t t = w * 64 + lane;
     A acc = C::inf(), run = C::inf();
     if ((uint64_t)t * L < B) {
-        const A *bk = buckets + (size_t)k * B + (size_t)t * L;
+        const A *bk = buckets + ((size_t)k * B + (size_t)t * L) * ACC_SPLIT;
         for (int i = (int)L - 1; i >= 0; i--) {
-            run = C::add(run, bk[i]);
+            for (uint32_t h = 0; h < ACC_SPLIT; h++) run = C::add(run, bk[(size_t)i * ACC_SPLIT + h]);
             acc = C::add(acc, run);
         }
     }
@@ -770,7 +779,7 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     size_t o_thist = carve((size_t)nb * ntiles * 2);
     size_t o_tbase = carve((size_t)nb * ntiles * 4);
     size_t o_entries = carve(ne * 4);
-    size_t o_buckets = carve((size_t)nb * sizeof(A));
+    size_t o_buckets = carve((size_t)nb * ACC_SPLIT * sizeof(A));
     size_t o_heavy = carve((size_t)max_heavy * 4);
     size_t o_hpart = carve((size_t)max_heavy * slices * sizeof(A));
     size_t o_wave = carve((size_t)nwin * wpw * 2 * sizeof(A));
@@ -827,7 +836,7 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(256), 0, st, bin_count, bin_start);
         hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, st, hist, nb, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets);
     }
-    hipLaunchKernelGGL((k_accumulate<C>), dim3((nb + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
+    hipLaunchKernelGGL((k_accumulate<C>), dim3((nb * ACC_SPLIT + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
     hipLaunchKernelGGL((k_accumulate_heavy<C>), dim3(1024), dim3(256), 0, st, d_bases, entries, offs, hist,
                        heavy_list, heavy_count, slices, hpart);
     hipLaunchKernelGGL((k_heavy_finish<C>), dim3(256), dim3(64), 0, st, heavy_list, heavy_count, slices, hpart, buckets);
