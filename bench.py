@@ -25,6 +25,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 ALG_BYTES_PER_PAIR = 96        # 64 B affine point + 32 B scalar, read once
+# The path is integer-VALU bound, so the roofline object also carries the field-multiplication
+# rate of the dominant kernel against the measured chip-wide ceiling of the 29-bit-limb
+# Montgomery product (tools/ubench_int.hip: 175 G mults/s at >= 4 waves/SIMD).
+FMUL_PEAK_G = 175.0
+FMULS_PER_PAIR = 16 * 10 + 8   # 16 mixed adds (8M+2S) + 8 beta-multiplies (GLV) per pair
 
 
 def main():
@@ -119,11 +124,16 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 limbs (254-bit Montgomery integers)", "data": "synthetic",
             "config": {"workload": "alt_bn128 G1 Pippenger MSM, n=2^%d random scalars per GPU" % args.log2n,
-                       "window_bits": lsa.msm_window_bits(n), "sharding": "index ranges, 1 RCCL all-gather of 96-B partials"
+                       "window_bits": lsa.msm_window_bits(n), "glv": True, "sharding": "index ranges, 1 RCCL all-gather of 96-B partials"
                        if world > 1 else "single GPU"},
-            "roofline": {"kernel": "k_accumulate<Fq>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "k_accumulate<CurveG1>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": acc_ms, "calls_averaged": stages["calls"]},
+                         "kernel_ms": acc_ms, "calls_averaged": stages["calls"],
+                         "valu": {"achieved_Gfmul_s": n * FMULS_PER_PAIR / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
+                                  "peak_Gfmul_s": FMUL_PEAK_G,
+                                  "frac": (n * FMULS_PER_PAIR / (acc_ms * 1e-3) / 1e9 / FMUL_PEAK_G) if acc_ms > 0 else 0.0,
+                                  "note": "254-bit field multiplications/s in k_accumulate vs the microbenchmarked "
+                                          "ceiling of the 9x29-bit Montgomery product on this chip"}},
             "stage_ms": {k: round(v, 4) for k, v in stages.items() if k not in ("calls", "reserved")},
         }
         if not args.no_cpu_baseline and world == 1:

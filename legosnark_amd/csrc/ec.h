@@ -44,7 +44,7 @@ struct XYZZ {
 
 // 2*(x,y) for an affine point (mdbl-2008-s-1)
 template <class F>
-LSA_HD_NOINLINE XYZZ<F> xyzz_dbl_affine(const Aff<F> &p) {
+LSA_HD XYZZ<F> xyzz_dbl_affine(const Aff<F> &p) {
     F U = p.y.dbl();
     F V = U.sqr();
     F W = U * V;
