@@ -36,6 +36,7 @@
 
 #include "ec.h"
 #include "fp29.h"
+#include "fp29x2.h"
 #include "glv.h"
 #include "quad29.h"
 #include "msm.h"
@@ -110,8 +111,28 @@ struct CurveG1 {
         return r;
     }
 };
+// G2 on the same 29-bit-limb field (fp29x2.h): Fq2 products with fused reductions; bases
+// packed to 128 B.  No GLV (the G2 endomorphism needs a 4-dimensional split): 16 windows.
+struct CurveG2 {
+    using Field = Fq2;
+    using Base = AffPackedG2;
+    using Acc = XYZZ29x2;
+    static constexpr bool GLV = false;
+    static __device__ __forceinline__ Acc inf() { return Acc::inf(); }
+    static __device__ __forceinline__ Acc madd(const Acc &a, const Base &b, bool negate, bool /*endo*/) {
+        Aff29x2 q = unpack_affine(b);
+        if (q.is_inf()) return a;
+        if (negate) q.y = sub_k<1>(F29x2::zero(), q.y);                // p - y per component
+        return g2_madd(a, q);
+    }
+    static __device__ __forceinline__ Acc add(const Acc &a, const Acc &b) { return g2_add(a, b); }
+    static __device__ __forceinline__ Acc dbl(const Acc &a) { return g2_dbl(a); }
+    static __device__ __forceinline__ Jac<Fq2> to_jac(const Acc &a) { return g2_to_jac(a); }
+    static __device__ __forceinline__ Base from_affine(const Aff<Fq2> &a) { return pack_affine_g2(a); }
+};
 template <class F> struct CurveOf { using type = CurveGeneric<F>; };
 template <> struct CurveOf<Fq> { using type = CurveG1; };
+template <> struct CurveOf<Fq2> { using type = CurveG2; };
 
 // ------------------------------------------------------------------------------------
 // kernel 0: Jacobian (libff layout) -> affine, per-lane Montgomery batch inversion
@@ -696,7 +717,7 @@ int msm_profile_last(float ms[LSA_MSM_STAGES]) {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-size_t msm_base_bytes(int group) { return group == 1 ? sizeof(CurveG1::Base) : sizeof(CurveGeneric<Fq2>::Base); }
+size_t msm_base_bytes(int group) { return group == 1 ? sizeof(CurveG1::Base) : sizeof(CurveG2::Base); }
 
 // Jacobian (libff layout, device) -> device-resident bases of the curve's pipeline:
 // batch-normalise to affine, then convert to the curve's base format.

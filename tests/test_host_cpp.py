@@ -1,0 +1,20 @@
+"""CPU suite: host-compiled unit tests of the device arithmetic headers (the same code the
+kernels compile): 29-bit-limb field + bound-aware XYZZ formulas against the canonical
+32-bit-limb code, and the GLV decomposition (k1 + k2*lambda == k mod r, |k_i| < 2^127)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", ["test_fp29", "test_glv", "test_fp29x2"])
+def test_host_cpp(name, tmp_path):
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cc")
+    if not os.path.exists(src):
+        pytest.skip(name + " not present")
+    exe = str(tmp_path / name)
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "legosnark_amd", "csrc"), src, "-o", exe])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-2000:]
