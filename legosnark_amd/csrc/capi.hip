@@ -112,7 +112,7 @@ int lsa_synchronize(void) {
     return LSA_OK;
 }
 
-unsigned lsa_msm_window_bits(size_t n) { return msm_window_bits(n); }
+unsigned lsa_msm_window_bits(size_t n) { return msm_window_bits(2 * n); }   // G1 (GLV: 2n virtual scalars)
 
 int lsa_profile_enable(int on) { msm_profile_enable(on != 0); return LSA_OK; }
 int lsa_profile_last_msm(float ms[LSA_MSM_STAGES]) { return msm_profile_last(ms); }

@@ -50,7 +50,7 @@ unsigned msm_window_bits(size_t n) {
     unsigned lg = 0;
     while ((size_t(1) << (lg + 1)) <= n) lg++;   // floor(log2 n), 0 for n <= 1
     int c = (int)lg - 4;
-    if (c < 4) c = 4;
+    if (c < 8) c = 8;        // few, wide windows keep the latency-bound fold short for tiny inputs
     if (c > 16) c = 16;
     return (unsigned)c;
 }
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(1024) void k_scatter(const int32_t *__restrict__ di
 #define ACC_SPLIT 2u            // lanes per bucket in k_accumulate
 #define SIZE_BINS 1025          // counts 0..1024 (heavy_threshold == 1024)
 template <class C>
-__global__ __launch_bounds__(256) void k_size_hist(const uint32_t *__restrict__ hist, uint32_t nb, uint32_t *__restrict__ bin_count) {
+__global__ __launch_bounds__(256) void k_size_hist(const uint32_t *__restrict__ hist, uint32_t nb, uint32_t thr, uint32_t *__restrict__ bin_count) {
     __shared__ uint32_t lcnt[SIZE_BINS];
     for (uint32_t t = threadIdx.x; t < SIZE_BINS; t += 256) lcnt[t] = 0;
     __syncthreads();
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void k_size_hist(const uint32_t *__restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         uint32_t g = base + j * 256;
-        if (g < nb) { uint32_t cnt = hist[g]; if (cnt > 0 && cnt < SIZE_BINS) atomicAdd(&lcnt[cnt], 1u); }
+        if (g < nb) { uint32_t cnt = hist[g]; if (cnt > 0 && cnt <= thr) atomicAdd(&lcnt[cnt], 1u); }
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < SIZE_BINS; t += 256) if (lcnt[t]) atomicAdd(&bin_count[t], lcnt[t]);
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void k_size_scan(const uint32_t *__restrict__ 
     if (threadIdx.x == 0) bin_start[0] = tot;     // number of buckets in the permutation
 }
 template <class C>
-__global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict__ hist, uint32_t nb, const uint32_t *__restrict__ bin_start,
+__global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict__ hist, uint32_t nb, uint32_t thr, const uint32_t *__restrict__ bin_start,
                                                       uint32_t *__restrict__ bin_cursor, uint32_t *__restrict__ perm,
                                                       uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count,
                                                       typename C::Acc *__restrict__ buckets) {
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict
         if (g < nb) {
             cnt[j] = hist[g];
             if (cnt[j] == 0) { for (uint32_t h = 0; h < ACC_SPLIT; h++) buckets[(size_t)g * ACC_SPLIT + h] = C::inf(); }
-            else if (cnt[j] >= SIZE_BINS) heavy_list[atomicAdd(heavy_count, 1u)] = g;
+            else if (cnt[j] > thr) heavy_list[atomicAdd(heavy_count, 1u)] = g;
             else rank[j] = atomicAdd(&lcnt[cnt[j]], 1u);
         }
     }
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         uint32_t g = base + j * 256;
-        if (g < nb && cnt[j] > 0 && cnt[j] < SIZE_BINS) perm[bin_start[cnt[j]] + lcnt[cnt[j]] + rank[j]] = g;
+        if (g < nb && cnt[j] > 0 && cnt[j] <= thr) perm[bin_start[cnt[j]] + lcnt[cnt[j]] + rank[j]] = g;
     }
 }
 
@@ -494,49 +494,64 @@ __device__ __forceinline__ typename C::Acc wave_sum(typename C::Acc v, unsigned 
     return v;
 }
 
-// Heavy buckets (population > threshold): a fixed grid of 256-lane workgroups loops over
-// (heavy bucket, slice) work items; the per-slice partials are summed by k_heavy_finish.
-// With uniformly random scalars heavy_count == 0 and both kernels exit at once.
+// Heavy buckets (population > threshold): k_heavy_plan cuts every heavy bucket into chunks of
+// HEAVY_CHUNK entries (exclusive scan of the chunk counts); k_accumulate_heavy gives each
+// chunk one wavefront (8 sequential mixed adds per lane, then a shuffle tree);
+// k_heavy_finish sums a bucket's chunk partials.  With uniformly random scalars and c | 128
+// there are no heavy buckets and all three exit at once.
+#define HEAVY_CHUNK 512u
+__global__ __launch_bounds__(256) void k_heavy_plan(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ heavy_list,
+                                                    const uint32_t *__restrict__ heavy_count, uint32_t *__restrict__ chunk_off) {
+    __shared__ uint32_t lds[4];
+    const uint32_t nh = *heavy_count;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nh; base += 256) {
+        uint32_t h = base + threadIdx.x;
+        uint32_t v = h < nh ? (hist[heavy_list[h]] + HEAVY_CHUNK - 1) / HEAVY_CHUNK : 0;
+        uint32_t tot;
+        uint32_t ex = block_exclusive_scan_256(v, lds, &tot);
+        if (h < nh) chunk_off[h] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) chunk_off[nh] = carry;      // total number of chunks
+}
+
 template <class C>
-__global__ __launch_bounds__(256) void k_accumulate_heavy(const typename C::Base *__restrict__ bases, const uint32_t *__restrict__ entries,
-                                                          const uint32_t *__restrict__ offs, const uint32_t *__restrict__ hist,
-                                                          const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ heavy_count,
-                                                          uint32_t slices, typename C::Acc *__restrict__ partials) {
-    __shared__ typename C::Acc wsum[4];
-    const uint32_t items = *heavy_count * slices;
-    for (uint32_t item = blockIdx.x; item < items; item += gridDim.x) {
-        uint32_t h = item / slices, sl = item % slices;
-        uint32_t g = heavy_list[h];
-        uint32_t cnt = hist[g];
+__global__ __launch_bounds__(64) void k_accumulate_heavy(const typename C::Base *__restrict__ bases, const uint32_t *__restrict__ entries,
+                                                         const uint32_t *__restrict__ offs, const uint32_t *__restrict__ hist,
+                                                         const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ heavy_count,
+                                                         const uint32_t *__restrict__ chunk_off, typename C::Acc *__restrict__ partials) {
+    const uint32_t nh = *heavy_count;
+    if (nh == 0) return;
+    const uint32_t total = chunk_off[nh];
+    const unsigned lane = threadIdx.x;
+    for (uint32_t v = blockIdx.x; v < total; v += gridDim.x) {
+        uint32_t lo = 0, hi = nh;                       // largest h with chunk_off[h] <= v
+        while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (chunk_off[mid] <= v) lo = mid; else hi = mid; }
+        const uint32_t g = heavy_list[lo];
+        const uint32_t cnt = hist[g];
+        const uint32_t start = (v - chunk_off[lo]) * HEAVY_CHUNK;
+        const uint32_t end = start + HEAVY_CHUNK < cnt ? start + HEAVY_CHUNK : cnt;
         const uint32_t *e = entries + offs[g];
-        uint32_t stride = slices * 256;
         typename C::Acc acc = C::inf();
-        for (uint32_t j = sl * 256 + threadIdx.x; j < cnt; j += stride) {
-            uint32_t v = e[j];
-            acc = C::madd(acc, bases[v & 0x3fffffffu], (v >> 31) != 0, ((v >> 30) & 1) != 0);
+        for (uint32_t j = start + lane; j < end; j += 64) {
+            uint32_t w = e[j];
+            acc = C::madd(acc, bases[w & 0x3fffffffu], (w >> 31) != 0, ((w >> 30) & 1) != 0);
         }
-        unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         acc = wave_sum<C>(acc, lane);
-        if (lane == 0) wsum[wv] = acc;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            typename C::Acc s = wsum[0];
-            for (int w = 1; w < 4; w++) s = C::add(s, wsum[w]);
-            partials[(size_t)h * slices + sl] = s;
-        }
-        __syncthreads();
+        if (lane == 0) partials[v] = acc;
     }
 }
 
 template <class C>
 __global__ __launch_bounds__(64) void k_heavy_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ heavy_count,
-                                                     uint32_t slices, const typename C::Acc *__restrict__ partials,
+                                                     const uint32_t *__restrict__ chunk_off, const typename C::Acc *__restrict__ partials,
                                                      typename C::Acc *__restrict__ buckets) {
     const uint32_t nh = *heavy_count;
     unsigned lane = threadIdx.x;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
         typename C::Acc acc = C::inf();
-        for (uint32_t j = lane; j < slices; j += 64) acc = C::add(acc, partials[(size_t)h * slices + j]);
+        for (uint32_t v = chunk_off[h] + lane; v < chunk_off[h + 1]; v += 64) acc = C::add(acc, partials[v]);
         acc = wave_sum<C>(acc, lane);
         if (lane == 0) {
             buckets[(size_t)heavy_list[h] * ACC_SPLIT] = acc;
@@ -770,7 +785,7 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         return LSA_OK;
     }
     if (n >= (size_t(1) << 27)) { set_error("msm: n too large (%zu)", n); return LSA_ERR_INVALID; }
-    const unsigned c = msm_window_bits(n);
+    const unsigned c = msm_window_bits(C::GLV ? 2 * n : n);             // sized by the virtual scalars
     const unsigned nwin = C::GLV ? (128 + c - 1) / c : num_windows(c);   // |k1|,|k2| < 2^127 (glv.h)
     const size_t nv = C::GLV ? 2 * n : n;                                  // virtual scalars
     const uint32_t B = 1u << (c - 1);
@@ -781,9 +796,13 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     while ((1u << logL) < L) logL++;
     const uint32_t T = B / L;
     const uint32_t wpw = (T + 63) / 64;              // wavefronts per window, <= 64
-    const uint32_t heavy_threshold = SIZE_BINS - 1;   // populations above this are split across workgroups
+    // Buckets far above the average population (skewed scalars; the partly filled top window
+    // when c does not divide the scalar length) are split across workgroups instead of being
+    // walked by two lanes.
+    const uint32_t avg_pop = (uint32_t)std::min<size_t>(nv / B + 1, SIZE_BINS);
+    const uint32_t heavy_threshold = std::min<uint32_t>(SIZE_BINS - 1, std::max<uint32_t>(64, 2 * avg_pop + 32));
     const uint32_t max_heavy = (uint32_t)std::min<size_t>(nb, ne / heavy_threshold + 1);
-    const uint32_t slices = 64;
+    const size_t max_chunks = ne / HEAVY_CHUNK + max_heavy + 1;
 
     // workspace carve-up
     size_t off = 0;
@@ -802,7 +821,8 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     size_t o_entries = carve(ne * 4);
     size_t o_buckets = carve((size_t)nb * ACC_SPLIT * sizeof(A));
     size_t o_heavy = carve((size_t)max_heavy * 4);
-    size_t o_hpart = carve((size_t)max_heavy * slices * sizeof(A));
+    size_t o_choff = carve((size_t)(max_heavy + 1) * 4);
+    size_t o_hpart = carve(max_chunks * sizeof(A));
     size_t o_wave = carve((size_t)nwin * wpw * 2 * sizeof(A));
     size_t o_win = carve((size_t)nwin * sizeof(A));
     if (g_ws.ensure(off) != 0) { set_error("msm: workspace allocation of %zu bytes failed", off); return LSA_ERR_NOMEM; }
@@ -820,6 +840,7 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     uint32_t *entries = (uint32_t *)(ws + o_entries);
     A *buckets = (A *)(ws + o_buckets);
     uint32_t *heavy_list = (uint32_t *)(ws + o_heavy);
+    uint32_t *chunk_off = (uint32_t *)(ws + o_choff);
     A *hpart = (A *)(ws + o_hpart);
     A *wave_out = (A *)(ws + o_wave);
     A *window_sums = (A *)(ws + o_win);
@@ -853,14 +874,15 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     mark();  // 3
     {
         const unsigned sb = (nb + 2047) / 2048;
-        hipLaunchKernelGGL((k_size_hist<C>), dim3(sb), dim3(256), 0, st, hist, nb, bin_count);
+        hipLaunchKernelGGL((k_size_hist<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_count);
         hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(256), 0, st, bin_count, bin_start);
-        hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, st, hist, nb, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets);
+        hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets);
     }
     hipLaunchKernelGGL((k_accumulate<C>), dim3((nb * ACC_SPLIT + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
-    hipLaunchKernelGGL((k_accumulate_heavy<C>), dim3(1024), dim3(256), 0, st, d_bases, entries, offs, hist,
-                       heavy_list, heavy_count, slices, hpart);
-    hipLaunchKernelGGL((k_heavy_finish<C>), dim3(256), dim3(64), 0, st, heavy_list, heavy_count, slices, hpart, buckets);
+    hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(256), 0, st, hist, heavy_list, heavy_count, chunk_off);
+    hipLaunchKernelGGL((k_accumulate_heavy<C>), dim3(4096), dim3(64), 0, st, d_bases, entries, offs, hist,
+                       heavy_list, heavy_count, chunk_off, hpart);
+    hipLaunchKernelGGL((k_heavy_finish<C>), dim3(256), dim3(64), 0, st, heavy_list, heavy_count, chunk_off, hpart, buckets);
     mark();  // 4
     hipLaunchKernelGGL((k_reduce1<C>), dim3(nwin * wpw), dim3(64), 0, st, buckets, B, L, logL, wpw, wave_out);
     hipLaunchKernelGGL((k_reduce2<C>), dim3(nwin), dim3(64), 0, st, wave_out, wpw, logL + 6, window_sums);
