@@ -114,7 +114,73 @@ struct F29 {
         r.l[8] = (uint32_t)acc;
         return r;
     }
-    friend LSA_HD F29 sqr(const F29 &a) { return mul(a, a); }
+    // a^2: cross terms once with doubled limbs (45 limb products instead of 81).  Input
+    // limbs may be loose (< 2^30): 4*2^61 + 2^60 + 9*2^58 < 2^64 per column.  [< 2p; tight]
+    friend LSA_HD F29 sqr(const F29 &a) {
+        uint32_t d[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) d[i] = a.l[i] << 1;
+        uint64_t acc = 0;
+        uint32_t m[9];
+        F29 r;
+#pragma unroll
+        for (int k = 0; k < 17; k++) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const int j = k - i;
+                if (j > i && j < 9) acc += (uint64_t)a.l[i] * d[j];
+            }
+            if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+            if (k < 9) {
+#pragma unroll
+                for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * p(k - i);
+                m[k] = ((uint32_t)acc * PINV) & MASK;
+                acc += (uint64_t)m[k] * p(0);
+            } else {
+#pragma unroll
+                for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * p(k - i);
+                r.l[k - 9] = (uint32_t)acc & MASK;
+            }
+            acc >>= 29;
+        }
+        r.l[8] = (uint32_t)acc;
+        return r;
+    }
+    // (a0*b0 + a1*b1) / 2^261 mod p with ONE reduction: both products accumulate in the same
+    // 64-bit columns.  Needs a0*b0 + a1*b1 < 169 p^2 and at most one loose operand per
+    // product (18*2^59 + 9*2^58 < 2^64).  [< 2p; tight]
+    friend LSA_HD F29 dot2(const F29 &a0, const F29 &b0, const F29 &a1, const F29 &b1) {
+        uint64_t acc = 0;
+        uint32_t m[9];
+        F29 r;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+#pragma unroll
+            for (int i = 0; i <= k; i++) {
+                acc += (uint64_t)a0.l[i] * b0.l[k - i];
+                acc += (uint64_t)a1.l[i] * b1.l[k - i];
+            }
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * p(k - i);
+            m[k] = ((uint32_t)acc * PINV) & MASK;
+            acc += (uint64_t)m[k] * p(0);
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; k++) {
+#pragma unroll
+            for (int i = k - 8; i < 9; i++) {
+                acc += (uint64_t)a0.l[i] * b0.l[k - i];
+                acc += (uint64_t)a1.l[i] * b1.l[k - i];
+            }
+#pragma unroll
+            for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * p(k - i);
+            r.l[k - 9] = (uint32_t)acc & MASK;
+            acc >>= 29;
+        }
+        r.l[8] = (uint32_t)acc;
+        return r;
+    }
 
     // value == 0 (mod p) for a tight value < 16p.  Necessary condition first: a multiple
     // k*p has low limb k*p_0, so k = l0 * p_0^-1 mod 2^29 must be < 16 (false positives
@@ -249,7 +315,7 @@ LSA_HD XYZZ29 xyzz29_dbl_affine(const Aff29 &b) {
     F29 xx = sqr(b.x);
     F29 M = add_lazy(add_lazy(xx, xx), xx).norm(); // [<6p; tight]
     F29 X3 = sub_k<4>(sqr(M), add_lazy(S, S));     // M^2 - 2S + 4p   [<6p]
-    F29 Y3 = sub_k<2>(mul(M, sub_k<8>(S, X3)), mul(W, b.y));   // [<4p]
+    F29 Y3 = dot2(M, sub_k<8>(S, X3), W, sub_k<1>(F29::zero(), b.y));   // M(S-X3) + W(p-y): 60 + 2  [<2p]
     return {X3, Y3, V, W};
 }
 
@@ -263,7 +329,7 @@ LSA_HD XYZZ29 xyzz29_dbl(const XYZZ29 &a) {
     F29 xx = sqr(a.X);
     F29 M = add_lazy(add_lazy(xx, xx), xx).norm(); // [<6p; tight]
     F29 X3 = sub_k<4>(sqr(M), add_lazy(S, S));     // [<6p]
-    F29 Y3 = sub_k<2>(mul(M, sub_k<8>(S, X3)), mul(W, a.Y));   // [<4p]
+    F29 Y3 = dot2(M, sub_k<8>(S, X3), W, sub_k<4>(F29::zero(), a.Y));   // M(S-X3) + W(4p-Y): 60 + 8  [<2p]
     return {X3, Y3, mul(V, a.ZZ), mul(W, a.ZZZ)};
 }
 
@@ -283,7 +349,7 @@ LSA_HD XYZZ29 xyzz29_madd(const XYZZ29 &a, const Aff29 &b) {
     F29 PPP = mul(Pd, PP);
     F29 Q = mul(a.X, PP);
     F29 X3 = sub_k<6>(sqr(R), add_lazy(PPP, add_lazy(Q, Q)));          // R^2 - PPP - 2Q + 6p  [<8p]
-    F29 Y3 = sub_k<2>(mul(R, sub_k<8>(Q, X3)), mul(a.Y, PPP));         // [<4p]
+    F29 Y3 = dot2(R, sub_k<8>(Q, X3), sub_k<4>(F29::zero(), a.Y), PPP);   // R(Q-X3) + (4p-Y1)PPP: 60 + 8  [<2p]
     return {X3, Y3, mul(a.ZZ, PP), mul(a.ZZZ, PPP)};
 }
 
@@ -305,7 +371,7 @@ LSA_HD XYZZ29 xyzz29_add(const XYZZ29 &a, const XYZZ29 &b) {
     F29 PPP = mul(Pd, PP);
     F29 Q = mul(U1, PP);
     F29 X3 = sub_k<6>(sqr(R), add_lazy(PPP, add_lazy(Q, Q)));
-    F29 Y3 = sub_k<2>(mul(R, sub_k<8>(Q, X3)), mul(S1, PPP));
+    F29 Y3 = dot2(R, sub_k<8>(Q, X3), sub_k<2>(F29::zero(), S1), PPP);    // R(Q-X3) + (2p-S1)PPP: 40 + 4  [<2p]
     return {X3, Y3, mul(mul(a.ZZ, b.ZZ), PP), mul(mul(a.ZZZ, b.ZZZ), PPP)};
 }
 

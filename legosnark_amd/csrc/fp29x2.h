@@ -16,40 +16,6 @@
 
 namespace lsa {
 
-// (a0*b0 + a1*b1) / 2^261 mod p, one reduction.  [< 2p; tight]
-LSA_HD F29 dot2(const F29 &a0, const F29 &b0, const F29 &a1, const F29 &b1) {
-    uint64_t acc = 0;
-    uint32_t m[9];
-    F29 r;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-#pragma unroll
-        for (int i = 0; i <= k; i++) {
-            acc += (uint64_t)a0.l[i] * b0.l[k - i];
-            acc += (uint64_t)a1.l[i] * b1.l[k - i];
-        }
-#pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F29::p(k - i);
-        m[k] = ((uint32_t)acc * F29::PINV) & F29::MASK;
-        acc += (uint64_t)m[k] * F29::p(0);
-        acc >>= 29;
-    }
-#pragma unroll
-    for (int k = 9; k < 17; k++) {
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) {
-            acc += (uint64_t)a0.l[i] * b0.l[k - i];
-            acc += (uint64_t)a1.l[i] * b1.l[k - i];
-        }
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * F29::p(k - i);
-        r.l[k - 9] = (uint32_t)acc & F29::MASK;
-        acc >>= 29;
-    }
-    r.l[8] = (uint32_t)acc;
-    return r;
-}
-
 // tight value < 8p  ->  same residue, < 4p
 LSA_HD F29 condsub4(const F29 &t) {
     F29 d;
