@@ -50,6 +50,8 @@ static int require_ready() {
 
 using namespace lsa;
 
+static void release_stage_buffers();
+
 struct lsa_bases {
     void *d_aff = nullptr;   // Aff<Fq> or Aff<Fq2> array
     size_t n = 0;
@@ -97,6 +99,7 @@ void lsa_shutdown(void) {
     if (!g.ready) return;
     (void)hipStreamSynchronize(g.stream);
     msm_release_workspace();
+    release_stage_buffers();
     (void)hipFree(g.d_result);
     (void)hipHostFree(g.h_result);
     (void)hipStreamDestroy(g.stream);
@@ -197,24 +200,48 @@ int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars, siz
 }
 
 }  // extern "C"
+// grow-only device staging buffers of the host-buffer entry points (the libff shim calls
+// lsa_g1_msm thousands of times with tiny inputs: no hipMalloc/hipFree per call)
+namespace {
+struct StageBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipStreamSynchronize(g.stream); (void)hipFree(p); }
+        p = nullptr; cap = 0;
+        size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+StageBuf g_stage_jac, g_stage_bases, g_stage_scalars;
+}  // namespace
+static void release_stage_buffers() { g_stage_jac.release(); g_stage_bases.release(); g_stage_scalars.release(); }
+
 template <class F>
 static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *out_jac, int group) {
     int rc = require_ready();
     if (rc) return rc;
     if (!out_jac || (n && (!bases_jac || !scalars))) { set_error("msm: null argument"); return LSA_ERR_INVALID; }
-    lsa_bases *b = nullptr;
-    rc = bases_create<F>(bases_jac, n, 0, group, &b);
-    if (rc) return rc;
-    void *d_sc = nullptr;
-    if (n) {
-        if (hipMalloc(&d_sc, n * sizeof(Fr)) != hipSuccess) { lsa_bases_destroy(b); set_error("msm: hipMalloc scalars failed"); return LSA_ERR_NOMEM; }
-        hipError_t e = hipMemcpyAsync(d_sc, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream);
-        if (e != hipSuccess) { (void)hipFree(d_sc); lsa_bases_destroy(b); set_error("msm: H2D failed: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
+    if (g_stage_jac.ensure(n * sizeof(Jac<F>)) || g_stage_bases.ensure(n * msm_base_bytes(group)) || g_stage_scalars.ensure(n * sizeof(Fr))) {
+        set_error("msm: staging allocation failed");
+        return LSA_ERR_NOMEM;
     }
-    rc = lsa_msm_run(b, 0, d_sc, n, out_jac);
-    if (d_sc) (void)hipFree(d_sc);
-    lsa_bases_destroy(b);
-    return rc;
+    if (n) {
+        HIPCHK(hipMemcpyAsync(g_stage_jac.p, bases_jac, n * sizeof(Jac<F>), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(g_stage_scalars.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+        rc = prepare_bases<F>((const Jac<F> *)g_stage_jac.p, g_stage_bases.p, n, g.stream);
+        if (rc) return rc;
+    }
+    rc = msm_device<F>(g_stage_bases.p, 0, (const Fr *)g_stage_scalars.p, n, (Jac<F> *)g.d_result, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(g.h_result, g.d_result, sizeof(Jac<F>), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    memcpy(out_jac, g.h_result, sizeof(Jac<F>));
+    return LSA_OK;
 }
 
 extern "C" {

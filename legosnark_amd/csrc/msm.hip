@@ -701,6 +701,7 @@ struct Workspace {
 };
 
 static Workspace g_ws;
+static Workspace g_prep_ws;   // prepare_bases staging
 // Per-stage HIP events on the library stream.  A ring of EV_POOL call slots so that
 // profiling never synchronises inside the timed loop; msm_profile_last() harvests.
 static constexpr int EV_POOL = 64;
@@ -712,6 +713,7 @@ static int g_ev_calls = 0;
 
 void msm_release_workspace() {
     g_ws.release();
+    g_prep_ws.release();
     if (g_ev_ready) { for (auto &row : g_ev) for (auto &e : row) (void)hipEventDestroy(e); g_ev_ready = false; }
 }
 void msm_profile_enable(bool on) { g_profile = on; g_ev_calls = 0; }
@@ -748,13 +750,13 @@ int prepare_bases(const Jac<F> *d_in, void *d_out, size_t n, hipStream_t st) {
         HIPCHK(hipGetLastError());
         return LSA_OK;
     }
-    Aff<F> *tmp = nullptr;
-    if (hipMalloc(&tmp, n * sizeof(Aff<F>)) != hipSuccess) { set_error("prepare_bases: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    // staging buffer for the normalised affine points: grow-only, reused across calls
+    // (every user is ordered on the same stream)
+    if (g_prep_ws.ensure(n * sizeof(Aff<F>)) != 0) { set_error("prepare_bases: staging allocation failed"); return LSA_ERR_NOMEM; }
+    Aff<F> *tmp = (Aff<F> *)g_prep_ws.ptr;
     hipLaunchKernelGGL((k_normalize<F, K>), dim3(blocks), dim3(256), 0, st, d_in, tmp, n);
     hipLaunchKernelGGL((k_convert_bases<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tmp, (typename C::Base *)d_out, n);
-    hipError_t e = hipStreamSynchronize(st);
-    (void)hipFree(tmp);
-    if (e != hipSuccess) { set_error("prepare_bases: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
+    HIPCHK(hipGetLastError());
     return LSA_OK;
 }
 template int prepare_bases<Fq>(const Jac<Fq> *, void *, size_t, hipStream_t);
