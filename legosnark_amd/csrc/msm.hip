@@ -656,18 +656,28 @@ __global__ __launch_bounds__(64) void k_fold(const typename C::Acc *__restrict__
 // have 4.  Lane q of the quad computes the q-th product of each level; results are
 // replicated with DPP quad_perm broadcasts (v_mov_b32_dpp, no LDS).  ~2.7x shorter chain.
 // ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_fold_quad(const XYZZ29 *__restrict__ window_sums, unsigned nwin, unsigned c, Jac<Fq> *__restrict__ out) {
+template <class A, class J>
+__device__ __forceinline__ void fold_quad_body(const A *__restrict__ window_sums, unsigned nwin, unsigned c, J *__restrict__ out) {
     if (threadIdx.x >= 4 || blockIdx.x != 0) return;
     const unsigned q = threadIdx.x & 3;
-    XYZZ29 r = window_sums[nwin - 1];
+    A r = window_sums[nwin - 1];
     pin_vgpr(r);
     for (int k = (int)nwin - 2; k >= 0; k--) {
         for (unsigned i = 0; i < c; i++) r = quad_dbl(r, q);
-        XYZZ29 w = window_sums[k];
+        A w = window_sums[k];
         pin_vgpr(w);
         r = quad_add(r, w, q);
     }
-    if (q == 0) *out = xyzz29_to_jac(r);
+    if (q == 0) {
+        if constexpr (std::is_same<A, XYZZ29>::value) *out = xyzz29_to_jac(r);
+        else *out = g2_to_jac(r);
+    }
+}
+__global__ __launch_bounds__(64) void k_fold_quad(const XYZZ29 *__restrict__ window_sums, unsigned nwin, unsigned c, Jac<Fq> *__restrict__ out) {
+    fold_quad_body(window_sums, nwin, c, out);
+}
+__global__ __launch_bounds__(64) void k_fold_quad_g2(const XYZZ29x2 *__restrict__ window_sums, unsigned nwin, unsigned c, Jac<Fq2> *__restrict__ out) {
+    fold_quad_body(window_sums, nwin, c, out);
 }
 
 // ------------------------------------------------------------------------------------
@@ -891,6 +901,8 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     mark();  // 5
     if constexpr (std::is_same<C, CurveG1>::value)
         hipLaunchKernelGGL(k_fold_quad, dim3(1), dim3(64), 0, st, window_sums, nwin, c, d_out);
+    else if constexpr (std::is_same<C, CurveG2>::value)
+        hipLaunchKernelGGL(k_fold_quad_g2, dim3(1), dim3(64), 0, st, window_sums, nwin, c, d_out);
     else
         hipLaunchKernelGGL((k_fold<C>), dim3(1), dim3(64), 0, st, window_sums, nwin, c, d_out);
     mark();  // 6
