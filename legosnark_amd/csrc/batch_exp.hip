@@ -4,61 +4,67 @@
 // (/root/reference/src/utils/util.h:119-134) and Interpolator::mkG1Exp/mkG2Exp
 // (/root/reference/src/prototools/interp.h:36-59):  out[i] = scalars[i] * base.
 //
-//   1 powers   pw[j] = 2^(w*j) * base                       (one lane, nwin*w doublings)
+//   1 powers   pw[j] = 2^(w*j) * base                       (one quad of lanes, nwin*w doublings)
 //   2 table    T[j][d] = d * pw[j], d < 2^w                 (one lane per entry, w steps)
-//   3 affine   batch-normalise the table (k_normalize, msm.hip)  -> 64/128 B entries, L2-resident
+//   3 affine   batch-normalise + pack the table (prepare_bases, msm.hip) -> 64/128 B entries, L2-resident
 //   4 main     one lane per scalar: Montgomery -> canonical, nwin table lookups,
-//              XYZZ mixed adds, Jacobian result (96/192 B) written coalesced.
+//              XYZZ mixed adds on 29-bit limbs, Jacobian result (96/192 B) written coalesced.
 // HBM traffic per scalar: 32 B in + 96 B (G1) / 192 B (G2) out; table reads hit L2.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "ec.h"
+#include "curves.h"
 #include "msm.h"
 
 namespace lsa {
 
-template <class F>
-__global__ __launch_bounds__(64) void k_bexp_powers(Jac<F> base, Jac<F> *__restrict__ pw, unsigned w, unsigned nwin) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Jac<F> cur = base;
+// pw[j] = 2^(w*j) * base as XYZZ; the doubling chain is sequential, so the point is shared by
+// a quad of lanes (quad29.h: 3 dependency levels per doubling instead of 9 products).
+template <class C>
+__global__ __launch_bounds__(64) void k_bexp_powers(Jac<typename C::Field> base, typename C::Acc *__restrict__ pw, unsigned w, unsigned nwin) {
+    if (threadIdx.x >= 4 || blockIdx.x != 0) return;
+    const unsigned q = threadIdx.x & 3;
+    typename C::Acc cur = C::from_jac(base);
     for (unsigned j = 0; j < nwin; j++) {
-        pw[j] = cur;
-        for (unsigned i = 0; i < w; i++) cur = jac_dbl(cur);
+        if (q == 0) pw[j] = cur;
+        for (unsigned i = 0; i < w; i++) cur = quad_dbl(cur, q);
     }
 }
 
-template <class F>
-__global__ __launch_bounds__(256) void k_bexp_table(const Jac<F> *__restrict__ pw, Jac<F> *__restrict__ tbl, unsigned w, unsigned nwin) {
+// T[j][d] = d * pw[j] (double-and-add, w steps), written as libff Jacobian for the
+// batch normalisation.
+template <class C>
+__global__ __launch_bounds__(256) void k_bexp_table(const typename C::Acc *__restrict__ pw, Jac<typename C::Field> *__restrict__ tbl,
+                                                    unsigned w, unsigned nwin) {
     unsigned g = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned per = 1u << w;
     if (g >= nwin * per) return;
     unsigned j = g >> w, d = g & (per - 1);
-    Jac<F> p = pw[j];
-    Jac<F> r = Jac<F>::inf();
+    typename C::Acc p = pw[j];
+    typename C::Acc r = C::inf();
     for (int b = (int)w - 1; b >= 0; b--) {
-        r = jac_dbl(r);
-        if ((d >> b) & 1) r = jac_add(r, p);
+        r = C::dbl(r);
+        if ((d >> b) & 1) r = C::add(r, p);
     }
-    tbl[g] = r;
+    tbl[g] = C::to_jac(r);
 }
 
-template <class F>
-__global__ __launch_bounds__(256) void k_bexp_main(const Aff<F> *__restrict__ tbl, const Fr *__restrict__ scalars, size_t n,
-                                                   unsigned w, unsigned nwin, Jac<F> *__restrict__ out) {
+template <class C>
+__global__ __launch_bounds__(256) void k_bexp_main(const typename C::Base *__restrict__ tbl, const Fr *__restrict__ scalars, size_t n,
+                                                   unsigned w, unsigned nwin, Jac<typename C::Field> *__restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t s[8];
     scalars[i].to_canonical(s);
-    XYZZ<F> acc = XYZZ<F>::inf();
+    typename C::Acc acc = C::inf();
     for (unsigned j = 0; j < nwin; j++) {
         unsigned bit = j * w;
         unsigned wd = bit >> 5, sh = bit & 31;
         uint64_t two = (uint64_t)(wd < 8 ? s[wd] : 0) | ((uint64_t)(wd + 1 < 8 ? s[wd + 1] : 0) << 32);
         uint32_t d = (uint32_t)(two >> sh) & ((1u << w) - 1);
-        if (d) acc = xyzz_madd(acc, tbl[((size_t)j << w) + d]);
+        if (d) acc = C::madd(acc, tbl[((size_t)j << w) + d], false, false);
     }
-    out[i] = xyzz_to_jac(acc);
+    out[i] = C::to_jac(acc);
 }
 
 #define HIPCHK(x)                                                                      \
@@ -76,29 +82,31 @@ unsigned batch_exp_window_bits(size_t n) { return n >= (size_t(1) << 16) ? 12 : 
 // temporary table, which is freed after a stream sync.
 template <class F>
 int batch_exp_device(const Jac<F> &base, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st) {
+    using C = typename CurveOf<F>::type;
     if (n == 0) return LSA_OK;
     const unsigned w = batch_exp_window_bits(n);
     const unsigned nwin = (254 + w - 1) / w;
     const size_t entries = (size_t)nwin << w;
-    Jac<F> *d_pw = nullptr, *d_tbl = nullptr;
-    Aff<F> *d_aff = nullptr;
-    if (hipMalloc(&d_pw, nwin * sizeof(Jac<F>)) != hipSuccess || hipMalloc(&d_tbl, entries * sizeof(Jac<F>)) != hipSuccess ||
-        hipMalloc(&d_aff, entries * sizeof(Aff<F>)) != hipSuccess) {
+    typename C::Acc *d_pw = nullptr;
+    Jac<F> *d_tbl = nullptr;
+    void *d_base = nullptr;
+    if (hipMalloc(&d_pw, nwin * sizeof(typename C::Acc)) != hipSuccess || hipMalloc(&d_tbl, entries * sizeof(Jac<F>)) != hipSuccess ||
+        hipMalloc(&d_base, entries * sizeof(typename C::Base)) != hipSuccess) {
         if (d_pw) (void)hipFree(d_pw);
         if (d_tbl) (void)hipFree(d_tbl);
         set_error("batch_exp: table allocation failed");
         return LSA_ERR_NOMEM;
     }
-    hipLaunchKernelGGL((k_bexp_powers<F>), dim3(1), dim3(64), 0, st, base, d_pw, w, nwin);
-    hipLaunchKernelGGL((k_bexp_table<F>), dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st, d_pw, d_tbl, w, nwin);
-    int rc = normalize_to_affine<F>(d_tbl, d_aff, entries, st);
+    hipLaunchKernelGGL((k_bexp_powers<C>), dim3(1), dim3(64), 0, st, base, d_pw, w, nwin);
+    hipLaunchKernelGGL((k_bexp_table<C>), dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, st, d_pw, d_tbl, w, nwin);
+    int rc = prepare_bases<F>(d_tbl, d_base, entries, st);
     if (!rc) {
-        hipLaunchKernelGGL((k_bexp_main<F>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_aff, d_scalars, n, w, nwin, d_out);
+        hipLaunchKernelGGL((k_bexp_main<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const typename C::Base *)d_base, d_scalars, n, w, nwin, d_out);
     }
     hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(d_pw);
     (void)hipFree(d_tbl);
-    (void)hipFree(d_aff);
+    (void)hipFree(d_base);
     if (rc) return rc;
     if (e != hipSuccess) { set_error("batch_exp: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
     return LSA_OK;

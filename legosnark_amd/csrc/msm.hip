@@ -34,11 +34,8 @@
 #include <type_traits>
 #include <vector>
 
-#include "ec.h"
-#include "fp29.h"
-#include "fp29x2.h"
+#include "curves.h"
 #include "glv.h"
-#include "quad29.h"
 #include "msm.h"
 
 namespace lsa {
@@ -56,83 +53,6 @@ unsigned msm_window_bits(size_t n) {
 }
 
 static inline unsigned num_windows(unsigned c) { return (255 + c - 1) / c; }
-
-// ------------------------------------------------------------------------------------
-// curve traits: which representation the bucket pipeline computes in
-// ------------------------------------------------------------------------------------
-// Generic: XYZZ over F with canonical saturated limbs (used for G2 = curve over Fq2).
-template <class F>
-struct CurveGeneric {
-    using Field = F;
-    using Base = Aff<F>;
-    using Acc = XYZZ<F>;
-    static constexpr bool GLV = false;
-    static __device__ __forceinline__ Acc inf() { return Acc::inf(); }
-    static __device__ __forceinline__ Acc madd(const Acc &a, const Base &b, bool negate, bool /*endo*/) {
-        Aff<F> q = b;
-        if (negate) q.y = q.y.neg();
-        return xyzz_madd(a, q);
-    }
-    static __device__ __forceinline__ Acc add(const Acc &a, const Acc &b) { return xyzz_add(a, b); }
-    static __device__ __forceinline__ Acc dbl(const Acc &a) { return xyzz_dbl(a); }
-    static __device__ __forceinline__ Jac<F> to_jac(const Acc &a) { return xyzz_to_jac(a); }
-    static __device__ __forceinline__ Base from_affine(const Aff<F> &a) { return a; }
-};
-// G1 on 9 x 29-bit unsaturated limbs (fp29.h); bases packed to 64 B.
-struct CurveG1 {
-    using Field = Fq;
-    using Base = AffPacked;
-    using Acc = XYZZ29;
-    static constexpr bool GLV = true;     // scalars split as k1 + k2*lambda (glv.h)
-    static __device__ __forceinline__ Acc inf() { return Acc::inf(); }
-    static __device__ __forceinline__ Acc madd(const Acc &a, const Base &b, bool negate, bool endo) {
-        Aff29 q = unpack_affine(b);
-        if (q.is_inf()) return a;
-        if (negate) q.y = sub_k<1>(F29::zero(), q.y);                  // p - y
-        if (endo) {                                                     // phi(x,y) = (beta*x, y)
-            constexpr uint32_t BETA29[9] = {0x0a337995u, 0x158d1d23u, 0x189c9b98u, 0x12fa4e45u, 0x185faadcu,
-                                            0x0176f16du, 0x0eed93bau, 0x14291140u, 0x000c0afeu};
-            q.x = mul(q.x, F29::from_limbs(BETA29));                    // [<2p; tight]
-        }
-        return xyzz29_madd(a, q);
-    }
-    static __device__ __forceinline__ Acc add(const Acc &a, const Acc &b) { return xyzz29_add(a, b); }
-    static __device__ __forceinline__ Acc dbl(const Acc &a) { return xyzz29_dbl(a); }
-    static __device__ __forceinline__ Jac<Fq> to_jac(const Acc &a) { return xyzz29_to_jac(a); }
-    static __device__ __forceinline__ Base from_affine(const Aff<Fq> &a) {
-        Base r;
-        if (a.is_inf()) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) { r.x[i] = 0; r.y[i] = 0; }
-        } else {
-            F29::from_mont256(a.x).canonical().pack256(r.x);
-            F29::from_mont256(a.y).canonical().pack256(r.y);
-        }
-        return r;
-    }
-};
-// G2 on the same 29-bit-limb field (fp29x2.h): Fq2 products with fused reductions; bases
-// packed to 128 B.  No GLV (the G2 endomorphism needs a 4-dimensional split): 16 windows.
-struct CurveG2 {
-    using Field = Fq2;
-    using Base = AffPackedG2;
-    using Acc = XYZZ29x2;
-    static constexpr bool GLV = false;
-    static __device__ __forceinline__ Acc inf() { return Acc::inf(); }
-    static __device__ __forceinline__ Acc madd(const Acc &a, const Base &b, bool negate, bool /*endo*/) {
-        Aff29x2 q = unpack_affine(b);
-        if (q.is_inf()) return a;
-        if (negate) q.y = sub_k<1>(F29x2::zero(), q.y);                // p - y per component
-        return g2_madd(a, q);
-    }
-    static __device__ __forceinline__ Acc add(const Acc &a, const Acc &b) { return g2_add(a, b); }
-    static __device__ __forceinline__ Acc dbl(const Acc &a) { return g2_dbl(a); }
-    static __device__ __forceinline__ Jac<Fq2> to_jac(const Acc &a) { return g2_to_jac(a); }
-    static __device__ __forceinline__ Base from_affine(const Aff<Fq2> &a) { return pack_affine_g2(a); }
-};
-template <class F> struct CurveOf { using type = CurveGeneric<F>; };
-template <> struct CurveOf<Fq> { using type = CurveG1; };
-template <> struct CurveOf<Fq2> { using type = CurveG2; };
 
 // ------------------------------------------------------------------------------------
 // kernel 0: Jacobian (libff layout) -> affine, per-lane Montgomery batch inversion
@@ -440,7 +360,7 @@ __global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict
 
 // ------------------------------------------------------------------------------------
 // kernel 4: bucket accumulation (one lane per bucket); heavy buckets deferred.
-// C = curve traits (CurveG1: 29-bit limbs, 64-B packed bases; CurveGeneric<Fq2>: G2).
+// C = curve traits (CurveG1: 29-bit limbs, 64-B packed bases; CurveG2: Fq2 on the same limbs, 128-B bases).
 // The next entry's point is fetched before the current mixed add is issued, so the
 // ~2 us gather latency hides under ~2300 VALU instructions of arithmetic.
 // ------------------------------------------------------------------------------------
