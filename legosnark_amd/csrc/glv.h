@@ -7,7 +7,8 @@
 // reduction and half the doubling chain of the final fold; phi costs one field product on
 // the gathered x.  The group element computed is unchanged (G1 has prime order r).
 //
-// Constants (derived and checked with oracle/pymodel: phi(Q) == lambda*Q, lattice basis by
+// Constants (derived and checked with the independent big-int model that also produces the
+// golden vectors: phi(Q) == lambda*Q, lattice basis by
 // the extended Euclidean algorithm on (r, lambda)):
 //   v1 = (a1, -|b1|), v2 = (a2, b2), det = +r;
 //   c1 = floor(k*g1 / 2^256), c2 = floor(k*g2 / 2^256), g1 = floor(b2*2^256/r), g2 = floor(|b1|*2^256/r);
