@@ -208,38 +208,42 @@ using Fq = Fp<FqParams>;
 using Fr = Fp<FrParams>;
 
 // ------------------------------------------------------------------ Fq2 = Fq[u]/(u^2+1)
-struct Fq2 {
-    Fq c0, c1;
-    static LSA_HD Fq2 zero() { return {Fq::zero(), Fq::zero()}; }
-    static LSA_HD Fq2 one() { return {Fq::one(), Fq::zero()}; }
+// Templated on the base-field representation B: Fq (libff layout, saturated limbs) for the
+// boundary / host code, Fs (fs29.h, 29-bit limbs) inside the pairing kernels.
+template <class B>
+struct Fq2T {
+    B c0, c1;
+    static LSA_HD Fq2T zero() { return {B::zero(), B::zero()}; }
+    static LSA_HD Fq2T one() { return {B::one(), B::zero()}; }
     LSA_HD bool is_zero() const { return c0.is_zero() && c1.is_zero(); }
-    LSA_HD bool operator==(const Fq2 &b) const { return c0 == b.c0 && c1 == b.c1; }
-    LSA_HD bool operator!=(const Fq2 &b) const { return !(*this == b); }
-    friend LSA_HD Fq2 operator+(const Fq2 &a, const Fq2 &b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
-    friend LSA_HD Fq2 operator-(const Fq2 &a, const Fq2 &b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
-    friend LSA_HD Fq2 operator*(const Fq2 &a, const Fq2 &b) {
-        Fq aa = a.c0 * b.c0, bb = a.c1 * b.c1;
-        Fq s = (a.c0 + a.c1) * (b.c0 + b.c1);
+    LSA_HD bool operator==(const Fq2T &b) const { return c0 == b.c0 && c1 == b.c1; }
+    LSA_HD bool operator!=(const Fq2T &b) const { return !(*this == b); }
+    friend LSA_HD Fq2T operator+(const Fq2T &a, const Fq2T &b) { return {a.c0 + b.c0, a.c1 + b.c1}; }
+    friend LSA_HD Fq2T operator-(const Fq2T &a, const Fq2T &b) { return {a.c0 - b.c0, a.c1 - b.c1}; }
+    friend LSA_HD Fq2T operator*(const Fq2T &a, const Fq2T &b) {
+        B aa = a.c0 * b.c0, bb = a.c1 * b.c1;
+        B s = (a.c0 + a.c1) * (b.c0 + b.c1);
         return {aa - bb, s - aa - bb};
     }
-    LSA_HD Fq2 sqr() const {
-        Fq m = c0 * c1;
+    LSA_HD Fq2T sqr() const {
+        B m = c0 * c1;
         return {(c0 + c1) * (c0 - c1), m + m};
     }
-    LSA_HD Fq2 neg() const { return {c0.neg(), c1.neg()}; }
-    LSA_HD Fq2 dbl() const { return {c0.dbl(), c1.dbl()}; }
-    LSA_HD Fq2 conj() const { return {c0, c1.neg()}; }
-    LSA_HD Fq2 mul_fq(const Fq &k) const { return {c0 * k, c1 * k}; }
+    LSA_HD Fq2T neg() const { return {c0.neg(), c1.neg()}; }
+    LSA_HD Fq2T dbl() const { return {c0.dbl(), c1.dbl()}; }
+    LSA_HD Fq2T conj() const { return {c0, c1.neg()}; }
+    LSA_HD Fq2T mul_fq(const B &k) const { return {c0 * k, c1 * k}; }
     // * xi, xi = 9 + u:  (9 c0 - c1) + (9 c1 + c0) u
-    LSA_HD Fq2 mul_xi() const {
-        Fq a8 = c0.dbl().dbl().dbl(), b8 = c1.dbl().dbl().dbl();
+    LSA_HD Fq2T mul_xi() const {
+        B a8 = c0.dbl().dbl().dbl(), b8 = c1.dbl().dbl().dbl();
         return {a8 + c0 - c1, b8 + c1 + c0};
     }
-    LSA_HD_NOINLINE Fq2 inverse() const {
-        Fq n = (c0.sqr() + c1.sqr()).inverse();
+    LSA_HD_NOINLINE Fq2T inverse() const {
+        B n = (c0.sqr() + c1.sqr()).inverse();
         return {c0 * n, (c1 * n).neg()};
     }
 };
+using Fq2 = Fq2T<Fq>;
 
 template <class F> struct FieldName;
 

@@ -1,0 +1,72 @@
+// legosnark_amd/csrc/fs29.h -- "strict" Fq on 9 x 29-bit limbs: the base field the pairing
+// kernels' extension tower (tower.h: Fq2T<B>, Fq6T<B>, Fq12T<B>) is instantiated on.
+//
+// fp29.h is a lazy representation whose callers track bounds by hand (the MSM formulas).
+// The tower has hundreds of additions, so here every value is kept tight and < 2p after
+// every operation: products use the carry-free 29-bit Montgomery multiplication (inputs
+// < 2p give outputs < 2p), sums and differences take one conditional subtraction of 2p
+// done with bit masks (no v_cndmask).  Equality is equality mod p.
+#pragma once
+#include "fp29.h"
+
+namespace lsa {
+
+// namespace-scope names for F29's hidden friends (usable where a member named sqr / mul hides them)
+LSA_HD F29 f29_sqr(const F29 &a) { return sqr(a); }
+LSA_HD F29 f29_mul(const F29 &a, const F29 &b) { return mul(a, b); }
+
+// tight value < 4p -> same residue, < 2p
+LSA_HD F29 condsub2(const F29 &t) {
+    F29 d;
+    int32_t c = 0;
+    uint64_t pc = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        pc += (uint64_t)F29::p(i) * 2u;
+        uint32_t pl = (i < 8) ? ((uint32_t)pc & F29::MASK) : (uint32_t)pc;
+        pc >>= 29;
+        int32_t v = (int32_t)t.l[i] - (int32_t)pl + c;
+        if (i < 8) { d.l[i] = (uint32_t)v & F29::MASK; c = v >> 29; }
+        else d.l[i] = (uint32_t)v;
+    }
+    const uint32_t keep = (uint32_t)((int32_t)d.l[8] >> 31);   // all ones if t < 2p
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = (t.l[i] & keep) | (d.l[i] & ~keep);
+    return r;
+}
+
+struct Fs {
+    F29 v;   // tight, < 2p
+    static LSA_HD Fs zero() { return {F29::zero()}; }
+    static LSA_HD Fs one() { return {F29::one()}; }
+    static LSA_HD Fs from_mont256(const Fq &x) { return {F29::from_mont256(x)}; }
+    LSA_HD Fq to_mont256() const { return v.to_mont256(); }
+    LSA_HD bool is_zero() const { return v.is_zero_mod_p(); }
+    friend LSA_HD Fs operator*(const Fs &a, const Fs &b) { return {f29_mul(a.v, b.v)}; }
+    LSA_HD Fs sqr() const { return {f29_sqr(v)}; }
+    friend LSA_HD Fs operator+(const Fs &a, const Fs &b) { return {condsub2(add_lazy(a.v, b.v).norm())}; }
+    friend LSA_HD Fs operator-(const Fs &a, const Fs &b) { return {condsub2(sub_k<2>(a.v, b.v))}; }
+    LSA_HD Fs neg() const { return {condsub2(sub_k<2>(F29::zero(), v))}; }
+    LSA_HD Fs dbl() const { return *this + *this; }
+    LSA_HD bool operator==(const Fs &b) const { return (*this - b).is_zero(); }
+    LSA_HD bool operator!=(const Fs &b) const { return !(*this == b); }
+    // a^(p-2) (Fermat)
+    LSA_HD_NOINLINE Fs inverse() const {
+        uint32_t e[8];
+        uint64_t br = 2;
+        for (int i = 0; i < 8; i++) {
+            uint64_t x = (uint64_t)FqParams::MOD[i] - br;
+            e[i] = (uint32_t)x;
+            br = (x >> 32) & 1;
+        }
+        Fs acc = one();
+        for (int i = 255; i >= 0; --i) {
+            acc = acc.sqr();
+            if ((e[i >> 5] >> (i & 31)) & 1) acc = acc * *this;
+        }
+        return acc;
+    }
+};
+
+}  // namespace lsa

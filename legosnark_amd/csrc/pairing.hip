@@ -19,30 +19,52 @@
 #include <vector>
 
 #include "ec.h"
+#include "fs29.h"
 #include "msm.h"
 #include "tower.h"
 
 namespace lsa {
 
-struct G2Proj { Fq2 X, Y, Z; };
-struct Line { Fq2 e0, eVW, eVV; };
+// The kernels compute on B = Fs (fs29.h: 9 x 29-bit limbs, carry-free Montgomery product)
+// and convert from / to libff's layout (Fq, R = 2^256) when they load inputs and store
+// results, so everything in memory stays in the C-ABI's byte layout.
+using PB = Fs;
+using P2 = Fq2T<PB>;
+using P12 = Fq12T<PB>;
+
+static __device__ __forceinline__ P2 load2(const Fq2 &v) { return {PB::from_mont256(v.c0), PB::from_mont256(v.c1)}; }
+static __device__ __noinline__ P12 load12(const Fq12 &v) {
+    P12 r;
+    const Fq *w = reinterpret_cast<const Fq *>(&v);
+    PB *o = reinterpret_cast<PB *>(&r);
+    for (int i = 0; i < 12; i++) o[i] = PB::from_mont256(w[i]);
+    return r;
+}
+static __device__ __noinline__ Fq12 store12(const P12 &v) {
+    Fq12 r;
+    Fq *w = reinterpret_cast<Fq *>(&r);
+    const PB *o = reinterpret_cast<const PB *>(&v);
+    for (int i = 0; i < 12; i++) w[i] = o[i].to_mont256();
+    return r;
+}
+
+struct G2Proj { P2 X, Y, Z; };
+struct Line { P2 e0, eVW, eVV; };
 
 // libff doubling_step_for_flipped_miller_loop
-static __device__ __noinline__ Line doubling_step(G2Proj &c) {
-    const Fq two_inv = []() { Fq t; for (int i = 0; i < 8; i++) t.l[i] = LSA_FQ_TWO_INV[i]; return t; }();
-    const Fq2 twist_b = fq2_const(LSA_TWIST_B);
-    Fq2 X = c.X, Y = c.Y, Z = c.Z;
-    Fq2 A = (X * Y).mul_fq(two_inv);
-    Fq2 B = Y.sqr();
-    Fq2 C = Z.sqr();
-    Fq2 D = C + C + C;
-    Fq2 E = twist_b * D;
-    Fq2 F = E + E + E;
-    Fq2 G = (B + F).mul_fq(two_inv);
-    Fq2 H = (Y + Z).sqr() - (B + C);
-    Fq2 I = E - B;
-    Fq2 J = X.sqr();
-    Fq2 E2 = E.sqr();
+static __device__ __noinline__ Line doubling_step(G2Proj &c, const PB &two_inv, const P2 &twist_b) {
+    P2 X = c.X, Y = c.Y, Z = c.Z;
+    P2 A = (X * Y).mul_fq(two_inv);
+    P2 B = Y.sqr();
+    P2 C = Z.sqr();
+    P2 D = C + C + C;
+    P2 E = twist_b * D;
+    P2 F = E + E + E;
+    P2 G = (B + F).mul_fq(two_inv);
+    P2 H = (Y + Z).sqr() - (B + C);
+    P2 I = E - B;
+    P2 J = X.sqr();
+    P2 E2 = E.sqr();
     c.X = A * (B - F);
     c.Y = G.sqr() - (E2 + E2 + E2);
     c.Z = B * H;
@@ -50,22 +72,22 @@ static __device__ __noinline__ Line doubling_step(G2Proj &c) {
 }
 
 // libff mixed_addition_step_for_flipped_miller_loop
-static __device__ __noinline__ Line addition_step(const Fq2 &x2, const Fq2 &y2, G2Proj &c) {
-    Fq2 X1 = c.X, Y1 = c.Y, Z1 = c.Z;
-    Fq2 D = X1 - x2 * Z1;
-    Fq2 E = Y1 - y2 * Z1;
-    Fq2 F = D.sqr();
-    Fq2 G = E.sqr();
-    Fq2 H = D * F;
-    Fq2 I = X1 * F;
-    Fq2 J = H + Z1 * G - (I + I);
+static __device__ __noinline__ Line addition_step(const P2 &x2, const P2 &y2, G2Proj &c) {
+    P2 X1 = c.X, Y1 = c.Y, Z1 = c.Z;
+    P2 D = X1 - x2 * Z1;
+    P2 E = Y1 - y2 * Z1;
+    P2 F = D.sqr();
+    P2 G = E.sqr();
+    P2 H = D * F;
+    P2 I = X1 * F;
+    P2 J = H + Z1 * G - (I + I);
     c.X = D * J;
     c.Y = E * (I - J) - (H * Y1);
     c.Z = Z1 * H;
     return {(E * x2 - D * y2).mul_xi(), D, E.neg()};
 }
 
-static __device__ __forceinline__ Fq12 apply_line(const Fq12 &f, const Line &l, const Fq &px, const Fq &py) {
+static __device__ __forceinline__ P12 apply_line(const P12 &f, const Line &l, const PB &px, const PB &py) {
     return fq12_mul_by_024(f, l.e0, l.eVW.mul_fq(py), l.eVV.mul_fq(px));
 }
 
@@ -74,26 +96,31 @@ static __device__ __forceinline__ int ate_bit(int i) {
     return (int)((LSA_ATE_LOOP_COUNT_LO >> i) & 1);
 }
 
-// precompute_G1 + precompute_G2 + miller_loop for one pair (libff layout in, Fq12 out)
-static __device__ __noinline__ Fq12 miller_one(const Jac<Fq> &P, const Jac<Fq2> &Q) {
+// precompute_G1 + precompute_G2 + miller_loop for one pair (libff layout in)
+static __device__ __noinline__ P12 miller_one(const Jac<Fq> &P, const Jac<Fq2> &Q) {
     // to_affine_coordinates(): O -> (0, 1, 0)
-    Fq px, py;
-    if (P.Z.is_zero()) { px = Fq::zero(); py = Fq::one(); }
+    PB px, py;
+    if (P.Z.is_zero()) { px = PB::zero(); py = PB::one(); }
     else {
-        Fq zi = P.Z.inverse(), zi2 = zi.sqr();
-        px = P.X * zi2; py = P.Y * (zi2 * zi);
+        PB zi = PB::from_mont256(P.Z).inverse(), zi2 = zi.sqr();
+        px = PB::from_mont256(P.X) * zi2; py = PB::from_mont256(P.Y) * (zi2 * zi);
     }
-    Fq2 qx, qy;
-    if (Q.Z.is_zero()) { qx = Fq2::zero(); qy = Fq2::one(); }
+    P2 qx, qy;
+    if (Q.Z.is_zero()) { qx = P2::zero(); qy = P2::one(); }
     else {
-        Fq2 zi = Q.Z.inverse(), zi2 = zi.sqr();
-        qx = Q.X * zi2; qy = Q.Y * (zi2 * zi);
+        P2 zi = load2(Q.Z).inverse(), zi2 = zi.sqr();
+        qx = load2(Q.X) * zi2; qy = load2(Q.Y) * (zi2 * zi);
     }
-    G2Proj R = {qx, qy, Fq2::one()};
-    Fq12 f = Fq12::one();
+    Fq ti;
+#pragma unroll
+    for (int i = 0; i < 8; i++) ti.l[i] = LSA_FQ_TWO_INV[i];
+    const PB two_inv = PB::from_mont256(ti);
+    const P2 twist_b = fq2_constT<PB>(LSA_TWIST_B);
+    G2Proj R = {qx, qy, P2::one()};
+    P12 f = P12::one();
     // bits of 6u+2 below the MSB (bit 64), MSB first
     for (int i = 63; i >= 0; --i) {
-        Line l = doubling_step(R);
+        Line l = doubling_step(R, two_inv, twist_b);
         f = fq12_sqr(f);
         f = apply_line(f, l, px, py);
         if (ate_bit(i)) {
@@ -102,9 +129,9 @@ static __device__ __noinline__ Fq12 miller_one(const Jac<Fq> &P, const Jac<Fq2> 
         }
     }
     // Q1 = pi(Q), Q2 = -pi^2(Q)   (mul_by_q on affine points: Z stays 1)
-    const Fq2 gx = fq2_const(LSA_TWIST_MUL_BY_Q_X), gy = fq2_const(LSA_TWIST_MUL_BY_Q_Y);
-    Fq2 q1x = gx * qx.conj(), q1y = gy * qy.conj();
-    Fq2 q2x = gx * q1x.conj(), q2y = (gy * q1y.conj()).neg();
+    const P2 gx = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_X), gy = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_Y);
+    P2 q1x = gx * qx.conj(), q1y = gy * qy.conj();
+    P2 q2x = gx * q1x.conj(), q2y = (gy * q1y.conj()).neg();
     Line l = addition_step(q1x, q1y, R);
     f = apply_line(f, l, px, py);
     l = addition_step(q2x, q2y, R);
@@ -112,39 +139,40 @@ static __device__ __noinline__ Fq12 miller_one(const Jac<Fq> &P, const Jac<Fq2> 
     return f;
 }
 
-static __device__ __noinline__ Fq12 exp_by_neg_z(const Fq12 &a) {
-    return fq12_pow_u64(a, LSA_FINAL_EXP_Z).unitary_inverse();
+// elt^(-z) for elt in the cyclotomic subgroup (libff alt_bn128_exp_by_neg_z: cyclotomic_exp + conj)
+static __device__ __noinline__ P12 exp_by_neg_z(const P12 &a) {
+    return fq12_cyclotomic_pow_u64(a, LSA_FINAL_EXP_Z).unitary_inverse();
 }
 
 // libff alt_bn128_final_exponentiation: first chunk (q^6-1)(q^2+1), last chunk by the
-// Fuentes-Castaneda et al. addition chain.
-static __device__ __noinline__ Fq12 final_exp_one(const Fq12 &elt) {
-    Fq12 A = elt.unitary_inverse();
-    Fq12 B = fq12_inverse(elt);
-    Fq12 C = A * B;
-    Fq12 D = fq12_frobenius<2>(C);
-    Fq12 first = D * C;
+// Fuentes-Castaneda et al. addition chain (squarings inside the chain are cyclotomic).
+static __device__ __noinline__ P12 final_exp_one(const P12 &elt) {
+    P12 A = elt.unitary_inverse();
+    P12 B = fq12_inverse(elt);
+    P12 C = A * B;
+    P12 D = fq12_frobenius<2>(C);
+    P12 first = D * C;
     A = exp_by_neg_z(first);
-    B = fq12_sqr(A);
-    C = fq12_sqr(B);
+    B = fq12_cyclotomic_sqr(A);
+    C = fq12_cyclotomic_sqr(B);
     D = C * B;
-    Fq12 E = exp_by_neg_z(D);
-    Fq12 F = fq12_sqr(E);
-    Fq12 G = exp_by_neg_z(F);
-    Fq12 H = D.unitary_inverse();
-    Fq12 I = G.unitary_inverse();
-    Fq12 J = I * E;
-    Fq12 K = J * H;
-    Fq12 L = K * B;
-    Fq12 M = K * E;
-    Fq12 N = M * first;
-    Fq12 O = fq12_frobenius<1>(L);
-    Fq12 Pp = O * N;
-    Fq12 Qq = fq12_frobenius<2>(K);
-    Fq12 Rr = Qq * Pp;
-    Fq12 S = first.unitary_inverse();
-    Fq12 T = S * L;
-    Fq12 U = fq12_frobenius<3>(T);
+    P12 E = exp_by_neg_z(D);
+    P12 F = fq12_cyclotomic_sqr(E);
+    P12 G = exp_by_neg_z(F);
+    P12 H = D.unitary_inverse();
+    P12 I = G.unitary_inverse();
+    P12 J = I * E;
+    P12 K = J * H;
+    P12 L = K * B;
+    P12 M = K * E;
+    P12 N = M * first;
+    P12 O = fq12_frobenius<1>(L);
+    P12 Pp = O * N;
+    P12 Qq = fq12_frobenius<2>(K);
+    P12 Rr = Qq * Pp;
+    P12 S = first.unitary_inverse();
+    P12 T = S * L;
+    P12 U = fq12_frobenius<3>(T);
     return U * Rr;
 }
 
@@ -152,13 +180,13 @@ __global__ __launch_bounds__(64) void k_miller(const Jac<Fq> *__restrict__ g1, c
                                                Fq12 *__restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = miller_one(g1[i], g2[i]);
+    out[i] = store12(miller_one(g1[i], g2[i]));
 }
 
 __global__ __launch_bounds__(64) void k_final_exp(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = final_exp_one(in[i]);
+    out[i] = store12(final_exp_one(load12(in[i])));
 }
 
 // out[i] = prod in[8i .. 8i+7]
@@ -166,9 +194,9 @@ __global__ __launch_bounds__(64) void k_fq12_prod8(const Fq12 *__restrict__ in, 
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t lo = i * 8;
     if (lo >= n) return;
-    Fq12 acc = in[lo];
-    for (size_t j = lo + 1; j < lo + 8 && j < n; j++) acc = acc * in[j];
-    out[i] = acc;
+    P12 acc = load12(in[lo]);
+    for (size_t j = lo + 1; j < lo + 8 && j < n; j++) acc = acc * load12(in[j]);
+    out[i] = store12(acc);
 }
 
 #define HIPCHK(x)                                                                      \
@@ -210,6 +238,6 @@ int fq12_product_device(void *d_buf, void *d_scratch, size_t n, void **result, h
     return LSA_OK;
 }
 
-size_t fq12_bytes() { return sizeof(Fq12); }
+size_t fq12_bytes() { return sizeof(Fq12); }   // libff layout in memory
 
 }  // namespace lsa
