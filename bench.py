@@ -101,6 +101,15 @@ def main():
     stages = lsa.profile_last_msm()
     lsa.profile_enable(False)
     elapsed = t1 - t0
+    # single-call latency (no overlap with a following call), for the record
+    lat = []
+    for _ in range(5):
+        barrier()
+        tl = time.perf_counter()
+        job.run(d_scalars)
+        lsa.synchronize()
+        lat.append(time.perf_counter() - tl)
+    latency_ms = sorted(lat)[len(lat) // 2] * 1e3
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -135,6 +144,9 @@ def main():
                                   "note": "254-bit field multiplications/s in k_accumulate vs the microbenchmarked "
                                           "ceiling of the 9x29-bit Montgomery product on this chip"}},
             "stage_ms": {k: round(v, 4) for k, v in stages.items() if k not in ("calls", "reserved")},
+            "single_call_latency_ms": latency_ms,
+            "pipelining": "the tail (reduce+fold) of step i runs on an internal stream and overlaps the front of "
+                          "step i+1; stage_ms are measured under that overlap; LSA_NO_OVERLAP=1 serialises",
         }
         if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "tests"))

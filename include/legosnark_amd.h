@@ -48,8 +48,14 @@ int lsa_device_count(void);
 const char *lsa_last_error(void);
 /* hipStream_t on which every kernel of this library is launched (for HIP-event timing). */
 void *lsa_stream(void);
-/* Block until all work queued on lsa_stream() has finished. */
+/* Block until all work queued by this library has finished. */
 int lsa_synchronize(void);
+/* The tail of an lsa_msm_run_async call (bucket reduction + fold) runs on an internal stream so
+ * that it overlaps the next call's front phase.  lsa_stream_join() makes lsa_stream() wait for
+ * every tail issued so far: call it before ordering foreign work (another stream's wait, a
+ * collective) after lsa_stream().  All synchronous entry points and lsa_*_sum_async join
+ * implicitly. */
+int lsa_stream_join(void);
 
 /* ---- variable-base MSM from host buffers ------------------------------------------- */
 /* out = sum_i scalars[i] * bases[i], i < n.
@@ -79,7 +85,8 @@ const void *lsa_bases_device_ptr(const lsa_bases *b);
  * (d_scalars_mont: device pointer, n x 32 B, Montgomery Fr).  out_jac is a HOST buffer
  * (96 B / 192 B); the call returns after the result has landed there. */
 int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars_mont, size_t n, void *out_jac);
-/* Same, asynchronous: result is written to the DEVICE buffer d_out_jac on lsa_stream(). */
+/* Same, asynchronous: result is written to the DEVICE buffer d_out_jac; it is ordered on
+ * lsa_stream() after lsa_stream_join() (or any synchronous call). */
 int lsa_msm_run_async(const lsa_bases *bases, size_t first, const void *d_scalars_mont, size_t n, void *d_out_jac);
 
 /* Window width (bits) the MSM uses for n pairs -- exposed for DESIGN.md / tests. */

@@ -106,6 +106,11 @@ def synchronize():
     _check(lib().lsa_synchronize())
 
 
+def stream_join():
+    """Make the library stream wait for the internally pipelined MSM tails issued so far."""
+    _check(lib().lsa_stream_join())
+
+
 def _host_ptr(a):
     assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)

@@ -108,8 +108,16 @@ void lsa_shutdown(void) {
 
 void *lsa_stream(void) { return g.ready ? (void *)g.stream : nullptr; }
 
+int lsa_stream_join(void) {
+    int rc = require_ready();
+    if (rc) return rc;
+    return msm_join(g.stream);
+}
+
 int lsa_synchronize(void) {
     int rc = require_ready();
+    if (rc) return rc;
+    rc = msm_join(g.stream);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));
     return LSA_OK;
@@ -192,6 +200,8 @@ int lsa_msm_run_async(const lsa_bases *bases, size_t first, const void *d_scalar
 int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars, size_t n, void *out_jac) {
     int rc = lsa_msm_run_async(bases, first, d_scalars, n, g.d_result);
     if (rc) return rc;
+    rc = msm_join(g.stream);
+    if (rc) return rc;
     size_t bytes = bases->group == 1 ? sizeof(Jac<Fq>) : sizeof(Jac<Fq2>);
     HIPCHK(hipMemcpyAsync(g.h_result, g.d_result, bytes, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -237,6 +247,8 @@ static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *
         if (rc) return rc;
     }
     rc = msm_device<F>(g_stage_bases.p, 0, (const Fr *)g_stage_scalars.p, n, (Jac<F> *)g.d_result, g.stream);
+    if (rc) return rc;
+    rc = msm_join(g.stream);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(g.h_result, g.d_result, sizeof(Jac<F>), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -327,12 +339,16 @@ int lsa_g1_sum_async(const void *d_pts, size_t n, void *d_out) {
     int rc = require_ready();
     if (rc) return rc;
     if (!d_out || (n && !d_pts)) { set_error("sum: null argument"); return LSA_ERR_INVALID; }
+    rc = msm_join(g.stream);
+    if (rc) return rc;
     return sum_points_device<Fq>((const Jac<Fq> *)d_pts, n, (Jac<Fq> *)d_out, g.stream);
 }
 int lsa_g2_sum_async(const void *d_pts, size_t n, void *d_out) {
     int rc = require_ready();
     if (rc) return rc;
     if (!d_out || (n && !d_pts)) { set_error("sum: null argument"); return LSA_ERR_INVALID; }
+    rc = msm_join(g.stream);
+    if (rc) return rc;
     return sum_points_device<Fq2>((const Jac<Fq2> *)d_pts, n, (Jac<Fq2> *)d_out, g.stream);
 }
 }  // extern "C"

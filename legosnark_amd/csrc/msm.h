@@ -43,6 +43,9 @@ int final_exp_device(const void *d_in_fq12, size_t n, void *d_out_fq12, hipStrea
 int fq12_product_device(void *d_buf, void *d_scratch, size_t n, void **result, hipStream_t st);
 size_t fq12_bytes();
 
+// Orders the results of earlier msm_device calls (whose tails run on an internal stream) on `st`.
+int msm_join(hipStream_t st);
+
 void msm_release_workspace();
 void msm_profile_enable(bool on);
 int msm_profile_last(float ms[LSA_MSM_STAGES]);

@@ -29,6 +29,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <type_traits>
@@ -630,8 +631,37 @@ struct Workspace {
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
 };
 
-static Workspace g_ws;
+static Workspace g_ws;        // front phase (digits .. accumulate): reused by every call, ordered on the caller's stream
 static Workspace g_prep_ws;   // prepare_bases staging
+
+// Pipelining of back-to-back MSMs: the tail (bucket reduction + fold, ~0.8 ms of pure latency
+// on a nearly idle chip) runs on an internal stream, so it overlaps the next call's
+// throughput-bound front (sort + accumulate).  The buffers the tail reads (buckets, wave
+// partials, window sums) are double-buffered per call parity and guarded by events; results
+// become ordered on the caller's stream again at msm_join() (every synchronous entry point and
+// lsa_stream_join() do that).  LSA_NO_OVERLAP=1 runs everything on the caller's stream.
+struct TailBuf {
+    Workspace ws;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+};
+static TailBuf g_tail[2];
+static hipStream_t g_tail_stream = nullptr;
+static hipEvent_t g_front_done = nullptr, g_join_ev = nullptr;
+static unsigned g_parity = 0;
+static bool g_tail_dirty = false;
+static int g_overlap = -1;
+
+int msm_join(hipStream_t st) {
+    if (g_tail_dirty) {
+        if (hipEventRecord(g_join_ev, g_tail_stream) != hipSuccess || hipStreamWaitEvent(st, g_join_ev, 0) != hipSuccess) {
+            set_error("msm_join: stream wait failed");
+            return LSA_ERR_HIP;
+        }
+        g_tail_dirty = false;
+    }
+    return LSA_OK;
+}
 // Per-stage HIP events on the library stream.  A ring of EV_POOL call slots so that
 // profiling never synchronises inside the timed loop; msm_profile_last() harvests.
 static constexpr int EV_POOL = 64;
@@ -642,6 +672,12 @@ static bool g_profile = false;
 static int g_ev_calls = 0;
 
 void msm_release_workspace() {
+    if (g_tail_stream) (void)hipStreamSynchronize(g_tail_stream);
+    for (auto &t : g_tail) { t.ws.release(); if (t.done) (void)hipEventDestroy(t.done); t.done = nullptr; t.pending = false; }
+    if (g_front_done) { (void)hipEventDestroy(g_front_done); g_front_done = nullptr; }
+    if (g_join_ev) { (void)hipEventDestroy(g_join_ev); g_join_ev = nullptr; }
+    if (g_tail_stream) { (void)hipStreamDestroy(g_tail_stream); g_tail_stream = nullptr; }
+    g_tail_dirty = false;
     g_ws.release();
     g_prep_ws.release();
     if (g_ev_ready) { for (auto &row : g_ev) for (auto &e : row) (void)hipEventDestroy(e); g_ev_ready = false; }
@@ -711,6 +747,8 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     using A = typename C::Acc;
     const typename C::Base *d_bases = (const typename C::Base *)d_bases_v + first;
     if (n == 0) {
+        int jr = msm_join(st);
+        if (jr) return jr;
         Jac<F> inf = Jac<F>::inf();
         HIPCHK(hipMemcpyAsync(d_out, &inf, sizeof inf, hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -751,13 +789,31 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     size_t o_thist = carve((size_t)nb * ntiles * 2);
     size_t o_tbase = carve((size_t)nb * ntiles * 4);
     size_t o_entries = carve(ne * 4);
-    size_t o_buckets = carve((size_t)nb * ACC_SPLIT * sizeof(A));
     size_t o_heavy = carve((size_t)max_heavy * 4);
     size_t o_choff = carve((size_t)(max_heavy + 1) * 4);
     size_t o_hpart = carve(max_chunks * sizeof(A));
-    size_t o_wave = carve((size_t)nwin * wpw * 2 * sizeof(A));
-    size_t o_win = carve((size_t)nwin * sizeof(A));
     if (g_ws.ensure(off) != 0) { set_error("msm: workspace allocation of %zu bytes failed", off); return LSA_ERR_NOMEM; }
+    // tail buffers of this call parity
+    if (g_overlap < 0) g_overlap = getenv("LSA_NO_OVERLAP") ? 0 : 1;
+    if (!g_tail[0].done) {
+        for (auto &t : g_tail) HIPCHK(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&g_front_done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&g_join_ev, hipEventDisableTiming));
+        if (g_overlap) HIPCHK(hipStreamCreateWithFlags(&g_tail_stream, hipStreamNonBlocking));
+    }
+    hipStream_t tail = g_overlap ? g_tail_stream : st;
+    TailBuf &tb = g_tail[g_parity];
+    size_t toff = 0;
+    auto tcarve = [&](size_t bytes) { size_t o = toff; toff = align_up(toff + bytes, 256); return o; };
+    size_t o_buckets = tcarve((size_t)nb * ACC_SPLIT * sizeof(A));
+    size_t o_wave = tcarve((size_t)nwin * wpw * 2 * sizeof(A));
+    size_t o_win = tcarve((size_t)nwin * sizeof(A));
+    if (tb.pending) {
+        if (toff > tb.ws.cap) HIPCHK(hipEventSynchronize(tb.done));   // about to reallocate: the old tail must be finished
+        HIPCHK(hipStreamWaitEvent(st, tb.done, 0));                     // the front may not overwrite buckets a tail still reads
+    }
+    if (tb.ws.ensure(toff) != 0) { set_error("msm: tail workspace allocation of %zu bytes failed", toff); return LSA_ERR_NOMEM; }
+    char *tws = (char *)tb.ws.ptr;
     char *ws = (char *)g_ws.ptr;
     uint32_t *hist = (uint32_t *)(ws + o_hist);
     uint32_t *heavy_count = hist + nb;
@@ -770,12 +826,12 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     uint16_t *tile_hist = (uint16_t *)(ws + o_thist);
     uint32_t *tile_base = (uint32_t *)(ws + o_tbase);
     uint32_t *entries = (uint32_t *)(ws + o_entries);
-    A *buckets = (A *)(ws + o_buckets);
+    A *buckets = (A *)(tws + o_buckets);
     uint32_t *heavy_list = (uint32_t *)(ws + o_heavy);
     uint32_t *chunk_off = (uint32_t *)(ws + o_choff);
     A *hpart = (A *)(ws + o_hpart);
-    A *wave_out = (A *)(ws + o_wave);
-    A *window_sums = (A *)(ws + o_win);
+    A *wave_out = (A *)(tws + o_wave);
+    A *window_sums = (A *)(tws + o_win);
 
     if (g_profile && !g_ev_ready) {
         for (auto &row : g_ev) for (auto &e : row) HIPCHK(hipEventCreate(&e));
@@ -783,9 +839,9 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     }
     int evi = 0;
     const int evslot = g_ev_calls % EV_POOL;
-    auto mark = [&]() { if (g_profile) (void)hipEventRecord(g_ev[evslot][evi++], st); };
+    auto mark = [&](hipStream_t s_) { if (g_profile) (void)hipEventRecord(g_ev[evslot][evi++], s_); };
 
-    mark();  // 0
+    mark(st);  // 0
     HIPCHK(hipMemsetAsync(heavy_count, 0, 4, st));
     HIPCHK(hipMemsetAsync(bin_count, 0, (size_t)3 * SIZE_BINS * 4, st));
     static bool lds_attr_set = false;
@@ -797,13 +853,13 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     hipLaunchKernelGGL((k_digits<C::GLV>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, c, nwin, digits);
     hipLaunchKernelGGL(k_rank, dim3(ntiles, nwin), dim3(1024), (size_t)B * 2, st, digits, nv, B, ntiles, rank, tile_hist);
     hipLaunchKernelGGL(k_tile_scan, dim3((nb + 255) / 256), dim3(256), 0, st, tile_hist, B, ntiles, nb, tile_base, hist);
-    mark();  // 1
+    mark(st);  // 1
     hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(256), 0, st, hist, nb, bsum);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bsum, scan_blocks);
     hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, hist, bsum, nb, offs);
-    mark();  // 2
+    mark(st);  // 2
     hipLaunchKernelGGL(k_scatter, dim3(ntiles, nwin), dim3(1024), (size_t)B * 4, st, digits, rank, offs, tile_base, nv, n, B, ntiles, entries);
-    mark();  // 3
+    mark(st);  // 3
     {
         const unsigned sb = (nb + 2047) / 2048;
         hipLaunchKernelGGL((k_size_hist<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_count);
@@ -815,17 +871,23 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     hipLaunchKernelGGL((k_accumulate_heavy<C>), dim3(4096), dim3(64), 0, st, d_bases, entries, offs, hist,
                        heavy_list, heavy_count, chunk_off, hpart);
     hipLaunchKernelGGL((k_heavy_finish<C>), dim3(256), dim3(64), 0, st, heavy_list, heavy_count, chunk_off, hpart, buckets);
-    mark();  // 4
-    hipLaunchKernelGGL((k_reduce1<C>), dim3(nwin * wpw), dim3(64), 0, st, buckets, B, L, logL, wpw, wave_out);
-    hipLaunchKernelGGL((k_reduce2<C>), dim3(nwin), dim3(64), 0, st, wave_out, wpw, logL + 6, window_sums);
-    mark();  // 5
+    mark(st);  // 4
+    if (tail != st) {
+        HIPCHK(hipEventRecord(g_front_done, st));
+        HIPCHK(hipStreamWaitEvent(tail, g_front_done, 0));
+    }
+    hipLaunchKernelGGL((k_reduce1<C>), dim3(nwin * wpw), dim3(64), 0, tail, buckets, B, L, logL, wpw, wave_out);
+    hipLaunchKernelGGL((k_reduce2<C>), dim3(nwin), dim3(64), 0, tail, wave_out, wpw, logL + 6, window_sums);
+    mark(tail);  // 5
     if constexpr (std::is_same<C, CurveG1>::value)
-        hipLaunchKernelGGL(k_fold_quad, dim3(1), dim3(64), 0, st, window_sums, nwin, c, d_out);
-    else if constexpr (std::is_same<C, CurveG2>::value)
-        hipLaunchKernelGGL(k_fold_quad_g2, dim3(1), dim3(64), 0, st, window_sums, nwin, c, d_out);
+        hipLaunchKernelGGL(k_fold_quad, dim3(1), dim3(64), 0, tail, window_sums, nwin, c, d_out);
     else
-        hipLaunchKernelGGL((k_fold<C>), dim3(1), dim3(64), 0, st, window_sums, nwin, c, d_out);
-    mark();  // 6
+        hipLaunchKernelGGL(k_fold_quad_g2, dim3(1), dim3(64), 0, tail, window_sums, nwin, c, d_out);
+    mark(tail);  // 6
+    HIPCHK(hipEventRecord(tb.done, tail));
+    tb.pending = true;
+    g_tail_dirty = (tail != st);
+    g_parity ^= 1;
     HIPCHK(hipGetLastError());
     if (g_profile) g_ev_calls++;
     return LSA_OK;

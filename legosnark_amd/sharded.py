@@ -75,6 +75,8 @@ def make_gpu_sharded(lsa, group, bases_handle, world, rank, dist=None):
 
     def local_msm(d_scalars, d_out):
         bases_handle.msm_async(d_scalars, d_out)
+        if world > 1:
+            lsa.stream_join()      # the partial must be ordered on the library stream before the collective
 
     def fold(gathered, n, d_total):
         lsa.sum_async(group, gathered, n, d_total)

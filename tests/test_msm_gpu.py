@@ -186,3 +186,31 @@ def test_sharded_path_on_one_gpu_with_virtual_peer(lsa):
     want = o.multi_exp("g1", bases, sc, chunks=2, mode="multi_exp")     # libff chunked sum
     assert canon("g1", got) == canon("g1", want)
     B.close()
+
+
+def test_pipelined_async_calls_with_changing_sizes(lsa):
+    """Back-to-back lsa_msm_run_async calls overlap one call's tail (reduce + fold, internal
+    stream) with the next call's front.  Results must not depend on that: different sizes
+    (different workspace layouts) and output slots, checked against synchronous runs."""
+    import torch
+    n = 20000
+    bases = o.arith_bases("g1", 777, 12345, n)
+    B = lsa.Bases("g1", bases)
+    sizes = [n, 37, 4096, 1, 9000, 12, 20000, 300, 1025, 5, 16384, 2]
+    scs = []
+    for i, m in enumerate(sizes):
+        sc, _ = o.random_scalars(m, seed=500 + i)
+        scs.append(torch.from_numpy(sc.view(np.int64)).to("cuda:0"))
+    outs = torch.zeros((len(sizes), 12), dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for i, m in enumerate(sizes):
+            B.msm_async(scs[i], outs[i], n=m)
+    lsa.synchronize()
+    got = outs.cpu().numpy().view(np.uint64)
+    for i, m in enumerate(sizes):
+        want = B.msm(scs[i], n=m)
+        assert canon("g1", got[i]) == canon("g1", want), (i, m)
+        ref = o.multi_exp("g1", bases[:m], scs[i].cpu().numpy().view(np.uint64), mode="mixed")
+        assert canon("g1", got[i]) == canon("g1", ref), (i, m)
+    B.close()
