@@ -55,13 +55,21 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # debug hooks to exercise the multi-process path on a one-GPU box: every rank on cuda:0 and
+    # a gloo collective (default: one rank per GPU, backend "nccl" = RCCL over xGMI)
+    if os.environ.get("LSA_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("LSA_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     lsa.init(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     n = 1 << args.log2n
     # ---- synthetic workload, generated on the GPU by the product's own batch_exp kernel:

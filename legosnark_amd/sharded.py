@@ -53,12 +53,20 @@ class ShardedMSM:
         if self.stream is not None:
             cur = self.torch.cuda.current_stream()
             cur.wait_stream(self.stream)            # partial is ready
-            self.dist.all_gather_into_tensor(self.gathered.view(-1), self.partial)
+            self._all_gather()
             self.stream.wait_stream(cur)            # gathered is ready
         else:
-            self.dist.all_gather_into_tensor(self.gathered.view(-1), self.partial)
+            self._all_gather()
         self.fold(self.gathered, self.world, self.total)
         return self.total
+
+    def _all_gather(self):
+        try:
+            self.dist.all_gather_into_tensor(self.gathered.view(-1), self.partial)
+        except (RuntimeError, NotImplementedError):
+            # backends without the tensor form (gloo): list form, same data movement
+            parts = [self.gathered[i] for i in range(self.world)]
+            self.dist.all_gather(parts, self.partial)
 
     def result_host(self, d_result):
         if self.stream is not None:
