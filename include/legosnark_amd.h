@@ -127,6 +127,10 @@ int lsa_miller_loop(const void *g1_jac, const void *g2_jac, size_t n, void *out_
 /* out = prod_i miller_loop(P_i, Q_i) (one Fq12, HOST): n = 2 is libff double_miller_loop
  * (src/gadgets/subspace.cc:147-163, src/gadgets/lipmaa.cc:187-207). Host pointers. */
 int lsa_miller_loop_product(const void *g1_jac, const void *g2_jac, size_t n, void *out_fq12);
+/* out = prod_i in[i] (one Fq12, HOST; 1 for n = 0): the GT/Fqk operator* chain of the verifiers
+ * (src/gadgets/subspace.cc:163-166, src/gadgets/poly.h:108-110) and the fold of the per-GPU
+ * partial products when a pairing batch is split across ranks.  Host pointers. */
+int lsa_fq12_product(const void *in_fq12, size_t n, void *out_fq12);
 /* out[i] = final_exponentiation(in[i]): replaces alt_bn128_pp::final_exponentiation
  * (src/utils/globl.h:103, src/gadgets/subspace.cc:166, src/gadgets/poly.h:110,122). */
 int lsa_final_exponentiation(const void *in_fq12, size_t n, void *out_fq12, int on_device);

@@ -75,6 +75,7 @@ def lib():
         L.lsa_miller_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.lsa_miller_loop_product.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.lsa_pairing_product.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.lsa_fq12_product.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.lsa_final_exponentiation.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         _lib = L
     return _lib
@@ -256,6 +257,14 @@ def pairing_product(g1, g2):
     g1, g2 = _pairs(g1, g2)
     out = np.zeros(48, dtype=np.uint64)
     _check(lib().lsa_pairing_product(_host_ptr(g1), _host_ptr(g2), len(g1), _host_ptr(out)))
+    return out
+
+
+def fq12_product(f):
+    """prod_i f[i] -> (48,) uint64 (Fq12 one for an empty batch)."""
+    f = np.ascontiguousarray(f, dtype=np.uint64).reshape(-1, 48)
+    out = np.zeros(48, dtype=np.uint64)
+    _check(lib().lsa_fq12_product(_host_ptr(f), len(f), _host_ptr(out)))
     return out
 
 

@@ -424,6 +424,26 @@ int lsa_miller_loop_product(const void *g1, const void *g2, size_t n, void *out)
 int lsa_pairing_product(const void *g1, const void *g2, size_t n, void *out) {
     return miller_product_host(g1, g2, n, out, true);
 }
+int lsa_fq12_product(const void *in, size_t n, void *out) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (!out || (n && !in)) { set_error("fq12_product: null argument"); return LSA_ERR_INVALID; }
+    if (n == 0) {
+        Fq12 one = Fq12::one();
+        memcpy(out, &one, sizeof one);
+        return LSA_OK;
+    }
+    DevBuf d_f, d_s;
+    void *res = nullptr;
+    if (d_f.alloc(n * fq12_bytes()) || d_s.alloc(((n + 7) / 8) * fq12_bytes())) { set_error("fq12_product: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    HIPCHK(hipMemcpyAsync(d_f.p, in, n * fq12_bytes(), hipMemcpyHostToDevice, g.stream));
+    rc = fq12_product_device(d_f.p, d_s.p, n, &res, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(g.h_result, res, fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    memcpy(out, g.h_result, fq12_bytes());
+    return LSA_OK;
+}
 int lsa_final_exponentiation(const void *in, size_t n, void *out, int on_device) {
     int rc = require_ready();
     if (rc) return rc;

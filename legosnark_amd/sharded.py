@@ -90,3 +90,45 @@ def make_gpu_sharded(lsa, group, bases_handle, world, rank, dist=None):
         lsa.sum_async(group, gathered, n, d_total)
 
     return ShardedMSM(group, world, rank, local_msm, fold, dev, dist=dist, stream=ext)
+
+
+class ShardedPairingProduct:
+    """final_exponentiation(prod_i miller_loop(P_i, Q_i)) with the batch split over ranks
+    ("Pairings"): rank r runs the Miller loops of its contiguous slice
+    and multiplies them locally, the 384-byte Fq12 partial products are all-gathered, every
+    rank multiplies the `world` partials in rank order and runs the one final exponentiation.
+    Fq12 multiplication is commutative, so the GT value equals the 1-GPU value bit for bit.
+
+    `local_product(g1, g2)` -> (48,) uint64 partial; `product(f)` -> (48,) uint64 product of
+    the rows of f; `final_exp(f)` -> (48,) uint64.  The defaults are the HIP library's
+    lsa_miller_loop_product / lsa_fq12_product / lsa_final_exponentiation."""
+
+    def __init__(self, world, rank, local_product, product, final_exp, dist=None, device="cpu"):
+        import torch
+        self.torch = torch
+        self.world, self.rank = world, rank
+        self.local_product, self.product, self.final_exp = local_product, product, final_exp
+        self.dist = dist
+        self.device = device
+
+    def run(self, g1, g2):
+        g1 = np.ascontiguousarray(g1, dtype=np.uint64).reshape(-1, 12)
+        g2 = np.ascontiguousarray(g2, dtype=np.uint64).reshape(-1, 24)
+        if len(g1) != len(g2):
+            raise ValueError("need as many G1 as G2 points")
+        lo, hi = shard_range(len(g1), self.world, self.rank)
+        partial = self.local_product(g1[lo:hi], g2[lo:hi])     # Fq12 one for an empty slice
+        if self.world > 1:
+            t = self.torch.from_numpy(partial.view(np.int64).copy()).to(self.device)
+            parts = [self.torch.empty_like(t) for _ in range(self.world)]
+            self.dist.all_gather(parts, t)
+            gathered = np.stack([p.cpu().numpy().view(np.uint64) for p in parts])
+            partial = self.product(gathered)
+        return self.final_exp(partial)
+
+
+def make_gpu_sharded_pairing(lsa, world, rank, dist=None):
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device()) if (dist is not None and dist.get_backend() == "nccl") else "cpu"
+    return ShardedPairingProduct(world, rank, lsa.miller_loop_product, lsa.fq12_product,
+                                 lambda f: lsa.final_exponentiation(f)[0], dist=dist, device=dev)

@@ -236,6 +236,21 @@ def fq12_one():
     return r
 
 
+def fq12_mul(a, b):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    r = np.zeros(48, dtype=np.uint64)
+    lib().ofq12_mul(_p(r), _p(a), _p(b))
+    return r
+
+
+def fq12_product(fs):
+    acc = fq12_one()
+    for f in np.asarray(fs, dtype=np.uint64).reshape(-1, 48):
+        acc = fq12_mul(acc, f)
+    return acc
+
+
 def fq12_to_model(f):
     """libff tower limbs (48,) Montgomery -> model's 6 Fp2 poly coefficients (canonical)."""
     f = np.asarray(f, dtype=np.uint64).reshape(12, 4)

@@ -87,3 +87,38 @@ def test_batched_planted_product_256(lsa):
     # break the relation -> not one
     qs2 = qs.copy(); qs2[0] = qs[1]
     assert not np.array_equal(lsa.pairing_product(ps, qs2), o.fq12_one())
+
+
+@pytest.mark.parametrize("n", [0, 1, 8, 9, 77])
+def test_fq12_product_vs_oracle(lsa, n):
+    ps = o.arith_bases("g1", 5, 3, max(n, 1))[:n]
+    qs = o.arith_bases("g2", 9, 2, max(n, 1))[:n]
+    fs = o.miller_loop_batch(ps, qs) if n else np.zeros((0, 48), np.uint64)
+    assert np.array_equal(lsa.fq12_product(fs), o.fq12_product(fs))
+
+
+def test_sharded_pairing_product_two_ranks_on_one_gpu(lsa):
+    """SURVEY.md section 8e, pairings: split the batch over ranks, all-gather the 384-byte
+    partial products, multiply, one final exponentiation.  Both ranks run here in turn (the
+    collective is replaced by a hand-over), the result must equal the unsplit GT value."""
+    from legosnark_amd import sharded
+    n = 13
+    ps = o.arith_bases("g1", 21, 4, n)
+    qs = o.arith_bases("g2", 8, 15, n)
+    partials = []
+    for r in range(2):
+        lo, hi = sharded.shard_range(n, 2, r)
+        partials.append(lsa.miller_loop_product(ps[lo:hi], qs[lo:hi]))
+
+    class FakeDist:
+        def get_backend(self):
+            return "gloo"
+
+        def all_gather(self, parts, t):
+            import torch
+            for i in range(2):
+                parts[i].copy_(torch.from_numpy(partials[i].view(np.int64)))
+
+    for r in range(2):
+        job = sharded.make_gpu_sharded_pairing(lsa, 2, r, dist=FakeDist())
+        assert np.array_equal(job.run(ps, qs), o.pairing_product(ps, qs))

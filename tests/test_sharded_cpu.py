@@ -79,3 +79,36 @@ def test_sharded_msm_world2_gloo(group, n):
         assert p.exitcode == 0
     results = sorted(q.get(timeout=5) for _ in range(2))
     assert results == [(0, True), (1, True)]
+
+
+def _pairing_worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ps = o.arith_bases("g1", 11, 5, n)
+        qs = o.arith_bases("g2", 7, 3, n)
+        job = sharded.ShardedPairingProduct(
+            world, rank,
+            local_product=lambda a, b: o.fq12_product(o.miller_loop_batch(a, b)),
+            product=o.fq12_product, final_exp=o.final_exponentiation, dist=dist)
+        got = job.run(ps, qs)
+        want = o.pairing_product(ps, qs)
+        q.put((rank, bool((got == want).all())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [5, 1])
+def test_sharded_pairing_product_world2_gloo(n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pairing_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    results = sorted(q.get(timeout=5) for _ in range(2))
+    assert results == [(0, True), (1, True)]
