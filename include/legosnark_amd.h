@@ -117,6 +117,23 @@ int lsa_g2_batch_exp(const void *base_jac, const void *scalars_mont, size_t n, v
 int lsa_g1_sum_async(const void *d_pts_jac, size_t n, void *d_out_jac);
 int lsa_g2_sum_async(const void *d_pts_jac, size_t n, void *d_out_jac);
 
+/* ---- variable-base batch scalar multiplication / sparse matrix in the exponent ---------- */
+/* out[i] = scalars[i] * pts[i], i < n: the independent 254-bit scalar multiplications of
+ * CPlink key generation -- `acc*one` and the one- and two-term multi_exp calls of sparsemexpG
+ * (src/utils/sparsemexp.h:62-90) -- and of init_as_random-style input generation
+ * (src/examples/cplink.cc:51-58) when the bases differ.  pts: libff G1 (96 B), scalars: Fr
+ * (32 B), out: libff G1.  on_device != 0: device pointers, else host pointers. */
+int lsa_g1_scalar_mul_batch(const void *pts_jac, const void *scalars_mont, size_t n, void *out_jac, int on_device);
+/* mtxmultiexp(out, exps, M) for a column-major sparse matrix of G1 elements
+ * (src/gadgets/subspace.cc:18-25 -> simplesparsemexp, src/utils/sparsemexp.cc:15-24):
+ *   out[j] = sum_{e = col_ptr[j]}^{col_ptr[j+1]-1} exps[rows[e]] * vals[e],   j < ncols.
+ * CSC layout: vals (nnz x 96 B libff G1) and rows (nnz x u32, the CoeffPos::pos of
+ * src/utils/matrix.h:35-42) ordered by column, col_ptr (ncols+1 x u64, col_ptr[0] = 0,
+ * col_ptr[ncols] = nnz).  exps: nrows x Fr.  out: ncols x libff G1 (infinity for an empty
+ * column).  Host pointers.  Row indices >= nrows are rejected (LSA_ERR_INVALID). */
+int lsa_g1_sparse_matrix_msm(const void *vals_jac, const uint32_t *rows, const uint64_t *col_ptr, size_t ncols,
+                             const void *exps_mont, size_t nrows, void *out_jac);
+
 /* ---- pairing ---------------------------------------------------------------------------- */
 /* out[i] = miller_loop(precompute_G1(P_i), precompute_G2(Q_i)), i < n: replaces libff
  * alt_bn128_pp::precompute_G1 / precompute_G2 / miller_loop (src/utils/globl.h:96-102,

@@ -72,6 +72,8 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         for name in ("lsa_g1_sum_async", "lsa_g2_sum_async"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.lsa_g1_scalar_mul_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.lsa_g1_sparse_matrix_msm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         L.lsa_miller_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.lsa_miller_loop_product.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.lsa_pairing_product.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -219,6 +221,40 @@ def batch_exp(group, base, scalars, out=None):
         import torch
         out = torch.empty((n, w), dtype=torch.int64, device=scalars.device)
     _check(fn(_host_ptr(base), _ptr(scalars), n, _ptr(out), 1))
+    return out
+
+
+def scalar_mul_batch(pts, scalars, out=None):
+    """out[i] = scalars[i] * pts[i] on G1 (variable base).  numpy in -> numpy out (host);
+    torch CUDA tensors in -> torch CUDA tensor out (device)."""
+    if isinstance(pts, np.ndarray):
+        pts = np.ascontiguousarray(pts, dtype=np.uint64).reshape(-1, 12)
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+        if len(pts) != len(scalars):
+            raise ValueError("need as many scalars as points")
+        out = np.zeros_like(pts)
+        _check(lib().lsa_g1_scalar_mul_batch(_host_ptr(pts), _host_ptr(scalars), len(pts), _host_ptr(out), 0))
+        return out
+    n = pts.numel() * pts.element_size() // 96
+    if out is None:
+        import torch
+        out = torch.empty((n, 12), dtype=torch.int64, device=pts.device)
+    _check(lib().lsa_g1_scalar_mul_batch(_ptr(pts), _ptr(scalars), n, _ptr(out), 1))
+    return out
+
+
+def sparse_matrix_msm(vals, rows, col_ptr, exps):
+    """mtxmultiexp on a CSC matrix of G1 elements: out[j] = sum_e exps[rows[e]] * vals[e]."""
+    vals = np.ascontiguousarray(vals, dtype=np.uint64).reshape(-1, 12)
+    rows = np.ascontiguousarray(rows, dtype=np.uint32)
+    col_ptr = np.ascontiguousarray(col_ptr, dtype=np.uint64)
+    exps = np.ascontiguousarray(exps, dtype=np.uint64).reshape(-1, 4)
+    ncols = len(col_ptr) - 1
+    if ncols < 0 or len(vals) != len(rows) or (ncols >= 0 and int(col_ptr[-1]) != len(vals)):
+        raise ValueError("inconsistent CSC arrays")
+    out = np.zeros((ncols, 12), dtype=np.uint64)
+    _check(lib().lsa_g1_sparse_matrix_msm(_host_ptr(vals), _host_ptr(rows), _host_ptr(col_ptr), ncols,
+                                          _host_ptr(exps), len(exps), _host_ptr(out)))
     return out
 
 

@@ -353,13 +353,76 @@ int lsa_g2_sum_async(const void *d_pts, size_t n, void *d_out) {
 }
 }  // extern "C"
 
-// ---------------------------------------------------------------- pairing
 namespace {
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
     int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1) == hipSuccess ? 0 : -1; }
 };
+}  // namespace
+
+// ---------------------------------------------------------------- variable-base scalar mul / sparse matrix
+extern "C" {
+int lsa_g1_scalar_mul_batch(const void *pts_jac, const void *scalars, size_t n, void *out_jac, int on_device) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (n == 0) return LSA_OK;
+    if (!pts_jac || !scalars || !out_jac) { set_error("scalar_mul_batch: null argument"); return LSA_ERR_INVALID; }
+    rc = msm_join(g.stream);
+    if (rc) return rc;
+    if (on_device) return g1_scalar_mul_device((const Jac<Fq> *)pts_jac, (const Fr *)scalars, nullptr, n, (Jac<Fq> *)out_jac, g.stream);
+    DevBuf d_p, d_s, d_o;
+    if (d_p.alloc(n * sizeof(Jac<Fq>)) || d_s.alloc(n * sizeof(Fr)) || d_o.alloc(n * sizeof(Jac<Fq>))) {
+        set_error("scalar_mul_batch: hipMalloc failed");
+        return LSA_ERR_NOMEM;
+    }
+    HIPCHK(hipMemcpyAsync(d_p.p, pts_jac, n * sizeof(Jac<Fq>), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(d_s.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    rc = g1_scalar_mul_device((const Jac<Fq> *)d_p.p, (const Fr *)d_s.p, nullptr, n, (Jac<Fq> *)d_o.p, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpy(out_jac, d_o.p, n * sizeof(Jac<Fq>), hipMemcpyDeviceToHost));
+    return LSA_OK;
+}
+
+int lsa_g1_sparse_matrix_msm(const void *vals_jac, const uint32_t *rows, const uint64_t *col_ptr, size_t ncols,
+                             const void *exps, size_t nrows, void *out_jac) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (ncols == 0) return LSA_OK;
+    if (!col_ptr || !out_jac) { set_error("sparse_matrix_msm: null argument"); return LSA_ERR_INVALID; }
+    const uint64_t nnz = col_ptr[ncols];
+    if (col_ptr[0] != 0) { set_error("sparse_matrix_msm: col_ptr[0] must be 0"); return LSA_ERR_INVALID; }
+    for (size_t j = 0; j < ncols; j++)
+        if (col_ptr[j] > col_ptr[j + 1]) { set_error("sparse_matrix_msm: col_ptr not monotone at column %zu", j); return LSA_ERR_INVALID; }
+    if (nnz && (!vals_jac || !rows || !exps)) { set_error("sparse_matrix_msm: null argument"); return LSA_ERR_INVALID; }
+    for (uint64_t e = 0; e < nnz; e++)
+        if (rows[e] >= nrows) { set_error("sparse_matrix_msm: row index %u out of range (%zu rows)", rows[e], nrows); return LSA_ERR_INVALID; }
+    rc = msm_join(g.stream);
+    if (rc) return rc;
+    DevBuf d_v, d_r, d_c, d_e, d_items, d_o;
+    if (d_v.alloc(nnz * sizeof(Jac<Fq>)) || d_r.alloc(nnz * sizeof(uint32_t)) || d_c.alloc((ncols + 1) * sizeof(uint64_t)) ||
+        d_e.alloc(nrows * sizeof(Fr)) || d_items.alloc(nnz * sizeof(Jac<Fq>)) || d_o.alloc(ncols * sizeof(Jac<Fq>))) {
+        set_error("sparse_matrix_msm: hipMalloc failed");
+        return LSA_ERR_NOMEM;
+    }
+    if (nnz) {
+        HIPCHK(hipMemcpyAsync(d_v.p, vals_jac, nnz * sizeof(Jac<Fq>), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(d_r.p, rows, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(d_e.p, exps, nrows * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    }
+    HIPCHK(hipMemcpyAsync(d_c.p, col_ptr, (ncols + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+    rc = g1_scalar_mul_device((const Jac<Fq> *)d_v.p, (const Fr *)d_e.p, (const uint32_t *)d_r.p, nnz, (Jac<Fq> *)d_items.p, g.stream);
+    if (rc) return rc;
+    rc = g1_column_sums_device((const Jac<Fq> *)d_items.p, (const uint64_t *)d_c.p, ncols, (Jac<Fq> *)d_o.p, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(out_jac, d_o.p, ncols * sizeof(Jac<Fq>), hipMemcpyDeviceToHost));
+    return LSA_OK;
+}
+}  // extern "C"
+
+// ---------------------------------------------------------------- pairing
+namespace {
 
 // uploads n (P,Q) pairs, runs the Miller loops; d_f receives n Fq12 values
 int miller_upload_run(const void *g1, const void *g2, size_t n, DevBuf &d_f) {

@@ -33,6 +33,11 @@ template <class F>
 int batch_exp_device(const Jac<F> &base, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st);
 unsigned batch_exp_window_bits(size_t n);
 
+// scalar_mul.hip: d_out[i] = d_scalars[d_sidx ? d_sidx[i] : i] * d_pts[i] (variable base, G1),
+// and per-column sums of a CSC-ordered item array.  Device pointers.
+int g1_scalar_mul_device(const Jac<Fq> *d_pts, const Fr *d_scalars, const uint32_t *d_sidx, size_t n, Jac<Fq> *d_out, hipStream_t st);
+int g1_column_sums_device(const Jac<Fq> *d_items, const uint64_t *d_col_ptr, size_t ncols, Jac<Fq> *d_out, hipStream_t st);
+
 // d_out = sum of n Jacobian points in d_in (device-resident).
 template <class F>
 int sum_points_device(const Jac<F> *d_in, size_t n, Jac<F> *d_out, hipStream_t st);

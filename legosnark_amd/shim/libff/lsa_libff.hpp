@@ -422,6 +422,43 @@ T multi_exp_with_mixed_addition(typename std::vector<T>::const_iterator vec_star
     return detail::msm_forward<T, FieldT>(vec_start, vec_end, scalar_start, scalar_end, chunks);
 }
 
+// ---- batched extensions (not libff API): operators whose reference implementation loops over
+// many tiny libff calls on the CPU.  A maintainer swaps the loop body for one call.
+//
+// mtxmultiexp(out, exps, m) of /root/reference/src/gadgets/subspace.cc:18-25 for a column-major
+// sparse matrix of G1 elements (ColG1 = vector<CoeffPos<G1>>, src/utils/matrix.h:35-45):
+//   out[j] = sum over (val, pos) in m[j] of exps[pos] * val.
+// Flattens the columns to CSC arrays and forwards to lsa_g1_sparse_matrix_msm (one batched
+// scalar-multiplication kernel + one per-column sum instead of |m| sparsemexpG calls).
+template <class Col, class FieldT>
+void lsa_mtxmultiexp(std::vector<alt_bn128_G1> &out, const std::vector<FieldT> &exps, const std::vector<Col> &m) {
+    std::vector<alt_bn128_G1> vals;
+    std::vector<uint32_t> rows;
+    std::vector<uint64_t> col_ptr(m.size() + 1, 0);
+    size_t nnz = 0;
+    for (const Col &c : m) nnz += c.size();
+    vals.reserve(nnz);
+    rows.reserve(nnz);
+    for (size_t j = 0; j < m.size(); j++) {
+        for (const auto &cp : m[j]) {
+            vals.push_back(cp.val);
+            rows.push_back((uint32_t)cp.pos);
+        }
+        col_ptr[j + 1] = vals.size();
+    }
+    out.assign(m.size(), alt_bn128_G1::zero());
+    lsa_require(lsa_g1_sparse_matrix_msm(vals.data(), rows.data(), col_ptr.data(), m.size(), exps.data(), exps.size(), out.data()),
+                "mtxmultiexp");
+}
+// out[i] = scalars[i] * pts[i] (the loop of src/examples/cplink.cc:51-58 when the bases differ)
+template <class FieldT>
+std::vector<alt_bn128_G1> lsa_scalar_mul_batch(const std::vector<alt_bn128_G1> &pts, const std::vector<FieldT> &scalars) {
+    const size_t n = pts.size() < scalars.size() ? pts.size() : scalars.size();
+    std::vector<alt_bn128_G1> out(n, alt_bn128_G1::zero());
+    lsa_require(lsa_g1_scalar_mul_batch(pts.data(), scalars.data(), n, out.data(), 0), "scalar_mul_batch");
+    return out;
+}
+
 // fixed-base tables: the GPU builds its own table per call, so the "table" only carries
 // the base point (get_window_table + batch_exp always travel together in the reference:
 // src/utils/util.h:125-133, src/prototools/interp.h:45-58).

@@ -109,6 +109,12 @@ size_t oracle_g2_exp_window_size(size_t num_scalars);
 void oracle_g1_batch_exp(og1_t *out, const og1_t *base, const ofp_t *scalars, size_t n, size_t window);
 void oracle_g2_batch_exp(og2_t *out, const og2_t *base, const ofp_t *scalars, size_t n, size_t window);
 
+/* ---- sparse matrix in the exponent (CPlink keygen): sparsemexpG for one column
+ * (/root/reference/src/utils/sparsemexp.h:62-90) and mtxmultiexp over a CSC matrix
+ * (/root/reference/src/gadgets/subspace.cc:18-25) ---- */
+void oracle_g1_sparsemexp_column(og1_t *out, const og1_t *vals, const uint32_t *pos, size_t nnz, const ofp_t *exps);
+void oracle_g1_mtxmultiexp(og1_t *out, const og1_t *vals, const uint32_t *rows, const uint64_t *col_ptr, size_t ncols, const ofp_t *exps);
+
 /* ---- test-input helper: out[i] = (a + i*b) * generator, un-normalised Jacobian ---- */
 void oracle_g1_arith_bases(og1_t *out, const ofp_t *a_mont, const ofp_t *b_mont, size_t n);
 void oracle_g2_arith_bases(og2_t *out, const ofp_t *a_mont, const ofp_t *b_mont, size_t n);

@@ -41,7 +41,7 @@ def lib():
 
 
 def _p(a):
-    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    assert a.dtype in (np.uint64, np.uint32) and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(C.c_void_p)
 
 
@@ -196,6 +196,26 @@ def batch_exp(group, base, scalars, window=None):
         window = getattr(lib(), "oracle_%s_exp_window_size" % group)(n)
     out = np.zeros((n, w), dtype=np.uint64)
     getattr(lib(), "oracle_%s_batch_exp" % group)(_p(out), _p(base), _p(scalars), C.c_size_t(n), C.c_size_t(window))
+    return out
+
+
+def g1_mul_batch(pts, scalars):
+    """out[i] = scalars[i] * pts[i] with libff's scalar * point (og1_mul)."""
+    pts = np.ascontiguousarray(pts, dtype=np.uint64).reshape(-1, 12)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros_like(pts)
+    for i in range(len(pts)):
+        lib().og1_mul(_p(out[i]), _p(pts[i]), _p(scalars[i]))
+    return out
+
+
+def mtxmultiexp(vals, rows, col_ptr, exps):
+    vals = np.ascontiguousarray(vals, dtype=np.uint64).reshape(-1, 12)
+    rows = np.ascontiguousarray(rows, dtype=np.uint32)
+    col_ptr = np.ascontiguousarray(col_ptr, dtype=np.uint64)
+    exps = np.ascontiguousarray(exps, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((len(col_ptr) - 1, 12), dtype=np.uint64)
+    lib().oracle_g1_mtxmultiexp(_p(out), _p(vals), _p(rows), _p(col_ptr), C.c_size_t(len(col_ptr) - 1), _p(exps))
     return out
 
 

@@ -186,3 +186,29 @@ def test_pairing_identities():
     inv = np.zeros(48, dtype=np.uint64)
     o.lib().ofq12_inverse(o._p(inv), o._p(f))
     assert np.array_equal(o.fq12_mul(f, inv), o.fq12_one())
+
+
+def test_oracle_mtxmultiexp_matches_plain_scalar_muls():
+    """sparsemexpG's three branches (zero entry, generator entry folded in Fr, multi_exp of the
+    rest) against the plain definition sum_e exps[row(e)] * vals[e] with libff scalar*point."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    pool = o.arith_bases("g1", 77, 13, 16)
+    gen = o.generator("g1")
+    nrows = 4
+    k, _ = o.random_scalars(nrows, seed=21)
+    vals, rows, col_ptr = [], [], [0]
+    for j in range(12):
+        for _ in range(j % 5):
+            t = rng.integers(0, 6)
+            vals.append(np.zeros(12, dtype=np.uint64) if t == 0 else gen if t == 1 else pool[rng.integers(0, 16)])
+            rows.append(int(rng.integers(0, nrows)))
+        col_ptr.append(len(vals))
+    vals = np.array(vals, dtype=np.uint64)
+    got = o.mtxmultiexp(vals, rows, col_ptr, k)
+    terms = o.g1_mul_batch(vals, k[np.array(rows, dtype=np.int64)])
+    for j in range(12):
+        acc = np.zeros(12, dtype=np.uint64)
+        for e in range(col_ptr[j], col_ptr[j + 1]):
+            acc = o.g1_add(acc, terms[e])
+        assert o.g1_canonical_affine(got[j]) == o.g1_canonical_affine(acc)

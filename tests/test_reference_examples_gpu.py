@@ -37,3 +37,12 @@ def test_hadamard_and_matrixsc_run():
     assert "had_lipmaa Prove" in r.stdout and "had_sc" in r.stdout
     r = run("matrixsc", "3")
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_keygen_matrix_batched_call_equals_reference_column_loop():
+    """legosnark_amd/shim/checks/keygen_check.cc: the reference's own mtxmultiexp column loop
+    (simplesparsemexp from its unchanged sparsemexp.cc) vs libff::lsa_mtxmultiexp on the CPlink
+    relation matrix; the program exits non-zero on any mismatching column."""
+    r = run("keygen_check", "10", "128")
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert '"mismatches": 0' in r.stdout
