@@ -134,6 +134,24 @@ int lsa_g1_scalar_mul_batch(const void *pts_jac, const void *scalars_mont, size_
 int lsa_g1_sparse_matrix_msm(const void *vals_jac, const uint32_t *rows, const uint64_t *col_ptr, size_t ncols,
                              const void *exps_mont, size_t nrows, void *out_jac);
 
+/* ---- Fr vectors around the MSMs --------------------------------------------------------- */
+/* Witness coefficients of CPPoly::prove (src/gadgets/poly.h:55-67): with v of length 2^d and the
+ * evaluation point r of length d, round i = 0..d-1 over m = 2^(d-1-i) pairs writes
+ *   w[start + p] = v[2p+1] - v[2p],   v'[p] = -v[2p]*(r[i]-1) + v[2p+1]*r[i],   start += m.
+ * w has 2^d entries (the last one stays zero, as in the reference's value-initialised vector);
+ * w[start .. start+m) is the scalar vector of the i-th MSM of the proof (poly.h:77-86) and can
+ * be passed to lsa_msm_run_async without leaving the device.  v is not modified.
+ * on_device != 0: v, r, w are device pointers; else host pointers. */
+int lsa_fr_cppoly_witness(const void *v_mont, size_t d, const void *r_mont, void *w_mont, int on_device);
+/* out = evalMLE(v, r) (MultiVPolyT::evalMLE, src/prototools/polytools.h:207-234): the
+ * multilinear extension of v (2^d entries, index bit i pairs with r[i]) at r.  One Fr.
+ * on_device != 0: v, r, out are device pointers; else host pointers. */
+int lsa_fr_eval_mle(const void *v_mont, size_t d, const void *r_mont, void *out_mont, int on_device);
+/* DPMle::pushRandomness (src/prototools/mle.h:199-210): cur[p] = old[p]*(1-r) + old[p+half]*r,
+ * p < half; old has 2*half entries, r is ONE Fr; cur may alias old.  on_device != 0: all three
+ * are device pointers and the call is asynchronous on lsa_stream(); else host pointers. */
+int lsa_fr_fold(const void *old_mont, size_t half, const void *r_mont, void *cur_mont, int on_device);
+
 /* ---- pairing ---------------------------------------------------------------------------- */
 /* out[i] = miller_loop(precompute_G1(P_i), precompute_G2(Q_i)), i < n: replaces libff
  * alt_bn128_pp::precompute_G1 / precompute_G2 / miller_loop (src/utils/globl.h:96-102,

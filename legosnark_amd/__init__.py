@@ -74,6 +74,9 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.lsa_g1_scalar_mul_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.lsa_g1_sparse_matrix_msm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.lsa_fr_cppoly_witness.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+        L.lsa_fr_eval_mle.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+        L.lsa_fr_fold.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.lsa_miller_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.lsa_miller_loop_product.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.lsa_pairing_product.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -256,6 +259,60 @@ def sparse_matrix_msm(vals, rows, col_ptr, exps):
     _check(lib().lsa_g1_sparse_matrix_msm(_host_ptr(vals), _host_ptr(rows), _host_ptr(col_ptr), ncols,
                                           _host_ptr(exps), len(exps), _host_ptr(out)))
     return out
+
+
+def _log2_exact(n):
+    d = int(n).bit_length() - 1
+    if n <= 0 or (1 << d) != n:
+        raise ValueError("length must be a power of two")
+    return d
+
+
+def cppoly_witness(v, r, out=None):
+    """CPPoly::prove witness coefficients (poly.h:55-67).  numpy (host) or torch CUDA tensors."""
+    if isinstance(v, np.ndarray):
+        v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
+        r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+        d = _log2_exact(len(v))
+        if len(r) != d:
+            raise ValueError("need log2(len(v)) evaluation coordinates")
+        w = np.zeros_like(v)
+        _check(lib().lsa_fr_cppoly_witness(_host_ptr(v), d, _host_ptr(r), _host_ptr(w), 0))
+        return w
+    d = _log2_exact(v.numel() * v.element_size() // 32)
+    if out is None:
+        import torch
+        out = torch.empty_like(v)
+    _check(lib().lsa_fr_cppoly_witness(_ptr(v), d, _ptr(r), _ptr(out), 1))
+    return out
+
+
+def eval_mle(v, r):
+    """MultiVPolyT::evalMLE (polytools.h:207-234).  Host numpy in -> (4,) uint64."""
+    v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    d = _log2_exact(len(v))
+    if len(r) != d:
+        raise ValueError("need log2(len(v)) evaluation coordinates")
+    out = np.zeros(4, dtype=np.uint64)
+    _check(lib().lsa_fr_eval_mle(_host_ptr(v), d, _host_ptr(r), _host_ptr(out), 0))
+    return out
+
+
+def eval_mle_device(d_v, d_r, d_out):
+    d = _log2_exact(d_v.numel() * d_v.element_size() // 32)
+    _check(lib().lsa_fr_eval_mle(_ptr(d_v), d, _ptr(d_r), _ptr(d_out), 1))
+    return d_out
+
+
+def fr_fold(old, r):
+    """DPMle::pushRandomness (mle.h:199-210) on a host vector: returns the folded half."""
+    old = np.ascontiguousarray(old, dtype=np.uint64).reshape(-1, 4)
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+    half = len(old) // 2
+    cur = np.zeros((half, 4), dtype=np.uint64)
+    _check(lib().lsa_fr_fold(_host_ptr(old), half, _host_ptr(r), _host_ptr(cur), 0))
+    return cur
 
 
 def sum_async(group, d_pts, n, d_out):

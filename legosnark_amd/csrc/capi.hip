@@ -421,6 +421,74 @@ int lsa_g1_sparse_matrix_msm(const void *vals_jac, const uint32_t *rows, const u
 }
 }  // extern "C"
 
+// ---------------------------------------------------------------- Fr vectors
+extern "C" {
+int lsa_fr_cppoly_witness(const void *v, size_t d, const void *r, void *w, int on_device) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (d > 40) { set_error("cppoly_witness: d = %zu too large", d); return LSA_ERR_INVALID; }
+    if (!v || !w || (d && !r)) { set_error("cppoly_witness: null argument"); return LSA_ERR_INVALID; }
+    const size_t N = (size_t)1 << d;
+    DevBuf d_tmp, d_v, d_r, d_w;
+    if (d_tmp.alloc((N / 2 + N / 4 + 1) * sizeof(Fr))) { set_error("cppoly_witness: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    if (on_device) {
+        rc = fr_cppoly_fold_device((const Fr *)v, d, (const Fr *)r, (Fr *)w, (Fr *)d_tmp.p, g.stream);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(g.stream));   // scratch is freed on return
+        return LSA_OK;
+    }
+    if (d_v.alloc(N * sizeof(Fr)) || d_r.alloc((d + 1) * sizeof(Fr)) || d_w.alloc(N * sizeof(Fr))) { set_error("cppoly_witness: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    HIPCHK(hipMemcpyAsync(d_v.p, v, N * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    if (d) HIPCHK(hipMemcpyAsync(d_r.p, r, d * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    rc = fr_cppoly_fold_device((const Fr *)d_v.p, d, (const Fr *)d_r.p, (Fr *)d_w.p, (Fr *)d_tmp.p, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(w, d_w.p, N * sizeof(Fr), hipMemcpyDeviceToHost));
+    return LSA_OK;
+}
+
+int lsa_fr_eval_mle(const void *v, size_t d, const void *r, void *out, int on_device) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (d > 40) { set_error("eval_mle: d = %zu too large", d); return LSA_ERR_INVALID; }
+    if (!v || !out || (d && !r)) { set_error("eval_mle: null argument"); return LSA_ERR_INVALID; }
+    const size_t N = (size_t)1 << d;
+    DevBuf d_tmp, d_v, d_r, d_o;
+    if (d_tmp.alloc((N / 2 + 1) * sizeof(Fr))) { set_error("eval_mle: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    if (on_device) {
+        rc = fr_eval_mle_device((const Fr *)v, d, (const Fr *)r, (Fr *)d_tmp.p, (Fr *)out, g.stream);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(g.stream));
+        return LSA_OK;
+    }
+    if (d_v.alloc(N * sizeof(Fr)) || d_r.alloc((d + 1) * sizeof(Fr)) || d_o.alloc(sizeof(Fr))) { set_error("eval_mle: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    HIPCHK(hipMemcpyAsync(d_v.p, v, N * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    if (d) HIPCHK(hipMemcpyAsync(d_r.p, r, d * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    rc = fr_eval_mle_device((const Fr *)d_v.p, d, (const Fr *)d_r.p, (Fr *)d_tmp.p, (Fr *)d_o.p, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(out, d_o.p, sizeof(Fr), hipMemcpyDeviceToHost));
+    return LSA_OK;
+}
+
+int lsa_fr_fold(const void *old, size_t half, const void *r, void *cur, int on_device) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (half == 0) return LSA_OK;
+    if (!old || !cur || !r) { set_error("fr_fold: null argument"); return LSA_ERR_INVALID; }
+    if (on_device) return fr_fold_halves_device((const Fr *)old, half, (const Fr *)r, (Fr *)cur, g.stream);
+    DevBuf d_v, d_r;
+    if (d_v.alloc(2 * half * sizeof(Fr)) || d_r.alloc(sizeof(Fr))) { set_error("fr_fold: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    HIPCHK(hipMemcpyAsync(d_v.p, old, 2 * half * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(d_r.p, r, sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    rc = fr_fold_halves_device((const Fr *)d_v.p, half, (const Fr *)d_r.p, (Fr *)d_v.p, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(cur, d_v.p, half * sizeof(Fr), hipMemcpyDeviceToHost));
+    return LSA_OK;
+}
+}  // extern "C"
+
 // ---------------------------------------------------------------- pairing
 namespace {
 

@@ -38,6 +38,11 @@ unsigned batch_exp_window_bits(size_t n);
 int g1_scalar_mul_device(const Jac<Fq> *d_pts, const Fr *d_scalars, const uint32_t *d_sidx, size_t n, Jac<Fq> *d_out, hipStream_t st);
 int g1_column_sums_device(const Jac<Fq> *d_items, const uint64_t *d_col_ptr, size_t ncols, Jac<Fq> *d_out, hipStream_t st);
 
+// fr_vec.hip: Fr streaming kernels (device pointers, asynchronous on st).
+int fr_cppoly_fold_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_w, Fr *d_tmp, hipStream_t st);
+int fr_fold_halves_device(const Fr *d_old, size_t half, const Fr *d_r, Fr *d_cur, hipStream_t st);
+int fr_eval_mle_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_tmp, Fr *d_out, hipStream_t st);
+
 // d_out = sum of n Jacobian points in d_in (device-resident).
 template <class F>
 int sum_points_device(const Jac<F> *d_in, size_t n, Jac<F> *d_out, hipStream_t st);

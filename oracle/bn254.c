@@ -458,3 +458,75 @@ void oracle_pairing_product(ofq12_t *out, const og1_t *p, const og2_t *q, size_t
     free(qp);
     oracle_final_exponentiation(out, &acc);
 }
+
+/* ---- Fr-vector loops around the MSMs (restated line by line from the reference) ---- */
+static inline void fr_add_(ofp_t *r, const ofp_t *a, const ofp_t *b) { ofp_add(r, a, b, 1); }
+static inline void fr_sub_(ofp_t *r, const ofp_t *a, const ofp_t *b) { ofp_sub(r, a, b, 1); }
+static inline void fr_mul_(ofp_t *r, const ofp_t *a, const ofp_t *b) { ofp_mul(r, a, b, 1); }
+static inline void fr_neg_(ofp_t *r, const ofp_t *a) { ofp_t z; fr_zero(&z); ofp_sub(r, &z, a, 1); }
+
+/* CPPoly::prove, witness coefficients: /root/reference/src/gadgets/poly.h:51-67.
+ * v: 2^d, r: d, w: 2^d (value-initialised to zero like `Scalars w_coeffs(1 << d)`). */
+void oracle_fr_cppoly_witness(ofp_t *w, const ofp_t *v, const ofp_t *r, size_t d) {
+    size_t N = (size_t)1 << d;
+    ofp_t *tmp = (ofp_t *)malloc(sizeof(ofp_t) * N);
+    ofp_t one; fr_one(&one);
+    memcpy(tmp, v, sizeof(ofp_t) * N);
+    memset(w, 0, sizeof(ofp_t) * N);
+    size_t start = 0;
+    for (size_t i = 0; i < d; i++) {
+        size_t bound = (size_t)1 << (d - i - 1);
+        ofp_t rm1; fr_sub_(&rm1, &r[i], &one);
+        for (size_t p = 0; p < bound; p++) {
+            size_t p0 = p << 1, p1 = (p << 1) + 1;
+            ofp_t n0, t0, t1;
+            fr_neg_(&n0, &tmp[p0]);
+            fr_add_(&w[start + p], &n0, &tmp[p1]);              /* -tmp_v[p0] + tmp_v[p1] */
+            fr_mul_(&t0, &n0, &rm1);                           /* -tmp_v[p0]*(r[i]-1) */
+            fr_mul_(&t1, &tmp[p1], &r[i]);
+            fr_add_(&tmp[p], &t0, &t1);
+        }
+        start += bound;
+    }
+    free(tmp);
+}
+
+/* MultiVPolyT::evalMLE: /root/reference/src/prototools/polytools.h:207-234
+ * (table of eq-monomials, then the dot product with v). */
+void oracle_fr_eval_mle(ofp_t *out, const ofp_t *v, const ofp_t *r, size_t d) {
+    size_t N = (size_t)1 << d;
+    ofp_t *products = (ofp_t *)malloc(sizeof(ofp_t) * N);
+    ofp_t f1; fr_one(&f1);
+    memset(products, 0, sizeof(ofp_t) * N);
+    products[0] = f1;
+    size_t idx = 1;
+    for (size_t i = 0; i < d; i++) {
+        size_t bound = (size_t)1 << i;
+        ofp_t omr; fr_sub_(&omr, &f1, &r[i]);
+        for (size_t p = 0; p < bound; p++) {
+            fr_mul_(&products[p + idx], &products[p], &r[i]);
+            fr_mul_(&products[p], &products[p], &omr);
+        }
+        idx += (size_t)1 << i;
+    }
+    ofp_t acc; fr_zero(&acc);
+    for (size_t p = 0; p < N; p++) {
+        ofp_t t; fr_mul_(&t, &v[p], &products[p]);
+        fr_add_(&acc, &acc, &t);
+    }
+    *out = acc;
+    free(products);
+}
+
+/* DPMle::pushRandomness: /root/reference/src/prototools/mle.h:199-210 with
+ * eqbit(bool, r) of src/prototools/mle.cc:12-15.  old: 2*half, cur: half. */
+void oracle_fr_push_randomness(ofp_t *cur, const ofp_t *old, const ofp_t *r, size_t half) {
+    ofp_t one, omr; fr_one(&one);
+    fr_sub_(&omr, &one, r);
+    for (size_t p = 0; p < half; p++) {
+        ofp_t t0, t1;
+        fr_mul_(&t0, &old[p], &omr);
+        fr_mul_(&t1, &old[p + half], r);
+        fr_add_(&cur[p], &t0, &t1);
+    }
+}

@@ -115,6 +115,14 @@ void oracle_g2_batch_exp(og2_t *out, const og2_t *base, const ofp_t *scalars, si
 void oracle_g1_sparsemexp_column(og1_t *out, const og1_t *vals, const uint32_t *pos, size_t nnz, const ofp_t *exps);
 void oracle_g1_mtxmultiexp(og1_t *out, const og1_t *vals, const uint32_t *rows, const uint64_t *col_ptr, size_t ncols, const ofp_t *exps);
 
+/* ---- Fr-vector loops around the MSMs ---- */
+/* CPPoly::prove witness coefficients (/root/reference/src/gadgets/poly.h:51-67) */
+void oracle_fr_cppoly_witness(ofp_t *w, const ofp_t *v, const ofp_t *r, size_t d);
+/* MultiVPolyT::evalMLE (/root/reference/src/prototools/polytools.h:207-234) */
+void oracle_fr_eval_mle(ofp_t *out, const ofp_t *v, const ofp_t *r, size_t d);
+/* DPMle::pushRandomness (/root/reference/src/prototools/mle.h:199-210) */
+void oracle_fr_push_randomness(ofp_t *cur, const ofp_t *old, const ofp_t *r, size_t half);
+
 /* ---- test-input helper: out[i] = (a + i*b) * generator, un-normalised Jacobian ---- */
 void oracle_g1_arith_bases(og1_t *out, const ofp_t *a_mont, const ofp_t *b_mont, size_t n);
 void oracle_g2_arith_bases(og2_t *out, const ofp_t *a_mont, const ofp_t *b_mont, size_t n);

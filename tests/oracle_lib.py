@@ -219,6 +219,30 @@ def mtxmultiexp(vals, rows, col_ptr, exps):
     return out
 
 
+def fr_cppoly_witness(v, r):
+    v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    w = np.zeros_like(v)
+    lib().oracle_fr_cppoly_witness(_p(w), _p(v), _p(r), C.c_size_t(len(r)))
+    return w
+
+
+def fr_eval_mle(v, r):
+    v = np.ascontiguousarray(v, dtype=np.uint64).reshape(-1, 4)
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().oracle_fr_eval_mle(_p(out), _p(v), _p(r), C.c_size_t(len(r)))
+    return out
+
+
+def fr_push_randomness(old, r):
+    old = np.ascontiguousarray(old, dtype=np.uint64).reshape(-1, 4)
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(4)
+    cur = np.zeros((len(old) // 2, 4), dtype=np.uint64)
+    lib().oracle_fr_push_randomness(_p(cur), _p(old), _p(r), C.c_size_t(len(old) // 2))
+    return cur
+
+
 def reduced_pairing(p, q):
     p = np.ascontiguousarray(p, dtype=np.uint64)
     q = np.ascontiguousarray(q, dtype=np.uint64)

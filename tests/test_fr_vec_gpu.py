@@ -1,0 +1,77 @@
+"""GPU parity tests for the Fr-vector kernels through the
+C-ABI: Fr values are canonical Montgomery residues, so outputs are compared byte for byte
+with the oracle's line-by-line restatement of the reference loops."""
+import numpy as np
+import pytest
+
+import oracle_lib as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("d", [0, 1, 2, 3, 9, 13])
+def test_cppoly_witness_vs_oracle(lsa, d):
+    v, _ = o.random_scalars(1 << d, seed=300 + d)
+    r, _ = o.random_scalars(max(d, 1), seed=400 + d)
+    r = r[:d]
+    got = lsa.cppoly_witness(v, r)
+    want = o.fr_cppoly_witness(v, r)
+    assert np.array_equal(got, want)
+    assert not got[-1].any()                       # value-initialised tail entry (poly.h:52)
+
+
+@pytest.mark.parametrize("d", [0, 1, 2, 7, 12])
+def test_eval_mle_vs_oracle(lsa, d):
+    v, _ = o.random_scalars(1 << d, seed=500 + d)
+    r, _ = o.random_scalars(max(d, 1), seed=600 + d)
+    r = r[:d]
+    assert np.array_equal(lsa.eval_mle(v, r), o.fr_eval_mle(v, r))
+
+
+def test_eval_mle_special_points(lsa):
+    """r in {0,1}^d selects one table entry; r = 0 and r = 1 exercise the (1-r) and r factors."""
+    d = 6
+    v, _ = o.random_scalars(1 << d, seed=77)
+    for idx in (0, 1, 37, 63):
+        r = np.array([o.fr_mont((idx >> i) & 1) for i in range(d)], dtype=np.uint64)
+        assert np.array_equal(lsa.eval_mle(v, r), v[idx])
+
+
+@pytest.mark.parametrize("half", [1, 2, 100, 4096])
+def test_push_randomness_vs_oracle(lsa, half):
+    old, _ = o.random_scalars(2 * half, seed=700 + half)
+    r, _ = o.random_scalars(1, seed=701)
+    assert np.array_equal(lsa.fr_fold(old, r[0]), o.fr_push_randomness(old, r[0]))
+
+
+def test_cppoly_prove_on_device_end_to_end(lsa):
+    """CPPoly::prove (poly.h:45-91) with nothing leaving the device between the fold and the
+    MSM ladder: w = witness coefficients (device), pf.witness[i] = MSM(g1s, w[start_i ..])."""
+    import torch
+    d = 10
+    N = 1 << d
+    v, _ = o.random_scalars(N, seed=801)
+    r, _ = o.random_scalars(d, seed=802)
+    bases = o.arith_bases("g1", 5150, 31, N)
+    B = lsa.Bases("g1", bases)
+    d_v = torch.from_numpy(v.view(np.int64)).to("cuda:0")
+    d_r = torch.from_numpy(r.view(np.int64)).to("cuda:0")
+    torch.cuda.synchronize()
+    d_w = lsa.cppoly_witness(d_v, d_r)
+    outs = torch.zeros((d, 12), dtype=torch.int64, device="cuda:0")
+    start = 0
+    for i in range(d):
+        m = 1 << (d - i - 1)
+        B.msm_async(d_w[start:start + m], outs[i], n=m)
+        start += m
+    lsa.synchronize()
+    w = o.fr_cppoly_witness(v, r)
+    assert np.array_equal(d_w.cpu().numpy().view(np.uint64), w)
+    got = outs.cpu().numpy().view(np.uint64)
+    start = 0
+    for i in range(d):
+        m = 1 << (d - i - 1)
+        want = o.multi_exp("g1", bases[:m], w[start:start + m], mode="mixed")
+        assert o.g1_canonical_affine(got[i]) == o.g1_canonical_affine(want)
+        start += m
+    B.close()

@@ -212,3 +212,43 @@ def test_oracle_mtxmultiexp_matches_plain_scalar_muls():
         for e in range(col_ptr[j], col_ptr[j + 1]):
             acc = o.g1_add(acc, terms[e])
         assert o.g1_canonical_affine(got[j]) == o.g1_canonical_affine(acc)
+
+
+def _fr_ints(a):
+    import numpy as np
+    Rinv = pow(o.MONT, -1, o.R)
+    return [o.limbs_to_int(x) * Rinv % o.R for x in np.asarray(a, dtype=np.uint64).reshape(-1, 4)]
+
+
+def test_oracle_fr_vector_loops_match_bigint_formulas():
+    """The Fr loops restated from poly.h:51-67, polytools.h:207-234 and mle.h:199-210 against
+    the same formulas evaluated with Python integers (independent of the C field code)."""
+    R = o.R
+    for d in (0, 1, 2, 5):
+        N = 1 << d
+        v_m, v = o.random_scalars(N, seed=100 + d)
+        r_m, r = (o.random_scalars(d, seed=200 + d) if d else (o.fr_mont_array([]).reshape(0, 4), []))
+        v, r = [int(x) for x in v], [int(x) for x in r]
+        # CPpoly witness recursion
+        tmp, w = list(v), [0] * N
+        start = 0
+        for i in range(d):
+            bound = 1 << (d - i - 1)
+            for p in range(bound):
+                a, b = tmp[2 * p], tmp[2 * p + 1]
+                w[start + p] = (b - a) % R
+                tmp[p] = (-a * (r[i] - 1) + b * r[i]) % R
+            start += bound
+        assert _fr_ints(o.fr_cppoly_witness(v_m, r_m)) == w
+        # multilinear extension: sum_p v[p] prod_i (bit_i(p) ? r_i : 1 - r_i)
+        want = 0
+        for p in range(N):
+            term = v[p]
+            for i in range(d):
+                term = term * (r[i] if (p >> i) & 1 else 1 - r[i]) % R
+            want = (want + term) % R
+        assert _fr_ints(o.fr_eval_mle(v_m, r_m)) == [want]
+        if d:
+            half = N // 2
+            got = _fr_ints(o.fr_push_randomness(v_m, r_m[0]))
+            assert got == [(v[p] * (1 - r[0]) + v[p + half] * r[0]) % R for p in range(half)]
