@@ -78,6 +78,13 @@ int lsa_g1_bases_create(const void *bases_jac, size_t n, int src_on_device, lsa_
 int lsa_g2_bases_create(const void *bases_jac, size_t n, int src_on_device, lsa_bases **out);
 void lsa_bases_destroy(lsa_bases *b);
 size_t lsa_bases_size(const lsa_bases *b);
+/* Resident vectors of at least `threshold` points (default 2^19; env LSA_PRECOMPUTE_MIN) also keep
+ * the pre-shifted copies 2^(16k)*P_i of every 16-bit window (G1: 8 x 64 B, G2: 16 x 128 B per
+ * point; LSA_PRECOMPUTE=0 disables), which removes the per-MSM Horner fold.  MSMs of at least
+ * `threshold` pairs on such a handle use them.  lsa_msm_set_table_threshold(0) restores the
+ * default; lsa_bases_has_table() tells whether a handle carries the copies. */
+void lsa_msm_set_table_threshold(size_t threshold);
+int lsa_bases_has_table(const lsa_bases *b);
 /* Device pointer to the normalised affine array (n x 64 B / 128 B), for inspection. */
 const void *lsa_bases_device_ptr(const lsa_bases *b);
 

@@ -56,6 +56,9 @@ def lib():
         L.lsa_bases_size.argtypes = [C.c_void_p]
         L.lsa_bases_device_ptr.restype = C.c_void_p
         L.lsa_bases_device_ptr.argtypes = [C.c_void_p]
+        L.lsa_bases_has_table.argtypes = [C.c_void_p]
+        L.lsa_msm_set_table_threshold.argtypes = [C.c_size_t]
+        L.lsa_msm_set_table_threshold.restype = None
         L.lsa_bases_destroy.argtypes = [C.c_void_p]
         L.lsa_bases_destroy.restype = None
         L.lsa_msm_window_bits.restype = C.c_uint
@@ -183,6 +186,9 @@ class Bases:
 
     def device_ptr(self):
         return lib().lsa_bases_device_ptr(self.handle)
+
+    def has_table(self):
+        return bool(lib().lsa_bases_has_table(self.handle))
 
     def close(self):
         if self.handle:
@@ -379,6 +385,11 @@ def profile_last_msm():
     d = dict(zip(STAGE_NAMES, [float(x) for x in ms]))
     d["calls"] = int(cnt)
     return d
+
+
+def set_table_threshold(n):
+    """Resident bases / MSMs of at least n points use pre-shifted window copies (0 = default 2^19)."""
+    lib().lsa_msm_set_table_threshold(int(n))
 
 
 def msm_window_bits(n):

@@ -53,9 +53,10 @@ using namespace lsa;
 static void release_stage_buffers();
 
 struct lsa_bases {
-    void *d_aff = nullptr;   // Aff<Fq> or Aff<Fq2> array
+    void *d_aff = nullptr;   // prepared bases (msm_base_bytes(group) each); with a table: window-major copies
     size_t n = 0;
     int group = 1;           // 1 = G1, 2 = G2
+    size_t table_stride = 0; // n when the pre-shifted windows 2^(16k)*P are resident, else 0
 };
 
 extern "C" {
@@ -141,7 +142,15 @@ static int bases_create(const void *bases_jac, size_t n, int src_on_device, int 
     if (n) {
         const Jac<F> *d_in = nullptr;
         void *tmp = nullptr;
-        if (hipMalloc(&b->d_aff, n * msm_base_bytes(group)) != hipSuccess) {
+        // Large resident CRS vectors also keep the pre-shifted windows (msm.hip, "merged
+        // windows"): nwin x the memory, no Horner fold per MSM.  LSA_PRECOMPUTE=0 opts out; a
+        // table that does not fit falls back to the plain layout.
+        const char *pe = getenv("LSA_PRECOMPUTE");
+        bool table = n >= msm_merge_min() && !(pe && pe[0] == '0');
+        const size_t tw = msm_table_windows(group);
+        if (table && (uint64_t)n * tw >= (1u << 30)) table = false;
+        if (table && hipMalloc(&b->d_aff, tw * n * msm_base_bytes(group)) != hipSuccess) { (void)hipGetLastError(); b->d_aff = nullptr; table = false; }
+        if (!table && hipMalloc(&b->d_aff, n * msm_base_bytes(group)) != hipSuccess) {
             delete b;
             set_error("bases_create: hipMalloc of %zu bytes failed", n * msm_base_bytes(group));
             return LSA_ERR_NOMEM;
@@ -159,6 +168,10 @@ static int bases_create(const void *bases_jac, size_t n, int src_on_device, int 
             d_in = (const Jac<F> *)tmp;
         }
         rc = prepare_bases<F>(d_in, b->d_aff, n, g.stream);
+        if (!rc && table) {
+            rc = precompute_windows<F>(b->d_aff, n, g.stream);
+            if (!rc) b->table_stride = n;
+        }
         hipError_t e = hipStreamSynchronize(g.stream);
         if (tmp) (void)hipFree(tmp);
         if (rc || e != hipSuccess) {
@@ -184,6 +197,8 @@ void lsa_bases_destroy(lsa_bases *b) {
     delete b;
 }
 size_t lsa_bases_size(const lsa_bases *b) { return b ? b->n : 0; }
+int lsa_bases_has_table(const lsa_bases *b) { return b && b->table_stride ? 1 : 0; }
+void lsa_msm_set_table_threshold(size_t n) { msm_set_merge_min(n); }
 const void *lsa_bases_device_ptr(const lsa_bases *b) { return b ? b->d_aff : nullptr; }
 
 // ---------------------------------------------------------------- MSM
@@ -193,8 +208,8 @@ int lsa_msm_run_async(const lsa_bases *bases, size_t first, const void *d_scalar
     if (!bases || !d_out_jac || (n && !d_scalars)) { set_error("msm_run: null argument"); return LSA_ERR_INVALID; }
     if (first > bases->n || n > bases->n - first) { set_error("msm_run: range [%zu,%zu) exceeds %zu bases", first, first + n, bases->n); return LSA_ERR_INVALID; }
     if (bases->group == 1)
-        return msm_device<Fq>(bases->d_aff, first, (const Fr *)d_scalars, n, (Jac<Fq> *)d_out_jac, g.stream);
-    return msm_device<Fq2>(bases->d_aff, first, (const Fr *)d_scalars, n, (Jac<Fq2> *)d_out_jac, g.stream);
+        return msm_device<Fq>(bases->d_aff, first, (const Fr *)d_scalars, n, (Jac<Fq> *)d_out_jac, g.stream, bases->table_stride);
+    return msm_device<Fq2>(bases->d_aff, first, (const Fr *)d_scalars, n, (Jac<Fq2> *)d_out_jac, g.stream, bases->table_stride);
 }
 
 int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars, size_t n, void *out_jac) {

@@ -25,8 +25,17 @@ int prepare_bases(const Jac<F> *d_in, void *d_out, size_t n, hipStream_t st);
 size_t msm_base_bytes(int group);
 
 // out = sum scalars[i] * bases[first + i]; everything device-resident; asynchronous on `st`.
+// table_stride != 0: d_bases is a window-major table of pre-shifted bases
+// (entry k*table_stride + i = 2^(16k) * P_i, k < msm_table_windows(group)) built by
+// precompute_windows(); used when n >= msm_merge_min().
 template <class F>
-int msm_device(const void *d_bases, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st);
+int msm_device(const void *d_bases, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride = 0);
+unsigned msm_table_windows(int group);
+size_t msm_merge_min();
+void msm_set_merge_min(size_t n);
+// fills windows 1.. of a table whose window 0 holds the n prepared bases
+template <class F>
+int precompute_windows(void *d_table, size_t n, hipStream_t st);
 
 // out[i] = scalars[i] * base (fixed base); d_scalars/d_out device-resident.
 template <class F>

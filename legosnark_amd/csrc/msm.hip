@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256) void k_scan_final(const uint32_t *__restrict__
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_scatter(const int32_t *__restrict__ digits, const uint16_t *__restrict__ rank,
                                                   const uint32_t *__restrict__ offs, const uint32_t *__restrict__ tile_base,
-                                                  size_t n, size_t npoints, uint32_t B, uint32_t ntiles, uint32_t *__restrict__ entries) {
+                                                  size_t n, size_t npoints, uint32_t B, uint32_t ntiles, uint32_t *__restrict__ entries,
+                                                  uint32_t win_stride) {
     extern __shared__ __attribute__((aligned(16))) uint32_t base[];   // B words
     const uint32_t t = blockIdx.x, k = blockIdx.y;
     const uint32_t *of = offs + (size_t)k * B;
@@ -274,7 +275,9 @@ __global__ __launch_bounds__(1024) void k_scatter(const int32_t *__restrict__ di
         if (sd != 0) {
             uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
             // entry = point index | endo << 30 | sign << 31   (virtual scalar i >= npoints: phi(point))
+            // win_stride != 0: window k reads its own pre-shifted copy of the bases (2^(c*k) * P)
             uint32_t pt = i < npoints ? (uint32_t)i : ((uint32_t)(i - npoints) | 0x40000000u);
+            pt += k * win_stride;
             entries[base[b] + rk[i]] = pt | (sd < 0 ? 0x80000000u : 0u);
         }
     }
@@ -290,7 +293,11 @@ __global__ __launch_bounds__(1024) void k_scatter(const int32_t *__restrict__ di
 #define ACC_SPLIT 2u            // lanes per bucket in k_accumulate
 #define SIZE_BINS 1025          // counts 0..1024 (heavy_threshold == 1024)
 template <class C>
-__global__ __launch_bounds__(256) void k_size_hist(const uint32_t *__restrict__ hist, uint32_t nb, uint32_t thr, uint32_t *__restrict__ bin_count) {
+__global__ __launch_bounds__(256) void k_size_hist(const uint32_t *__restrict__ hist, uint32_t nb, uint32_t thr, uint32_t *__restrict__ bin_count,
+                                                   uint32_t group_size) {
+    // group_size != 0: buckets are ordered group by group (a group = one window's 2^(c-1)
+    // buckets, a multiple of this block's 2048), by population inside each group
+    bin_count += (group_size ? (blockIdx.x * 2048u) / group_size : 0u) * SIZE_BINS;
     __shared__ uint32_t lcnt[SIZE_BINS];
     for (uint32_t t = threadIdx.x; t < SIZE_BINS; t += 256) lcnt[t] = 0;
     __syncthreads();
@@ -303,32 +310,42 @@ __global__ __launch_bounds__(256) void k_size_hist(const uint32_t *__restrict__ 
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < SIZE_BINS; t += 256) if (lcnt[t]) atomicAdd(&bin_count[t], lcnt[t]);
 }
-// bin_start[b] = number of buckets with a larger population (descending order); total in bin_start[0]
-__global__ __launch_bounds__(256) void k_size_scan(const uint32_t *__restrict__ bin_count, uint32_t *__restrict__ bin_start) {
+// bin_start[g][b] = number of buckets ordered before population b of group g (groups ascending,
+// populations descending); the total goes to bin_start[0][0]
+__global__ __launch_bounds__(256) void k_size_scan(const uint32_t *__restrict__ bin_count, uint32_t *__restrict__ bin_start, uint32_t ngroups) {
     __shared__ uint32_t lds[4];
-    // lane t owns bins [SIZE_BINS-1-4t-3 .. SIZE_BINS-1-4t], visited from large to small
-    uint32_t v[4], s = 0;
+    uint32_t carry = 0;
+    for (uint32_t gidx = 0; gidx < ngroups; gidx++) {
+        const uint32_t *bc = bin_count + gidx * SIZE_BINS;
+        uint32_t *bs = bin_start + gidx * SIZE_BINS;
+        // lane t owns bins [SIZE_BINS-1-4t-3 .. SIZE_BINS-1-4t], visited from large to small
+        uint32_t v[4], s = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int bin = (int)SIZE_BINS - 1 - (int)(threadIdx.x * 4 + j);
-        v[j] = (bin >= 1) ? bin_count[bin] : 0;
-        s += v[j];
-    }
-    uint32_t tot;
-    uint32_t run = block_exclusive_scan_256(s, lds, &tot);
+        for (int j = 0; j < 4; j++) {
+            int bin = (int)SIZE_BINS - 1 - (int)(threadIdx.x * 4 + j);
+            v[j] = (bin >= 1) ? bc[bin] : 0;
+            s += v[j];
+        }
+        uint32_t tot;
+        uint32_t run = carry + block_exclusive_scan_256(s, lds, &tot);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int bin = (int)SIZE_BINS - 1 - (int)(threadIdx.x * 4 + j);
-        if (bin >= 1) bin_start[bin] = run;
-        run += v[j];
+        for (int j = 0; j < 4; j++) {
+            int bin = (int)SIZE_BINS - 1 - (int)(threadIdx.x * 4 + j);
+            if (bin >= 1) bs[bin] = run;
+            run += v[j];
+        }
+        carry += tot;
     }
-    if (threadIdx.x == 0) bin_start[0] = tot;     // number of buckets in the permutation
+    if (threadIdx.x == 0) bin_start[0] = carry;     // number of buckets in the permutation
 }
 template <class C>
 __global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict__ hist, uint32_t nb, uint32_t thr, const uint32_t *__restrict__ bin_start,
                                                       uint32_t *__restrict__ bin_cursor, uint32_t *__restrict__ perm,
                                                       uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count,
-                                                      typename C::Acc *__restrict__ buckets) {
+                                                      typename C::Acc *__restrict__ buckets, uint32_t group_size) {
+    const uint32_t goff = (group_size ? (blockIdx.x * 2048u) / group_size : 0u) * SIZE_BINS;
+    bin_start += goff;
+    bin_cursor += goff;
     __shared__ uint32_t lcnt[SIZE_BINS];
     for (uint32_t t = threadIdx.x; t < SIZE_BINS; t += 256) lcnt[t] = 0;
     __syncthreads();
@@ -482,65 +499,84 @@ __global__ __launch_bounds__(64) void k_heavy_finish(const uint32_t *__restrict_
 }
 
 // ------------------------------------------------------------------------------------
-// kernel 5: bucket reduction.  For lanes j = 0..63 holding (acc_j, run_j) returns in lane 0
+// kernel 5: bucket reduction  sum_b (b+1) * S_b  per window.  Pure latency (a few thousand
+// point additions on an otherwise idle chip), so every point is shared by a QUAD of lanes
+// (quad29.h: one field product per lane per dependency level, ~2.7x shorter per addition than a
+// lane-private one) and a wavefront holds 16 points.
+//
+// For quads j = 0..15 of a wavefront holding (acc_j, run_j) the helper returns in quad 0
 //   ACC = sum_j acc_j + 2^log_mult * sum_j j*run_j      RUN = sum_j run_j
-// using an inclusive suffix scan of run (6 shuffle steps), then two tree sums.
+// using an inclusive suffix scan of run over the quads (4 shuffle steps), then two tree sums.
 // ------------------------------------------------------------------------------------
-template <class C>
-__device__ __forceinline__ void wave_weighted(typename C::Acc &acc, typename C::Acc &run, unsigned log_mult, unsigned lane) {
-    using A = typename C::Acc;
-    for (unsigned d = 1; d < 64; d <<= 1) {          // suffix scan: run_j <- sum_{i >= j} run_i
-        A t = shfl_down_acc(run, d);
-        if (lane + d < 64) run = C::add(run, t);
+template <class A>
+__device__ __forceinline__ void quadwave_weighted(A &acc, A &run, unsigned log_mult, unsigned lane) {
+    const unsigned q = lane & 3, qi = lane >> 2;
+    for (unsigned d = 1; d < 16; d <<= 1) {          // suffix scan: run_j <- sum_{i >= j} run_i
+        A t = shfl_down_acc(run, 4 * d);
+        if (qi + d < 16) run = quad_add(run, t, q);
     }
-    A s = (lane == 0) ? C::inf() : run;              // sum_{k=1..63} Suf_k = sum_j j*run_j
-    s = wave_sum<C>(s, lane);
-    acc = wave_sum<C>(acc, lane);
-    if (lane == 0) {
-        for (unsigned i = 0; i < log_mult; i++) s = C::dbl(s);
-        acc = C::add(acc, s);
+    A s = (qi == 0) ? A::inf() : run;                // sum_{k=1..15} Suf_k = sum_j j*run_j
+    for (unsigned d = 8; d >= 1; d >>= 1) {
+        A t = shfl_down_acc(s, 4 * d);
+        if (qi + d < 16) s = quad_add(s, t, q);
+        A u = shfl_down_acc(acc, 4 * d);
+        if (qi + d < 16) acc = quad_add(acc, u, q);
+    }
+    if (qi == 0) {
+        for (unsigned i = 0; i < log_mult; i++) s = quad_dbl(s, q);
+        acc = quad_add(acc, s, q);
     }
 }
 
-// Level 1: T = B/L lanes per window (padded to a multiple of 64); lane t owns buckets
-// [t*L, (t+1)*L).  Writes one (ACC,RUN) pair per wavefront.
+// Level 1: T = B/L quads per window; quad t owns buckets [t*L, (t+1)*L) (their ACC_SPLIT partial
+// sums are folded in here).  Writes one (ACC,RUN) pair per wavefront (16 quads = 16*L buckets).
+// merge_windows > 0 (pre-shifted bases): bucket b of all `merge_windows` windows holds multiples
+// of the same weight, so the windows are summed here and there is a single output window.
 template <class C>
 __global__ __launch_bounds__(64) void k_reduce1(const typename C::Acc *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t logL,
-                                                uint32_t waves_per_window, typename C::Acc *__restrict__ wave_out) {
+                                                uint32_t waves_per_window, uint32_t merge_windows, typename C::Acc *__restrict__ wave_out) {
     using A = typename C::Acc;
     uint32_t wave = blockIdx.x;                 // global wave id = k*waves_per_window + w
     uint32_t k = wave / waves_per_window, w = wave % waves_per_window;
-    unsigned lane = threadIdx.x;
-    uint32_t t = w * 64 + lane;
-    A acc = C::inf(), run = C::inf();
+    const unsigned lane = threadIdx.x, q = lane & 3;
+    uint32_t t = w * 16 + (lane >> 2);
+    A acc = A::inf(), run = A::inf();
     if ((uint64_t)t * L < B) {
         const A *bk = buckets + ((size_t)k * B + (size_t)t * L) * ACC_SPLIT;
         for (int i = (int)L - 1; i >= 0; i--) {
-            for (uint32_t h = 0; h < ACC_SPLIT; h++) run = C::add(run, bk[(size_t)i * ACC_SPLIT + h]);
-            acc = C::add(acc, run);
+            for (uint32_t h = 0; h < ACC_SPLIT; h++) run = quad_add(run, bk[(size_t)i * ACC_SPLIT + h], q);
+            for (uint32_t kk = 1; kk < merge_windows; kk++)
+                for (uint32_t h = 0; h < ACC_SPLIT; h++) run = quad_add(run, bk[((size_t)kk * B + i) * ACC_SPLIT + h], q);
+            acc = quad_add(acc, run, q);
         }
     }
-    wave_weighted<C>(acc, run, logL, lane);
+    quadwave_weighted(acc, run, logL, lane);
     if (lane == 0) {
         wave_out[2 * (size_t)wave] = acc;
         wave_out[2 * (size_t)wave + 1] = run;
     }
 }
 
-// Level 2: one wavefront per window folds the <= 64 wave pairs of level 1.
+// Level >= 2: per window, every wavefront folds 16 consecutive (ACC,RUN) pairs of the previous
+// level (each covering 2^log_mult buckets) into one; the last level (m_out == 1) leaves the
+// window sum in out[2*k].
 template <class C>
-__global__ __launch_bounds__(64) void k_reduce2(const typename C::Acc *__restrict__ wave_in, uint32_t waves_per_window, uint32_t log_mult,
-                                                typename C::Acc *__restrict__ window_sums) {
+__global__ __launch_bounds__(64) void k_reduce2(const typename C::Acc *__restrict__ in, uint32_t m_in, uint32_t m_out, uint32_t log_mult,
+                                                typename C::Acc *__restrict__ out) {
     using A = typename C::Acc;
-    uint32_t k = blockIdx.x;
-    unsigned lane = threadIdx.x;
-    A acc = C::inf(), run = C::inf();
-    if (lane < waves_per_window) {
-        acc = wave_in[2 * ((size_t)k * waves_per_window + lane)];
-        run = wave_in[2 * ((size_t)k * waves_per_window + lane) + 1];
+    const uint32_t k = blockIdx.x / m_out, w = blockIdx.x % m_out;
+    const unsigned lane = threadIdx.x;
+    const uint32_t j = w * 16 + (lane >> 2);
+    A acc = A::inf(), run = A::inf();
+    if (j < m_in) {
+        acc = in[2 * ((size_t)k * m_in + j)];
+        run = in[2 * ((size_t)k * m_in + j) + 1];
     }
-    wave_weighted<C>(acc, run, log_mult, lane);
-    if (lane == 0) window_sums[k] = acc;
+    quadwave_weighted(acc, run, log_mult, lane);
+    if (lane == 0) {
+        out[2 * ((size_t)k * m_out + w)] = acc;
+        out[2 * ((size_t)k * m_out + w) + 1] = run;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -555,21 +591,6 @@ __device__ __forceinline__ void pin_vgpr(A &a) {
     for (int i = 0; i < (int)(sizeof(A) / 4); i++) asm volatile("" : "+v"(w[i]));
 }
 
-template <class C>
-__global__ __launch_bounds__(64) void k_fold(const typename C::Acc *__restrict__ window_sums, unsigned nwin, unsigned c,
-                                             Jac<typename C::Field> *__restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    typename C::Acc r = window_sums[nwin - 1];
-    pin_vgpr(r);
-    for (int k = (int)nwin - 2; k >= 0; k--) {
-        for (unsigned i = 0; i < c; i++) r = C::dbl(r);
-        typename C::Acc w = window_sums[k];
-        pin_vgpr(w);
-        r = C::add(r, w);
-    }
-    *out = C::to_jac(r);
-}
-
 // ------------------------------------------------------------------------------------
 // kernel 6b (G1): the same Horner fold with each point shared by a QUAD of lanes.  The 240
 // doublings are inherently sequential, so the lever is latency per doubling: the 9 field
@@ -581,11 +602,12 @@ template <class A, class J>
 __device__ __forceinline__ void fold_quad_body(const A *__restrict__ window_sums, unsigned nwin, unsigned c, J *__restrict__ out) {
     if (threadIdx.x >= 4 || blockIdx.x != 0) return;
     const unsigned q = threadIdx.x & 3;
-    A r = window_sums[nwin - 1];
+    // window_sums holds (ACC,RUN) pairs of the last reduction level: window k at index 2k
+    A r = window_sums[2 * (nwin - 1)];
     pin_vgpr(r);
     for (int k = (int)nwin - 2; k >= 0; k--) {
         for (unsigned i = 0; i < c; i++) r = quad_dbl(r, q);
-        A w = window_sums[k];
+        A w = window_sums[2 * k];
         pin_vgpr(w);
         r = quad_add(r, w, q);
     }
@@ -741,8 +763,64 @@ int normalize_to_affine(const Jac<F> *d_in, Aff<F> *d_out, size_t n, hipStream_t
 template int normalize_to_affine<Fq>(const Jac<Fq> *, Aff<Fq> *, size_t, hipStream_t);
 template int normalize_to_affine<Fq2>(const Jac<Fq2> *, Aff<Fq2> *, size_t, hipStream_t);
 
+// ------------------------------------------------------------------------------------
+// Pre-shifted bases ("merged windows").  A resident CRS can carry, next to P_i, the multiples
+// 2^(16k) * P_i for every window k of a c = 16 decomposition (window-major: entry k*N + i).
+// Window k then gathers from its own copy, every window's bucket b has weight (b+1) and the
+// windows are summed bucket-wise in the reduction: the Horner fold -- c*(nwin-1) sequential
+// doublings, 0.3 ms (G1) / 1.8 ms (G2) of pure latency -- disappears and the reduction runs
+// over one window instead of nwin.  Costs nwin x the base memory (G1: 8 x 64 B, G2: 16 x 128 B
+// per point) and one pass of nwin*16 doublings + a batch normalisation per key.
+// ------------------------------------------------------------------------------------
+static constexpr unsigned MERGED_C = 16;
+template <class C> static constexpr unsigned merged_windows() { return C::GLV ? 128 / MERGED_C : (255 + MERGED_C - 1) / MERGED_C; }
+unsigned msm_table_windows(int group) { return group == 1 ? merged_windows<CurveG1>() : merged_windows<CurveG2>(); }
+
+static size_t g_merge_min = 0;
+static const bool g_merge_always = getenv("LSA_PRECOMPUTE_ALWAYS") != nullptr;   // tests / experiments
+void msm_set_merge_min(size_t n) { g_merge_min = n; }     // 0: back to LSA_PRECOMPUTE_MIN / the default
+size_t msm_merge_min() {
+    if (g_merge_min == 0) {
+        const char *e = getenv("LSA_PRECOMPUTE_MIN");
+        g_merge_min = e && atoll(e) > 0 ? (size_t)atoll(e) : (size_t)1 << 19;
+    }
+    return g_merge_min;
+}
+
+template <class C>
+__global__ __launch_bounds__(256) void k_shift_window(const typename C::Base *__restrict__ prev, Jac<typename C::Field> *__restrict__ out,
+                                                      size_t n, unsigned c) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    typename C::Acc p = C::madd(C::inf(), prev[i], false, false);   // infinity stays infinity
+    for (unsigned j = 0; j < c; j++) p = C::dbl(p);
+    out[i] = C::to_jac(p);
+}
+
+// d_table: msm_table_windows(group) * n entries, window 0 (= the bases) already filled.
 template <class F>
-int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st) {
+int precompute_windows(void *d_table, size_t n, hipStream_t st) {
+    using C = typename CurveOf<F>::type;
+    if (n == 0) return LSA_OK;
+    Jac<F> *tmp = nullptr;
+    if (hipMalloc(&tmp, n * sizeof(Jac<F>)) != hipSuccess) { set_error("precompute_windows: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    typename C::Base *tbl = (typename C::Base *)d_table;
+    int rc = LSA_OK;
+    for (unsigned k = 1; k < merged_windows<C>() && !rc; k++) {
+        hipLaunchKernelGGL((k_shift_window<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tbl + (size_t)(k - 1) * n, tmp, n, MERGED_C);
+        rc = prepare_bases<F>(tmp, tbl + (size_t)k * n, n, st);
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error("precompute_windows: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
+    return LSA_OK;
+}
+template int precompute_windows<Fq>(void *, size_t, hipStream_t);
+template int precompute_windows<Fq2>(void *, size_t, hipStream_t);
+
+template <class F>
+int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride) {
     using C = typename CurveOf<F>::type;
     using A = typename C::Acc;
     const typename C::Base *d_bases = (const typename C::Base *)d_bases_v + first;
@@ -755,17 +833,28 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         return LSA_OK;
     }
     if (n >= (size_t(1) << 27)) { set_error("msm: n too large (%zu)", n); return LSA_ERR_INVALID; }
-    const unsigned c = msm_window_bits(C::GLV ? 2 * n : n);             // sized by the virtual scalars
+    // Pre-shifted bases trade ~7 % of accumulate throughput (8x the gather footprint) for a
+    // tail without the Horner fold: a win for an isolated call (latency), a loss when calls are
+    // queued back to back and the tail is hidden under the next front anyway.  So on G1 the
+    // table is used only when no earlier call's tail is still in flight.  On G2 the fold is
+    // 1.8 ms of a 6.7 ms call -- too long to hide -- and the table always wins.
+    bool busy = false;
+    for (auto &t : g_tail) if (t.pending && hipEventQuery(t.done) == hipErrorNotReady) busy = true;
+    (void)hipGetLastError();
+    const bool merged = table_stride != 0 && n >= msm_merge_min() && (!busy || !C::GLV || g_merge_always);
+    if (merged && (uint64_t)table_stride * merged_windows<C>() >= (1u << 30)) { set_error("msm: base table too large for 30-bit entries"); return LSA_ERR_INVALID; }
+    const unsigned c = merged ? MERGED_C : msm_window_bits(C::GLV ? 2 * n : n);   // sized by the virtual scalars
     const unsigned nwin = C::GLV ? (128 + c - 1) / c : num_windows(c);   // |k1|,|k2| < 2^127 (glv.h)
     const size_t nv = C::GLV ? 2 * n : n;                                  // virtual scalars
     const uint32_t B = 1u << (c - 1);
     const uint32_t nb = nwin * B;
     const size_t ne = nv * nwin;
-    const uint32_t L = B > 4096 ? B / 4096 : 1;
+    const uint32_t L = merged ? 1 : (B > 4096 ? B / 4096 : 1);   // buckets per quad in the first reduction level
     uint32_t logL = 0;
     while ((1u << logL) < L) logL++;
-    const uint32_t T = B / L;
-    const uint32_t wpw = (T + 63) / 64;              // wavefronts per window, <= 64
+    const uint32_t T = B / L;                        // quads per window
+    const uint32_t wpw = (T + 15) / 16;              // wavefronts per window (16 quads each)
+    const uint32_t kw = merged ? 1 : nwin;           // windows leaving the reduction
     // Buckets far above the average population (skewed scalars; the partly filled top window
     // when c does not divide the scalar length) are split across workgroups instead of being
     // walked by two lanes.
@@ -781,7 +870,8 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     size_t o_offs = carve((size_t)nb * 4);
     const uint32_t scan_blocks = (nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;   // <= 1024 since nb <= 2^20
     size_t o_bsum = carve((size_t)scan_blocks * 4);
-    size_t o_bins = carve((size_t)3 * SIZE_BINS * 4);   // bin_count | bin_start | bin_cursor
+    const uint32_t ngroups = 1;                         // (window-major ordering of the merged mode measured slower than one global order)
+    size_t o_bins = carve((size_t)3 * ngroups * SIZE_BINS * 4);   // bin_count | bin_start | bin_cursor
     size_t o_perm = carve((size_t)nb * 4);
     const uint32_t ntiles = (uint32_t)((nv + SORT_TILE - 1) / SORT_TILE);
     size_t o_digits = carve(ne * 4);
@@ -806,8 +896,8 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     size_t toff = 0;
     auto tcarve = [&](size_t bytes) { size_t o = toff; toff = align_up(toff + bytes, 256); return o; };
     size_t o_buckets = tcarve((size_t)nb * ACC_SPLIT * sizeof(A));
-    size_t o_wave = tcarve((size_t)nwin * wpw * 2 * sizeof(A));
-    size_t o_win = tcarve((size_t)nwin * sizeof(A));
+    size_t o_wave = tcarve((size_t)kw * wpw * 2 * sizeof(A));
+    size_t o_win = tcarve((size_t)kw * ((wpw + 15) / 16) * 2 * sizeof(A));   // reduction levels ping-pong between the two
     if (tb.pending) {
         if (toff > tb.ws.cap) HIPCHK(hipEventSynchronize(tb.done));   // about to reallocate: the old tail must be finished
         HIPCHK(hipStreamWaitEvent(st, tb.done, 0));                     // the front may not overwrite buckets a tail still reads
@@ -819,7 +909,7 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     uint32_t *heavy_count = hist + nb;
     uint32_t *offs = (uint32_t *)(ws + o_offs);
     uint32_t *bsum = (uint32_t *)(ws + o_bsum);
-    uint32_t *bin_count = (uint32_t *)(ws + o_bins), *bin_start = bin_count + SIZE_BINS, *bin_cursor = bin_start + SIZE_BINS;
+    uint32_t *bin_count = (uint32_t *)(ws + o_bins), *bin_start = bin_count + ngroups * SIZE_BINS, *bin_cursor = bin_start + ngroups * SIZE_BINS;
     uint32_t *perm = (uint32_t *)(ws + o_perm);
     int32_t *digits = (int32_t *)(ws + o_digits);
     uint16_t *rank = (uint16_t *)(ws + o_rank);
@@ -843,7 +933,7 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
 
     mark(st);  // 0
     HIPCHK(hipMemsetAsync(heavy_count, 0, 4, st));
-    HIPCHK(hipMemsetAsync(bin_count, 0, (size_t)3 * SIZE_BINS * 4, st));
+    HIPCHK(hipMemsetAsync(bin_count, 0, (size_t)3 * ngroups * SIZE_BINS * 4, st));
     static bool lds_attr_set = false;
     if (!lds_attr_set) {   // > 64 KiB of dynamic LDS needs an explicit opt-in
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
@@ -858,13 +948,14 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bsum, scan_blocks);
     hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, hist, bsum, nb, offs);
     mark(st);  // 2
-    hipLaunchKernelGGL(k_scatter, dim3(ntiles, nwin), dim3(1024), (size_t)B * 4, st, digits, rank, offs, tile_base, nv, n, B, ntiles, entries);
+    hipLaunchKernelGGL(k_scatter, dim3(ntiles, nwin), dim3(1024), (size_t)B * 4, st, digits, rank, offs, tile_base, nv, n, B, ntiles, entries, merged ? (uint32_t)table_stride : 0u);
     mark(st);  // 3
     {
         const unsigned sb = (nb + 2047) / 2048;
-        hipLaunchKernelGGL((k_size_hist<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_count);
-        hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(256), 0, st, bin_count, bin_start);
-        hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets);
+        const uint32_t gsz = 0u;
+        hipLaunchKernelGGL((k_size_hist<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_count, gsz);
+        hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(256), 0, st, bin_count, bin_start, ngroups);
+        hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets, gsz);
     }
     hipLaunchKernelGGL((k_accumulate<C>), dim3((nb * ACC_SPLIT + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
     hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(256), 0, st, hist, heavy_list, heavy_count, chunk_off);
@@ -876,13 +967,22 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         HIPCHK(hipEventRecord(g_front_done, st));
         HIPCHK(hipStreamWaitEvent(tail, g_front_done, 0));
     }
-    hipLaunchKernelGGL((k_reduce1<C>), dim3(nwin * wpw), dim3(64), 0, tail, buckets, B, L, logL, wpw, wave_out);
-    hipLaunchKernelGGL((k_reduce2<C>), dim3(nwin), dim3(64), 0, tail, wave_out, wpw, logL + 6, window_sums);
+    hipLaunchKernelGGL((k_reduce1<C>), dim3(kw * wpw), dim3(64), 0, tail, buckets, B, L, logL, wpw, merged ? nwin : 0u, wave_out);
+    A *lvl_in = wave_out, *lvl_out = window_sums;
+    uint32_t m = wpw, lm = logL + 4;                 // m pairs per window, each covering 2^lm buckets
+    do {
+        const uint32_t m_out = (m + 15) / 16;
+        hipLaunchKernelGGL((k_reduce2<C>), dim3(kw * m_out), dim3(64), 0, tail, lvl_in, m, m_out, lm, lvl_out);
+        std::swap(lvl_in, lvl_out);
+        m = m_out;
+        lm += 4;
+    } while (m > 1);
     mark(tail);  // 5
+    // lvl_in[2*k] = sum of window k (pairs of (ACC,RUN): stride 2)
     if constexpr (std::is_same<C, CurveG1>::value)
-        hipLaunchKernelGGL(k_fold_quad, dim3(1), dim3(64), 0, tail, window_sums, nwin, c, d_out);
+        hipLaunchKernelGGL(k_fold_quad, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, d_out);
     else
-        hipLaunchKernelGGL(k_fold_quad_g2, dim3(1), dim3(64), 0, tail, window_sums, nwin, c, d_out);
+        hipLaunchKernelGGL(k_fold_quad_g2, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, d_out);
     mark(tail);  // 6
     HIPCHK(hipEventRecord(tb.done, tail));
     tb.pending = true;
@@ -892,7 +992,7 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     if (g_profile) g_ev_calls++;
     return LSA_OK;
 }
-template int msm_device<Fq>(const void *, size_t, const Fr *, size_t, Jac<Fq> *, hipStream_t);
-template int msm_device<Fq2>(const void *, size_t, const Fr *, size_t, Jac<Fq2> *, hipStream_t);
+template int msm_device<Fq>(const void *, size_t, const Fr *, size_t, Jac<Fq> *, hipStream_t, size_t);
+template int msm_device<Fq2>(const void *, size_t, const Fr *, size_t, Jac<Fq2> *, hipStream_t, size_t);
 
 }  // namespace lsa

@@ -188,14 +188,19 @@ def test_sharded_path_on_one_gpu_with_virtual_peer(lsa):
     B.close()
 
 
-def test_pipelined_async_calls_with_changing_sizes(lsa):
+@pytest.mark.parametrize("table_threshold", [0, 1, 4000])
+def test_pipelined_async_calls_with_changing_sizes(lsa, table_threshold):
     """Back-to-back lsa_msm_run_async calls overlap one call's tail (reduce + fold, internal
     stream) with the next call's front.  Results must not depend on that: different sizes
-    (different workspace layouts) and output slots, checked against synchronous runs."""
+    (different workspace layouts) and output slots, checked against synchronous runs.
+    With a table threshold the handle also carries the pre-shifted window copies, and calls
+    switch between the merged path (idle device) and the plain one (queued calls)."""
     import torch
     n = 20000
     bases = o.arith_bases("g1", 777, 12345, n)
+    lsa.set_table_threshold(table_threshold)
     B = lsa.Bases("g1", bases)
+    assert B.has_table() == (table_threshold != 0)
     sizes = [n, 37, 4096, 1, 9000, 12, 20000, 300, 1025, 5, 16384, 2]
     scs = []
     for i, m in enumerate(sizes):
@@ -214,3 +219,38 @@ def test_pipelined_async_calls_with_changing_sizes(lsa):
         ref = o.multi_exp("g1", bases[:m], scs[i].cpu().numpy().view(np.uint64), mode="mixed")
         assert canon("g1", got[i]) == canon("g1", ref), (i, m)
     B.close()
+    lsa.set_table_threshold(0)
+
+
+@pytest.mark.parametrize("group,n", [("g1", 1), ("g1", 3000), ("g2", 700)])
+def test_preshifted_window_tables_vs_oracle(lsa, group, n):
+    """Resident bases with the pre-shifted copies 2^(16k)*P (merged windows, msm.hip): forced on
+    at small n, full range and sub-ranges, against the oracle; then the same handle below the
+    threshold takes the plain path and must agree."""
+    import torch
+    lsa.set_table_threshold(1)
+    try:
+        bases = o.arith_bases(group, 4242 + n, 17, n)
+        if n > 10:
+            bases[5] = 0                                     # infinity among the bases
+        B = lsa.Bases(group, bases)
+        assert B.has_table()
+        sc, _ = o.random_scalars(n, seed=900 + n)
+        if n > 10:
+            sc[0] = o.fr_mont(0); sc[1] = o.fr_mont(1); sc[2] = o.fr_mont(o.R - 1)
+        d_s = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        torch.cuda.synchronize()
+        got = B.msm(d_s)
+        want = o.multi_exp(group, bases, sc, mode="mixed")
+        assert canon(group, got) == canon(group, want)
+        if n > 10:
+            first, m = 7, n - 100
+            got = B.msm(d_s[first:first + m], n=m, first=first)
+            want = o.multi_exp(group, bases[first:first + m], sc[first:first + m], mode="mixed")
+            assert canon(group, got) == canon(group, want)
+        lsa.set_table_threshold(1 << 30)                     # same handle, plain path
+        got = B.msm(d_s)
+        assert canon(group, got) == canon(group, o.multi_exp(group, bases, sc, mode="mixed"))
+        B.close()
+    finally:
+        lsa.set_table_threshold(0)
