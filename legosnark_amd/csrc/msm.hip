@@ -528,13 +528,28 @@ __device__ __forceinline__ void quadwave_weighted(A &acc, A &run, unsigned log_m
     }
 }
 
-// Level 1: T = B/L quads per window; quad t owns buckets [t*L, (t+1)*L) (their ACC_SPLIT partial
+// Pre-shifted bases: bucket b of every window holds multiples of the same weight (b+1), so the
+// windows are summed bucket-wise first.  Two lanes per bucket, each adding the partial sums of
+// half the windows with lane-private additions (throughput-bound: nwin*ACC_SPLIT*B additions);
+// the reduction then runs over ONE window whose buckets have two partials.
+template <class C>
+__global__ __launch_bounds__(256) void k_merge_windows(const typename C::Acc *__restrict__ buckets, uint32_t B, uint32_t nwin,
+                                                       typename C::Acc *__restrict__ sums) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * B) return;
+    const uint32_t b = t >> 1, half = t & 1;
+    const uint32_t k0 = half * (nwin / 2), k1 = half ? nwin : nwin / 2;
+    typename C::Acc acc = C::inf();
+    for (uint32_t k = k0; k < k1; k++)
+        for (uint32_t h = 0; h < ACC_SPLIT; h++) acc = C::add(acc, buckets[((size_t)k * B + b) * ACC_SPLIT + h]);
+    sums[t] = acc;
+}
+
+// Level 1: T = B/L quads per window; quad t owns buckets [t*L, (t+1)*L) (their `split` partial
 // sums are folded in here).  Writes one (ACC,RUN) pair per wavefront (16 quads = 16*L buckets).
-// merge_windows > 0 (pre-shifted bases): bucket b of all `merge_windows` windows holds multiples
-// of the same weight, so the windows are summed here and there is a single output window.
 template <class C>
 __global__ __launch_bounds__(64) void k_reduce1(const typename C::Acc *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t logL,
-                                                uint32_t waves_per_window, uint32_t merge_windows, typename C::Acc *__restrict__ wave_out) {
+                                                uint32_t waves_per_window, uint32_t split, typename C::Acc *__restrict__ wave_out) {
     using A = typename C::Acc;
     uint32_t wave = blockIdx.x;                 // global wave id = k*waves_per_window + w
     uint32_t k = wave / waves_per_window, w = wave % waves_per_window;
@@ -542,11 +557,9 @@ __global__ __launch_bounds__(64) void k_reduce1(const typename C::Acc *__restric
     uint32_t t = w * 16 + (lane >> 2);
     A acc = A::inf(), run = A::inf();
     if ((uint64_t)t * L < B) {
-        const A *bk = buckets + ((size_t)k * B + (size_t)t * L) * ACC_SPLIT;
+        const A *bk = buckets + ((size_t)k * B + (size_t)t * L) * split;
         for (int i = (int)L - 1; i >= 0; i--) {
-            for (uint32_t h = 0; h < ACC_SPLIT; h++) run = quad_add(run, bk[(size_t)i * ACC_SPLIT + h], q);
-            for (uint32_t kk = 1; kk < merge_windows; kk++)
-                for (uint32_t h = 0; h < ACC_SPLIT; h++) run = quad_add(run, bk[((size_t)kk * B + i) * ACC_SPLIT + h], q);
+            for (uint32_t h = 0; h < split; h++) run = quad_add(run, bk[(size_t)i * split + h], q);
             acc = quad_add(acc, run, q);
         }
     }
@@ -656,31 +669,38 @@ struct Workspace {
 static Workspace g_ws;        // front phase (digits .. accumulate): reused by every call, ordered on the caller's stream
 static Workspace g_prep_ws;   // prepare_bases staging
 
-// Pipelining of back-to-back MSMs: the tail (bucket reduction + fold, ~0.8 ms of pure latency
-// on a nearly idle chip) runs on an internal stream, so it overlaps the next call's
-// throughput-bound front (sort + accumulate).  The buffers the tail reads (buckets, wave
-// partials, window sums) are double-buffered per call parity and guarded by events; results
-// become ordered on the caller's stream again at msm_join() (every synchronous entry point and
+// Pipelining of back-to-back MSMs: the tail (bucket reduction + fold, 0.4-0.8 ms of pure latency
+// on a nearly idle chip) runs on an internal stream, so it overlaps the next calls'
+// throughput-bound fronts (sort + accumulate).  The buffers a tail reads (buckets, wave
+// partials, window sums) belong to its slot and are guarded by events; results become ordered
+// on the caller's stream again at msm_join() (every synchronous entry point and
 // lsa_stream_join() do that).  LSA_NO_OVERLAP=1 runs everything on the caller's stream.
+// NTAIL tail slots, each with its own stream and buffers, used round-robin: the tails of
+// consecutive calls are independent, and for small MSMs (CPpoly's ladder) a tail is longer than
+// a front, so several run at once.  Each tail computes its result into the slot and publishes
+// it to the caller's buffer with a 96/192-byte copy that waits for the previous call's copy:
+// results appear in call order even when a later tail finishes first.
+static constexpr int NTAIL = 4;
 struct TailBuf {
     Workspace ws;
-    hipEvent_t done = nullptr;
-    bool pending = false;
+    hipEvent_t done = nullptr;     // recorded after the slot's result has been published
+    hipStream_t stream = nullptr;
+    bool pending = false;          // a tail has been issued on this slot
+    bool unjoined = false;         // ... and the caller's stream has not waited for it yet
 };
-static TailBuf g_tail[2];
-static hipStream_t g_tail_stream = nullptr;
-static hipEvent_t g_front_done = nullptr, g_join_ev = nullptr;
-static unsigned g_parity = 0;
-static bool g_tail_dirty = false;
+static TailBuf g_tail[NTAIL];
+static hipEvent_t g_front_done = nullptr;
+static unsigned g_slot = 0;
 static int g_overlap = -1;
 
 int msm_join(hipStream_t st) {
-    if (g_tail_dirty) {
-        if (hipEventRecord(g_join_ev, g_tail_stream) != hipSuccess || hipStreamWaitEvent(st, g_join_ev, 0) != hipSuccess) {
+    for (auto &t : g_tail) {
+        if (!t.unjoined) continue;
+        if (hipStreamWaitEvent(st, t.done, 0) != hipSuccess) {
             set_error("msm_join: stream wait failed");
             return LSA_ERR_HIP;
         }
-        g_tail_dirty = false;
+        t.unjoined = false;
     }
     return LSA_OK;
 }
@@ -694,12 +714,13 @@ static bool g_profile = false;
 static int g_ev_calls = 0;
 
 void msm_release_workspace() {
-    if (g_tail_stream) (void)hipStreamSynchronize(g_tail_stream);
-    for (auto &t : g_tail) { t.ws.release(); if (t.done) (void)hipEventDestroy(t.done); t.done = nullptr; t.pending = false; }
+    for (auto &t : g_tail) {
+        if (t.stream) { (void)hipStreamSynchronize(t.stream); (void)hipStreamDestroy(t.stream); t.stream = nullptr; }
+        t.ws.release();
+        if (t.done) (void)hipEventDestroy(t.done);
+        t.done = nullptr; t.pending = false; t.unjoined = false;
+    }
     if (g_front_done) { (void)hipEventDestroy(g_front_done); g_front_done = nullptr; }
-    if (g_join_ev) { (void)hipEventDestroy(g_join_ev); g_join_ev = nullptr; }
-    if (g_tail_stream) { (void)hipStreamDestroy(g_tail_stream); g_tail_stream = nullptr; }
-    g_tail_dirty = false;
     g_ws.release();
     g_prep_ws.release();
     if (g_ev_ready) { for (auto &row : g_ev) for (auto &e : row) (void)hipEventDestroy(e); g_ev_ready = false; }
@@ -849,7 +870,7 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     const uint32_t B = 1u << (c - 1);
     const uint32_t nb = nwin * B;
     const size_t ne = nv * nwin;
-    const uint32_t L = merged ? 1 : (B > 4096 ? B / 4096 : 1);   // buckets per quad in the first reduction level
+    const uint32_t L = B > 4096 ? B / 4096 : 1;      // buckets per quad in the first reduction level
     uint32_t logL = 0;
     while ((1u << logL) < L) logL++;
     const uint32_t T = B / L;                        // quads per window
@@ -886,23 +907,30 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     // tail buffers of this call parity
     if (g_overlap < 0) g_overlap = getenv("LSA_NO_OVERLAP") ? 0 : 1;
     if (!g_tail[0].done) {
-        for (auto &t : g_tail) HIPCHK(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+        for (auto &t : g_tail) {
+            HIPCHK(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+            if (g_overlap) HIPCHK(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
+        }
         HIPCHK(hipEventCreateWithFlags(&g_front_done, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&g_join_ev, hipEventDisableTiming));
-        if (g_overlap) HIPCHK(hipStreamCreateWithFlags(&g_tail_stream, hipStreamNonBlocking));
     }
-    hipStream_t tail = g_overlap ? g_tail_stream : st;
-    TailBuf &tb = g_tail[g_parity];
+    TailBuf &tb = g_tail[g_slot];
+    TailBuf &prev = g_tail[(g_slot + NTAIL - 1) % NTAIL];
+    hipStream_t tail = g_overlap ? tb.stream : st;
     size_t toff = 0;
     auto tcarve = [&](size_t bytes) { size_t o = toff; toff = align_up(toff + bytes, 256); return o; };
     size_t o_buckets = tcarve((size_t)nb * ACC_SPLIT * sizeof(A));
     size_t o_wave = tcarve((size_t)kw * wpw * 2 * sizeof(A));
     size_t o_win = tcarve((size_t)kw * ((wpw + 15) / 16) * 2 * sizeof(A));   // reduction levels ping-pong between the two
-    if (tb.pending) {
-        if (toff > tb.ws.cap) HIPCHK(hipEventSynchronize(tb.done));   // about to reallocate: the old tail must be finished
-        HIPCHK(hipStreamWaitEvent(st, tb.done, 0));                     // the front may not overwrite buckets a tail still reads
+    size_t o_msum = tcarve(merged ? (size_t)2 * B * sizeof(A) : 0);           // bucket-wise sums over the windows
+    size_t o_res = tcarve(sizeof(Jac<F>));                                     // this call's result before it is published
+    // all slots grow together, so that a new problem size pays its allocations in one call
+    // instead of once per slot
+    for (auto &t : g_tail) {
+        if (toff <= t.ws.cap) continue;
+        if (t.pending) HIPCHK(hipEventSynchronize(t.done));            // about to reallocate: the old tail must be finished
+        if (t.ws.ensure(toff) != 0) { set_error("msm: tail workspace allocation of %zu bytes failed", toff); return LSA_ERR_NOMEM; }
     }
-    if (tb.ws.ensure(toff) != 0) { set_error("msm: tail workspace allocation of %zu bytes failed", toff); return LSA_ERR_NOMEM; }
+    if (tb.pending) HIPCHK(hipStreamWaitEvent(st, tb.done, 0));        // the front may not overwrite buckets a tail still reads
     char *tws = (char *)tb.ws.ptr;
     char *ws = (char *)g_ws.ptr;
     uint32_t *hist = (uint32_t *)(ws + o_hist);
@@ -967,7 +995,13 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         HIPCHK(hipEventRecord(g_front_done, st));
         HIPCHK(hipStreamWaitEvent(tail, g_front_done, 0));
     }
-    hipLaunchKernelGGL((k_reduce1<C>), dim3(kw * wpw), dim3(64), 0, tail, buckets, B, L, logL, wpw, merged ? nwin : 0u, wave_out);
+    if (merged) {
+        A *msum = (A *)(tws + o_msum);
+        hipLaunchKernelGGL((k_merge_windows<C>), dim3((2 * B + 255) / 256), dim3(256), 0, tail, buckets, B, nwin, msum);
+        hipLaunchKernelGGL((k_reduce1<C>), dim3(wpw), dim3(64), 0, tail, msum, B, L, logL, wpw, 2u, wave_out);
+    } else {
+        hipLaunchKernelGGL((k_reduce1<C>), dim3(kw * wpw), dim3(64), 0, tail, buckets, B, L, logL, wpw, ACC_SPLIT, wave_out);
+    }
     A *lvl_in = wave_out, *lvl_out = window_sums;
     uint32_t m = wpw, lm = logL + 4;                 // m pairs per window, each covering 2^lm buckets
     do {
@@ -979,15 +1013,20 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     } while (m > 1);
     mark(tail);  // 5
     // lvl_in[2*k] = sum of window k (pairs of (ACC,RUN): stride 2)
+    Jac<F> *res = tail != st ? (Jac<F> *)(tws + o_res) : d_out;
     if constexpr (std::is_same<C, CurveG1>::value)
-        hipLaunchKernelGGL(k_fold_quad, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, d_out);
+        hipLaunchKernelGGL(k_fold_quad, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, res);
     else
-        hipLaunchKernelGGL(k_fold_quad_g2, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, d_out);
+        hipLaunchKernelGGL(k_fold_quad_g2, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, res);
+    if (tail != st) {
+        if (prev.pending && &prev != &tb) HIPCHK(hipStreamWaitEvent(tail, prev.done, 0));   // publish in call order
+        HIPCHK(hipMemcpyAsync(d_out, res, sizeof(Jac<F>), hipMemcpyDeviceToDevice, tail));
+    }
     mark(tail);  // 6
     HIPCHK(hipEventRecord(tb.done, tail));
     tb.pending = true;
-    g_tail_dirty = (tail != st);
-    g_parity ^= 1;
+    tb.unjoined = (tail != st);
+    g_slot = (g_slot + 1) % NTAIL;
     HIPCHK(hipGetLastError());
     if (g_profile) g_ev_calls++;
     return LSA_OK;
