@@ -22,6 +22,7 @@
 #include "fs29.h"
 #include "msm.h"
 #include "tower.h"
+#include "w12.h"
 
 namespace lsa {
 
@@ -139,42 +140,7 @@ static __device__ __noinline__ P12 miller_one(const Jac<Fq> &P, const Jac<Fq2> &
     return f;
 }
 
-// elt^(-z) for elt in the cyclotomic subgroup (libff alt_bn128_exp_by_neg_z: cyclotomic_exp + conj)
-static __device__ __noinline__ P12 exp_by_neg_z(const P12 &a) {
-    return fq12_cyclotomic_pow_u64(a, LSA_FINAL_EXP_Z).unitary_inverse();
-}
-
-// libff alt_bn128_final_exponentiation: first chunk (q^6-1)(q^2+1), last chunk by the
-// Fuentes-Castaneda et al. addition chain (squarings inside the chain are cyclotomic).
-static __device__ __noinline__ P12 final_exp_one(const P12 &elt) {
-    P12 A = elt.unitary_inverse();
-    P12 B = fq12_inverse(elt);
-    P12 C = A * B;
-    P12 D = fq12_frobenius<2>(C);
-    P12 first = D * C;
-    A = exp_by_neg_z(first);
-    B = fq12_cyclotomic_sqr(A);
-    C = fq12_cyclotomic_sqr(B);
-    D = C * B;
-    P12 E = exp_by_neg_z(D);
-    P12 F = fq12_cyclotomic_sqr(E);
-    P12 G = exp_by_neg_z(F);
-    P12 H = D.unitary_inverse();
-    P12 I = G.unitary_inverse();
-    P12 J = I * E;
-    P12 K = J * H;
-    P12 L = K * B;
-    P12 M = K * E;
-    P12 N = M * first;
-    P12 O = fq12_frobenius<1>(L);
-    P12 Pp = O * N;
-    P12 Qq = fq12_frobenius<2>(K);
-    P12 Rr = Qq * Pp;
-    P12 S = first.unitary_inverse();
-    P12 T = S * L;
-    P12 U = fq12_frobenius<3>(T);
-    return U * Rr;
-}
+static __device__ __noinline__ P12 final_exp_one(const P12 &elt) { return fq12_final_exponentiation(elt); }
 
 __global__ __launch_bounds__(64) void k_miller(const Jac<Fq> *__restrict__ g1, const Jac<Fq2> *__restrict__ g2, size_t n,
                                                Fq12 *__restrict__ out) {
@@ -187,6 +153,34 @@ __global__ __launch_bounds__(64) void k_final_exp(const Fq12 *__restrict__ in, s
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     out[i] = store12(final_exp_one(load12(in[i])));
+}
+
+// One wavefront per element (w12.h): 36-lane Fq12 products out of LDS.  ~10x shorter chain than
+// k_final_exp; used whenever fewer elements than the chip has lanes are in flight.
+struct WaveExec {
+    template <class F>
+    __device__ __forceinline__ void par(F f) {
+        f(threadIdx.x);
+        __syncthreads();
+    }
+};
+// libff Fq12 layout (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2, each Fq2 = 2 Fq) <-> slot: lane
+// l < 12 moves Fq number l, which is part l%2 of tower coefficient t = l/2, i.e. of w^(2*(t%3) + t/3).
+static __device__ __forceinline__ Fs *w12_fq_ref(Fq2S *slot, unsigned l) {
+    const unsigned t = l >> 1, k = 2 * (t % 3) + t / 3;
+    return (l & 1) ? &slot[k].c1 : &slot[k].c0;
+}
+__global__ __launch_bounds__(64) void k_final_exp_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
+    __shared__ Fq2S lds[W12_LDS_FQ2];
+    const size_t e = blockIdx.x;
+    if (e >= n) return;
+    const unsigned lane = threadIdx.x;
+    WaveExec ex;
+    W12<WaveExec> w{ex, lds, lds + 6 * W12_SLOTS};
+    if (lane < 12) *w12_fq_ref(w.slot(0), lane) = Fs::from_mont256(reinterpret_cast<const Fq *>(&in[e])[lane]);
+    __syncthreads();
+    w.final_exponentiation();
+    if (lane < 12) reinterpret_cast<Fq *>(&out[e])[lane] = w12_fq_ref(w.slot(0), lane)->to_mont256();
 }
 
 // out[i] = prod in[8i .. 8i+7]
@@ -218,7 +212,10 @@ int miller_device(const void *d_g1, const void *d_g2, size_t n, void *d_out, hip
 
 int final_exp_device(const void *d_in, size_t n, void *d_out, hipStream_t st) {
     if (n == 0) return LSA_OK;
-    hipLaunchKernelGGL(k_final_exp, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);
+    if (n < 16384)   // fewer elements than lanes to fill the chip: one wavefront per element
+        hipLaunchKernelGGL(k_final_exp_wave, dim3((unsigned)n), dim3(64), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);
+    else
+        hipLaunchKernelGGL(k_final_exp, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }

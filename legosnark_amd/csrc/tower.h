@@ -197,4 +197,44 @@ LSA_HD_NOINLINE Fq12T<B> fq12_cyclotomic_pow_u64(const Fq12T<B> &a, uint64_t e) 
     return acc;
 }
 
+// elt^(-z) for elt in the cyclotomic subgroup (libff alt_bn128_exp_by_neg_z: cyclotomic_exp + conj)
+template <class B>
+LSA_HD_NOINLINE Fq12T<B> fq12_exp_by_neg_z(const Fq12T<B> &a) {
+    return fq12_cyclotomic_pow_u64(a, LSA_FINAL_EXP_Z).unitary_inverse();
+}
+
+// libff alt_bn128_final_exponentiation: first chunk (q^6-1)(q^2+1), last chunk by the
+// Fuentes-Castaneda et al. addition chain (squarings inside the chain are cyclotomic).
+template <class B>
+LSA_HD_NOINLINE Fq12T<B> fq12_final_exponentiation(const Fq12T<B> &elt) {
+    using P12 = Fq12T<B>;
+    P12 A = elt.unitary_inverse();
+    P12 Bv = fq12_inverse(elt);
+    P12 C = A * Bv;
+    P12 D = fq12_frobenius<2>(C);
+    P12 first = D * C;
+    A = fq12_exp_by_neg_z(first);
+    Bv = fq12_cyclotomic_sqr(A);
+    C = fq12_cyclotomic_sqr(Bv);
+    D = C * Bv;
+    P12 E = fq12_exp_by_neg_z(D);
+    P12 F = fq12_cyclotomic_sqr(E);
+    P12 G = fq12_exp_by_neg_z(F);
+    P12 H = D.unitary_inverse();
+    P12 I = G.unitary_inverse();
+    P12 J = I * E;
+    P12 K = J * H;
+    P12 L = K * Bv;
+    P12 M = K * E;
+    P12 N = M * first;
+    P12 O = fq12_frobenius<1>(L);
+    P12 Pp = O * N;
+    P12 Qq = fq12_frobenius<2>(K);
+    P12 Rr = Qq * Pp;
+    P12 S = first.unitary_inverse();
+    P12 T = S * L;
+    P12 U = fq12_frobenius<3>(T);
+    return U * Rr;
+}
+
 }  // namespace lsa
