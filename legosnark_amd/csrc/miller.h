@@ -1,0 +1,299 @@
+// legosnark_amd/csrc/miller.h -- the optimal-ate Miller loop of alt_bn128 in two shapes:
+//
+//   miller_one()  one pairing per lane (k_miller, pairing.hip): libff's
+//                 doubling_step_for_flipped_miller_loop / mixed_addition_step_for_flipped_miller_loop
+//                 fused with the evaluation at P and the sparse product into f, so libff's
+//                 ~20-KB G2_precomp table never exists.
+//   WMiller       one pairing per WAVEFRONT on top of the W12 engine (w12.h): every round is one
+//                 parallel Fq2-product phase -- 36 lanes for f*f or f*line, up to 6 more for
+//                 the G2 point arithmetic and the line coefficients -- and one combine phase
+//                 (anti-diagonal sums of f on 6 lanes, the point's additions on one lane).
+//                 3 rounds per doubling step, 4 per addition step, ~10x shorter than the
+//                 one-lane chain; what a verifier with a handful of pairings needs.
+// Both follow libff's formulas value for value (the projective representative of the G2 point
+// scales the lines, and miller_loop values are part of the API), so the results are the same
+// canonical Fq12 elements.  Host + device; tests/cpp/test_w12.cc runs one against the other.
+#pragma once
+#include "ec.h"
+#include "fs29.h"
+#include "tower.h"
+#include "w12.h"
+
+namespace lsa {
+
+using PB = Fs;
+using P2 = Fq2T<PB>;
+using P12 = Fq12T<PB>;
+
+LSA_HD P2 load2(const Fq2 &v) { return {PB::from_mont256(v.c0), PB::from_mont256(v.c1)}; }
+
+struct G2Proj { P2 X, Y, Z; };
+struct Line { P2 e0, eVW, eVV; };
+
+// libff doubling_step_for_flipped_miller_loop
+LSA_HD_NOINLINE Line doubling_step(G2Proj &c, const PB &two_inv, const P2 &twist_b) {
+    P2 X = c.X, Y = c.Y, Z = c.Z;
+    P2 A = (X * Y).mul_fq(two_inv);
+    P2 B = Y.sqr();
+    P2 C = Z.sqr();
+    P2 D = C + C + C;
+    P2 E = twist_b * D;
+    P2 F = E + E + E;
+    P2 G = (B + F).mul_fq(two_inv);
+    P2 H = (Y + Z).sqr() - (B + C);
+    P2 I = E - B;
+    P2 J = X.sqr();
+    P2 E2 = E.sqr();
+    c.X = A * (B - F);
+    c.Y = G.sqr() - (E2 + E2 + E2);
+    c.Z = B * H;
+    return {I.mul_xi(), H.neg(), J + J + J};
+}
+
+// libff mixed_addition_step_for_flipped_miller_loop
+LSA_HD_NOINLINE Line addition_step(const P2 &x2, const P2 &y2, G2Proj &c) {
+    P2 X1 = c.X, Y1 = c.Y, Z1 = c.Z;
+    P2 D = X1 - x2 * Z1;
+    P2 E = Y1 - y2 * Z1;
+    P2 F = D.sqr();
+    P2 G = E.sqr();
+    P2 H = D * F;
+    P2 I = X1 * F;
+    P2 J = H + Z1 * G - (I + I);
+    c.X = D * J;
+    c.Y = E * (I - J) - (H * Y1);
+    c.Z = Z1 * H;
+    return {(E * x2 - D * y2).mul_xi(), D, E.neg()};
+}
+
+LSA_HD P12 apply_line(const P12 &f, const Line &l, const PB &px, const PB &py) {
+    return fq12_mul_by_024(f, l.e0, l.eVW.mul_fq(py), l.eVV.mul_fq(px));
+}
+
+LSA_HD int ate_bit(int i) {
+    if (i >= 64) return (int)((LSA_ATE_LOOP_COUNT_HI >> (i - 64)) & 1);
+    return (int)((LSA_ATE_LOOP_COUNT_LO >> i) & 1);
+}
+
+// libff to_affine_coordinates() on both inputs: O -> (0, 1, 0)
+struct AffinePair { PB px, py; P2 qx, qy; };
+LSA_HD_NOINLINE AffinePair miller_affine_inputs(const Jac<Fq> &P, const Jac<Fq2> &Q) {
+    AffinePair r;
+    if (P.Z.is_zero()) { r.px = PB::zero(); r.py = PB::one(); }
+    else if (P.Z == Fq::one()) { r.px = PB::from_mont256(P.X); r.py = PB::from_mont256(P.Y); }
+    else {
+        PB zi = PB::from_mont256(P.Z).inverse(), zi2 = zi.sqr();
+        r.px = PB::from_mont256(P.X) * zi2; r.py = PB::from_mont256(P.Y) * (zi2 * zi);
+    }
+    if (Q.Z.is_zero()) { r.qx = P2::zero(); r.qy = P2::one(); }
+    else if (Q.Z == Fq2::one()) { r.qx = load2(Q.X); r.qy = load2(Q.Y); }
+    else {
+        P2 zi = load2(Q.Z).inverse(), zi2 = zi.sqr();
+        r.qx = load2(Q.X) * zi2; r.qy = load2(Q.Y) * (zi2 * zi);
+    }
+    return r;
+}
+
+// precompute_G1 + precompute_G2 + miller_loop for one pair (libff layout in)
+LSA_HD_NOINLINE P12 miller_one(const Jac<Fq> &P, const Jac<Fq2> &Q) {
+    const AffinePair in = miller_affine_inputs(P, Q);
+    const PB px = in.px, py = in.py;
+    const P2 qx = in.qx, qy = in.qy;
+    Fq ti;
+#pragma unroll
+    for (int i = 0; i < 8; i++) ti.l[i] = LSA_FQ_TWO_INV[i];
+    const PB two_inv = PB::from_mont256(ti);
+    const P2 twist_b = fq2_constT<PB>(LSA_TWIST_B);
+    G2Proj R = {qx, qy, P2::one()};
+    P12 f = P12::one();
+    // bits of 6u+2 below the MSB (bit 64), MSB first
+    for (int i = 63; i >= 0; --i) {
+        Line l = doubling_step(R, two_inv, twist_b);
+        f = fq12_sqr(f);
+        f = apply_line(f, l, px, py);
+        if (ate_bit(i)) {
+            l = addition_step(qx, qy, R);
+            f = apply_line(f, l, px, py);
+        }
+    }
+    // Q1 = pi(Q), Q2 = -pi^2(Q)   (mul_by_q on affine points: Z stays 1)
+    const P2 gx = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_X), gy = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_Y);
+    P2 q1x = gx * qx.conj(), q1y = gy * qy.conj();
+    P2 q2x = gx * q1x.conj(), q2y = (gy * q1y.conj()).neg();
+    Line l = addition_step(q1x, q1y, R);
+    f = apply_line(f, l, px, py);
+    l = addition_step(q2x, q2y, R);
+    f = apply_line(f, l, px, py);
+    return f;
+}
+
+// ------------------------------------------------------------------------------------
+// one pairing per wavefront
+// ------------------------------------------------------------------------------------
+static constexpr int WM_SIDE = 6;                          // side products per round
+enum WMVar {                                               // Fq2 variables in LDS next to the W12 slots
+    WM_RX, WM_RY, WM_RZ, WM_S,                             // current point, S = RY + RZ
+    WM_QX, WM_QY, WM_Q1X, WM_Q1Y, WM_Q2X, WM_Q2Y,          // Q, pi(Q), -pi^2(Q)
+    WM_PX, WM_PY, WM_TWB,                                  // (px,0), (py,0), twist_b
+    WM_A, WM_B, WM_D, WM_E, WM_H, WM_NH, WM_J3, WM_BMF, WM_G,      // doubling step
+    WM_DD, WM_EE, WM_NE, WM_F, WM_GG, WM_HH, WM_I, WM_ZG, WM_JJ, WM_IMJ,   // addition step
+    WM_NVARS
+};
+static constexpr int WM_LDS_FQ2 = W12_LDS_FQ2 + WM_NVARS + WM_SIDE;
+
+template <class X>
+struct WMiller {
+    W12<X> w;      // slot 0: f, slot 1: the line as a full element (zeros at w^1, w^2, w^5)
+    Fq2S *V;       // WM_NVARS variables
+    Fq2S *G;       // WM_SIDE side products of the current round
+    enum { SF = 0, SL = 1 };
+
+    struct Side { int8_t a[WM_SIDE], b[WM_SIDE]; int n; };
+
+    // product phase: lanes < 36: slot(fa)[i] * slot(fb)[j] (when fmul); lanes 36 .. 36+n-1: side products
+    LSA_HD void products(bool fmul, int fa, int fb, const Side sd) {
+        Fq2S *A = w.slot(fa), *B = w.slot(fb), *Pp = w.P, *Vv = V, *Gg = G;
+        w.x.par([=](unsigned lane) {
+            const Fq2S *pa = Vv, *pb = Vv;
+            Fq2S *pd = nullptr;
+            if (lane < 36) {
+                if (fmul) { pa = A + lane / 6; pb = B + lane % 6; pd = Pp + lane; }
+            } else if ((int)lane - 36 < sd.n) {
+                const int k = (int)lane - 36;
+                pa = Vv + sd.a[k]; pb = Vv + sd.b[k]; pd = Gg + k;
+            }
+            if (pd) *pd = w12_fq2_mul(*pa, *pb);
+        });
+    }
+    LSA_HD void set_line(const Fq2S &e0, const Fq2S &evw, const Fq2S &evv) const {
+        Fq2S *L = w.slot(SL);
+        L[0] = e0; L[3] = evw; L[4] = evv;      // w^0: ell_0, w^3: ell_VW * py, w^4: ell_VV * px
+    }
+
+    // f <- f^2 * line(2R), R <- 2R
+    LSA_HD void doubling_round() {
+        WMiller self = *this;
+        Fq2S *Vv = V, *Gg = G;
+        // round 1: f*f | X*Y, Y^2, Z^2, (Y+Z)^2, X^2
+        products(true, SF, SF, Side{{WM_RX, WM_RY, WM_RZ, WM_S, WM_RX, 0}, {WM_RY, WM_RY, WM_RZ, WM_S, WM_RX, 0}, 5});
+        w.x.par([=](unsigned lane) {
+            if (lane < 12) w12_reduce_lane12(lane, self.w.P, self.w.slot(SF));
+            else if (lane == 12) {
+                Fq2S B = Gg[1], C = Gg[2], J = Gg[4];
+                Fq2S H = Gg[3] - (B + C);
+                Vv[WM_A] = Fq2S{Gg[0].c0.halve(), Gg[0].c1.halve()};
+                Vv[WM_B] = B;
+                Vv[WM_D] = C + C + C;
+                Vv[WM_H] = H;
+                Vv[WM_NH] = H.neg();
+                Vv[WM_J3] = J + J + J;
+            }
+        });
+        // round 2: twist_b*D, B*H, (-H)*py, (3J)*px
+        products(false, SF, SF, Side{{WM_TWB, WM_B, WM_NH, WM_J3, 0, 0}, {WM_D, WM_H, WM_PY, WM_PX, 0, 0}, 4});
+        w.x.par([=](unsigned lane) {
+            if (lane == 12) {
+                Fq2S E = Gg[0], B = Vv[WM_B];
+                Fq2S F = E + E + E;
+                Fq2S BF = B + F;
+                Vv[WM_E] = E;
+                Vv[WM_G] = Fq2S{BF.c0.halve(), BF.c1.halve()};
+                Vv[WM_BMF] = B - F;
+                Vv[WM_RZ] = Gg[1];
+                self.set_line((E - B).mul_xi(), Gg[2], Gg[3]);
+            }
+        });
+        // round 3: f*line | E^2, A*(B-F), G^2
+        products(true, SF, SL, Side{{WM_E, WM_A, WM_G, 0, 0, 0}, {WM_E, WM_BMF, WM_G, 0, 0, 0}, 3});
+        w.x.par([=](unsigned lane) {
+            if (lane < 12) w12_reduce_lane12(lane, self.w.P, self.w.slot(SF));
+            else if (lane == 12) {
+                Fq2S E2 = Gg[0];
+                Fq2S Y3 = Gg[2] - (E2 + E2 + E2);
+                Vv[WM_RX] = Gg[1];
+                Vv[WM_RY] = Y3;
+                Vv[WM_S] = Y3 + Vv[WM_RZ];
+            }
+        });
+    }
+
+    // f <- f * line(R + (x2,y2)), R <- R + (x2,y2)
+    LSA_HD void addition_round(int x2, int y2) {
+        WMiller self = *this;
+        Fq2S *Vv = V, *Gg = G;
+        // round 1: x2*Z1, y2*Z1
+        products(false, SF, SF, Side{{(int8_t)x2, (int8_t)y2, 0, 0, 0, 0}, {WM_RZ, WM_RZ, 0, 0, 0, 0}, 2});
+        w.x.par([=](unsigned lane) {
+            if (lane == 12) {
+                Fq2S D = Vv[WM_RX] - Gg[0], E = Vv[WM_RY] - Gg[1];
+                Vv[WM_DD] = D;
+                Vv[WM_EE] = E;
+                Vv[WM_NE] = E.neg();
+            }
+        });
+        // round 2: D^2, E^2, E*x2, D*y2, D*py, (-E)*px
+        products(false, SF, SF, Side{{WM_DD, WM_EE, WM_EE, WM_DD, WM_DD, WM_NE}, {WM_DD, WM_EE, (int8_t)x2, (int8_t)y2, WM_PY, WM_PX}, 6});
+        w.x.par([=](unsigned lane) {
+            if (lane == 12) {
+                Vv[WM_F] = Gg[0];
+                Vv[WM_GG] = Gg[1];
+                self.set_line((Gg[2] - Gg[3]).mul_xi(), Gg[4], Gg[5]);
+            }
+        });
+        // round 3: f*line | D*F, X1*F, Z1*G
+        products(true, SF, SL, Side{{WM_DD, WM_RX, WM_RZ, 0, 0, 0}, {WM_F, WM_F, WM_GG, 0, 0, 0}, 3});
+        w.x.par([=](unsigned lane) {
+            if (lane < 12) w12_reduce_lane12(lane, self.w.P, self.w.slot(SF));
+            else if (lane == 12) {
+                Fq2S H = Gg[0], I = Gg[1];
+                Fq2S J = H + Gg[2] - (I + I);
+                Vv[WM_HH] = H;
+                Vv[WM_JJ] = J;
+                Vv[WM_IMJ] = I - J;
+            }
+        });
+        // round 4: D*J, E*(I-J), H*Y1, Z1*H
+        products(false, SF, SF, Side{{WM_DD, WM_EE, WM_HH, WM_RZ, 0, 0}, {WM_JJ, WM_IMJ, WM_RY, WM_HH, 0, 0}, 4});
+        w.x.par([=](unsigned lane) {
+            if (lane == 12) {
+                Fq2S Y3 = Gg[1] - Gg[2];
+                Vv[WM_RX] = Gg[0];
+                Vv[WM_RY] = Y3;
+                Vv[WM_RZ] = Gg[3];
+                Vv[WM_S] = Y3 + Gg[3];
+            }
+        });
+    }
+
+    // f (slot 0) <- miller_loop(P, Q)
+    LSA_HD void run(const Jac<Fq> &P, const Jac<Fq2> &Q) {
+        Fq2S *Vv = V;
+        Fq2S *F0 = w.slot(SF), *L = w.slot(SL);
+        w.x.par([=](unsigned lane) {
+            if (lane == 0) {
+                const AffinePair in = miller_affine_inputs(P, Q);
+                const P2 gx = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_X), gy = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_Y);
+                P2 q1x = gx * in.qx.conj(), q1y = gy * in.qy.conj();
+                Vv[WM_QX] = in.qx; Vv[WM_QY] = in.qy;
+                Vv[WM_Q1X] = q1x; Vv[WM_Q1Y] = q1y;
+                Vv[WM_Q2X] = gx * q1x.conj(); Vv[WM_Q2Y] = (gy * q1y.conj()).neg();
+                Vv[WM_PX] = Fq2S{in.px, PB::zero()}; Vv[WM_PY] = Fq2S{in.py, PB::zero()};
+                Vv[WM_TWB] = fq2_constT<PB>(LSA_TWIST_B);
+                Vv[WM_RX] = in.qx; Vv[WM_RY] = in.qy; Vv[WM_RZ] = P2::one();
+                Vv[WM_S] = in.qy + P2::one();
+            } else if (lane >= 8 && lane < 14) {
+                const unsigned k = lane - 8;
+                F0[k] = k == 0 ? P2::one() : P2::zero();
+                L[k] = P2::zero();
+            }
+        });
+        for (int i = 63; i >= 0; --i) {
+            doubling_round();
+            if (ate_bit(i)) addition_round(WM_QX, WM_QY);
+        }
+        addition_round(WM_Q1X, WM_Q1Y);
+        addition_round(WM_Q2X, WM_Q2Y);
+    }
+};
+
+}  // namespace lsa

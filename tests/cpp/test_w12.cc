@@ -4,7 +4,7 @@
 #include <cstdio>
 #include <random>
 #include <vector>
-#include "w12.h"
+#include "miller.h"
 using namespace lsa;
 static std::mt19937_64 rng(5);
 static int fails = 0;
@@ -62,6 +62,26 @@ int main() {
         CHECK(w.load_tower(0) == want, "final exponentiation");
         // the result is an r-th root of unity of the cyclotomic subgroup: unitary
         CHECK(fq12_mul(want, want.unitary_inverse()) == Fq12S::one(), "unitary result");
+    }
+    // wavefront Miller loop vs the one-lane loop (the formulas are plain field arithmetic, so
+    // random coordinates exercise them; Z = 1 and Z != 1 inputs)
+    {
+        CHECK(Fs::from_mont256(rand_fq()).halve().dbl() != Fs::zero(), "halve nonzero");
+        for (int t = 0; t < 50; t++) {
+            Fq a = rand_fq();
+            Fs h = Fs::from_mont256(a).halve();
+            CHECK((h + h).to_mont256() == a, "halve");
+        }
+        std::vector<Fq2S> lds2(WM_LDS_FQ2);
+        for (int t = 0; t < 3; t++) {
+            Jac<Fq> Pp = {rand_fq(), rand_fq(), t == 0 ? Fq::one() : rand_fq()};
+            Jac<Fq2> Qq = {{rand_fq(), rand_fq()}, {rand_fq(), rand_fq()}, t == 0 ? Fq2::one() : Fq2{rand_fq(), rand_fq()}};
+            if (t == 2) Pp.Z = Fq::zero();
+            W12<LoopExec> w2{ex, lds2.data(), lds2.data() + 6 * W12_SLOTS};
+            WMiller<LoopExec> m{w2, lds2.data() + W12_LDS_FQ2, lds2.data() + W12_LDS_FQ2 + WM_NVARS};
+            m.run(Pp, Qq);
+            CHECK(w2.load_tower(0) == miller_one(Pp, Qq), "wave miller loop");
+        }
     }
     printf(fails ? "FAILED (%d)\n" : "PASS\n", fails);
     return fails ? 1 : 0;
