@@ -36,6 +36,23 @@ LSA_HD F29 condsub2(const F29 &t) {
     return r;
 }
 
+// x/2 for a tight x: (x + p*(x odd)) >> 1.  Same field element as x * two_inv.
+LSA_HD F29 f29_halve(const F29 &v) {
+    const uint32_t odd = 0u - (v.l[0] & 1u);
+    F29 t;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        uint32_t s = v.l[i] + (F29::p(i) & odd) + c;
+        if (i < 8) { t.l[i] = s & F29::MASK; c = s >> 29; }
+        else t.l[i] = s;
+    }
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = (t.l[i] >> 1) | (i < 8 ? ((t.l[i + 1] & 1u) << 28) : 0u);
+    return r;
+}
+
 struct Fs {
     F29 v;   // tight, < 2p
     static LSA_HD Fs zero() { return {F29::zero()}; }
@@ -49,22 +66,7 @@ struct Fs {
     friend LSA_HD Fs operator-(const Fs &a, const Fs &b) { return {condsub2(sub_k<2>(a.v, b.v))}; }
     LSA_HD Fs neg() const { return {condsub2(sub_k<2>(F29::zero(), v))}; }
     LSA_HD Fs dbl() const { return *this + *this; }
-    // x/2: (x + p*(x odd)) >> 1, < 1.5p.  Same field element as x * two_inv.
-    LSA_HD Fs halve() const {
-        const uint32_t odd = 0u - (v.l[0] & 1u);
-        F29 t;
-        uint32_t c = 0;
-#pragma unroll
-        for (int i = 0; i < 9; i++) {
-            uint32_t s = v.l[i] + (F29::p(i) & odd) + c;
-            if (i < 8) { t.l[i] = s & F29::MASK; c = s >> 29; }
-            else t.l[i] = s;
-        }
-        F29 r;
-#pragma unroll
-        for (int i = 0; i < 9; i++) r.l[i] = (t.l[i] >> 1) | (i < 8 ? ((t.l[i + 1] & 1u) << 28) : 0u);
-        return {r};
-    }
+    LSA_HD Fs halve() const { return {f29_halve(v)}; }     // < 1.5p
     LSA_HD bool operator==(const Fs &b) const { return (*this - b).is_zero(); }
     LSA_HD bool operator!=(const Fs &b) const { return !(*this == b); }
     // a^(p-2) (Fermat)

@@ -170,7 +170,25 @@ struct WMiller {
         L[0] = e0; L[3] = evw; L[4] = evv;      // w^0: ell_0, w^3: ell_VW * py, w^4: ell_VV * px
     }
 
-    // f <- f^2 * line(2R), R <- 2R
+    // ---- lazy Fq2 helpers of the combine phases.  Values live in LDS as Fq2S but follow the
+    // engine's operand contract (w12.h: tight limbs, a-operands < 4p, b-operands < 20p)
+    // instead of Fs's "< 2p"; every line carries its bound in multiples of p.
+    static LSA_HD F29x2 ld(const Fq2S &v) { return {v.c0.v, v.c1.v}; }
+    static LSA_HD Fq2S st(const F29x2 &v) { return {Fs{v.c0}, Fs{v.c1}}; }
+    static LSA_HD F29x2 triple(const F29x2 &a) { return add_lazy(add_lazy(a, a), a).norm(); }             // [3x]
+    static LSA_HD F29x2 halve2(const F29x2 &a) { return {f29_halve(a.c0), f29_halve(a.c1)}; }             // [x/2 + 0.5]
+    static LSA_HD F29x2 csub2(const F29x2 &a) { return {condsub2(a.c0), condsub2(a.c1)}; }                // [<4] -> [<2]
+    // xi * t for t < 2:  (9 t0 - t1 + 2p,  9 t1 + t0)   [< 20]
+    static LSA_HD F29x2 xi_times(const F29x2 &t) {
+        F29 a8, b8;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { a8.l[i] = t.c0.l[i] << 3; b8.l[i] = t.c1.l[i] << 3; }
+        a8 = w12_norm_u(a8);
+        b8 = w12_norm_u(b8);
+        return {sub_k<2>(add_lazy(a8, t.c0), t.c1), add_lazy(add_lazy(b8, t.c1), t.c0).norm()};
+    }
+
+    // f <- f^2 * line(2R), R <- 2R.   Invariant between rounds: RX, RY, RZ < 2, S = RY + RZ < 4.
     LSA_HD void doubling_round() {
         WMiller self = *this;
         Fq2S *Vv = V, *Gg = G;
@@ -179,28 +197,27 @@ struct WMiller {
         w.x.par([=](unsigned lane) {
             if (lane < 12) w12_reduce_lane12(lane, self.w.P, self.w.slot(SF));
             else if (lane == 12) {
-                Fq2S B = Gg[1], C = Gg[2], J = Gg[4];
-                Fq2S H = Gg[3] - (B + C);
-                Vv[WM_A] = Fq2S{Gg[0].c0.halve(), Gg[0].c1.halve()};
-                Vv[WM_B] = B;
-                Vv[WM_D] = C + C + C;
-                Vv[WM_H] = H;
-                Vv[WM_NH] = H.neg();
-                Vv[WM_J3] = J + J + J;
+                const F29x2 B = ld(Gg[1]), C = ld(Gg[2]);
+                const F29x2 H = sub_k<4>(ld(Gg[3]), add_lazy(B, C));        // (Y+Z)^2 - (B+C) + 4p   [<6]
+                Vv[WM_A] = st(halve2(ld(Gg[0])));                            // X*Y/2                  [<1.5]
+                Vv[WM_B] = Gg[1];
+                Vv[WM_D] = st(triple(C));                                    // 3C                     [<6]
+                Vv[WM_H] = st(H);
+                Vv[WM_NH] = st(sub_k<6>(F29x2::zero(), H));                  // 6p - H                 [<=6]
+                Vv[WM_J3] = st(triple(ld(Gg[4])));                           // 3 X^2                  [<6]
             }
         });
-        // round 2: twist_b*D, B*H, (-H)*py, (3J)*px
-        products(false, SF, SF, Side{{WM_TWB, WM_B, WM_NH, WM_J3, 0, 0}, {WM_D, WM_H, WM_PY, WM_PX, 0, 0}, 4});
+        // round 2: twist_b*D, B*H, py*(-H), px*(3J)      (the larger operand second)
+        products(false, SF, SF, Side{{WM_TWB, WM_B, WM_PY, WM_PX, 0, 0}, {WM_D, WM_H, WM_NH, WM_J3, 0, 0}, 4});
         w.x.par([=](unsigned lane) {
             if (lane == 12) {
-                Fq2S E = Gg[0], B = Vv[WM_B];
-                Fq2S F = E + E + E;
-                Fq2S BF = B + F;
-                Vv[WM_E] = E;
-                Vv[WM_G] = Fq2S{BF.c0.halve(), BF.c1.halve()};
-                Vv[WM_BMF] = B - F;
-                Vv[WM_RZ] = Gg[1];
-                self.set_line((E - B).mul_xi(), Gg[2], Gg[3]);
+                const F29x2 E = ld(Gg[0]), B = ld(Vv[WM_B]);
+                const F29x2 F = triple(E);                                   // 3E                     [<6]
+                Vv[WM_E] = Gg[0];
+                Vv[WM_G] = st(condsub4(halve2(add_lazy(B, F).norm())));      // (B+F)/2  [<4.5] -> [<4]
+                Vv[WM_BMF] = st(sub_k<6>(B, F));                             // B - F + 6p             [<8]
+                Vv[WM_RZ] = Gg[1];                                           // Z3 = B*H               [<2]
+                self.set_line(st(xi_times(csub2(sub_k<2>(E, B)))), Gg[2], Gg[3]);   // xi*(E-B) [<20], [<2], [<2]
             }
         });
         // round 3: f*line | E^2, A*(B-F), G^2
@@ -208,16 +225,15 @@ struct WMiller {
         w.x.par([=](unsigned lane) {
             if (lane < 12) w12_reduce_lane12(lane, self.w.P, self.w.slot(SF));
             else if (lane == 12) {
-                Fq2S E2 = Gg[0];
-                Fq2S Y3 = Gg[2] - (E2 + E2 + E2);
-                Vv[WM_RX] = Gg[1];
-                Vv[WM_RY] = Y3;
-                Vv[WM_S] = Y3 + Vv[WM_RZ];
+                const F29x2 Y3 = csub2(condsub4(sub_k<6>(ld(Gg[2]), triple(ld(Gg[0])))));   // G^2 - 3E^2 + 6p [<8] -> [<2]
+                Vv[WM_RX] = Gg[1];                                           // X3                     [<2]
+                Vv[WM_RY] = st(Y3);
+                Vv[WM_S] = st(add_lazy(Y3, ld(Vv[WM_RZ])).norm());           // [<4]
             }
         });
     }
 
-    // f <- f * line(R + (x2,y2)), R <- R + (x2,y2)
+    // f <- f * line(R + (x2,y2)), R <- R + (x2,y2);  x2, y2 < 2
     LSA_HD void addition_round(int x2, int y2) {
         WMiller self = *this;
         Fq2S *Vv = V, *Gg = G;
@@ -225,19 +241,19 @@ struct WMiller {
         products(false, SF, SF, Side{{(int8_t)x2, (int8_t)y2, 0, 0, 0, 0}, {WM_RZ, WM_RZ, 0, 0, 0, 0}, 2});
         w.x.par([=](unsigned lane) {
             if (lane == 12) {
-                Fq2S D = Vv[WM_RX] - Gg[0], E = Vv[WM_RY] - Gg[1];
-                Vv[WM_DD] = D;
-                Vv[WM_EE] = E;
-                Vv[WM_NE] = E.neg();
+                const F29x2 E = sub_k<2>(ld(Vv[WM_RY]), ld(Gg[1]));          // Y1 - y2 Z1 + 2p        [<4]
+                Vv[WM_DD] = st(sub_k<2>(ld(Vv[WM_RX]), ld(Gg[0])));          // X1 - x2 Z1 + 2p        [<4]
+                Vv[WM_EE] = st(E);
+                Vv[WM_NE] = st(sub_k<4>(F29x2::zero(), E));                  // 4p - E                 [<=4]
             }
         });
-        // round 2: D^2, E^2, E*x2, D*y2, D*py, (-E)*px
-        products(false, SF, SF, Side{{WM_DD, WM_EE, WM_EE, WM_DD, WM_DD, WM_NE}, {WM_DD, WM_EE, (int8_t)x2, (int8_t)y2, WM_PY, WM_PX}, 6});
+        // round 2: D^2, E^2, E*x2, D*y2, D*py, px*(-E)
+        products(false, SF, SF, Side{{WM_DD, WM_EE, WM_EE, WM_DD, WM_DD, WM_PX}, {WM_DD, WM_EE, (int8_t)x2, (int8_t)y2, WM_PY, WM_NE}, 6});
         w.x.par([=](unsigned lane) {
             if (lane == 12) {
                 Vv[WM_F] = Gg[0];
                 Vv[WM_GG] = Gg[1];
-                self.set_line((Gg[2] - Gg[3]).mul_xi(), Gg[4], Gg[5]);
+                self.set_line(st(xi_times(csub2(sub_k<2>(ld(Gg[2]), ld(Gg[3]))))), Gg[4], Gg[5]);
             }
         });
         // round 3: f*line | D*F, X1*F, Z1*G
@@ -245,22 +261,22 @@ struct WMiller {
         w.x.par([=](unsigned lane) {
             if (lane < 12) w12_reduce_lane12(lane, self.w.P, self.w.slot(SF));
             else if (lane == 12) {
-                Fq2S H = Gg[0], I = Gg[1];
-                Fq2S J = H + Gg[2] - (I + I);
-                Vv[WM_HH] = H;
-                Vv[WM_JJ] = J;
-                Vv[WM_IMJ] = I - J;
+                const F29x2 H = ld(Gg[0]), I = ld(Gg[1]);
+                const F29x2 J = sub_k<4>(add_lazy(H, ld(Gg[2])), add_lazy(I, I));   // H + Z1 G - 2I + 4p [<8]
+                Vv[WM_HH] = Gg[0];
+                Vv[WM_JJ] = st(J);
+                Vv[WM_IMJ] = st(sub_k<8>(I, J));                             // I - J + 8p             [<10]
             }
         });
         // round 4: D*J, E*(I-J), H*Y1, Z1*H
         products(false, SF, SF, Side{{WM_DD, WM_EE, WM_HH, WM_RZ, 0, 0}, {WM_JJ, WM_IMJ, WM_RY, WM_HH, 0, 0}, 4});
         w.x.par([=](unsigned lane) {
             if (lane == 12) {
-                Fq2S Y3 = Gg[1] - Gg[2];
+                const F29x2 Y3 = csub2(sub_k<2>(ld(Gg[1]), ld(Gg[2])));      // [<4] -> [<2]
                 Vv[WM_RX] = Gg[0];
-                Vv[WM_RY] = Y3;
+                Vv[WM_RY] = st(Y3);
                 Vv[WM_RZ] = Gg[3];
-                Vv[WM_S] = Y3 + Gg[3];
+                Vv[WM_S] = st(add_lazy(Y3, ld(Gg[3])).norm());               // [<4]
             }
         });
     }

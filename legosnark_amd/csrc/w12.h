@@ -27,11 +27,12 @@ using Fq12S = Fq12T<Fs>;
 static constexpr int W12_SLOTS = 12;                     // Fq12 registers in LDS
 static constexpr int W12_LDS_FQ2 = W12_SLOTS * 6 + 36;   // + the 36 partial products
 
-// Fq2 product on tight operands with two fused reductions (fp29x2.h: c0 = a0*b0 + a1*(2p - b1),
+// Fq2 product with two fused reductions (fp29x2.h: c0 = a0*b0 + a1*(20p - b1),
 // c1 = a0*b1 + a1*b0, each accumulated in one set of 64-bit columns): ~600 instructions
-// instead of ~1100 for Karatsuba on reduced values.  [< 2p; tight]
+// instead of ~1100 for Karatsuba on reduced values.  Operand contract of the whole engine:
+// tight limbs, a's components < 4p, b's components < 20p (2*4*20 = 160 < 169).  [< 2p; tight]
 LSA_HD Fq2S w12_fq2_mul(const Fq2S &a, const Fq2S &b) {
-    F29x2 r = mul<2>(F29x2{a.c0.v, a.c1.v}, F29x2{b.c0.v, b.c1.v});
+    F29x2 r = mul<20>(F29x2{a.c0.v, a.c1.v}, F29x2{b.c0.v, b.c1.v});
     return {Fs{r.c0}, Fs{r.c1}};
 }
 
