@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=20)
-    ap.add_argument("--cpu-sample-log2", type=int, default=18,
+    ap.add_argument("--cpu-sample-log2", type=int, default=20,
                     help="pairs of the same workload timed on the host CPU (2^k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()

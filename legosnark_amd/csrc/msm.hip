@@ -636,6 +636,12 @@ __global__ __launch_bounds__(64) void k_fold_quad_g2(const XYZZ29x2 *__restrict_
     fold_quad_body(window_sums, nwin, c, out);
 }
 
+// publishes a slot's result into the caller's buffer (a 96/192-byte hipMemcpyAsync costs ~30 us
+// as a runtime copy kernel; this is one wavefront)
+__global__ __launch_bounds__(64) void k_publish(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, unsigned words) {
+    if (threadIdx.x < words) dst[threadIdx.x] = src[threadIdx.x];
+}
+
 // ------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------
@@ -1020,7 +1026,8 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         hipLaunchKernelGGL(k_fold_quad_g2, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, res);
     if (tail != st) {
         if (prev.pending && &prev != &tb) HIPCHK(hipStreamWaitEvent(tail, prev.done, 0));   // publish in call order
-        HIPCHK(hipMemcpyAsync(d_out, res, sizeof(Jac<F>), hipMemcpyDeviceToDevice, tail));
+        static_assert(sizeof(Jac<F>) / 4 <= 64, "one wavefront publishes the result");
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, tail, (const uint32_t *)res, (uint32_t *)d_out, (unsigned)(sizeof(Jac<F>) / 4));
     }
     mark(tail);  // 6
     HIPCHK(hipEventRecord(tb.done, tail));
