@@ -56,6 +56,10 @@ int lsa_synchronize(void);
  * collective) after lsa_stream().  All synchronous entry points and lsa_*_sum_async join
  * implicitly. */
 int lsa_stream_join(void);
+/* The same for a stream of the caller's (hipStream_t): it waits for the tails issued so far,
+ * lsa_stream() does not -- the next MSM's front keeps overlapping them.  With LSA_NO_OVERLAP=1
+ * there are no internal streams and the caller must order `stream` after lsa_stream() itself. */
+int lsa_stream_join_to(void *stream);
 
 /* ---- variable-base MSM from host buffers ------------------------------------------- */
 /* out = sum_i scalars[i] * bases[i], i < n.
@@ -123,6 +127,9 @@ int lsa_g2_batch_exp(const void *base_jac, const void *scalars_mont, size_t n, v
  * libff's `final = final + partial[i]` loop over chunks (multi_exp). */
 int lsa_g1_sum_async(const void *d_pts_jac, size_t n, void *d_out_jac);
 int lsa_g2_sum_async(const void *d_pts_jac, size_t n, void *d_out_jac);
+/* The same on a stream of the caller's (hipStream_t) instead of lsa_stream(). */
+int lsa_g1_sum_on(const void *d_pts_jac, size_t n, void *d_out_jac, void *stream);
+int lsa_g2_sum_on(const void *d_pts_jac, size_t n, void *d_out_jac, void *stream);
 
 /* ---- variable-base batch scalar multiplication / sparse matrix in the exponent ---------- */
 /* out[i] = scalars[i] * pts[i], i < n: the independent 254-bit scalar multiplications of

@@ -75,6 +75,9 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         for name in ("lsa_g1_sum_async", "lsa_g2_sum_async"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        for name in ("lsa_g1_sum_on", "lsa_g2_sum_on"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.lsa_stream_join_to.argtypes = [C.c_void_p]
         L.lsa_g1_scalar_mul_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.lsa_g1_sparse_matrix_msm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         L.lsa_fr_cppoly_witness.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
@@ -118,6 +121,18 @@ def synchronize():
 def stream_join():
     """Make the library stream wait for the internally pipelined MSM tails issued so far."""
     _check(lib().lsa_stream_join())
+
+
+def stream_join_to(stream_handle):
+    """Make another HIP stream (raw handle) wait for the MSM tails issued so far; the library
+    stream itself keeps running ahead."""
+    _check(lib().lsa_stream_join_to(C.c_void_p(int(stream_handle))))
+
+
+def sum_on(group, d_pts, n, d_out, stream_handle):
+    """d_out = sum of n device-resident Jacobian points, on the given HIP stream."""
+    fn = lib().lsa_g1_sum_on if group == "g1" else lib().lsa_g2_sum_on
+    _check(fn(_ptr(d_pts), n, _ptr(d_out), C.c_void_p(int(stream_handle))))
 
 
 def _host_ptr(a):

@@ -350,6 +350,24 @@ int lsa_g1_batch_exp(const void *base_jac, const void *scalars, size_t n, void *
 int lsa_g2_batch_exp(const void *base_jac, const void *scalars, size_t n, void *out_jac, int on_device) {
     return batch_exp_any<Fq2>(base_jac, scalars, n, out_jac, on_device);
 }
+// the same on a caller-supplied stream, without touching lsa_stream(): lets the collective and
+// the fold of step i run beside the MSM front of step i+1
+}  // extern "C"
+template <class F>
+static int sum_on_any(const void *d_pts, size_t n, void *d_out, void *stream) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (!d_out || (n && !d_pts)) { set_error("sum: null argument"); return LSA_ERR_INVALID; }
+    return sum_points_device<F>((const Jac<F> *)d_pts, n, (Jac<F> *)d_out, (hipStream_t)stream);
+}
+extern "C" {
+int lsa_g1_sum_on(const void *d_pts, size_t n, void *d_out, void *stream) { return sum_on_any<Fq>(d_pts, n, d_out, stream); }
+int lsa_g2_sum_on(const void *d_pts, size_t n, void *d_out, void *stream) { return sum_on_any<Fq2>(d_pts, n, d_out, stream); }
+int lsa_stream_join_to(void *stream) {
+    int rc = require_ready();
+    if (rc) return rc;
+    return msm_join_to((hipStream_t)stream);
+}
 int lsa_g1_sum_async(const void *d_pts, size_t n, void *d_out) {
     int rc = require_ready();
     if (rc) return rc;

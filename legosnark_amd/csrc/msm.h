@@ -64,6 +64,8 @@ size_t fq12_bytes();
 
 // Orders the results of earlier msm_device calls (whose tails run on an internal stream) on `st`.
 int msm_join(hipStream_t st);
+// Makes `other` wait for them instead and leaves `st` alone.
+int msm_join_to(hipStream_t other);
 
 void msm_release_workspace();
 void msm_profile_enable(bool on);

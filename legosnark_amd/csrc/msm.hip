@@ -710,6 +710,17 @@ int msm_join(hipStream_t st) {
     }
     return LSA_OK;
 }
+// `other` waits for every tail issued so far; the caller's own stream is left alone
+int msm_join_to(hipStream_t other) {
+    for (auto &t : g_tail) {
+        if (!t.pending || !t.stream) continue;
+        if (hipStreamWaitEvent(other, t.done, 0) != hipSuccess) {
+            set_error("msm_join_to: stream wait failed");
+            return LSA_ERR_HIP;
+        }
+    }
+    return LSA_OK;
+}
 // Per-stage HIP events on the library stream.  A ring of EV_POOL call slots so that
 // profiling never synchronises inside the timed loop; msm_profile_last() harvests.
 static constexpr int EV_POOL = 64;

@@ -28,9 +28,16 @@ def shard_range(n, world, rank):
 class ShardedMSM:
     """One instance per rank.  `local_msm(d_scalars, d_out)` writes this rank's partial
     (Jacobian limbs, int64[w]) into d_out; `fold(gathered, world, d_total)` sums the
-    gathered partials."""
+    gathered partials.
 
-    def __init__(self, group, world, rank, local_msm, fold, device, dist=None, stream=None):
+    With `stream` (the library's HIP stream) and `side` (a second stream) the exchange step of
+    call i -- wait for the MSM tail, all-gather, fold -- runs on `side`, so the library stream
+    is free to start the front of call i+1: the pipelining a single GPU gets from the
+    internal tail streams survives the collective.  Buffers rotate over DEPTH calls."""
+
+    DEPTH = 4
+
+    def __init__(self, group, world, rank, local_msm, fold, device, dist=None, stream=None, side=None, join_side=None):
         import torch
         self.torch = torch
         self.group = group
@@ -38,58 +45,80 @@ class ShardedMSM:
         self.world, self.rank = world, rank
         self.local_msm, self.fold = local_msm, fold
         self.dist = dist
-        self.stream = stream
-        self.partial = torch.zeros(self.w, dtype=torch.int64, device=device)
-        self.gathered = torch.zeros((world, self.w), dtype=torch.int64, device=device)
-        self.total = torch.zeros(self.w, dtype=torch.int64, device=device)
+        self.stream, self.side, self.join_side = stream, side, join_side
+        depth = self.DEPTH if side is not None else 1
+        self.partial = [torch.zeros(self.w, dtype=torch.int64, device=device) for _ in range(depth)]
+        self.gathered = [torch.zeros((world, self.w), dtype=torch.int64, device=device) for _ in range(depth)]
+        self.total = [torch.zeros(self.w, dtype=torch.int64, device=device) for _ in range(depth)]
+        self.done = [None] * depth
+        self.calls = 0
 
     def run(self, d_scalars):
-        """Asynchronous; returns the device tensor holding the sum (identical on every rank).
-        The local MSM and the fold run on the library's HIP stream, the all-gather on
-        torch's current stream; the two are ordered with stream waits (no host sync)."""
-        self.local_msm(d_scalars, self.partial)
+        """Asynchronous; returns the device tensor holding the sum (identical on every rank);
+        read it through result_host()."""
+        j = self.calls % len(self.partial)
+        self.calls += 1
+        if self.world > 1 and self.side is not None and self.done[j] is not None:
+            self.stream.wait_event(self.done[j])         # buffer set j was last used DEPTH calls ago
+        self.local_msm(d_scalars, self.partial[j])
         if self.world == 1:
-            return self.partial
-        if self.stream is not None:
+            return self.partial[j]
+        if self.side is not None:
+            self.side.wait_stream(self.stream)            # front of this call (and everything before it)
+            self.join_side(self.side)                     # ... and its tail, without stalling the library stream
+            with self.torch.cuda.stream(self.side):
+                self._all_gather(j)
+                self.fold(self.gathered[j], self.world, self.total[j], self.side)
+                self.done[j] = self.side.record_event()
+        elif self.stream is not None:
             cur = self.torch.cuda.current_stream()
-            cur.wait_stream(self.stream)            # partial is ready
-            self._all_gather()
-            self.stream.wait_stream(cur)            # gathered is ready
+            cur.wait_stream(self.stream)                  # partial is ready
+            self._all_gather(j)
+            self.stream.wait_stream(cur)                  # gathered is ready
+            self.fold(self.gathered[j], self.world, self.total[j], None)
         else:
-            self._all_gather()
-        self.fold(self.gathered, self.world, self.total)
-        return self.total
+            self._all_gather(j)
+            self.fold(self.gathered[j], self.world, self.total[j], None)
+        return self.total[j]
 
-    def _all_gather(self):
+    def _all_gather(self, j):
         try:
-            self.dist.all_gather_into_tensor(self.gathered.view(-1), self.partial)
+            self.dist.all_gather_into_tensor(self.gathered[j].view(-1), self.partial[j])
         except (RuntimeError, NotImplementedError):
             # backends without the tensor form (gloo): list form, same data movement
-            parts = [self.gathered[i] for i in range(self.world)]
-            self.dist.all_gather(parts, self.partial)
+            parts = [self.gathered[j][i] for i in range(self.world)]
+            self.dist.all_gather(parts, self.partial[j])
 
     def result_host(self, d_result):
+        if self.side is not None:
+            self.side.synchronize()
         if self.stream is not None:
             self.stream.synchronize()
         return d_result.cpu().numpy().view(np.uint64).copy()
 
 
 def make_gpu_sharded(lsa, group, bases_handle, world, rank, dist=None):
-    """Wire ShardedMSM to the HIP library: local MSM over the rank's device-resident
-    bases, RCCL all-gather enqueued on the library's own stream, fold with lsa_*_sum."""
+    """Wire ShardedMSM to the HIP library: local MSM over the rank's device-resident bases,
+    the all-gather (RCCL when the backend is "nccl") and the fold with lsa_*_sum on a side
+    stream that waits for the MSM's tail."""
     import torch
     dev = torch.device("cuda", torch.cuda.current_device())
     ext = torch.cuda.ExternalStream(lsa.stream_handle(), device=dev)
+    side = torch.cuda.Stream(device=dev) if world > 1 else None
 
     def local_msm(d_scalars, d_out):
         bases_handle.msm_async(d_scalars, d_out)
-        if world > 1:
-            lsa.stream_join()      # the partial must be ordered on the library stream before the collective
 
-    def fold(gathered, n, d_total):
-        lsa.sum_async(group, gathered, n, d_total)
+    def fold(gathered, n, d_total, stream):
+        if stream is None:
+            lsa.sum_async(group, gathered, n, d_total)
+        else:
+            lsa.sum_on(group, gathered, n, d_total, stream.cuda_stream)
 
-    return ShardedMSM(group, world, rank, local_msm, fold, dev, dist=dist, stream=ext)
+    def join_side(stream):
+        lsa.stream_join_to(stream.cuda_stream)
+
+    return ShardedMSM(group, world, rank, local_msm, fold, dev, dist=dist, stream=ext, side=side, join_side=join_side)
 
 
 class ShardedPairingProduct:

@@ -180,7 +180,7 @@ def test_sharded_path_on_one_gpu_with_virtual_peer(lsa):
     job = sharded.make_gpu_sharded(lsa, "g1", B, 2, 0, dist=FakeDist())
     d_s = torch.from_numpy(sc[lo0:hi0].view(np.int64)).to("cuda:0")
     torch.cuda.synchronize()
-    for _ in range(3):
+    for _ in range(7):                                                  # more calls than rotating buffer sets
         res = job.run(d_s)
     got = job.result_host(res)
     want = o.multi_exp("g1", bases, sc, chunks=2, mode="multi_exp")     # libff chunked sum

@@ -49,7 +49,7 @@ def _worker(rank, world, port, group, n, q):
             part = o.multi_exp(group, bases[lo:hi], d_scalars.numpy().view(np.uint64).reshape(-1, 4), mode="mixed")
             d_out.copy_(torch.from_numpy(part.view(np.int64)))
 
-        def fold(gathered, cnt, d_total):
+        def fold(gathered, cnt, d_total, stream=None):
             add = o.g1_add if group == "g1" else o.g2_add
             acc = gathered[0].numpy().view(np.uint64).copy()
             for i in range(1, cnt):
