@@ -174,6 +174,21 @@ def main():
                           % (min(args.cpu_sample_log2, args.log2n), os.cpu_count()),
                 "seconds": tc, "gpu_result_matches_cpu": bool(same),
             }
+            # libff's MULTICORE build: chunks = threads (src/utils/globl.h:67-69), here every host core
+            # the process may use
+            try:
+                nthr = len(os.sched_getaffinity(0))
+            except AttributeError:
+                nthr = os.cpu_count() or 1
+            if nthr > 1:
+                tm = time.perf_counter()
+                refm = o.multi_exp("g1", hb, hs, chunks=nthr, threads=nthr, mode="mixed")
+                tm = time.perf_counter() - tm
+                out["cpu_baseline"]["multicore"] = {
+                    "value": ns / tm, "unit": "pairs/s", "cores": nthr, "seconds": tm,
+                    "sample": "same pairs, chunks = threads = %d (libff MULTICORE chunking)" % nthr,
+                    "matches_single_core": o.g1_canonical_affine(refm) == o.g1_canonical_affine(ref),
+                }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
