@@ -166,6 +166,24 @@ int lsa_fr_eval_mle(const void *v_mont, size_t d, const void *r_mont, void *out_
  * are device pointers and the call is asynchronous on lsa_stream(); else host pointers. */
 int lsa_fr_fold(const void *old_mont, size_t half, const void *r_mont, void *cur_mont, int on_device);
 
+/* One round polynomial of the sumcheck prover (CPSumcheck::make_new_h_poly,
+ * src/gadgets/sumcheck.h:85-106):
+ *   h_j(X) = sum_{p < half} betaPoly(j,p)(X) * prod_{t < m} mlePoly_t(j,p)(X),
+ * mlePoly_t(j,p) = tables[t][p]*(1-X) + tables[t][p+half]*X (DPMle::getMLEPoly, mle.h:217-226; the
+ * tables are the DPMle curVTable's, 2*half entries each), betaPoly(j,p) =
+ * eqbit_poly(rho_j) * pre * suff[p] (DPBeta::getBetaPoly, mle.h:74-82: pre = getBetaPre(j-1),
+ * suff = beta_suff_rho_cur, half entries, NULL = all ones as for j+1 > d-1).  rho_j == NULL drops
+ * the beta factor altogether (DPBetaDummy, mle.h:148-166).  1 <= m <= 4.
+ * out_coeffs (HOST): m+2 coefficients of h_j, lowest degree first (m+1 when rho_j == NULL).
+ * pre, rho_j: HOST pointers to one Fr each.  on_device != 0: suff and tables[t] are device
+ * pointers (the array `tables` itself is a host array of m pointers); else host pointers. */
+int lsa_fr_sumcheck_round(const void *suff_mont, const void *const *tables, size_t m, size_t half, const void *pre_mont,
+                          const void *rho_j_mont, void *out_coeffs_mont, int on_device);
+/* DPBeta::pushRandomness, suffix table (src/prototools/mle.h:46-53): cur[p] = old[half + p] * k,
+ * p < half (k = rhoInvs[j+1], ONE Fr, HOST pointer); cur may alias old.  on_device != 0: old,
+ * cur are device pointers, asynchronous on lsa_stream(); else host pointers. */
+int lsa_fr_scale_upper(const void *old_mont, size_t half, const void *k_mont, void *cur_mont, int on_device);
+
 /* ---- pairing ---------------------------------------------------------------------------- */
 /* out[i] = miller_loop(precompute_G1(P_i), precompute_G2(Q_i)), i < n: replaces libff
  * alt_bn128_pp::precompute_G1 / precompute_G2 / miller_loop (src/utils/globl.h:96-102,

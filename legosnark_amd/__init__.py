@@ -83,6 +83,8 @@ def lib():
         L.lsa_fr_cppoly_witness.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.lsa_fr_eval_mle.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.lsa_fr_fold.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+        L.lsa_fr_sumcheck_round.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.lsa_fr_scale_upper.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.lsa_miller_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.lsa_miller_loop_product.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.lsa_pairing_product.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -333,6 +335,42 @@ def fr_fold(old, r):
     half = len(old) // 2
     cur = np.zeros((half, 4), dtype=np.uint64)
     _check(lib().lsa_fr_fold(_host_ptr(old), half, _host_ptr(r), _host_ptr(cur), 0))
+    return cur
+
+
+def sumcheck_round(tables, suff=None, pre=None, rho_j=None):
+    """Coefficients of the sumcheck round polynomial h_j (make_new_h_poly, sumcheck.h:85-106).
+    tables: list of m vectors of 2*half Fr (numpy -> host path, torch CUDA tensors -> device
+    path); suff: half Fr or None; pre, rho_j: (4,) uint64 or None.  Returns (m+2, 4) uint64
+    ((m+1, 4) without the beta factor)."""
+    m = len(tables)
+    on_device = not isinstance(tables[0], np.ndarray)
+    if on_device:
+        half = tables[0].numel() * tables[0].element_size() // 64
+        ptrs = (C.c_void_p * m)(*[t.data_ptr() for t in tables])
+        sp = C.c_void_p(suff.data_ptr()) if suff is not None else None
+    else:
+        tables = [np.ascontiguousarray(t, dtype=np.uint64).reshape(-1, 4) for t in tables]
+        half = len(tables[0]) // 2
+        ptrs = (C.c_void_p * m)(*[t.ctypes.data for t in tables])
+        if suff is not None:
+            suff = np.ascontiguousarray(suff, dtype=np.uint64).reshape(-1, 4)
+        sp = _host_ptr(suff) if suff is not None else None
+    pre_a = np.ascontiguousarray(pre, dtype=np.uint64).reshape(4) if pre is not None else None
+    rho_a = np.ascontiguousarray(rho_j, dtype=np.uint64).reshape(4) if rho_j is not None else None
+    out = np.zeros((m + (2 if rho_a is not None else 1), 4), dtype=np.uint64)
+    _check(lib().lsa_fr_sumcheck_round(sp, ptrs, m, half, _host_ptr(pre_a) if pre_a is not None else None,
+                                       _host_ptr(rho_a) if rho_a is not None else None, _host_ptr(out), 1 if on_device else 0))
+    return out
+
+
+def fr_scale_upper(old, k):
+    """DPBeta suffix update on a host vector: cur[p] = old[half + p] * k."""
+    old = np.ascontiguousarray(old, dtype=np.uint64).reshape(-1, 4)
+    k = np.ascontiguousarray(k, dtype=np.uint64).reshape(4)
+    half = len(old) // 2
+    cur = np.zeros((half, 4), dtype=np.uint64)
+    _check(lib().lsa_fr_scale_upper(_host_ptr(old), half, _host_ptr(k), _host_ptr(cur), 0))
     return cur
 
 

@@ -504,6 +504,57 @@ int lsa_fr_eval_mle(const void *v, size_t d, const void *r, void *out, int on_de
     return LSA_OK;
 }
 
+int lsa_fr_sumcheck_round(const void *suff, const void *const *tables, size_t m, size_t half, const void *pre, const void *rho_j,
+                          void *out_coeffs, int on_device) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (!tables || !out_coeffs || m == 0 || m > 4 || half == 0) { set_error("sumcheck_round: invalid argument (1 <= m <= 4, half > 0)"); return LSA_ERR_INVALID; }
+    if (rho_j && !pre) { set_error("sumcheck_round: rho_j without pre"); return LSA_ERR_INVALID; }
+    for (size_t t = 0; t < m; t++) if (!tables[t]) { set_error("sumcheck_round: null table"); return LSA_ERR_INVALID; }
+    const size_t ncoef = m + (rho_j ? 2 : 1);
+    DevBuf d_partial, d_out, d_suff, d_tab[4];
+    if (d_partial.alloc(fr_sumcheck_scratch_elems() * sizeof(Fr)) || d_out.alloc(8 * sizeof(Fr))) { set_error("sumcheck_round: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    const Fr *tabs[4] = {nullptr, nullptr, nullptr, nullptr};
+    const Fr *sf = (const Fr *)suff;
+    if (on_device) {
+        for (size_t t = 0; t < m; t++) tabs[t] = (const Fr *)tables[t];
+    } else {
+        for (size_t t = 0; t < m; t++) {
+            if (d_tab[t].alloc(2 * half * sizeof(Fr))) { set_error("sumcheck_round: hipMalloc failed"); return LSA_ERR_NOMEM; }
+            HIPCHK(hipMemcpyAsync(d_tab[t].p, tables[t], 2 * half * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+            tabs[t] = (const Fr *)d_tab[t].p;
+        }
+        if (suff) {
+            if (d_suff.alloc(half * sizeof(Fr))) { set_error("sumcheck_round: hipMalloc failed"); return LSA_ERR_NOMEM; }
+            HIPCHK(hipMemcpyAsync(d_suff.p, suff, half * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+            sf = (const Fr *)d_suff.p;
+        }
+    }
+    rc = fr_sumcheck_round_device(sf, tabs, m, half, (const Fr *)pre, (const Fr *)rho_j, (Fr *)d_partial.p, (Fr *)d_out.p, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(out_coeffs, d_out.p, ncoef * sizeof(Fr), hipMemcpyDeviceToHost));
+    return LSA_OK;
+}
+
+int lsa_fr_scale_upper(const void *old, size_t half, const void *k, void *cur, int on_device) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (half == 0) return LSA_OK;
+    if (!old || !cur || !k) { set_error("fr_scale_upper: null argument"); return LSA_ERR_INVALID; }
+    Fr kk;
+    memcpy(&kk, k, sizeof kk);
+    if (on_device) return fr_scale_upper_device((const Fr *)old, half, kk, (Fr *)cur, g.stream);
+    DevBuf d_v;
+    if (d_v.alloc(2 * half * sizeof(Fr))) { set_error("fr_scale_upper: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    HIPCHK(hipMemcpyAsync(d_v.p, old, 2 * half * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    rc = fr_scale_upper_device((const Fr *)d_v.p, half, kk, (Fr *)d_v.p, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(cur, d_v.p, half * sizeof(Fr), hipMemcpyDeviceToHost));
+    return LSA_OK;
+}
+
 int lsa_fr_fold(const void *old, size_t half, const void *r, void *cur, int on_device) {
     int rc = require_ready();
     if (rc) return rc;

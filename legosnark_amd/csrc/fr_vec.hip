@@ -46,6 +46,81 @@ __global__ __launch_bounds__(256) void k_fold_halves(const Fr *old, size_t half,
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Sumcheck round polynomial (CPSumcheck::make_new_h_poly, /root/reference/src/gadgets/sumcheck.h:85-106):
+//   h_j(X) = sum_{p < half} betaPoly(j,p)(X) * prod_t mlePoly_t(j,p)(X)
+// with mlePoly_t(j,p) = V_t[p] (1-X) + V_t[p+half] X          (DPMle::getMLEPoly, mle.h:217-226)
+// and  betaPoly(j,p)  = eqbit_poly(rho_j) * pre * suff[p]      (DPBeta::getBetaPoly, mle.h:74-82),
+// i.e. h_j = eqbit_poly(rho_j) * pre * S(X),  S(X) = sum_p suff[p] prod_t (V_t[p] + (V_t[p+half] - V_t[p]) X).
+// k_sumcheck_partial accumulates the m+1 coefficients of S per lane over a grid-stride loop and
+// tree-sums them per block through LDS; k_sumcheck_finish adds the block partials and applies
+// the linear factor.  Fr values are canonical, so the coefficients equal the reference's
+// whatever the summation order.  Streams 32*(2m+1) bytes per p.
+// ------------------------------------------------------------------------------------
+static constexpr int SC_MAX_M = 4;
+struct ScTables { const Fr *t[SC_MAX_M]; };
+
+__global__ __launch_bounds__(256) void k_sumcheck_partial(const Fr *__restrict__ suff, ScTables tabs, unsigned m, size_t half,
+                                                         Fr *__restrict__ partial) {
+    __shared__ Fr lds[256];
+    Fr c[SC_MAX_M + 1];
+    for (unsigned i = 0; i <= m; i++) c[i] = Fr::zero();
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < half; p += (size_t)gridDim.x * blockDim.x) {
+        Fr q[SC_MAX_M + 1];
+        q[0] = suff ? suff[p] : Fr::one();
+        unsigned deg = 0;
+        for (unsigned t = 0; t < m; t++) {
+            const Fr v0 = tabs.t[t][p], dv = tabs.t[t][p + half] - v0;
+            q[deg + 1] = q[deg] * dv;                    // q <- q * (v0 + dv X)
+            for (unsigned i = deg; i >= 1; i--) q[i] = q[i] * v0 + q[i - 1] * dv;
+            q[0] = q[0] * v0;
+            deg++;
+        }
+        for (unsigned i = 0; i <= m; i++) c[i] = c[i] + q[i];
+    }
+    for (unsigned i = 0; i <= m; i++) {
+        lds[threadIdx.x] = c[i];
+        __syncthreads();
+        for (unsigned s = 128; s >= 1; s >>= 1) {
+            if (threadIdx.x < s) lds[threadIdx.x] = lds[threadIdx.x] + lds[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * (SC_MAX_M + 1) + i] = lds[0];
+        __syncthreads();
+    }
+}
+
+// out[0..m(+1)] = (have_beta ? ((1-rho) + (2rho-1) X) * pre : 1) * sum of the block partials
+__global__ __launch_bounds__(64) void k_sumcheck_finish(const Fr *__restrict__ partial, unsigned nblocks, unsigned m, int have_beta,
+                                                        Fr pre, Fr rho, Fr *__restrict__ out) {
+    __shared__ Fr S[SC_MAX_M + 1];
+    const unsigned i = threadIdx.x;
+    if (i <= m) {
+        Fr acc = Fr::zero();
+        for (unsigned b = 0; b < nblocks; b++) acc = acc + partial[(size_t)b * (SC_MAX_M + 1) + i];
+        S[i] = acc;
+    }
+    __syncthreads();
+    if (!have_beta) {
+        if (i <= m) out[i] = S[i];
+        return;
+    }
+    if (i <= m + 1) {
+        const Fr e0 = (Fr::one() - rho) * pre, e1 = (rho + rho - Fr::one()) * pre;
+        Fr v = Fr::zero();
+        if (i <= m) v = v + S[i] * e0;
+        if (i >= 1) v = v + S[i - 1] * e1;
+        out[i] = v;
+    }
+}
+
+// DPBeta::pushRandomness suffix update (/root/reference/src/prototools/mle.h:46-53):
+//   cur[p] = old[half + p] * k,  p < half   (cur may alias old)
+__global__ __launch_bounds__(256) void k_scale_upper(const Fr *old, size_t half, Fr k, Fr *cur) {
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < half; p += (size_t)gridDim.x * blockDim.x)
+        cur[p] = old[p + half] * k;
+}
+
 #define HIPCHK(x)                                                                      \
     do {                                                                               \
         hipError_t e_ = (x);                                                           \
@@ -103,6 +178,30 @@ int fr_eval_mle_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_tmp, Fr *d_
         hipLaunchKernelGGL(k_fold_halves, dim3(stream_blocks(half)), dim3(256), 0, st, src, half, d_r + i, dst);
         src = dst;
     }
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
+
+// d_out: m+1 (no beta factor) or m+2 coefficients (device).  d_partial: scratch of
+// 1024*(SC_MAX_M+1) elements.  Asynchronous on st.
+int fr_sumcheck_round_device(const Fr *d_suff, const Fr *const *d_tables, size_t m, size_t half, const Fr *pre, const Fr *rho,
+                             Fr *d_partial, Fr *d_out, hipStream_t st) {
+    if (m == 0 || m > SC_MAX_M) { set_error("sumcheck_round: m = %zu not in 1..%d", m, SC_MAX_M); return LSA_ERR_INVALID; }
+    ScTables tabs;
+    for (int t = 0; t < SC_MAX_M; t++) tabs.t[t] = t < (int)m ? d_tables[t] : nullptr;
+    size_t b = (half + 255) / 256;
+    const unsigned blocks = (unsigned)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+    hipLaunchKernelGGL(k_sumcheck_partial, dim3(blocks), dim3(256), 0, st, d_suff, tabs, (unsigned)m, half, d_partial);
+    hipLaunchKernelGGL(k_sumcheck_finish, dim3(1), dim3(64), 0, st, d_partial, blocks, (unsigned)m, rho ? 1 : 0,
+                       pre ? *pre : Fr::one(), rho ? *rho : Fr::zero(), d_out);
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
+size_t fr_sumcheck_scratch_elems() { return (size_t)1024 * (SC_MAX_M + 1); }
+
+int fr_scale_upper_device(const Fr *d_old, size_t half, const Fr &k, Fr *d_cur, hipStream_t st) {
+    if (half == 0) return LSA_OK;
+    hipLaunchKernelGGL(k_scale_upper, dim3(stream_blocks(half)), dim3(256), 0, st, d_old, half, k, d_cur);
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }

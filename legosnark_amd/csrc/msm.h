@@ -51,6 +51,10 @@ int g1_column_sums_device(const Jac<Fq> *d_items, const uint64_t *d_col_ptr, siz
 int fr_cppoly_fold_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_w, Fr *d_tmp, hipStream_t st);
 int fr_fold_halves_device(const Fr *d_old, size_t half, const Fr *d_r, Fr *d_cur, hipStream_t st);
 int fr_eval_mle_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_tmp, Fr *d_out, hipStream_t st);
+int fr_sumcheck_round_device(const Fr *d_suff, const Fr *const *d_tables, size_t m, size_t half, const Fr *pre, const Fr *rho,
+                             Fr *d_partial, Fr *d_out, hipStream_t st);
+size_t fr_sumcheck_scratch_elems();
+int fr_scale_upper_device(const Fr *d_old, size_t half, const Fr &k, Fr *d_cur, hipStream_t st);
 
 // d_out = sum of n Jacobian points in d_in (device-resident).
 template <class F>

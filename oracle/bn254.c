@@ -530,3 +530,55 @@ void oracle_fr_push_randomness(ofp_t *cur, const ofp_t *old, const ofp_t *r, siz
         fr_add_(&cur[p], &t0, &t1);
     }
 }
+
+/* CPSumcheck::make_new_h_poly: /root/reference/src/gadgets/sumcheck.h:85-106, with
+ * DPBeta::getBetaPoly (src/prototools/mle.h:74-82; eqbit_poly(r) = {1-r, 2r-1},
+ * src/prototools/mle.cc:23-29; PolyT::mul(scalar) and PolyT::mul(PolyT), polytools.h:54-71)
+ * and DPMle::getMLEPoly (mle.h:217-226: eqbit_poly(0)*V[p] + eqbit_poly(1)*V[p+half],
+ * eqbit_poly(bool) = 1-X or X, mle.cc:17-20).  Restated literally: per p the beta polynomial,
+ * then one polynomial product per table, then the sum.  rho_j == NULL: DPBetaDummy (beta
+ * polynomial = 1).  out: m+2 coefficients (m+1 without beta). */
+void oracle_fr_sumcheck_round(ofp_t *out, const ofp_t *suff, const ofp_t *const *tables, size_t m, size_t half,
+                              const ofp_t *pre, const ofp_t *rho_j) {
+    ofp_t one; fr_one(&one);
+    size_t nout = m + (rho_j ? 2 : 1);
+    for (size_t i = 0; i < nout; i++) fr_zero(&out[i]);
+    for (size_t p = 0; p < half; p++) {
+        ofp_t poly[8], tmp[8];
+        size_t deg;
+        if (rho_j) {
+            /* eqbit_poly(rho_j).mul(pre * suff) */
+            ofp_t s, two_r, e0, e1;
+            if (suff) fr_mul_(&s, pre, &suff[p]); else fr_mul_(&s, pre, &one);
+            fr_sub_(&e0, &one, rho_j);
+            fr_add_(&two_r, rho_j, rho_j);
+            fr_sub_(&e1, &two_r, &one);
+            fr_mul_(&poly[0], &e0, &s);
+            fr_mul_(&poly[1], &e1, &s);
+            deg = 1;
+        } else {
+            poly[0] = one;
+            deg = 0;
+        }
+        for (size_t t = 0; t < m; t++) {
+            /* mle_poly = (1-X)*v0 + X*v1 = {v0, v1 - v0}: eqbit_poly(0).mul(v0) = {v0, -v0}, eqbit_poly(1).mul(v1) = {0, v1}, add */
+            ofp_t c0 = tables[t][p], nv0, c1;
+            fr_neg_(&nv0, &tables[t][p]);
+            fr_add_(&c1, &nv0, &tables[t][p + half]);
+            for (size_t i = 0; i <= deg + 1; i++) fr_zero(&tmp[i]);
+            for (size_t i = 0; i <= deg; i++) {
+                ofp_t x;
+                fr_mul_(&x, &poly[i], &c0); fr_add_(&tmp[i], &tmp[i], &x);
+                fr_mul_(&x, &poly[i], &c1); fr_add_(&tmp[i + 1], &tmp[i + 1], &x);
+            }
+            deg++;
+            for (size_t i = 0; i <= deg; i++) poly[i] = tmp[i];
+        }
+        for (size_t i = 0; i <= deg; i++) fr_add_(&out[i], &out[i], &poly[i]);
+    }
+}
+
+/* DPBeta::pushRandomness, suffix table: /root/reference/src/prototools/mle.h:46-53 */
+void oracle_fr_scale_upper(ofp_t *cur, const ofp_t *old, const ofp_t *k, size_t half) {
+    for (size_t p = 0; p < half; p++) fr_mul_(&cur[p], &old[half + p], k);
+}

@@ -123,6 +123,12 @@ void oracle_fr_eval_mle(ofp_t *out, const ofp_t *v, const ofp_t *r, size_t d);
 /* DPMle::pushRandomness (/root/reference/src/prototools/mle.h:199-210) */
 void oracle_fr_push_randomness(ofp_t *cur, const ofp_t *old, const ofp_t *r, size_t half);
 
+/* CPSumcheck::make_new_h_poly (/root/reference/src/gadgets/sumcheck.h:85-106); rho_j == NULL: DPBetaDummy */
+void oracle_fr_sumcheck_round(ofp_t *out, const ofp_t *suff, const ofp_t *const *tables, size_t m, size_t half,
+                              const ofp_t *pre, const ofp_t *rho_j);
+/* DPBeta::pushRandomness suffix update (/root/reference/src/prototools/mle.h:46-53) */
+void oracle_fr_scale_upper(ofp_t *cur, const ofp_t *old, const ofp_t *k, size_t half);
+
 /* ---- test-input helper: out[i] = (a + i*b) * generator, un-normalised Jacobian ---- */
 void oracle_g1_arith_bases(og1_t *out, const ofp_t *a_mont, const ofp_t *b_mont, size_t n);
 void oracle_g2_arith_bases(og2_t *out, const ofp_t *a_mont, const ofp_t *b_mont, size_t n);

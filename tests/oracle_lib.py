@@ -243,6 +243,25 @@ def fr_push_randomness(old, r):
     return cur
 
 
+def fr_sumcheck_round(tables, suff=None, pre=None, rho_j=None):
+    tables = [np.ascontiguousarray(t, dtype=np.uint64).reshape(-1, 4) for t in tables]
+    m, half = len(tables), len(tables[0]) // 2
+    ptrs = (C.c_void_p * m)(*[t.ctypes.data for t in tables])
+    out = np.zeros((m + (2 if rho_j is not None else 1), 4), dtype=np.uint64)
+    sp = _p(np.ascontiguousarray(suff, dtype=np.uint64)) if suff is not None else None
+    pp = _p(np.ascontiguousarray(pre, dtype=np.uint64)) if pre is not None else None
+    rp = _p(np.ascontiguousarray(rho_j, dtype=np.uint64)) if rho_j is not None else None
+    lib().oracle_fr_sumcheck_round(_p(out), sp, ptrs, C.c_size_t(m), C.c_size_t(half), pp, rp)
+    return out
+
+
+def fr_scale_upper(old, k):
+    old = np.ascontiguousarray(old, dtype=np.uint64).reshape(-1, 4)
+    cur = np.zeros((len(old) // 2, 4), dtype=np.uint64)
+    lib().oracle_fr_scale_upper(_p(cur), _p(old), _p(np.ascontiguousarray(k, dtype=np.uint64)), C.c_size_t(len(old) // 2))
+    return cur
+
+
 def reduced_pairing(p, q):
     p = np.ascontiguousarray(p, dtype=np.uint64)
     q = np.ascontiguousarray(q, dtype=np.uint64)

@@ -75,3 +75,50 @@ def test_cppoly_prove_on_device_end_to_end(lsa):
         assert o.g1_canonical_affine(got[i]) == o.g1_canonical_affine(want)
         start += m
     B.close()
+
+
+@pytest.mark.parametrize("m,half,beta,suff", [(2, 1, True, True), (2, 7, True, True), (2, 5000, True, True), (2, 300, True, False),
+                                              (1, 64, True, True), (3, 1000, True, True), (4, 33, False, False), (2, 70000, False, False)])
+def test_sumcheck_round_vs_oracle(lsa, m, half, beta, suff):
+    tabs = [o.random_scalars(2 * half, seed=2000 + 7 * m + t)[0] for t in range(m)]
+    s = o.random_scalars(half, seed=31 + m)[0] if suff else None
+    pr = o.random_scalars(2, seed=32 + m)[0]
+    kw = dict(suff=s, pre=pr[0], rho_j=pr[1]) if beta else {}
+    got = lsa.sumcheck_round(tabs, **kw)
+    want = o.fr_sumcheck_round(tabs, **kw)
+    assert np.array_equal(got, want)
+
+
+def test_sumcheck_prover_inner_loop_on_device(lsa):
+    """The per-round device work of CPSumcheck::prove at d = 8 (two MLE tables + the beta suffix
+    table, all resident): round polynomial, then pushRandomness on every table and the suffix
+    update -- against the same sequence in the oracle."""
+    import torch
+    d = 8
+    N = 1 << d
+    a, _ = o.random_scalars(N, seed=41)
+    b, _ = o.random_scalars(N, seed=42)
+    suff, _ = o.random_scalars(N // 2, seed=43)
+    rs, _ = o.random_scalars(d, seed=44)
+    ks, _ = o.random_scalars(d, seed=45)
+    pre, _ = o.random_scalars(d, seed=46)
+    rho, _ = o.random_scalars(d, seed=47)
+    to_dev = lambda x: torch.from_numpy(x.view(np.int64).copy()).to("cuda:0")
+    d_a, d_b, d_s, d_r = to_dev(a), to_dev(b), to_dev(suff), to_dev(rs)
+    torch.cuda.synchronize()
+    ha, hb, hs = a.copy(), b.copy(), suff.copy()
+    for j in range(d):
+        half = 1 << (d - j - 1)
+        use_suff = j + 1 <= d - 1
+        got = lsa.sumcheck_round([d_a[:2 * half], d_b[:2 * half]], suff=d_s[:half] if use_suff else None, pre=pre[j], rho_j=rho[j])
+        want = o.fr_sumcheck_round([ha[:2 * half], hb[:2 * half]], suff=hs[:half] if use_suff else None, pre=pre[j], rho_j=rho[j])
+        assert np.array_equal(got, want), j
+        for dv, hv in ((d_a, ha), (d_b, hb)):
+            lsa._check(lsa.lib().lsa_fr_fold(dv.data_ptr(), half, d_r[j].data_ptr(), dv.data_ptr(), 1))
+            hv[:half] = o.fr_push_randomness(hv[:2 * half], rs[j])
+        if half >= 2:
+            lsa._check(lsa.lib().lsa_fr_scale_upper(d_s.data_ptr(), half // 2, lsa._host_ptr(ks[j]), d_s.data_ptr(), 1))
+            hs[:half // 2] = o.fr_scale_upper(hs[:half], ks[j])
+    lsa.synchronize()
+    assert np.array_equal(d_a[:1].cpu().numpy().view(np.uint64), ha[:1])
+    assert np.array_equal(d_b[:1].cpu().numpy().view(np.uint64), hb[:1])

@@ -252,3 +252,39 @@ def test_oracle_fr_vector_loops_match_bigint_formulas():
             half = N // 2
             got = _fr_ints(o.fr_push_randomness(v_m, r_m[0]))
             assert got == [(v[p] * (1 - r[0]) + v[p + half] * r[0]) % R for p in range(half)]
+
+
+def test_oracle_sumcheck_round_matches_bigint_formula():
+    """make_new_h_poly restated with polynomial products per p, against
+    h_j = ((1-rho) + (2rho-1)X) * pre * sum_p suff[p] prod_t (v0 + (v1-v0) X) in Python integers."""
+    R = o.R
+    for m, half, beta in ((2, 8, True), (1, 4, True), (3, 5, True), (2, 6, False)):
+        tabs_m, tabs = [], []
+        for t in range(m):
+            a_m, a = o.random_scalars(2 * half, seed=1000 + 10 * m + t)
+            tabs_m.append(a_m); tabs.append([int(x) for x in a])
+        s_m, s = o.random_scalars(half, seed=77 + m)
+        pr_m, pr = o.random_scalars(2, seed=78 + m)
+        S = [0] * (m + 1)
+        for p in range(half):
+            q = [int(s[p]) if beta else 1]
+            for t in range(m):
+                v0, dv = tabs[t][p], (tabs[t][p + half] - tabs[t][p]) % R
+                nq = [0] * (len(q) + 1)
+                for i, c in enumerate(q):
+                    nq[i] = (nq[i] + c * v0) % R
+                    nq[i + 1] = (nq[i + 1] + c * dv) % R
+                q = nq
+            S = [(x + y) % R for x, y in zip(S, q)]
+        if beta:
+            pre, rho = int(pr[0]), int(pr[1])
+            e0, e1 = (1 - rho) * pre % R, (2 * rho - 1) * pre % R
+            want = [((S[i] * e0 if i <= m else 0) + (S[i - 1] * e1 if i >= 1 else 0)) % R for i in range(m + 2)]
+            got = o.fr_sumcheck_round(tabs_m, suff=s_m, pre=pr_m[0], rho_j=pr_m[1])
+        else:
+            want = S
+            got = o.fr_sumcheck_round(tabs_m)
+        assert _fr_ints(got) == want
+    old_m, old = o.random_scalars(10, seed=5)
+    k_m, k = o.random_scalars(1, seed=6)
+    assert _fr_ints(o.fr_scale_upper(old_m, k_m[0])) == [int(old[5 + p]) * int(k[0]) % R for p in range(5)]
