@@ -257,3 +257,38 @@ def test_preshifted_window_tables_vs_oracle(lsa, group, n):
         B.close()
     finally:
         lsa.set_table_threshold(0)
+
+
+@pytest.mark.parametrize("use_table", [True, False])
+def test_skewed_scalars_at_the_table_threshold(lsa, use_table):
+    """n = 2^19 + 3 (just above the default table threshold) with the scalar shapes of the
+    reference's examples: u[i] = i and i^2 (src/examples/hadamard.cc:130-135), 31-bit values
+    (src/examples/matrixsc.cc:50-53), one repeated scalar, mostly zeros.  Heavy buckets and
+    partly filled windows, on the pre-shifted-table path and on the plain one; checked by the
+    known-discrete-log identity."""
+    import torch
+    n = (1 << 19) + 3
+    a, b = 0xA5A5A5A5A5A5A5A5A5A5 << 40 | 0x31, 0x1234567 << 20 | 0x5
+    bases = o.arith_bases("g1", a, b, n)
+    lsa.set_table_threshold(0 if use_table else 1 << 30)
+    try:
+        B = lsa.Bases("g1", bases)
+        assert B.has_table() == (use_table and TABLES_ENABLED)
+        rng = np.random.default_rng(9)
+        shapes = {
+            "i": [i for i in range(n)],
+            "i^2": [i * i for i in range(n)],
+            "31-bit": [int(x) for x in rng.integers(0, 1 << 31, size=n)],
+            "repeated": [0x1234567890ABCDEF1234567890ABCDEF % R] * n,
+            "sparse": [(int(x) if i % 1000 == 0 else 0) for i, x in enumerate(rng.integers(0, 1 << 62, size=n))],
+        }
+        g = o.generator("g1")
+        for name, sc in shapes.items():
+            d_s = torch.from_numpy(o.fr_mont_array(sc).view(np.int64)).to("cuda:0")
+            torch.cuda.synchronize()
+            got = B.msm(d_s)
+            k = sum(s * (a + i * b) for i, s in enumerate(sc)) % R
+            assert canon("g1", got) == canon("g1", o.g1_mul(g, o.fr_mont(k))), name
+        B.close()
+    finally:
+        lsa.set_table_threshold(0)
