@@ -184,6 +184,15 @@ int lsa_fr_sumcheck_round(const void *suff_mont, const void *const *tables, size
  * cur are device pointers, asynchronous on lsa_stream(); else host pointers. */
 int lsa_fr_scale_upper(const void *old_mont, size_t half, const void *k_mont, void *cur_mont, int on_device);
 
+/* In-place radix-2 NTT of 2^log_n Fr values, natural order in and out: replaces libfqfft
+ * basic_radix2_domain<Fr>::FFT / iFFT / cosetFFT / icosetFFT as used by the Lipmaa gadget
+ * (src/gadgets/lipmaa.cc:68-81,102-175).  omega: a primitive 2^log_n-th root of unity (HOST, one
+ * Fr; libff::get_root_of_unity).  inverse == 0: a[k] <- sum_i a[i] omega^(ik), after a[i] *= g^i
+ * when coset_g != NULL (cosetFFT).  inverse != 0: the same with omega^-1, then a[k] *= 1/n and,
+ * with coset_g, *= g^-k (iFFT / icosetFFT).  coset_g: HOST, one Fr, or NULL.
+ * on_device != 0: a is a device pointer; else a host pointer.  log_n <= 28. */
+int lsa_fr_ntt(void *a_mont, size_t log_n, const void *omega_mont, int inverse, const void *coset_g_mont, int on_device);
+
 /* ---- pairing ---------------------------------------------------------------------------- */
 /* out[i] = miller_loop(precompute_G1(P_i), precompute_G2(Q_i)), i < n: replaces libff
  * alt_bn128_pp::precompute_G1 / precompute_G2 / miller_loop (src/utils/globl.h:96-102,

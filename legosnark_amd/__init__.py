@@ -83,6 +83,7 @@ def lib():
         L.lsa_fr_cppoly_witness.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.lsa_fr_eval_mle.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.lsa_fr_fold.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+        L.lsa_fr_ntt.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.lsa_fr_sumcheck_round.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.lsa_fr_scale_upper.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.lsa_miller_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
@@ -372,6 +373,22 @@ def fr_scale_upper(old, k):
     cur = np.zeros((half, 4), dtype=np.uint64)
     _check(lib().lsa_fr_scale_upper(_host_ptr(old), half, _host_ptr(k), _host_ptr(cur), 0))
     return cur
+
+
+def fr_ntt(a, omega, inverse=False, coset=None):
+    """libfqfft radix-2 FFT / iFFT / cosetFFT / icosetFFT over Fr.  numpy (host, returns a new
+    array) or torch CUDA tensor (device, in place)."""
+    omega = np.ascontiguousarray(omega, dtype=np.uint64).reshape(4)
+    cg = np.ascontiguousarray(coset, dtype=np.uint64).reshape(4) if coset is not None else None
+    if isinstance(a, np.ndarray):
+        out = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4).copy()
+        log_n = _log2_exact(len(out))
+        _check(lib().lsa_fr_ntt(_host_ptr(out), log_n, _host_ptr(omega), 1 if inverse else 0,
+                                _host_ptr(cg) if cg is not None else None, 0))
+        return out
+    log_n = _log2_exact(a.numel() * a.element_size() // 32)
+    _check(lib().lsa_fr_ntt(_ptr(a), log_n, _host_ptr(omega), 1 if inverse else 0, _host_ptr(cg) if cg is not None else None, 1))
+    return a
 
 
 def sum_async(group, d_pts, n, d_out):

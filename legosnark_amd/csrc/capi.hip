@@ -555,6 +555,31 @@ int lsa_fr_scale_upper(const void *old, size_t half, const void *k, void *cur, i
     return LSA_OK;
 }
 
+int lsa_fr_ntt(void *a, size_t log_n, const void *omega, int inverse, const void *coset_g, int on_device) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (log_n > 28) { set_error("fr_ntt: log_n = %zu exceeds the 2-adicity of Fr (28)", log_n); return LSA_ERR_INVALID; }
+    if (!a || !omega) { set_error("fr_ntt: null argument"); return LSA_ERR_INVALID; }
+    if (log_n == 0) return LSA_OK;
+    const size_t n = (size_t)1 << log_n;
+    Fr w, gco;
+    memcpy(&w, omega, sizeof w);
+    if (coset_g) memcpy(&gco, coset_g, sizeof gco);
+    DevBuf d_tw, d_a;
+    if (d_tw.alloc((n / 2 + 1) * sizeof(Fr))) { set_error("fr_ntt: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    Fr *da = (Fr *)a;
+    if (!on_device) {
+        if (d_a.alloc(n * sizeof(Fr))) { set_error("fr_ntt: hipMalloc failed"); return LSA_ERR_NOMEM; }
+        HIPCHK(hipMemcpyAsync(d_a.p, a, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+        da = (Fr *)d_a.p;
+    }
+    rc = fr_ntt_device(da, (unsigned)log_n, w, inverse != 0, coset_g ? &gco : nullptr, (Fr *)d_tw.p, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));      // the twiddle table is freed on return
+    if (!on_device) HIPCHK(hipMemcpy(a, d_a.p, n * sizeof(Fr), hipMemcpyDeviceToHost));
+    return LSA_OK;
+}
+
 int lsa_fr_fold(const void *old, size_t half, const void *r, void *cur, int on_device) {
     int rc = require_ready();
     if (rc) return rc;

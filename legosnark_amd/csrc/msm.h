@@ -56,6 +56,9 @@ int fr_sumcheck_round_device(const Fr *d_suff, const Fr *const *d_tables, size_t
 size_t fr_sumcheck_scratch_elems();
 int fr_scale_upper_device(const Fr *d_old, size_t half, const Fr &k, Fr *d_cur, hipStream_t st);
 
+// ntt.hip: in-place radix-2 NTT of 2^log_n Fr values (device), d_tw: 2^(log_n-1) scratch elements
+int fr_ntt_device(Fr *d_a, unsigned log_n, const Fr &omega, bool inverse, const Fr *coset, Fr *d_tw, hipStream_t st);
+
 // d_out = sum of n Jacobian points in d_in (device-resident).
 template <class F>
 int sum_points_device(const Jac<F> *d_in, size_t n, Jac<F> *d_out, hipStream_t st);

@@ -1,9 +1,10 @@
-// Host-only radix-2 evaluation domain with libfqfft's interface
+// Radix-2 evaluation domain with libfqfft's interface
 // (libfqfft/evaluation_domain/{evaluation_domain,get_evaluation_domain}.hpp), enough for
 // /root/reference/src/prototools/interp.h:62-78 and src/gadgets/lipmaa.cc:46-175 to compile,
-// link and run.  OUT OF SCOPE for the GPU path (Fr NTT, Lipmaa only -- SURVEY.md section
-// 8f rank 4).  Unlike libfqfft, sizes are always rounded up to a power of two (basic radix-2
-// domain); the extended / step domains are not provided.
+// link and run.  FFT / iFFT / cosetFFT / icosetFFT forward to the GPU NTT (lsa_fr_ntt,
+// csrc/ntt.hip); the O(m) helpers (Lagrange coefficients,
+// vanishing polynomial) are inline host glue.  Unlike libfqfft, sizes are always rounded up to
+// a power of two (basic radix-2 domain); the extended / step domains are not provided.
 #pragma once
 #include <memory>
 #include <stdexcept>
@@ -21,47 +22,16 @@ public:
     evaluation_domain(const size_t m_) : m(m_), omega(libff::get_root_of_unity<FieldT>(m_)) {}
     virtual ~evaluation_domain() {}
 
-    static void fft_inplace(std::vector<FieldT> &a, const FieldT &w) {
-        const size_t n = a.size();
-        for (size_t i = 1, j = 0; i < n; i++) {          // bit reversal
-            size_t bit = n >> 1;
-            for (; j & bit; bit >>= 1) j ^= bit;
-            j ^= bit;
-            if (i < j) std::swap(a[i], a[j]);
-        }
-        for (size_t len = 2; len <= n; len <<= 1) {
-            FieldT wl = w;
-            for (size_t k = len; k < n; k <<= 1) wl = wl.squared();
-            for (size_t i = 0; i < n; i += len) {
-                FieldT x = FieldT::one();
-                for (size_t j = 0; j < len / 2; j++) {
-                    FieldT u = a[i + j], v = a[i + j + len / 2] * x;
-                    a[i + j] = u + v;
-                    a[i + j + len / 2] = u - v;
-                    x *= wl;
-                }
-            }
-        }
-    }
     void check(const std::vector<FieldT> &a) const { if (a.size() != m) throw std::invalid_argument("evaluation_domain: expected a.size() == m"); }
-    virtual void FFT(std::vector<FieldT> &a) { check(a); fft_inplace(a, omega); }
-    virtual void iFFT(std::vector<FieldT> &a) {
+    size_t log_m() const { size_t l = 0; while ((size_t(1) << l) < m) l++; return l; }
+    void ntt(std::vector<FieldT> &a, int inverse, const FieldT *g) {
         check(a);
-        fft_inplace(a, omega.inverse());
-        const FieldT sconst = FieldT((unsigned long)m).inverse();
-        for (auto &x : a) x *= sconst;
+        libff::lsa_require(lsa_fr_ntt(a.data(), log_m(), &omega, inverse, g, 0), "evaluation_domain FFT");
     }
-    virtual void cosetFFT(std::vector<FieldT> &a, const FieldT &g) {
-        FieldT u = FieldT::one();
-        for (auto &x : a) { x *= u; u *= g; }
-        FFT(a);
-    }
-    virtual void icosetFFT(std::vector<FieldT> &a, const FieldT &g) {
-        iFFT(a);
-        const FieldT gi = g.inverse();
-        FieldT u = FieldT::one();
-        for (auto &x : a) { x *= u; u *= gi; }
-    }
+    virtual void FFT(std::vector<FieldT> &a) { ntt(a, 0, nullptr); }
+    virtual void iFFT(std::vector<FieldT> &a) { ntt(a, 1, nullptr); }
+    virtual void cosetFFT(std::vector<FieldT> &a, const FieldT &g) { ntt(a, 0, &g); }
+    virtual void icosetFFT(std::vector<FieldT> &a, const FieldT &g) { ntt(a, 1, &g); }
     virtual std::vector<FieldT> evaluate_all_lagrange_polynomials(const FieldT &t) {
         std::vector<FieldT> u(m, FieldT::zero());
         if ((t ^ (unsigned long)m) == FieldT::one()) {

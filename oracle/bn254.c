@@ -582,3 +582,56 @@ void oracle_fr_sumcheck_round(ofp_t *out, const ofp_t *suff, const ofp_t *const 
 void oracle_fr_scale_upper(ofp_t *cur, const ofp_t *old, const ofp_t *k, size_t half) {
     for (size_t p = 0; p < half; p++) fr_mul_(&cur[p], &old[half + p], k);
 }
+
+/* libfqfft _basic_radix2_FFT [upstream, recalled] as used through basic_radix2_domain by
+ * /root/reference/src/gadgets/lipmaa.cc:102-175: in-place bit-reversal, then log n
+ * butterfly levels with w_m = omega^(n/m).  a: n = 2^log_n elements of Fr. */
+void oracle_fr_radix2_fft(ofp_t *a, size_t log_n, const ofp_t *omega) {
+    const size_t n = (size_t)1 << log_n;
+    for (size_t k = 0; k < n; k++) {
+        size_t rk = 0;
+        for (size_t b = 0; b < log_n; b++) if (k & ((size_t)1 << b)) rk |= (size_t)1 << (log_n - 1 - b);
+        if (k < rk) { ofp_t t = a[k]; a[k] = a[rk]; a[rk] = t; }
+    }
+    size_t m = 1;
+    for (size_t s = 1; s <= log_n; s++) {
+        /* w_m = omega^(n / 2m) */
+        ofp_t w_m = *omega;
+        for (size_t e = 2 * m; e < n; e <<= 1) fr_mul_(&w_m, &w_m, &w_m);
+        for (size_t k = 0; k < n; k += 2 * m) {
+            ofp_t w; fr_one(&w);
+            for (size_t j = 0; j < m; j++) {
+                ofp_t t;
+                fr_mul_(&t, &w, &a[k + j + m]);
+                fr_sub_(&a[k + j + m], &a[k + j], &t);
+                fr_add_(&a[k + j], &a[k + j], &t);
+                fr_mul_(&w, &w, &w_m);
+            }
+        }
+        m *= 2;
+    }
+}
+/* basic_radix2_domain::iFFT (FFT with omega^-1, then * 1/n), cosetFFT (_multiply_by_coset then
+ * FFT), icosetFFT (iFFT then _multiply_by_coset with g^-1) [upstream, recalled] */
+void oracle_fr_domain_transform(ofp_t *a, size_t log_n, const ofp_t *omega, int inverse, const ofp_t *coset_g) {
+    const size_t n = (size_t)1 << log_n;
+    ofp_t one; fr_one(&one);
+    if (!inverse) {
+        if (coset_g) { ofp_t u = *coset_g; for (size_t i = 1; i < n; i++) { fr_mul_(&a[i], &a[i], &u); fr_mul_(&u, &u, coset_g); } }
+        oracle_fr_radix2_fft(a, log_n, omega);
+        return;
+    }
+    ofp_t wi, ninv, nn;
+    ofp_inv(&wi, omega, 1);
+    oracle_fr_radix2_fft(a, log_n, &wi);
+    fr_zero(&nn);
+    for (size_t i = 0; i < n; i++) fr_add_(&nn, &nn, &one);      /* FieldT(n) */
+    ofp_inv(&ninv, &nn, 1);
+    for (size_t i = 0; i < n; i++) fr_mul_(&a[i], &a[i], &ninv);
+    if (coset_g) {
+        ofp_t gi, u;
+        ofp_inv(&gi, coset_g, 1);
+        u = gi;
+        for (size_t i = 1; i < n; i++) { fr_mul_(&a[i], &a[i], &u); fr_mul_(&u, &u, &gi); }
+    }
+}

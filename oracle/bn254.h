@@ -129,6 +129,11 @@ void oracle_fr_sumcheck_round(ofp_t *out, const ofp_t *suff, const ofp_t *const 
 /* DPBeta::pushRandomness suffix update (/root/reference/src/prototools/mle.h:46-53) */
 void oracle_fr_scale_upper(ofp_t *cur, const ofp_t *old, const ofp_t *k, size_t half);
 
+/* libfqfft basic_radix2_domain FFT / iFFT / cosetFFT / icosetFFT over Fr [upstream, recalled];
+ * reference call sites /root/reference/src/gadgets/lipmaa.cc:68-81,102-175 */
+void oracle_fr_radix2_fft(ofp_t *a, size_t log_n, const ofp_t *omega);
+void oracle_fr_domain_transform(ofp_t *a, size_t log_n, const ofp_t *omega, int inverse, const ofp_t *coset_g);
+
 /* ---- test-input helper: out[i] = (a + i*b) * generator, un-normalised Jacobian ---- */
 void oracle_g1_arith_bases(og1_t *out, const ofp_t *a_mont, const ofp_t *b_mont, size_t n);
 void oracle_g2_arith_bases(og2_t *out, const ofp_t *a_mont, const ofp_t *b_mont, size_t n);

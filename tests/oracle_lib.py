@@ -262,6 +262,28 @@ def fr_scale_upper(old, k):
     return cur
 
 
+FR_TWO_ADICITY = 28
+FR_GENERATOR = 5          # libff alt_bn128 Fr::multiplicative_generator
+
+
+def fr_root_of_unity(log_n):
+    """Python int: a primitive 2^log_n-th root of unity of Fr, libff get_root_of_unity's choice
+    (root_of_unity = generator^((r-1)/2^s), squared s - log_n times)."""
+    w = pow(FR_GENERATOR, (R - 1) >> FR_TWO_ADICITY, R)
+    for _ in range(FR_TWO_ADICITY - log_n):
+        w = w * w % R
+    return w
+
+
+def fr_domain_transform(a, omega, inverse=False, coset=None):
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4).copy()
+    log_n = len(a).bit_length() - 1
+    cg = _p(np.ascontiguousarray(coset, dtype=np.uint64)) if coset is not None else None
+    lib().oracle_fr_domain_transform(_p(a), C.c_size_t(log_n), _p(np.ascontiguousarray(omega, dtype=np.uint64)),
+                                     C.c_int(1 if inverse else 0), cg)
+    return a
+
+
 def reduced_pairing(p, q):
     p = np.ascontiguousarray(p, dtype=np.uint64)
     q = np.ascontiguousarray(q, dtype=np.uint64)

@@ -122,3 +122,44 @@ def test_sumcheck_prover_inner_loop_on_device(lsa):
     lsa.synchronize()
     assert np.array_equal(d_a[:1].cpu().numpy().view(np.uint64), ha[:1])
     assert np.array_equal(d_b[:1].cpu().numpy().view(np.uint64), hb[:1])
+
+
+@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 10, 11, 13, 16])
+def test_ntt_vs_oracle(lsa, log_n):
+    """libfqfft FFT / iFFT / cosetFFT / icosetFFT over Fr, byte for byte against the restated
+    _basic_radix2_FFT (sizes below, at and above the 1024-element LDS tile)."""
+    n = 1 << log_n
+    a, _ = o.random_scalars(n, seed=3000 + log_n)
+    w = o.fr_mont(o.fr_root_of_unity(log_n))
+    g = o.fr_mont(o.FR_GENERATOR)
+    for inverse in (False, True):
+        for coset in (None, g):
+            got = lsa.fr_ntt(a, w, inverse=inverse, coset=coset)
+            want = o.fr_domain_transform(a, w, inverse=inverse, coset=coset) if log_n else a
+            assert np.array_equal(got, want), (inverse, coset is not None)
+
+
+def test_ntt_round_trip_full_size_on_device(lsa):
+    """n = 2^20 on a device-resident vector: icosetFFT(cosetFFT(a)) == a, and the transform of a
+    delta at position 1 is the geometric sequence omega^k (checked at sampled positions)."""
+    import torch
+    log_n = 20
+    n = 1 << log_n
+    gen = torch.Generator(device="cuda:0").manual_seed(5)
+    d_a = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device="cuda:0", generator=gen)
+    d_a[:, 3] &= (1 << 60) - 1
+    keep = d_a.clone()
+    wi = o.fr_root_of_unity(log_n)
+    w, g = o.fr_mont(wi), o.fr_mont(o.FR_GENERATOR)
+    lsa.fr_ntt(d_a, w, coset=g)
+    assert not torch.equal(d_a, keep)
+    lsa.fr_ntt(d_a, w, inverse=True, coset=g)
+    lsa.synchronize()
+    assert torch.equal(d_a, keep)
+    delta = torch.zeros((n, 4), dtype=torch.int64, device="cuda:0")
+    delta[1] = torch.from_numpy(o.fr_mont(1).view(np.int64))
+    lsa.fr_ntt(delta, w)
+    lsa.synchronize()
+    host = delta.cpu().numpy().view(np.uint64)
+    for k in (0, 1, 2, 1023, 1024, 65537, n - 1):
+        assert np.array_equal(host[k], o.fr_mont(pow(wi, k, o.R))), k

@@ -288,3 +288,25 @@ def test_oracle_sumcheck_round_matches_bigint_formula():
     old_m, old = o.random_scalars(10, seed=5)
     k_m, k = o.random_scalars(1, seed=6)
     assert _fr_ints(o.fr_scale_upper(old_m, k_m[0])) == [int(old[5 + p]) * int(k[0]) % R for p in range(5)]
+
+
+def test_oracle_radix2_fft_is_the_dft():
+    """The restated _basic_radix2_FFT against the definition a[k] = sum_i a[i] w^(ik) in Python
+    integers; iFFT / coset variants by their defining identities."""
+    R = o.R
+    for log_n in (1, 2, 3, 5):
+        n = 1 << log_n
+        w = o.fr_root_of_unity(log_n)
+        assert pow(w, n, R) == 1 and pow(w, n // 2, R) == R - 1
+        a_m, a = o.random_scalars(n, seed=300 + log_n)
+        a = [int(x) for x in a]
+        w_m = o.fr_mont(w)
+        g = 5
+        got = _fr_ints(o.fr_domain_transform(a_m, w_m))
+        assert got == [sum(a[i] * pow(w, i * k, R) for i in range(n)) % R for k in range(n)]
+        back = _fr_ints(o.fr_domain_transform(o.fr_domain_transform(a_m, w_m), w_m, inverse=True))
+        assert back == a
+        cos = _fr_ints(o.fr_domain_transform(a_m, w_m, coset=o.fr_mont(g)))
+        assert cos == [sum(a[i] * pow(g, i, R) * pow(w, i * k, R) for i in range(n)) % R for k in range(n)]
+        back = _fr_ints(o.fr_domain_transform(o.fr_domain_transform(a_m, w_m, coset=o.fr_mont(g)), w_m, inverse=True, coset=o.fr_mont(g)))
+        assert back == a
