@@ -292,3 +292,28 @@ def test_skewed_scalars_at_the_table_threshold(lsa, use_table):
         B.close()
     finally:
         lsa.set_table_threshold(0)
+
+
+def test_msm_random_sweep_vs_oracle(lsa):
+    """Many small random instances (sizes, both groups, un-normalised bases, scalars of random bit
+    lengths, sprinkled zeros / ones / infinities) against the oracle: a net for rare paths of the
+    lazy 29-bit arithmetic (zero tests, P + P, P + (-P)) that fixed-size tests may never hit."""
+    rng = random.Random(20261001)
+    for case in range(36):
+        group = "g1" if case % 3 else "g2"
+        n = rng.randrange(1, 1200 if group == "g1" else 300)
+        bases = o.arith_bases(group, rng.randrange(1, R), rng.randrange(1, R), n)
+        bits = rng.choice([1, 8, 31, 64, 127, 128, 200, 254])
+        sc, _ = o.random_scalars(n, seed=rng.randrange(1 << 30), bits=bits)
+        for _ in range(rng.randrange(0, 4)):
+            i = rng.randrange(n)
+            sc[i] = o.fr_mont(rng.choice([0, 1, R - 1, 2]))
+        if n > 3 and rng.random() < 0.5:
+            bases[rng.randrange(n)] = 0                    # infinity
+        if n > 3 and rng.random() < 0.5:
+            i, j = rng.randrange(n), rng.randrange(n)
+            bases[i] = bases[j]                            # repeated base (P + P in a bucket when the digits agree)
+            sc[i] = sc[j]
+        got = lsa.msm(group, bases, sc)
+        want = o.multi_exp(group, bases, sc, mode="mixed")
+        assert canon(group, got) == canon(group, want), (case, group, n, bits)
