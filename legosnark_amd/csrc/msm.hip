@@ -291,10 +291,12 @@ __global__ __launch_bounds__(1024) void k_scatter(const int32_t *__restrict__ di
 // get their identity written here, over-threshold ones go to the heavy list.
 // ------------------------------------------------------------------------------------
 #define ACC_SPLIT 2u            // lanes per bucket in k_accumulate
-#define SIZE_BINS 1025          // counts 0..1024 (heavy_threshold == 1024)
+#define SIZE_BINS 1025          // bin 0 unused (total), bins 1..1024
+// population -> bin: ((cnt - 1) >> bin_shift) + 1 in [1, SIZE_BINS - 1] for cnt in [1, thr]
+__device__ __forceinline__ uint32_t size_bin(uint32_t cnt, uint32_t bin_shift) { return ((cnt - 1) >> bin_shift) + 1; }
 template <class C>
 __global__ __launch_bounds__(256) void k_size_hist(const uint32_t *__restrict__ hist, uint32_t nb, uint32_t thr, uint32_t *__restrict__ bin_count,
-                                                   uint32_t group_size) {
+                                                   uint32_t group_size, uint32_t bin_shift) {
     // group_size != 0: buckets are ordered group by group (a group = one window's 2^(c-1)
     // buckets, a multiple of this block's 2048), by population inside each group
     bin_count += (group_size ? (blockIdx.x * 2048u) / group_size : 0u) * SIZE_BINS;
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256) void k_size_hist(const uint32_t *__restrict__ 
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         uint32_t g = base + j * 256;
-        if (g < nb) { uint32_t cnt = hist[g]; if (cnt > 0 && cnt <= thr) atomicAdd(&lcnt[cnt], 1u); }
+        if (g < nb) { uint32_t cnt = hist[g]; if (cnt > 0 && cnt <= thr) atomicAdd(&lcnt[size_bin(cnt, bin_shift)], 1u); }
     }
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < SIZE_BINS; t += 256) if (lcnt[t]) atomicAdd(&bin_count[t], lcnt[t]);
@@ -342,7 +344,7 @@ template <class C>
 __global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict__ hist, uint32_t nb, uint32_t thr, const uint32_t *__restrict__ bin_start,
                                                       uint32_t *__restrict__ bin_cursor, uint32_t *__restrict__ perm,
                                                       uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count,
-                                                      typename C::Acc *__restrict__ buckets, uint32_t group_size) {
+                                                      typename C::Acc *__restrict__ buckets, uint32_t group_size, uint32_t bin_shift) {
     const uint32_t goff = (group_size ? (blockIdx.x * 2048u) / group_size : 0u) * SIZE_BINS;
     bin_start += goff;
     bin_cursor += goff;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict
             cnt[j] = hist[g];
             if (cnt[j] == 0) { for (uint32_t h = 0; h < ACC_SPLIT; h++) buckets[(size_t)g * ACC_SPLIT + h] = C::inf(); }
             else if (cnt[j] > thr) heavy_list[atomicAdd(heavy_count, 1u)] = g;
-            else rank[j] = atomicAdd(&lcnt[cnt[j]], 1u);
+            else rank[j] = atomicAdd(&lcnt[size_bin(cnt[j], bin_shift)], 1u);
         }
     }
     __syncthreads();
@@ -372,7 +374,10 @@ __global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         uint32_t g = base + j * 256;
-        if (g < nb && cnt[j] > 0 && cnt[j] <= thr) perm[bin_start[cnt[j]] + lcnt[cnt[j]] + rank[j]] = g;
+        if (g < nb && cnt[j] > 0 && cnt[j] <= thr) {
+            const uint32_t bin = size_bin(cnt[j], bin_shift);
+            perm[bin_start[bin] + lcnt[bin] + rank[j]] = g;
+        }
     }
 }
 
@@ -896,8 +901,10 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     // Buckets far above the average population (skewed scalars; the partly filled top window
     // when c does not divide the scalar length) are split across workgroups instead of being
     // walked by two lanes.
-    const uint32_t avg_pop = (uint32_t)std::min<size_t>(nv / B + 1, SIZE_BINS);
-    const uint32_t heavy_threshold = std::min<uint32_t>(SIZE_BINS - 1, std::max<uint32_t>(64, 2 * avg_pop + 32));
+    const uint32_t avg_pop = (uint32_t)(nv / B + 1);
+    const uint32_t heavy_threshold = std::max<uint32_t>(64, 2 * avg_pop + 32);
+    uint32_t bin_shift = 0;                          // populations above 1024 share bins (the order only balances wavefronts)
+    while (((heavy_threshold - 1) >> bin_shift) + 1 > SIZE_BINS - 1) bin_shift++;
     const uint32_t max_heavy = (uint32_t)std::min<size_t>(nb, ne / heavy_threshold + 1);
     const size_t max_chunks = ne / HEAVY_CHUNK + max_heavy + 1;
 
@@ -998,9 +1005,9 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     {
         const unsigned sb = (nb + 2047) / 2048;
         const uint32_t gsz = 0u;
-        hipLaunchKernelGGL((k_size_hist<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_count, gsz);
+        hipLaunchKernelGGL((k_size_hist<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_count, gsz, bin_shift);
         hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(256), 0, st, bin_count, bin_start, ngroups);
-        hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets, gsz);
+        hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets, gsz, bin_shift);
     }
     hipLaunchKernelGGL((k_accumulate<C>), dim3((nb * ACC_SPLIT + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
     hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(256), 0, st, hist, heavy_list, heavy_count, chunk_off);
