@@ -16,6 +16,7 @@
 // Independent pairings are embarrassingly parallel; products are folded 8-ary.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <vector>
 
 #include "ec.h"
@@ -103,6 +104,27 @@ __global__ __launch_bounds__(64) void k_miller_wave(const Jac<Fq> *__restrict__ 
     if (lane < 12) reinterpret_cast<Fq *>(&out[e])[lane] = w12_fq_ref(w.slot(0), lane)->to_mont256();
 }
 
+// Six lanes per pairing, ten pairings per wavefront (miller.h, G6Miller): the batch shape.
+__global__ __launch_bounds__(64) void k_miller_g6(const Jac<Fq> *__restrict__ g1, const Jac<Fq2> *__restrict__ g2, size_t n,
+                                                  Fq12 *__restrict__ out) {
+    __shared__ Fq2S lds[G6_LDS_FQ2];
+    const size_t lo = (size_t)blockIdx.x * G6_GROUPS;
+    if (lo >= n) return;
+    const unsigned count = (unsigned)(n - lo < (size_t)G6_GROUPS ? n - lo : (size_t)G6_GROUPS);
+    const unsigned lane = threadIdx.x, g = lane / 6, k = lane % 6;
+    WaveExec ex;
+    G6Miller<WaveExec> m{ex, lds};
+    m.run(g1 + lo, g2 + lo, count);
+    if (g < count) {
+        // coefficient k of w^k sits at tower position t = (k & 1) * 3 + (k >> 1): Fq numbers 2t, 2t+1
+        const unsigned t = (k & 1) * 3 + (k >> 1);
+        const Fq2S c = lds[g * G6_STRIDE + G6_F + k];
+        Fq *o = reinterpret_cast<Fq *>(&out[lo + g]);
+        o[2 * t] = c.c0.to_mont256();
+        o[2 * t + 1] = c.c1.to_mont256();
+    }
+}
+
 // out[b] = prod in[8b .. 8b+7], one wavefront per group of 8 (W12 products)
 __global__ __launch_bounds__(64) void k_fq12_prod8_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
     __shared__ Fq2S lds[W12_LDS_FQ2];
@@ -143,8 +165,15 @@ __global__ __launch_bounds__(64) void k_fq12_prod8(const Fq12 *__restrict__ in, 
 
 int miller_device(const void *d_g1, const void *d_g2, size_t n, void *d_out, hipStream_t st) {
     if (n == 0) return LSA_OK;
-    if (n < 16384)   // fewer pairings than lanes to fill the chip: one wavefront per pairing
+    // up to ~1 wavefront per SIMD the one-pairing-per-wavefront kernel has the shorter chain
+    // (1.3 ms); beyond that ten pairings per wavefront win (2.9 ms flat up to ~10^4 pairings, then
+    // throughput-bound); from 2^16 on one lane per pairing does the least total work.
+    static const int force = getenv("LSA_MILLER_KERNEL") ? atoi(getenv("LSA_MILLER_KERNEL")) : 0;   // 1: wave, 2: g6, 3: lane
+    const int pick = force ? force : (n <= 1536 ? 1 : (n < 65536 ? 2 : 3));
+    if (pick == 1)
         hipLaunchKernelGGL(k_miller_wave, dim3((unsigned)n), dim3(64), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, n, (Fq12 *)d_out);
+    else if (pick == 2)
+        hipLaunchKernelGGL(k_miller_g6, dim3((unsigned)((n + G6_GROUPS - 1) / G6_GROUPS)), dim3(64), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, n, (Fq12 *)d_out);
     else
         hipLaunchKernelGGL(k_miller, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, n,
                            (Fq12 *)d_out);

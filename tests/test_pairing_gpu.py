@@ -122,3 +122,48 @@ def test_sharded_pairing_product_two_ranks_on_one_gpu(lsa):
     for r in range(2):
         job = sharded.make_gpu_sharded_pairing(lsa, 2, r, dist=FakeDist())
         assert np.array_equal(job.run(ps, qs), o.pairing_product(ps, qs))
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+def test_every_miller_kernel_vs_oracle(kernel):
+    """The library picks the Miller-loop kernel by batch size (one pairing per wavefront / ten
+    per wavefront with six lanes each / one per lane); LSA_MILLER_KERNEL forces one.  Each is run
+    in its own process on 25 pairs (two full groups of ten and a partial one) with
+    un-normalised inputs and an infinity, byte for byte against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import legosnark_amd as lsa, oracle_lib as o\n"
+        "lsa.init(0)\n"
+        "ps = o.arith_bases('g1', 77, 5, 25); qs = o.arith_bases('g2', 99, 7, 25)\n"
+        "ps[3] = 0\n"
+        "ps[4] = o.generator('g1'); qs[4] = o.generator('g2')\n"
+        "assert np.array_equal(lsa.miller_loop(ps, qs), o.miller_loop_batch(ps, qs))\n"
+        "assert np.array_equal(lsa.pairing_product(ps, qs), o.pairing_product(ps, qs))\n"
+        "print('OK')\n"
+    ) % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, LSA_MILLER_KERNEL=str(kernel))
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:]
+
+
+def test_large_batch_takes_the_grouped_kernel_and_matches(lsa):
+    """2000 pairs (above the one-wavefront-per-pairing range): product of the Miller values
+    against the oracle on a sample, and the planted relation prod e(a_i G1, b_i G2) = 1 with
+    sum a_i b_i = 0 mod r over the whole batch."""
+    rng = random.Random(5)
+    n = 2000
+    a = [rng.randrange(1, R) for _ in range(n)]
+    b = [rng.randrange(1, R) for _ in range(n - 1)]
+    s = sum(x * y for x, y in zip(a, b)) % R
+    b.append((-s) * pow(a[-1], -1, R) % R)
+    ps = lsa.batch_exp("g1", o.generator("g1"), o.fr_mont_array(a))
+    qs = lsa.batch_exp("g2", o.generator("g2"), o.fr_mont_array(b))
+    f = lsa.miller_loop(ps, qs)
+    for i in (0, 9, 10, 1234, n - 1):
+        assert np.array_equal(f[i], o.miller_loop_batch(ps[i:i + 1], qs[i:i + 1])[0]), i
+    assert np.array_equal(lsa.pairing_product(ps, qs), o.fq12_one())
