@@ -5,7 +5,10 @@
  * include, link or call this; only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py use it, as the checker / reported baseline.
  *
- * PARITY PINNING: libff / libsnark are un-vendored submodules of the reference
+ * PARITY PINNING -- "parity unpinned" in the brief's strict sense: the reference holds no golden
+ * vectors or known-answer tests for this path and cannot be built or run here, so nothing below
+ * is checked against bytes produced by libff itself.  What pins it instead is listed under
+ * (i)-(iii).  libff / libsnark are un-vendored submodules of the reference
  * (/root/reference/.gitmodules:1-6, depends/libsnark is empty, pinned commit
  * unknown), so there is no reference binary and the reference holds no golden
  * vectors.  This restatement follows libff's published
