@@ -5,7 +5,7 @@
  * include, link or call this; only tests/, __graft_entry__.smoke() and the
  * cpu_baseline leg of bench.py use it, as the checker / reported baseline.
  *
- * PARITY PINNING -- "parity unpinned" in the brief's strict sense: the reference holds no golden
+ * PARITY PINNING -- "parity unpinned" in the strict sense: the reference holds no golden
  * vectors or known-answer tests for this path and cannot be built or run here, so nothing below
  * is checked against bytes produced by libff itself.  What pins it instead is listed under
  * (i)-(iii).  libff / libsnark are un-vendored submodules of the reference
