@@ -512,4 +512,193 @@ struct G6Miller {
     }
 };
 
+// ------------------------------------------------------------------------------------
+// TWELVE lanes per pairing, five pairings per wavefront (G12): the same round structure with
+// one Fq COMPONENT per lane.  A lone wavefront already saturates its SIMD's 64-bit
+// multiply-add pipe, so a batch that leaves SIMDs idle (fewer than ~10^4 pairings with G6) gets
+// faster only by doing less per lane on more SIMDs.  Lane (k, part) computes component `part`
+// of coefficient k: each Fq2 product costs it ONE fused two-product reduction (dot2), and the
+// wrapped terms (i + j >= 6) take their a-operand from XF = xi * F, kept next to F, so that a
+// coefficient is a plain sum of six (three) dot2 results and one reduction -- no cross-lane xi
+// step.  Operand contract of these products: a < 20p (F or xi*F), b < 2p (F or the line, whose
+// first coefficient is reduced here for that reason).
+// ------------------------------------------------------------------------------------
+static constexpr int G12_GROUPS = 5;
+static constexpr int G12_F = 0, G12_XF = 6, G12_T = 12, G12_L = 18, G12_V = 21, G12_G = G12_V + WM_NVARS, G12_STRIDE = G12_G + WM_SIDE;
+static constexpr int G12_LDS_FQ2 = G12_GROUPS * G12_STRIDE;
+
+// component `part` of a*b: part 0: a0*b0 + a1*(KB p - b1), part 1: a0*b1 + a1*b0.  b's components < KB p.
+template <int KB>
+LSA_HD F29 g12_comp_mul(unsigned part, const Fq2S &a, const Fq2S &b) {
+    const uint32_t pm = 0u - part;
+    const F29 nb1 = sub_k<KB>(F29::zero(), b.c1.v);
+    F29 y0, y1;
+#pragma unroll
+    for (int l = 0; l < 9; l++) {
+        y0.l[l] = (b.c1.v.l[l] & pm) | (b.c0.v.l[l] & ~pm);
+        y1.l[l] = (b.c0.v.l[l] & pm) | (nb1.l[l] & ~pm);
+    }
+    return dot2(a.c0.v, y0, a.c1.v, y1);
+}
+LSA_HD Fs &g12_part(Fq2S &v, unsigned part) { return part ? v.c1 : v.c0; }
+
+template <class X>
+struct G12Miller {
+    X &x;
+    Fq2S *mem;          // G12_LDS_FQ2 elements
+    using WM = WMiller<X>;
+    struct Side { int8_t a[WM_SIDE], b[WM_SIDE]; int n; };
+
+    LSA_HD void products(int mode, const Side sd) {
+        Fq2S *m = mem;
+        x.par([=](unsigned lane) {
+            const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
+            if (g >= (unsigned)G12_GROUPS) return;
+            Fq2S *base = m + g * G12_STRIDE;
+            if (mode) {
+                const int terms = mode == 1 ? 6 : 3;
+                F29 sum = F29::zero();
+                for (int t = 0; t < terms; t++) {
+                    // mode 1: a index t, b = F[k - t];  mode 2: b = L[t] (w^0, w^3, w^4), a index k - {0,3,4}
+                    int ai = mode == 1 ? t : (int)k - (t == 0 ? 0 : t + 2);
+                    int bi = mode == 1 ? (int)k - t : t;
+                    bool wrap;
+                    if (mode == 1) { wrap = bi < 0; if (wrap) bi += 6; }
+                    else { wrap = ai < 0; if (wrap) ai += 6; }
+                    const Fq2S &a = base[(wrap ? G12_XF : G12_F) + ai];
+                    const Fq2S &b = base[(mode == 1 ? G12_F : G12_L) + bi];
+                    sum = add_lazy(sum, g12_comp_mul<2>(part, a, b));
+                }
+                g12_part(base[G12_T + k], part) = Fs{mul(w12_norm_u(sum), F29::one())};     // < 12p -> < 2p
+            }
+            if ((int)k < sd.n) g12_part(base[G12_G + k], part) = Fs{g12_comp_mul<20>(part, base[G12_V + sd.a[k]], base[G12_V + sd.b[k]])};
+        });
+    }
+    template <class Body>
+    LSA_HD void combine(bool fcopy, Body body) {
+        Fq2S *m = mem;
+        x.par([=](unsigned lane) {
+            const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
+            if (g >= (unsigned)G12_GROUPS || part) return;
+            Fq2S *base = m + g * G12_STRIDE;
+            if (fcopy) {
+                const Fq2S t = base[G12_T + k];
+                base[G12_F + k] = t;
+                base[G12_XF + k] = WM::st(WM::xi_times(WM::ld(t)));                        // [< 20]
+            }
+            if (k == 0) body(base + G12_V, base + G12_G, base + G12_L);
+        });
+    }
+    // xi * t brought back under 2p (the line's first coefficient is a b-operand here)
+    static LSA_HD Fq2S xi_reduced(const F29x2 &t) {
+        const F29x2 v = WM::xi_times(t);
+        return {Fs{mul(v.c0, F29::one())}, Fs{mul(v.c1, F29::one())}};
+    }
+
+    LSA_HD void doubling_round() {
+        products(1, Side{{WM_RX, WM_RY, WM_RZ, WM_S, WM_RX, 0}, {WM_RY, WM_RY, WM_RZ, WM_S, WM_RX, 0}, 5});
+        combine(true, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
+            const F29x2 B = WM::ld(Gg[1]), C = WM::ld(Gg[2]);
+            const F29x2 H = sub_k<4>(WM::ld(Gg[3]), add_lazy(B, C));
+            Vv[WM_A] = WM::st(WM::halve2(WM::ld(Gg[0])));
+            Vv[WM_B] = Gg[1];
+            Vv[WM_D] = WM::st(WM::triple(C));
+            Vv[WM_H] = WM::st(H);
+            Vv[WM_NH] = WM::st(sub_k<6>(F29x2::zero(), H));
+            Vv[WM_J3] = WM::st(WM::triple(WM::ld(Gg[4])));
+        });
+        products(0, Side{{WM_TWB, WM_B, WM_PY, WM_PX, 0, 0}, {WM_D, WM_H, WM_NH, WM_J3, 0, 0}, 4});
+        combine(false, [](Fq2S *Vv, Fq2S *Gg, Fq2S *L) {
+            const F29x2 E = WM::ld(Gg[0]), B = WM::ld(Vv[WM_B]);
+            const F29x2 F = WM::triple(E);
+            Vv[WM_E] = Gg[0];
+            Vv[WM_G] = WM::st(condsub4(WM::halve2(add_lazy(B, F).norm())));
+            Vv[WM_BMF] = WM::st(sub_k<6>(B, F));
+            Vv[WM_RZ] = Gg[1];
+            L[0] = xi_reduced(WM::csub2(sub_k<2>(E, B)));
+            L[1] = Gg[2];
+            L[2] = Gg[3];
+        });
+        products(2, Side{{WM_E, WM_A, WM_G, 0, 0, 0}, {WM_E, WM_BMF, WM_G, 0, 0, 0}, 3});
+        combine(true, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
+            const F29x2 Y3 = WM::csub2(condsub4(sub_k<6>(WM::ld(Gg[2]), WM::triple(WM::ld(Gg[0])))));
+            Vv[WM_RX] = Gg[1];
+            Vv[WM_RY] = WM::st(Y3);
+            Vv[WM_S] = WM::st(add_lazy(Y3, WM::ld(Vv[WM_RZ])).norm());
+        });
+    }
+
+    LSA_HD void addition_round(int x2, int y2) {
+        products(0, Side{{(int8_t)x2, (int8_t)y2, 0, 0, 0, 0}, {WM_RZ, WM_RZ, 0, 0, 0, 0}, 2});
+        combine(false, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
+            const F29x2 E = sub_k<2>(WM::ld(Vv[WM_RY]), WM::ld(Gg[1]));
+            Vv[WM_DD] = WM::st(sub_k<2>(WM::ld(Vv[WM_RX]), WM::ld(Gg[0])));
+            Vv[WM_EE] = WM::st(E);
+            Vv[WM_NE] = WM::st(sub_k<4>(F29x2::zero(), E));
+        });
+        products(0, Side{{WM_DD, WM_EE, WM_EE, WM_DD, WM_DD, WM_PX}, {WM_DD, WM_EE, (int8_t)x2, (int8_t)y2, WM_PY, WM_NE}, 6});
+        combine(false, [](Fq2S *Vv, Fq2S *Gg, Fq2S *L) {
+            Vv[WM_F] = Gg[0];
+            Vv[WM_GG] = Gg[1];
+            L[0] = xi_reduced(WM::csub2(sub_k<2>(WM::ld(Gg[2]), WM::ld(Gg[3]))));
+            L[1] = Gg[4];
+            L[2] = Gg[5];
+        });
+        products(2, Side{{WM_DD, WM_RX, WM_RZ, 0, 0, 0}, {WM_F, WM_F, WM_GG, 0, 0, 0}, 3});
+        combine(true, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
+            const F29x2 H = WM::ld(Gg[0]), I = WM::ld(Gg[1]);
+            const F29x2 J = sub_k<4>(add_lazy(H, WM::ld(Gg[2])), add_lazy(I, I));
+            Vv[WM_HH] = Gg[0];
+            Vv[WM_JJ] = WM::st(J);
+            Vv[WM_IMJ] = WM::st(sub_k<8>(I, J));
+        });
+        products(0, Side{{WM_DD, WM_EE, WM_HH, WM_RZ, 0, 0}, {WM_JJ, WM_IMJ, WM_RY, WM_HH, 0, 0}, 4});
+        combine(false, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
+            const F29x2 Y3 = WM::csub2(sub_k<2>(WM::ld(Gg[1]), WM::ld(Gg[2])));
+            Vv[WM_RX] = Gg[0];
+            Vv[WM_RY] = WM::st(Y3);
+            Vv[WM_RZ] = Gg[3];
+            Vv[WM_S] = WM::st(add_lazy(Y3, WM::ld(Gg[3])).norm());
+        });
+    }
+
+    LSA_HD void run(const Jac<Fq> *P, const Jac<Fq2> *Q, unsigned count) {
+        Fq2S *m = mem;
+        x.par([=](unsigned lane) {
+            const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
+            if (g >= (unsigned)G12_GROUPS || part) return;
+            Fq2S *base = m + g * G12_STRIDE;
+            Fq2S *Vv = base + G12_V;
+            const Fq2S f0 = k == 0 ? P2::one() : P2::zero();
+            base[G12_F + k] = f0;
+            base[G12_XF + k] = WM::st(WM::xi_times(WM::ld(f0)));
+            if (k == 0) {
+                AffinePair in;
+                if (g < count) in = miller_affine_inputs(P[g], Q[g]);
+                else { in.px = PB::zero(); in.py = PB::one(); in.qx = P2::zero(); in.qy = P2::one(); }
+                const P2 gx = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_X), gy = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_Y);
+                P2 q1x = gx * in.qx.conj(), q1y = gy * in.qy.conj();
+                Vv[WM_QX] = in.qx; Vv[WM_QY] = in.qy;
+                Vv[WM_Q1X] = q1x; Vv[WM_Q1Y] = q1y;
+                Vv[WM_Q2X] = gx * q1x.conj(); Vv[WM_Q2Y] = (gy * q1y.conj()).neg();
+                Vv[WM_PX] = Fq2S{in.px, PB::zero()}; Vv[WM_PY] = Fq2S{in.py, PB::zero()};
+                Vv[WM_TWB] = fq2_constT<PB>(LSA_TWIST_B);
+                Vv[WM_RX] = in.qx; Vv[WM_RY] = in.qy; Vv[WM_RZ] = P2::one();
+                Vv[WM_S] = in.qy + P2::one();
+            }
+        });
+        for (int i = 63; i >= 0; --i) {
+            doubling_round();
+            if (ate_bit(i)) addition_round(WM_QX, WM_QY);
+        }
+        addition_round(WM_Q1X, WM_Q1Y);
+        addition_round(WM_Q2X, WM_Q2Y);
+    }
+    LSA_HD Fq12S result(unsigned g) const {
+        Fq12S t;
+        for (int k = 0; k < 6; k++) w12_tower_ref(t, k) = mem[g * G12_STRIDE + G12_F + k];
+        return t;
+    }
+};
+
 }  // namespace lsa

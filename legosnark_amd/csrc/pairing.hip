@@ -125,6 +125,25 @@ __global__ __launch_bounds__(64) void k_miller_g6(const Jac<Fq> *__restrict__ g1
     }
 }
 
+// Twelve lanes per pairing, five pairings per wavefront (miller.h, G12Miller): batches that would
+// leave SIMDs idle with ten pairings per wavefront.
+__global__ __launch_bounds__(64) void k_miller_g12(const Jac<Fq> *__restrict__ g1, const Jac<Fq2> *__restrict__ g2, size_t n,
+                                                   Fq12 *__restrict__ out) {
+    __shared__ Fq2S lds[G12_LDS_FQ2];
+    const size_t lo = (size_t)blockIdx.x * G12_GROUPS;
+    if (lo >= n) return;
+    const unsigned count = (unsigned)(n - lo < (size_t)G12_GROUPS ? n - lo : (size_t)G12_GROUPS);
+    const unsigned lane = threadIdx.x, g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
+    WaveExec ex;
+    G12Miller<WaveExec> m{ex, lds};
+    m.run(g1 + lo, g2 + lo, count);
+    if (g < count) {
+        const unsigned t = (k & 1) * 3 + (k >> 1);                  // tower position of w^k
+        const Fq2S c = lds[g * G12_STRIDE + G12_F + k];
+        reinterpret_cast<Fq *>(&out[lo + g])[2 * t + part] = (part ? c.c1 : c.c0).to_mont256();
+    }
+}
+
 // out[b] = prod in[8b .. 8b+7], one wavefront per group of 8 (W12 products)
 __global__ __launch_bounds__(64) void k_fq12_prod8_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
     __shared__ Fq2S lds[W12_LDS_FQ2];
@@ -166,12 +185,15 @@ __global__ __launch_bounds__(64) void k_fq12_prod8(const Fq12 *__restrict__ in, 
 int miller_device(const void *d_g1, const void *d_g2, size_t n, void *d_out, hipStream_t st) {
     if (n == 0) return LSA_OK;
     // up to ~1 wavefront per SIMD the one-pairing-per-wavefront kernel has the shorter chain
-    // (1.3 ms); beyond that ten pairings per wavefront win (2.9 ms flat up to ~10^4 pairings, then
-    // throughput-bound); from 2^16 on one lane per pairing does the least total work.
-    static const int force = getenv("LSA_MILLER_KERNEL") ? atoi(getenv("LSA_MILLER_KERNEL")) : 0;   // 1: wave, 2: g6, 3: lane
-    const int pick = force ? force : (n <= 1536 ? 1 : (n < 65536 ? 2 : 3));
+    // (1.3 ms); then five pairings per wavefront (twelve lanes each) while that still leaves at
+    // most one wavefront per SIMD, then ten per wavefront (2.9 ms flat up to ~10^4 pairings,
+    // throughput-bound beyond); from 2^16 on one lane per pairing does the least total work.
+    static const int force = getenv("LSA_MILLER_KERNEL") ? atoi(getenv("LSA_MILLER_KERNEL")) : 0;   // 1: wave, 2: g6, 3: lane, 4: g12
+    const int pick = force ? force : (n <= 1536 ? 1 : (n <= 5120 ? 4 : (n < 65536 ? 2 : 3)));
     if (pick == 1)
         hipLaunchKernelGGL(k_miller_wave, dim3((unsigned)n), dim3(64), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, n, (Fq12 *)d_out);
+    else if (pick == 4)
+        hipLaunchKernelGGL(k_miller_g12, dim3((unsigned)((n + G12_GROUPS - 1) / G12_GROUPS)), dim3(64), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, n, (Fq12 *)d_out);
     else if (pick == 2)
         hipLaunchKernelGGL(k_miller_g6, dim3((unsigned)((n + G6_GROUPS - 1) / G6_GROUPS)), dim3(64), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, n, (Fq12 *)d_out);
     else

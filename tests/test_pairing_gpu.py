@@ -124,10 +124,10 @@ def test_sharded_pairing_product_two_ranks_on_one_gpu(lsa):
         assert np.array_equal(job.run(ps, qs), o.pairing_product(ps, qs))
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3])
+@pytest.mark.parametrize("kernel", [1, 2, 3, 4])
 def test_every_miller_kernel_vs_oracle(kernel):
     """The library picks the Miller-loop kernel by batch size (one pairing per wavefront / ten
-    per wavefront with six lanes each / one per lane); LSA_MILLER_KERNEL forces one.  Each is run
+    per wavefront with six lanes each / one per lane / five per wavefront with twelve lanes each); LSA_MILLER_KERNEL forces one.  Each is run
     in its own process on 25 pairs (two full groups of ten and a partial one) with
     un-normalised inputs and an infinity, byte for byte against the oracle."""
     import os
