@@ -141,6 +141,57 @@ enum WMVar {                                               // Fq2 variables in L
 };
 static constexpr int WM_LDS_FQ2 = W12_LDS_FQ2 + WM_NVARS + WM_SIDE;
 
+// Start-up of a wavefront / group engine, shared by TWO lanes: sel 0 brings the G1 point to
+// affine form (libff to_affine_coordinates: O -> (0, 1)) and stores (px,0), (py,0), twist_b;
+// sel 1 does the G2 point and derives pi(Q), -pi^2(Q) and R = Q.  Each needs one base-field
+// inversion (Z, resp. the norm of Z) when its point is not normalised; written so that both lanes
+// run that ~0.2 ms Fermat chain in the same instruction stream instead of one after the other.
+LSA_HD void wm_setup(unsigned sel, bool valid, const Jac<Fq> *P, const Jac<Fq2> *Q, Fq2S *Vv) {
+    PB z = PB::one();
+    P2 qz = P2::one();
+    bool need = false, inf = true;
+    if (valid) {
+        if (sel == 0) {
+            inf = P->Z.is_zero();
+            need = !inf && !(P->Z == Fq::one());
+            if (need) z = PB::from_mont256(P->Z);
+        } else {
+            inf = Q->Z.is_zero();
+            need = !inf && !(Q->Z == Fq2::one());
+            if (need) { qz = load2(Q->Z); z = qz.c0.sqr() + qz.c1.sqr(); }
+        }
+    }
+    PB zi = PB::one();
+    if (need) zi = z.inverse();
+    if (sel == 0) {
+        PB px = PB::zero(), py = PB::one();
+        if (!inf) {
+            px = PB::from_mont256(P->X); py = PB::from_mont256(P->Y);
+            if (need) { const PB zi2 = zi.sqr(); px = px * zi2; py = py * (zi2 * zi); }
+        }
+        Vv[WM_PX] = Fq2S{px, PB::zero()};
+        Vv[WM_PY] = Fq2S{py, PB::zero()};
+        Vv[WM_TWB] = fq2_constT<PB>(LSA_TWIST_B);
+    } else {
+        P2 qx = P2::zero(), qy = P2::one();
+        if (!inf) {
+            qx = load2(Q->X); qy = load2(Q->Y);
+            if (need) {
+                const P2 zinv = {qz.c0 * zi, (qz.c1 * zi).neg()};      // Fq2 inverse = conj / norm
+                const P2 zi2 = zinv.sqr();
+                qx = qx * zi2; qy = qy * (zi2 * zinv);
+            }
+        }
+        const P2 gx = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_X), gy = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_Y);
+        const P2 q1x = gx * qx.conj(), q1y = gy * qy.conj();
+        Vv[WM_QX] = qx; Vv[WM_QY] = qy;
+        Vv[WM_Q1X] = q1x; Vv[WM_Q1Y] = q1y;
+        Vv[WM_Q2X] = gx * q1x.conj(); Vv[WM_Q2Y] = (gy * q1y.conj()).neg();
+        Vv[WM_RX] = qx; Vv[WM_RY] = qy; Vv[WM_RZ] = P2::one();
+        Vv[WM_S] = qy + P2::one();
+    }
+}
+
 template <class X>
 struct WMiller {
     W12<X> w;      // slot 0: f, slot 1: the line as a full element (zeros at w^1, w^2, w^5)
@@ -286,17 +337,8 @@ struct WMiller {
         Fq2S *Vv = V;
         Fq2S *F0 = w.slot(SF), *L = w.slot(SL);
         w.x.par([=](unsigned lane) {
-            if (lane == 0) {
-                const AffinePair in = miller_affine_inputs(P, Q);
-                const P2 gx = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_X), gy = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_Y);
-                P2 q1x = gx * in.qx.conj(), q1y = gy * in.qy.conj();
-                Vv[WM_QX] = in.qx; Vv[WM_QY] = in.qy;
-                Vv[WM_Q1X] = q1x; Vv[WM_Q1Y] = q1y;
-                Vv[WM_Q2X] = gx * q1x.conj(); Vv[WM_Q2Y] = (gy * q1y.conj()).neg();
-                Vv[WM_PX] = Fq2S{in.px, PB::zero()}; Vv[WM_PY] = Fq2S{in.py, PB::zero()};
-                Vv[WM_TWB] = fq2_constT<PB>(LSA_TWIST_B);
-                Vv[WM_RX] = in.qx; Vv[WM_RY] = in.qy; Vv[WM_RZ] = P2::one();
-                Vv[WM_S] = in.qy + P2::one();
+            if (lane < 2) {
+                wm_setup(lane, true, &P, &Q, Vv);
             } else if (lane >= 8 && lane < 14) {
                 const unsigned k = lane - 8;
                 F0[k] = k == 0 ? P2::one() : P2::zero();
@@ -482,19 +524,8 @@ struct G6Miller {
             Fq2S *base = m + g * G6_STRIDE;
             Fq2S *Vv = base + G6_V;
             base[G6_F + k] = k == 0 ? P2::one() : P2::zero();
-            if (k == 0) {
-                AffinePair in;
-                if (g < count) in = miller_affine_inputs(P[g], Q[g]);
-                else { in.px = PB::zero(); in.py = PB::one(); in.qx = P2::zero(); in.qy = P2::one(); }
-                const P2 gx = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_X), gy = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_Y);
-                P2 q1x = gx * in.qx.conj(), q1y = gy * in.qy.conj();
-                Vv[WM_QX] = in.qx; Vv[WM_QY] = in.qy;
-                Vv[WM_Q1X] = q1x; Vv[WM_Q1Y] = q1y;
-                Vv[WM_Q2X] = gx * q1x.conj(); Vv[WM_Q2Y] = (gy * q1y.conj()).neg();
-                Vv[WM_PX] = Fq2S{in.px, PB::zero()}; Vv[WM_PY] = Fq2S{in.py, PB::zero()};
-                Vv[WM_TWB] = fq2_constT<PB>(LSA_TWIST_B);
-                Vv[WM_RX] = in.qx; Vv[WM_RY] = in.qy; Vv[WM_RZ] = P2::one();
-                Vv[WM_S] = in.qy + P2::one();
+            if (k < 2) {
+                wm_setup(k, g < count, P + g, Q + g, Vv);
             }
         });
         for (int i = 63; i >= 0; --i) {
@@ -672,19 +703,8 @@ struct G12Miller {
             const Fq2S f0 = k == 0 ? P2::one() : P2::zero();
             base[G12_F + k] = f0;
             base[G12_XF + k] = WM::st(WM::xi_times(WM::ld(f0)));
-            if (k == 0) {
-                AffinePair in;
-                if (g < count) in = miller_affine_inputs(P[g], Q[g]);
-                else { in.px = PB::zero(); in.py = PB::one(); in.qx = P2::zero(); in.qy = P2::one(); }
-                const P2 gx = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_X), gy = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_Y);
-                P2 q1x = gx * in.qx.conj(), q1y = gy * in.qy.conj();
-                Vv[WM_QX] = in.qx; Vv[WM_QY] = in.qy;
-                Vv[WM_Q1X] = q1x; Vv[WM_Q1Y] = q1y;
-                Vv[WM_Q2X] = gx * q1x.conj(); Vv[WM_Q2Y] = (gy * q1y.conj()).neg();
-                Vv[WM_PX] = Fq2S{in.px, PB::zero()}; Vv[WM_PY] = Fq2S{in.py, PB::zero()};
-                Vv[WM_TWB] = fq2_constT<PB>(LSA_TWIST_B);
-                Vv[WM_RX] = in.qx; Vv[WM_RY] = in.qy; Vv[WM_RZ] = P2::one();
-                Vv[WM_S] = in.qy + P2::one();
+            if (k < 2) {
+                wm_setup(k, g < count, P + g, Q + g, Vv);
             }
         });
         for (int i = 63; i >= 0; --i) {
