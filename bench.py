@@ -118,6 +118,25 @@ def main():
         lsa.synchronize()
         lat.append(time.perf_counter() - tl)
     latency_ms = sorted(lat)[len(lat) // 2] * 1e3
+    # the second half of BASELINE.json's metric, "CPlink prover ms": SubspaceSnark::prove
+    # (src/gadgets/subspace.cc:78-85) is ONE multiExpMA over the N+2 meaningful CRS points with
+    # w = (0, rF, u) (src/examples/cplink.cc:107-108); timed as a blocking lsa_msm_run call on a
+    # resident CRS, host result included.
+    cplink_ms = None
+    if world == 1:
+        npl = n + 2
+        crs = lsa.Bases("g1", lsa.batch_exp("g1", curve.generator("g1"), random_fr(npl)), on_device=True)
+        w_vec = random_fr(npl)
+        w_vec[0] = 0
+        torch.cuda.synchronize()
+        crs.msm(w_vec)
+        tl = []
+        for _ in range(5):
+            t_ = time.perf_counter()
+            crs.msm(w_vec)
+            tl.append(time.perf_counter() - t_)
+        cplink_ms = sorted(tl)[len(tl) // 2] * 1e3
+        crs.close()
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -153,6 +172,7 @@ def main():
                                           "ceiling of the 9x29-bit Montgomery product on this chip"}},
             "stage_ms": {k: round(v, 4) for k, v in stages.items() if k not in ("calls", "reserved")},
             "single_call_latency_ms": latency_ms,
+            "cplink_prover_ms": cplink_ms,
             "pipelining": "the tail (reduce+fold) of step i runs on an internal stream and overlaps the front of "
                           "step i+1; stage_ms are measured under that overlap; LSA_NO_OVERLAP=1 serialises",
         }
