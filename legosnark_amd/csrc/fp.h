@@ -124,6 +124,49 @@ struct Fp {
     // Invariant t < 2*MOD < 2^255 after every outer iteration, so only one transient
     // overflow limb is needed.
     static LSA_HD Fp mul_inline(const Fp &a, const Fp &b) {
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__) && !defined(LSA_FP_HOST32)
+        // Host side (the shim's cold operators, the host unit tests): the same CIOS on four
+        // 64-bit limbs, ~3x fewer multiplications.  Same canonical result.
+        typedef unsigned __int128 u128;
+        uint64_t x[4], y[4], q[4];
+        for (int i = 0; i < 4; i++) {
+            x[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+            y[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
+            q[i] = (uint64_t)P::MOD[2 * i] | ((uint64_t)P::MOD[2 * i + 1] << 32);
+        }
+        uint64_t pinv = (uint64_t)0 - (uint64_t)P::INV;       // p^-1 mod 2^32 in the low half ...
+        pinv *= 2 - q[0] * pinv;                              // ... lifted to 2^64 by one Newton step
+        const uint64_t ninv = (uint64_t)0 - pinv;             // -p^-1 mod 2^64
+        uint64_t t[5] = {0, 0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) {
+            u128 c = 0;
+            for (int j = 0; j < 4; j++) {
+                c += (u128)x[j] * y[i] + t[j];
+                t[j] = (uint64_t)c;
+                c >>= 64;
+            }
+            c += t[4];
+            t[4] = (uint64_t)c;
+            const uint64_t top = (uint64_t)(c >> 64);
+            const uint64_t m = t[0] * ninv;
+            c = (u128)m * q[0] + t[0];
+            c >>= 64;
+            for (int j = 1; j < 4; j++) {
+                c += (u128)m * q[j] + t[j];
+                t[j - 1] = (uint64_t)c;
+                c >>= 64;
+            }
+            c += t[4];
+            t[3] = (uint64_t)c;
+            t[4] = top + (uint64_t)(c >> 64);
+        }
+        uint32_t w[8];
+        for (int i = 0; i < 4; i++) { w[2 * i] = (uint32_t)t[i]; w[2 * i + 1] = (uint32_t)(t[i] >> 32); }
+        reduce_once(w);                                       // t < 2*MOD < 2^255: t[4] == 0
+        Fp r64;
+        for (int i = 0; i < 8; i++) r64.l[i] = w[i];
+        return r64;
+#else
         uint32_t t[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) t[i] = 0;
@@ -153,6 +196,7 @@ struct Fp {
 #pragma unroll
         for (int i = 0; i < 8; i++) r.l[i] = t[i];
         return r;
+#endif
     }
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(LSA_INLINE_FIELD_MUL)
     // On the device the ~600-instruction product is a real function (arguments and

@@ -18,3 +18,16 @@ def test_host_cpp(name, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "legosnark_amd", "csrc"), src, "-o", exe])
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("name", ["test_fp29", "test_glv", "test_tower29"])
+def test_host_cpp_with_the_32_bit_limb_product(name, tmp_path):
+    """On the host Fp's Montgomery product runs on four 64-bit limbs; the device compiles the
+    32-bit-limb CIOS.  LSA_FP_HOST32 forces the device variant on the host: the same tests must
+    pass with either, i.e. both agree with the independent 29-bit-limb code and the integer
+    identities."""
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cc")
+    exe = str(tmp_path / (name + "_32"))
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-DLSA_FP_HOST32", "-I", os.path.join(ROOT, "legosnark_amd", "csrc"), src, "-o", exe])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-2000:]
