@@ -243,8 +243,12 @@ struct StageBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 StageBuf g_stage_jac, g_stage_bases, g_stage_scalars;
+StageBuf g_pair_p, g_pair_q, g_pair_f, g_pair_s, g_pair_o;     // pairing host path: points, Miller values, product scratch, result
 }  // namespace
-static void release_stage_buffers() { g_stage_jac.release(); g_stage_bases.release(); g_stage_scalars.release(); }
+static void release_stage_buffers() {
+    g_stage_jac.release(); g_stage_bases.release(); g_stage_scalars.release();
+    g_pair_p.release(); g_pair_q.release(); g_pair_f.release(); g_pair_s.release(); g_pair_o.release();
+}
 
 template <class F>
 static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *out_jac, int group) {
@@ -601,26 +605,23 @@ int lsa_fr_fold(const void *old, size_t half, const void *r, void *cur, int on_d
 // ---------------------------------------------------------------- pairing
 namespace {
 
-// uploads n (P,Q) pairs, runs the Miller loops; d_f receives n Fq12 values
-int miller_upload_run(const void *g1, const void *g2, size_t n, DevBuf &d_f) {
-    DevBuf d_p, d_q;
-    if (d_p.alloc(n * sizeof(Jac<Fq>)) || d_q.alloc(n * sizeof(Jac<Fq2>)) || d_f.alloc(n * fq12_bytes())) {
+// uploads n (P,Q) pairs and runs the Miller loops into the grow-only staging buffer g_pair_f (a
+// verifier calls this thousands of times: no hipMalloc / hipFree, which also keeps the device
+// from idling down between the upload and the kernel)
+int miller_upload_run(const void *g1, const void *g2, size_t n) {
+    if (g_pair_p.ensure(n * sizeof(Jac<Fq>)) || g_pair_q.ensure(n * sizeof(Jac<Fq2>)) || g_pair_f.ensure(n * fq12_bytes())) {
         set_error("pairing: hipMalloc failed");
         return LSA_ERR_NOMEM;
     }
-    HIPCHK(hipMemcpyAsync(d_p.p, g1, n * sizeof(Jac<Fq>), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(d_q.p, g2, n * sizeof(Jac<Fq2>), hipMemcpyHostToDevice, g.stream));
-    int rc = miller_device(d_p.p, d_q.p, n, d_f.p, g.stream);
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(g.stream));
-    return LSA_OK;
+    HIPCHK(hipMemcpyAsync(g_pair_p.p, g1, n * sizeof(Jac<Fq>), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g_pair_q.p, g2, n * sizeof(Jac<Fq2>), hipMemcpyHostToDevice, g.stream));
+    return miller_device(g_pair_p.p, g_pair_q.p, n, g_pair_f.p, g.stream);
 }
 
 int miller_product_host(const void *g1, const void *g2, size_t n, void *out, bool final_exp) {
     int rc = require_ready();
     if (rc) return rc;
     if (!out || (n && (!g1 || !g2))) { set_error("pairing: null argument"); return LSA_ERR_INVALID; }
-    DevBuf d_f, d_s, d_o;
     void *res = nullptr;
     if (n == 0) {
         // empty product = 1; final_exponentiation(1) = 1
@@ -628,15 +629,15 @@ int miller_product_host(const void *g1, const void *g2, size_t n, void *out, boo
         memcpy(out, &one, sizeof one);
         return LSA_OK;
     }
-    rc = miller_upload_run(g1, g2, n, d_f);
+    rc = miller_upload_run(g1, g2, n);
     if (rc) return rc;
-    if (d_s.alloc(((n + 7) / 8) * fq12_bytes()) || d_o.alloc(fq12_bytes())) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
-    rc = fq12_product_device(d_f.p, d_s.p, n, &res, g.stream);
+    if (g_pair_s.ensure(((n + 7) / 8) * fq12_bytes()) || g_pair_o.ensure(fq12_bytes())) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    rc = fq12_product_device(g_pair_f.p, g_pair_s.p, n, &res, g.stream);
     if (rc) return rc;
     if (final_exp) {
-        rc = final_exp_device(res, 1, d_o.p, g.stream);
+        rc = final_exp_device(res, 1, g_pair_o.p, g.stream);
         if (rc) return rc;
-        res = d_o.p;
+        res = g_pair_o.p;
     }
     HIPCHK(hipMemcpyAsync(g.h_result, res, fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -652,10 +653,10 @@ int lsa_miller_loop(const void *g1, const void *g2, size_t n, void *out, int on_
     if (n == 0) return LSA_OK;
     if (!g1 || !g2 || !out) { set_error("miller_loop: null argument"); return LSA_ERR_INVALID; }
     if (on_device) return miller_device(g1, g2, n, out, g.stream);
-    DevBuf d_f;
-    rc = miller_upload_run(g1, g2, n, d_f);
+    rc = miller_upload_run(g1, g2, n);
     if (rc) return rc;
-    HIPCHK(hipMemcpy(out, d_f.p, n * fq12_bytes(), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(out, g_pair_f.p, n * fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
     return LSA_OK;
 }
 int lsa_miller_loop_product(const void *g1, const void *g2, size_t n, void *out) {
@@ -690,13 +691,12 @@ int lsa_final_exponentiation(const void *in, size_t n, void *out, int on_device)
     if (n == 0) return LSA_OK;
     if (!in || !out) { set_error("final_exponentiation: null argument"); return LSA_ERR_INVALID; }
     if (on_device) return final_exp_device(in, n, out, g.stream);
-    DevBuf d_i, d_o;
-    if (d_i.alloc(n * fq12_bytes()) || d_o.alloc(n * fq12_bytes())) { set_error("final_exponentiation: hipMalloc failed"); return LSA_ERR_NOMEM; }
-    HIPCHK(hipMemcpyAsync(d_i.p, in, n * fq12_bytes(), hipMemcpyHostToDevice, g.stream));
-    rc = final_exp_device(d_i.p, n, d_o.p, g.stream);
+    if (g_pair_f.ensure(n * fq12_bytes()) || g_pair_s.ensure(n * fq12_bytes())) { set_error("final_exponentiation: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    HIPCHK(hipMemcpyAsync(g_pair_f.p, in, n * fq12_bytes(), hipMemcpyHostToDevice, g.stream));
+    rc = final_exp_device(g_pair_f.p, n, g_pair_s.p, g.stream);
     if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, g_pair_s.p, n * fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
-    HIPCHK(hipMemcpy(out, d_o.p, n * fq12_bytes(), hipMemcpyDeviceToHost));
     return LSA_OK;
 }
 }  // extern "C"

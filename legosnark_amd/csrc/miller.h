@@ -626,9 +626,27 @@ struct G12Miller {
         return {Fs{mul(v.c0, F29::one())}, Fs{mul(v.c1, F29::one())}};
     }
 
-    LSA_HD void doubling_round() {
-        products(1, Side{{WM_RX, WM_RY, WM_RZ, WM_S, WM_RX, 0}, {WM_RY, WM_RY, WM_RZ, WM_S, WM_RX, 0}, 5});
-        combine(true, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
+    // The Miller loop as a table-driven sequence of steps through ONE call site, so that the
+    // kernel holds one copy of the product phase and one of the combine phase (~25 KB of code
+    // that stays in the instruction cache) instead of seven inlined copies of each.
+    // ops 0-2: the three rounds of a doubling step, 3-6: the four rounds of an addition step.
+    struct Step { int mode; bool fcopy; Side sd; };
+    static LSA_HD Step step_of(int op, int x2, int y2) {
+        const int8_t X2 = (int8_t)x2, Y2 = (int8_t)y2;
+        switch (op) {
+        case 0: return {1, true, Side{{WM_RX, WM_RY, WM_RZ, WM_S, WM_RX, 0}, {WM_RY, WM_RY, WM_RZ, WM_S, WM_RX, 0}, 5}};
+        case 1: return {0, false, Side{{WM_TWB, WM_B, WM_PY, WM_PX, 0, 0}, {WM_D, WM_H, WM_NH, WM_J3, 0, 0}, 4}};
+        case 2: return {2, true, Side{{WM_E, WM_A, WM_G, 0, 0, 0}, {WM_E, WM_BMF, WM_G, 0, 0, 0}, 3}};
+        case 3: return {0, false, Side{{X2, Y2, 0, 0, 0, 0}, {WM_RZ, WM_RZ, 0, 0, 0, 0}, 2}};
+        case 4: return {0, false, Side{{WM_DD, WM_EE, WM_EE, WM_DD, WM_DD, WM_PX}, {WM_DD, WM_EE, X2, Y2, WM_PY, WM_NE}, 6}};
+        case 5: return {2, true, Side{{WM_DD, WM_RX, WM_RZ, 0, 0, 0}, {WM_F, WM_F, WM_GG, 0, 0, 0}, 3}};
+        default: return {0, false, Side{{WM_DD, WM_EE, WM_HH, WM_RZ, 0, 0}, {WM_JJ, WM_IMJ, WM_RY, WM_HH, 0, 0}, 4}};
+        }
+    }
+    // the point / line arithmetic after the products of round `op` (lane 0 of the group)
+    static LSA_HD void combine_op(int op, Fq2S *Vv, Fq2S *Gg, Fq2S *L) {
+        switch (op) {
+        case 0: {
             const F29x2 B = WM::ld(Gg[1]), C = WM::ld(Gg[2]);
             const F29x2 H = sub_k<4>(WM::ld(Gg[3]), add_lazy(B, C));
             Vv[WM_A] = WM::st(WM::halve2(WM::ld(Gg[0])));
@@ -637,9 +655,8 @@ struct G12Miller {
             Vv[WM_H] = WM::st(H);
             Vv[WM_NH] = WM::st(sub_k<6>(F29x2::zero(), H));
             Vv[WM_J3] = WM::st(WM::triple(WM::ld(Gg[4])));
-        });
-        products(0, Side{{WM_TWB, WM_B, WM_PY, WM_PX, 0, 0}, {WM_D, WM_H, WM_NH, WM_J3, 0, 0}, 4});
-        combine(false, [](Fq2S *Vv, Fq2S *Gg, Fq2S *L) {
+        } break;
+        case 1: {
             const F29x2 E = WM::ld(Gg[0]), B = WM::ld(Vv[WM_B]);
             const F29x2 F = WM::triple(E);
             Vv[WM_E] = Gg[0];
@@ -649,48 +666,41 @@ struct G12Miller {
             L[0] = xi_reduced(WM::csub2(sub_k<2>(E, B)));
             L[1] = Gg[2];
             L[2] = Gg[3];
-        });
-        products(2, Side{{WM_E, WM_A, WM_G, 0, 0, 0}, {WM_E, WM_BMF, WM_G, 0, 0, 0}, 3});
-        combine(true, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
+        } break;
+        case 2: {
             const F29x2 Y3 = WM::csub2(condsub4(sub_k<6>(WM::ld(Gg[2]), WM::triple(WM::ld(Gg[0])))));
             Vv[WM_RX] = Gg[1];
             Vv[WM_RY] = WM::st(Y3);
             Vv[WM_S] = WM::st(add_lazy(Y3, WM::ld(Vv[WM_RZ])).norm());
-        });
-    }
-
-    LSA_HD void addition_round(int x2, int y2) {
-        products(0, Side{{(int8_t)x2, (int8_t)y2, 0, 0, 0, 0}, {WM_RZ, WM_RZ, 0, 0, 0, 0}, 2});
-        combine(false, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
+        } break;
+        case 3: {
             const F29x2 E = sub_k<2>(WM::ld(Vv[WM_RY]), WM::ld(Gg[1]));
             Vv[WM_DD] = WM::st(sub_k<2>(WM::ld(Vv[WM_RX]), WM::ld(Gg[0])));
             Vv[WM_EE] = WM::st(E);
             Vv[WM_NE] = WM::st(sub_k<4>(F29x2::zero(), E));
-        });
-        products(0, Side{{WM_DD, WM_EE, WM_EE, WM_DD, WM_DD, WM_PX}, {WM_DD, WM_EE, (int8_t)x2, (int8_t)y2, WM_PY, WM_NE}, 6});
-        combine(false, [](Fq2S *Vv, Fq2S *Gg, Fq2S *L) {
+        } break;
+        case 4: {
             Vv[WM_F] = Gg[0];
             Vv[WM_GG] = Gg[1];
             L[0] = xi_reduced(WM::csub2(sub_k<2>(WM::ld(Gg[2]), WM::ld(Gg[3]))));
             L[1] = Gg[4];
             L[2] = Gg[5];
-        });
-        products(2, Side{{WM_DD, WM_RX, WM_RZ, 0, 0, 0}, {WM_F, WM_F, WM_GG, 0, 0, 0}, 3});
-        combine(true, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
+        } break;
+        case 5: {
             const F29x2 H = WM::ld(Gg[0]), I = WM::ld(Gg[1]);
             const F29x2 J = sub_k<4>(add_lazy(H, WM::ld(Gg[2])), add_lazy(I, I));
             Vv[WM_HH] = Gg[0];
             Vv[WM_JJ] = WM::st(J);
             Vv[WM_IMJ] = WM::st(sub_k<8>(I, J));
-        });
-        products(0, Side{{WM_DD, WM_EE, WM_HH, WM_RZ, 0, 0}, {WM_JJ, WM_IMJ, WM_RY, WM_HH, 0, 0}, 4});
-        combine(false, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
+        } break;
+        default: {
             const F29x2 Y3 = WM::csub2(sub_k<2>(WM::ld(Gg[1]), WM::ld(Gg[2])));
             Vv[WM_RX] = Gg[0];
             Vv[WM_RY] = WM::st(Y3);
             Vv[WM_RZ] = Gg[3];
             Vv[WM_S] = WM::st(add_lazy(Y3, WM::ld(Gg[3])).norm());
-        });
+        } break;
+        }
     }
 
     LSA_HD void run(const Jac<Fq> *P, const Jac<Fq2> *Q, unsigned count) {
@@ -707,12 +717,21 @@ struct G12Miller {
                 wm_setup(k, g < count, P + g, Q + g, Vv);
             }
         });
-        for (int i = 63; i >= 0; --i) {
-            doubling_round();
-            if (ate_bit(i)) addition_round(WM_QX, WM_QY);
+        // phases 0..63: doubling step (+ addition of Q when the bit of 6u+2 is set); 64, 65: the
+        // additions of pi(Q) and -pi^2(Q)
+#pragma unroll 1
+        for (int ph = 0; ph < 66; ph++) {
+            const bool dbl = ph < 64;
+            const bool add = dbl ? ate_bit(63 - ph) != 0 : true;
+            const int x2 = ph == 64 ? WM_Q1X : (ph == 65 ? WM_Q2X : WM_QX), y2 = x2 + 1;
+            const int first = dbl ? 0 : 3, last = add ? 7 : 3;
+#pragma unroll 1
+            for (int op = first; op < last; op++) {
+                const Step st = step_of(op, x2, y2);
+                products(st.mode, st.sd);
+                combine(st.fcopy, [=](Fq2S *Vv, Fq2S *Gg, Fq2S *L) { combine_op(op, Vv, Gg, L); });
+            }
         }
-        addition_round(WM_Q1X, WM_Q1Y);
-        addition_round(WM_Q2X, WM_Q2Y);
     }
     LSA_HD Fq12S result(unsigned g) const {
         Fq12S t;

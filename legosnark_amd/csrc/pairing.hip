@@ -70,6 +70,7 @@ struct WaveExec {
         f(threadIdx.x);
         __syncthreads();
     }
+    __device__ __forceinline__ unsigned nlanes() const { return blockDim.x; }
 };
 // libff Fq12 layout (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2, each Fq2 = 2 Fq) <-> slot: lane
 // l < 12 moves Fq number l, which is part l%2 of tower coefficient t = l/2, i.e. of w^(2*(t%3) + t/3).
@@ -77,7 +78,7 @@ static __device__ __forceinline__ Fs *w12_fq_ref(Fq2S *slot, unsigned l) {
     const unsigned t = l >> 1, k = 2 * (t % 3) + t / 3;
     return (l & 1) ? &slot[k].c1 : &slot[k].c0;
 }
-__global__ __launch_bounds__(64) void k_final_exp_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
+__global__ __launch_bounds__(128) void k_final_exp_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
     __shared__ Fq2S lds[W12_LDS_FQ2];
     const size_t e = blockIdx.x;
     if (e >= n) return;
@@ -145,14 +146,14 @@ __global__ __launch_bounds__(64) void k_miller_g12(const Jac<Fq> *__restrict__ g
 }
 
 // out[b] = prod in[8b .. 8b+7], one wavefront per group of 8 (W12 products)
-__global__ __launch_bounds__(64) void k_fq12_prod8_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
+__global__ __launch_bounds__(128) void k_fq12_prod8_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
     __shared__ Fq2S lds[W12_LDS_FQ2];
     const size_t lo = (size_t)blockIdx.x * 8;
     if (lo >= n) return;
     const unsigned lane = threadIdx.x;
     WaveExec ex;
     W12<WaveExec> w{ex, lds, lds + 6 * W12_SLOTS};
-    for (unsigned x = lane; x < 96; x += 64) {          // 8 elements x 12 Fq
+    for (unsigned x = lane; x < 96; x += blockDim.x) {  // 8 elements x 12 Fq
         const unsigned e = x / 12, l = x % 12;
         Fs v = (l == 0) ? Fs::one() : Fs::zero();       // missing inputs = 1
         if (lo + e < n) v = Fs::from_mont256(reinterpret_cast<const Fq *>(&in[lo + e])[l]);
@@ -206,7 +207,7 @@ int miller_device(const void *d_g1, const void *d_g2, size_t n, void *d_out, hip
 int final_exp_device(const void *d_in, size_t n, void *d_out, hipStream_t st) {
     if (n == 0) return LSA_OK;
     if (n < 16384)   // fewer elements than lanes to fill the chip: one wavefront per element
-        hipLaunchKernelGGL(k_final_exp_wave, dim3((unsigned)n), dim3(64), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);
+        hipLaunchKernelGGL(k_final_exp_wave, dim3((unsigned)n), dim3(128), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);   // two wavefronts per element
     else
         hipLaunchKernelGGL(k_final_exp, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);
     HIPCHK(hipGetLastError());
@@ -219,7 +220,7 @@ int fq12_product_device(void *d_buf, void *d_scratch, size_t n, void **result, h
     Fq12 *a = (Fq12 *)d_buf, *b = (Fq12 *)d_scratch;
     while (n > 1) {
         size_t m = (n + 7) / 8;
-        if (m < 16384) hipLaunchKernelGGL(k_fq12_prod8_wave, dim3((unsigned)m), dim3(64), 0, st, a, n, b);
+        if (m < 16384) hipLaunchKernelGGL(k_fq12_prod8_wave, dim3((unsigned)m), dim3(128), 0, st, a, n, b);
         else hipLaunchKernelGGL(k_fq12_prod8, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, a, n, b);
         Fq12 *t = a; a = b; b = t;
         n = m;

@@ -3,17 +3,19 @@
 // A final exponentiation (and a Miller loop) is a chain of ~10^4 dependent base-field products:
 // one lane per pairing (pairing.hip, k_miller / k_final_exp) leaves the chip idle unless tens of
 // thousands of pairings are in flight, and a single pairing takes >20 ms.  Here an Fq12 value
-// is a polynomial sum_k a_k w^k, a_k in Fq2, w^6 = xi, kept in LDS; a product is computed by 36
-// lanes (lane 6i+j: a_i * b_j in Fq2) followed by a 6-lane reduction along the anti-diagonals
-//   c_k = sum_{i+j=k} a_i b_j + xi * sum_{i+j=k+6} a_i b_j,
-// i.e. one Fq2 product + ~7 Fq2 additions of latency instead of 18 Fq2 products.  The polynomial
+// is a polynomial sum_k a_k w^k, a_k in Fq2, w^6 = xi, kept in LDS; a product
+//   c_k = sum_{i+j=k} a_i b_j + xi * sum_{i+j=k+6} a_i b_j
+// is computed from its 36 partial products a_i b_j in parallel -- one Fq component of one partial
+// product per lane in W12::mul (72 lanes, two wavefronts), one whole Fq2 product per lane in the
+// Miller engines of miller.h -- followed by a 12-lane reduction along the anti-diagonals: one
+// product + a handful of lazy additions of latency instead of 18 Fq2 products.  The polynomial
 // basis is a permutation of libff's tower basis (c0.c0, c1.c0, c0.c1, c1.c1, c0.c2, c1.c2), and
 // field values are canonical, so every result is bit-identical to the tower code's.
 //
 // The code is written against an executor X with  template<class F> void par(F f)  that runs
-// f(lane) for the 64 lanes and then synchronises: on the device X is the wavefront itself
-// (f(threadIdx.x); __syncthreads()), in tests/cpp/test_w12.cc it is a loop over lane ids, so
-// the host tests run the very same sequence of phases.
+// f(lane) for its lanes and then synchronises, and  nlanes() : on the device X is the workgroup
+// itself (f(threadIdx.x); __syncthreads()), in tests/cpp/test_w12.cc it is a loop over 64 lane
+// ids, so the host tests run the very same sequence of phases.
 #pragma once
 #include "fp29x2.h"
 #include "fs29.h"
@@ -86,6 +88,30 @@ LSA_HD void w12_reduce_lane12(unsigned lane, const Fq2S *Pp, Fq2S *D) {
     if (part) D[k].c1 = res; else D[k].c0 = res;
 }
 
+// xi * t for t < 2 (tight):  (9 t0 - t1 + 2p,  9 t1 + t0)   [< 20; tight]
+LSA_HD F29x2 w12_xi_times(const F29x2 &t) {
+    F29 a8, b8;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { a8.l[i] = t.c0.l[i] << 3; b8.l[i] = t.c1.l[i] << 3; }
+    a8 = w12_norm_u(a8);
+    b8 = w12_norm_u(b8);
+    return {sub_k<2>(add_lazy(a8, t.c0), t.c1), add_lazy(add_lazy(b8, t.c1), t.c0).norm()};
+}
+// component `part` of a*b: part 0: a0*b0 + a1*(KB p - b1), part 1: a0*b1 + a1*b0; b's components
+// < KB p and 2 * bound(a) * KB < 169.  [< 2p; tight]
+template <int KB>
+LSA_HD F29 w12_comp_mul(unsigned part, const Fq2S &a, const Fq2S &b) {
+    const uint32_t pm = 0u - part;
+    const F29 nb1 = sub_k<KB>(F29::zero(), b.c1.v);
+    F29 y0, y1;
+#pragma unroll
+    for (int l = 0; l < 9; l++) {
+        y0.l[l] = (b.c1.v.l[l] & pm) | (b.c0.v.l[l] & ~pm);
+        y1.l[l] = (b.c0.v.l[l] & pm) | (nb1.l[l] & ~pm);
+    }
+    return dot2(a.c0.v, y0, a.c1.v, y1);
+}
+
 // tower <-> polynomial basis: poly index k -> (which Fq6 half, which coefficient)
 LSA_HD Fq2S &w12_tower_ref(Fq12S &t, int k) {
     Fq6T<Fs> &h = (k & 1) ? t.c1 : t.c0;
@@ -100,14 +126,43 @@ struct W12 {
 
     LSA_HD Fq2S *slot(int s) const { return R + 6 * s; }
 
-    // d = a * b   (d may alias a or b)
+    // d = a * b   (d may alias a or b; both operands < 2p, as every value of a final
+    // exponentiation is).  One Fq COMPONENT of one partial product per lane -- 72 tasks, one
+    // fused two-product reduction (dot2) each, spread over the executor's lanes (two wavefronts
+    // on the device) -- with the wrapped terms (i + j >= 6) taking xi*a_i as their a-operand, so
+    // that coefficient k is the plain sum of six partial products and one reduction by a
+    // Montgomery product with 1.  ~430 + ~350 instructions per lane instead of ~600 + ~500 for
+    // whole Fq2 products and a xi step in the reduction.
     LSA_HD_NOINLINE void mul(int d, int a, int b) {
         Fq2S *A = slot(a), *B = slot(b), *D = slot(d), *Pp = P;
+        const unsigned nl = x.nlanes();
         x.par([=](unsigned lane) {
-            if (lane < 36) Pp[lane] = w12_fq2_mul(A[lane / 6], B[lane % 6]);
+            for (unsigned t = lane; t < 72; t += nl) {
+                const unsigned i = t / 12, j = (t >> 1) % 6, part = t & 1;
+                const Fq2S ai = A[i];
+                const F29x2 xa = w12_xi_times(F29x2{ai.c0.v, ai.c1.v});        // [< 20]
+                const uint32_t wrap = 0u - (uint32_t)(i + j >= 6);
+                Fq2S asel;
+#pragma unroll
+                for (int l = 0; l < 9; l++) {
+                    asel.c0.v.l[l] = (xa.c0.l[l] & wrap) | (ai.c0.v.l[l] & ~wrap);
+                    asel.c1.v.l[l] = (xa.c1.l[l] & wrap) | (ai.c1.v.l[l] & ~wrap);
+                }
+                const Fs r = {w12_comp_mul<2>(part, asel, B[j])};
+                if (part) Pp[i * 6 + j].c1 = r; else Pp[i * 6 + j].c0 = r;
+            }
         });
         x.par([=](unsigned lane) {
-            if (lane < 12) w12_reduce_lane12(lane, Pp, D);
+            if (lane < 12) {
+                const unsigned k = lane >> 1, part = lane & 1;
+                F29 sum = F29::zero();
+                for (int i = 0; i < 6; i++) {
+                    const Fq2S &t = Pp[i * 6 + ((int)k - i + 6) % 6];
+                    sum = add_lazy(sum, part ? t.c1.v : t.c0.v);
+                }
+                const Fs r = {f29_mul(w12_norm_u(sum), F29::one())};          // < 12p -> < 2p
+                if (part) D[k].c1 = r; else D[k].c0 = r;
+            }
         });
     }
     LSA_HD void sqr(int d, int a) { mul(d, a, a); }

@@ -22,6 +22,7 @@ static Fq rand_fq() {
 static Fq12S rand12() { Fq12S r; Fs *o = reinterpret_cast<Fs *>(&r); for (int i = 0; i < 12; i++) o[i] = Fs::from_mont256(rand_fq()); return r; }
 struct LoopExec {
     template <class F> void par(F f) { for (unsigned l = 0; l < 64; l++) f(l); }
+    unsigned nlanes() const { return 64; }
 };
 int main() {
     std::vector<Fq2S> lds(W12_LDS_FQ2);
