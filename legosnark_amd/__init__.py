@@ -152,6 +152,27 @@ def _ptr(x):
     return C.c_void_p(int(x))
 
 
+_ext_stream = {}
+
+
+def _after_torch(*tensors):
+    """Order the library's HIP stream after torch's current stream when any argument is a torch
+    CUDA tensor: the kernels behind these helpers run on lsa_stream(), a non-blocking stream that
+    torch's streams are not implicitly ordered with, so inputs still being written by pending
+    torch kernels would otherwise be read early.  (Results flow the other way through
+    synchronize() / stream_join(); see INTEGRATION.md.)"""
+    if not any(hasattr(t, "data_ptr") and getattr(t, "is_cuda", False) for t in tensors):
+        return
+    import torch
+    dev = torch.cuda.current_device()
+    h = lib().lsa_stream()
+    key = (dev, h)
+    ext = _ext_stream.get(key)
+    if ext is None:
+        ext = _ext_stream[key] = torch.cuda.ExternalStream(h, device=torch.device("cuda", dev))
+    ext.wait_stream(torch.cuda.current_stream())
+
+
 def _group_width(group):
     if group not in ("g1", "g2"):
         raise ValueError(group)
@@ -180,6 +201,7 @@ class Bases:
         if on_device:
             n = bases.numel() * bases.element_size() // (self.w * 8)
             ptr = C.c_void_p(bases.data_ptr())
+            _after_torch(bases)
         else:
             bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, self.w)
             n = len(bases)
@@ -194,12 +216,14 @@ class Bases:
         if n is None:
             n = self.n - first
         out = np.zeros(self.w, dtype=np.uint64)
+        _after_torch(d_scalars)
         _check(lib().lsa_msm_run(self.handle, first, _ptr(d_scalars), n, _host_ptr(out)))
         return out
 
     def msm_async(self, d_scalars, d_out, n=None, first=0):
         if n is None:
             n = self.n - first
+        _after_torch(d_scalars, d_out)
         _check(lib().lsa_msm_run_async(self.handle, first, _ptr(d_scalars), n, _ptr(d_out)))
 
     def device_ptr(self):
@@ -247,6 +271,7 @@ def batch_exp(group, base, scalars, out=None):
     if out is None:
         import torch
         out = torch.empty((n, w), dtype=torch.int64, device=scalars.device)
+    _after_torch(scalars, out)
     _check(fn(_host_ptr(base), _ptr(scalars), n, _ptr(out), 1))
     return out
 
@@ -266,6 +291,7 @@ def scalar_mul_batch(pts, scalars, out=None):
     if out is None:
         import torch
         out = torch.empty((n, 12), dtype=torch.int64, device=pts.device)
+    _after_torch(pts, scalars, out)
     _check(lib().lsa_g1_scalar_mul_batch(_ptr(pts), _ptr(scalars), n, _ptr(out), 1))
     return out
 
@@ -307,6 +333,7 @@ def cppoly_witness(v, r, out=None):
     if out is None:
         import torch
         out = torch.empty_like(v)
+    _after_torch(v, r, out)
     _check(lib().lsa_fr_cppoly_witness(_ptr(v), d, _ptr(r), _ptr(out), 1))
     return out
 
@@ -325,6 +352,7 @@ def eval_mle(v, r):
 
 def eval_mle_device(d_v, d_r, d_out):
     d = _log2_exact(d_v.numel() * d_v.element_size() // 32)
+    _after_torch(d_v, d_r, d_out)
     _check(lib().lsa_fr_eval_mle(_ptr(d_v), d, _ptr(d_r), _ptr(d_out), 1))
     return d_out
 
@@ -347,6 +375,7 @@ def sumcheck_round(tables, suff=None, pre=None, rho_j=None):
     m = len(tables)
     on_device = not isinstance(tables[0], np.ndarray)
     if on_device:
+        _after_torch(*tables, suff)
         half = tables[0].numel() * tables[0].element_size() // 64
         ptrs = (C.c_void_p * m)(*[t.data_ptr() for t in tables])
         sp = C.c_void_p(suff.data_ptr()) if suff is not None else None
@@ -387,6 +416,7 @@ def fr_ntt(a, omega, inverse=False, coset=None):
                                 _host_ptr(cg) if cg is not None else None, 0))
         return out
     log_n = _log2_exact(a.numel() * a.element_size() // 32)
+    _after_torch(a)
     _check(lib().lsa_fr_ntt(_ptr(a), log_n, _host_ptr(omega), 1 if inverse else 0, _host_ptr(cg) if cg is not None else None, 1))
     return a
 
@@ -394,6 +424,7 @@ def fr_ntt(a, omega, inverse=False, coset=None):
 def sum_async(group, d_pts, n, d_out):
     """d_out = sum of n device-resident Jacobian points (async on the library stream)."""
     fn = lib().lsa_g1_sum_async if group == "g1" else lib().lsa_g2_sum_async
+    _after_torch(d_pts, d_out)
     _check(fn(_ptr(d_pts), n, _ptr(d_out)))
 
 

@@ -37,7 +37,8 @@ class ShardedMSM:
 
     DEPTH = 4
 
-    def __init__(self, group, world, rank, local_msm, fold, device, dist=None, stream=None, side=None, join_side=None):
+    def __init__(self, group, world, rank, local_msm, fold, device, dist=None, stream=None, side=None, join_side=None,
+                 join_main=None, sync=None):
         import torch
         self.torch = torch
         self.group = group
@@ -46,6 +47,12 @@ class ShardedMSM:
         self.local_msm, self.fold = local_msm, fold
         self.dist = dist
         self.stream, self.side, self.join_side = stream, side, join_side
+        # join_main: orders the library stream after the MSM tails issued so far (lsa_stream_join);
+        # sync: the same plus a host-side wait (lsa_synchronize)
+        self.join_main, self.sync = join_main, sync
+        # collective form, chosen once: RCCL has all_gather_into_tensor; gloo only the list form
+        backend = dist.get_backend() if (dist is not None and hasattr(dist, "get_backend")) else "nccl"
+        self.tensor_form = backend == "nccl"
         depth = self.DEPTH if side is not None else 1
         self.partial = [torch.zeros(self.w, dtype=torch.int64, device=device) for _ in range(depth)]
         self.gathered = [torch.zeros((world, self.w), dtype=torch.int64, device=device) for _ in range(depth)]
@@ -72,6 +79,8 @@ class ShardedMSM:
                 self.done[j] = self.side.record_event()
         elif self.stream is not None:
             cur = self.torch.cuda.current_stream()
+            if self.join_main is not None:
+                self.join_main()                          # the tail that publishes the partial
             cur.wait_stream(self.stream)                  # partial is ready
             self._all_gather(j)
             self.stream.wait_stream(cur)                  # gathered is ready
@@ -82,9 +91,9 @@ class ShardedMSM:
         return self.total[j]
 
     def _all_gather(self, j):
-        try:
+        if self.tensor_form:
             self.dist.all_gather_into_tensor(self.gathered[j].view(-1), self.partial[j])
-        except (RuntimeError, NotImplementedError):
+        else:
             # backends without the tensor form (gloo): list form, same data movement
             parts = [self.gathered[j][i] for i in range(self.world)]
             self.dist.all_gather(parts, self.partial[j])
@@ -92,7 +101,9 @@ class ShardedMSM:
     def result_host(self, d_result):
         if self.side is not None:
             self.side.synchronize()
-        if self.stream is not None:
+        if self.sync is not None:
+            self.sync()                                   # MSM tails (internal streams) + library stream
+        elif self.stream is not None:
             self.stream.synchronize()
         return d_result.cpu().numpy().view(np.uint64).copy()
 
@@ -118,7 +129,8 @@ def make_gpu_sharded(lsa, group, bases_handle, world, rank, dist=None):
     def join_side(stream):
         lsa.stream_join_to(stream.cuda_stream)
 
-    return ShardedMSM(group, world, rank, local_msm, fold, dev, dist=dist, stream=ext, side=side, join_side=join_side)
+    return ShardedMSM(group, world, rank, local_msm, fold, dev, dist=dist, stream=ext, side=side, join_side=join_side,
+                      join_main=lsa.stream_join, sync=lsa.synchronize)
 
 
 class ShardedPairingProduct:

@@ -582,6 +582,17 @@ void oracle_fr_sumcheck_round(ofp_t *out, const ofp_t *suff, const ofp_t *const 
 void oracle_fr_scale_upper(ofp_t *cur, const ofp_t *old, const ofp_t *k, size_t half) {
     for (size_t p = 0; p < half; p++) fr_mul_(&cur[p], &old[half + p], k);
 }
+/* test-input helper: out = sum_i a[i] * b[i] in Fr (the O(n) check value of the
+ * known-discrete-log identity at n = 2^20 .. 2^24) */
+void oracle_fr_dot(ofp_t *out, const ofp_t *a, const ofp_t *b, size_t n) {
+    ofp_t acc, t;
+    memset(&acc, 0, sizeof acc);
+    for (size_t i = 0; i < n; i++) {
+        fr_mul_(&t, &a[i], &b[i]);
+        ofp_add(&acc, &acc, &t, 1);
+    }
+    *out = acc;
+}
 
 /* libfqfft _basic_radix2_FFT [upstream, recalled] as used through basic_radix2_domain by
  * /root/reference/src/gadgets/lipmaa.cc:102-175: in-place bit-reversal, then log n

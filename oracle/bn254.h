@@ -137,6 +137,8 @@ void oracle_fr_scale_upper(ofp_t *cur, const ofp_t *old, const ofp_t *k, size_t 
 void oracle_fr_radix2_fft(ofp_t *a, size_t log_n, const ofp_t *omega);
 void oracle_fr_domain_transform(ofp_t *a, size_t log_n, const ofp_t *omega, int inverse, const ofp_t *coset_g);
 
+/* ---- test-input helper: out = sum_i a[i]*b[i] in Fr ---- */
+void oracle_fr_dot(ofp_t *out, const ofp_t *a, const ofp_t *b, size_t n);
 /* ---- test-input helper: out[i] = (a + i*b) * generator, un-normalised Jacobian ---- */
 void oracle_g1_arith_bases(og1_t *out, const ofp_t *a_mont, const ofp_t *b_mont, size_t n);
 void oracle_g2_arith_bases(og2_t *out, const ofp_t *a_mont, const ofp_t *b_mont, size_t n);

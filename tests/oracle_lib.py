@@ -365,6 +365,16 @@ def arith_bases(group, a, b, n):
     return out
 
 
+def fr_dot(a, b):
+    """sum_i a[i]*b[i] in Fr (Montgomery limbs in and out as a python int field value)."""
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    b = np.ascontiguousarray(b, dtype=np.uint64).reshape(-1, 4)
+    assert len(a) == len(b)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().oracle_fr_dot(_p(out), _p(a), _p(b), C.c_size_t(len(a)))
+    return limbs_to_int(out) * pow(MONT, -1, R) % R
+
+
 def generator(group):
     w = 12 if group == "g1" else 24
     out = np.zeros(w, dtype=np.uint64)
