@@ -1,17 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- alt_bn128 G1 Pippenger MSM throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--total-log2n T]
 
-One "step" = one multi-scalar multiplication over n = 2^20 point-scalar pairs per GPU
-(BASELINE.json configs[1]: "alt_bn128 G1 Pippenger MSM, n=2^20 random scalars"), through
-the C-ABI (lsa_msm_run_async), with bases (affine, 64 B) and scalars (Montgomery Fr, 32 B)
-already resident in HBM.  For N > 1 (launched by torch.distributed.run, one rank per GPU)
-every rank runs its own 2^20-pair slice of an N*2^20 MSM and the 96-byte Jacobian partials
-are combined with one RCCL all-gather + fold per step (weak scaling).
+One "step" = one multi-scalar multiplication through the C-ABI with bases (prepared affine,
+64 B) and scalars (Montgomery Fr, 32 B) already resident in HBM.
 
-Prints ONE JSON line (rank 0) with the throughput, a `roofline` object for the dominant
-kernel (bucket accumulation; HBM-bound accounting of 96 algorithmic bytes per pair) and a
+* default (weak scaling): n = 2^20 point-scalar pairs per GPU (BASELINE.json configs[1]:
+  "alt_bn128 G1 Pippenger MSM, n=2^20 random scalars").  For N > 1 (launched by
+  torch.distributed.run, one rank per GPU) rank r owns the r-th contiguous 2^20-pair range of an
+  N*2^20 MSM and the 96-byte Jacobian partials are combined with ONE RCCL all-gather + fold per
+  step, issued by the library itself (lsa_msm_run_sharded_async, csrc/comm.hip).
+* --total-log2n T (strong scaling, BASELINE.json configs[3] at T=24): ONE CPlink-prover MSM over
+  n = 2^T + 2 pairs (w[0] = 0, src/gadgets/subspace.cc:78-85) split across the N ranks by
+  libff's chunk rule (lsa_shard_range).  Runs with N > 1 also measure it after the weak loop
+  and report it as "cplink_sharded" in the same JSON line.
+
+Inputs follow SURVEY.md section 8(d): scalars uniform in [0, r) from splitmix64-seeded
+xoshiro256** (seed 0x4C45474F534E4152); bases P_i = (a + i*b)*G1, handed to the library as
+un-normalised Jacobian points (random Z) and, in a second run, normalised (Z = 1).  The result
+of the timed loop's last step is checked by the known-discrete-log identity.
+
+Prints ONE JSON line (rank 0) with the throughput, a `roofline` object for the dominant kernel
+(bucket accumulation; 96 algorithmic bytes per pair against the HBM peak, plus the field-
+multiplication rate against the measured integer ceiling, which is what really bounds it) and a
 `cpu_baseline` object (the oracle = libff-algorithm restatement, timed on this host).
 """
 import argparse
@@ -29,7 +41,16 @@ ALG_BYTES_PER_PAIR = 96        # 64 B affine point + 32 B scalar
 # rate of the dominant kernel against the measured chip-wide ceiling of the 29-bit-limb
 # Montgomery product (tools/ubench_int.hip: 175 G mults/s at >= 4 waves/SIMD).
 FMUL_PEAK_G = 175.0
-FMULS_PER_PAIR = 16 * 10 + 8   # 16 mixed adds (8M+2S) + 8 beta-multiplies (GLV) per pair
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -38,15 +59,18 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--total-log2n", type=int, default=0,
+                    help="strong scaling: one CPlink-prover MSM over 2^T + 2 pairs split across the ranks")
     ap.add_argument("--cpu-sample-log2", type=int, default=20,
                     help="pairs of the same workload timed on the host CPU (2^k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import legosnark_amd as lsa
-    from legosnark_amd import curve, sharded
+    from legosnark_amd import curve, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -55,41 +79,41 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    # debug hooks to exercise the multi-process path on a one-GPU box: every rank on cuda:0 and
-    # a gloo collective (default: one rank per GPU, backend "nccl" = RCCL over xGMI)
-    if os.environ.get("LSA_BENCH_SINGLE_DEVICE"):
-        local_rank = 0
-    backend = os.environ.get("LSA_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     lsa.init(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("nccl", device_id=dev)
+        # the library's own RCCL communicator: rank 0 creates the id, torch broadcasts the 128 bytes
+        idt = torch.zeros(lsa.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(lsa.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, src=0)
+        comm_kind = "capi"
+        try:
+            if os.environ.get("LSA_BENCH_COMM", "capi") != "capi":
+                raise lsa.LsaError("torch.distributed exchange requested")
+            lsa.comm_init(rank, world, bytes(idt.cpu().numpy().tobytes()))
+            ok = 1
+        except lsa.LsaError as e:
+            sys.stderr.write("rank %d: C-ABI communicator unavailable (%s)\n" % (rank, e))
+            ok = 0
+        # every rank must take the same path
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            comm_kind = "torch"              # round-1 path: torch.distributed all-gather + lsa_g1_sum_on
+            if ok:
+                lsa.comm_destroy()
 
-    n = 1 << args.log2n
-    # ---- synthetic workload, generated on the GPU by the product's own batch_exp kernel:
-    # bases P_i = x_i * G1 for random x_i (un-normalised Jacobian, libff layout), then
-    # normalised to affine by lsa_g1_bases_create; scalars are random Montgomery
-    # representatives < 2^252 < r, i.e. uniformly spread field elements.
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0x4C45474F + rank)
+    if world == 1:
+        comm_kind = "none"
+    G1 = curve.generator("g1")
 
-    def random_fr(count):
-        t = torch.randint(-(1 << 63), (1 << 63) - 1, (count, 4), dtype=torch.int64, device=dev, generator=gen)
-        t[:, 3] &= (1 << 60) - 1
-        return t.contiguous()
-
-    x = random_fr(n)
-    bases_jac = lsa.batch_exp("g1", curve.generator("g1"), x)
-    B = lsa.Bases("g1", bases_jac, on_device=True)
-    d_scalars = random_fr(n)
-    torch.cuda.synchronize()
-    job = sharded.make_gpu_sharded(lsa, "g1", B, world, rank, dist=dist)
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
 
     def barrier():
         if world > 1:
@@ -97,101 +121,253 @@ def main():
         lsa.synchronize()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        job.run(d_scalars)
-    barrier()
-    lsa.profile_enable(True)     # per-stage HIP events on the library stream; no host sync
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = job.run(d_scalars)
-    barrier()
-    t1 = time.perf_counter()
-    stages = lsa.profile_last_msm()
-    lsa.profile_enable(False)
-    elapsed = t1 - t0
+    def affine_of(pt_host):
+        return lsa.normalize("g1", np.ascontiguousarray(pt_host, dtype=np.uint64).reshape(1, 12))[0]
+
+    def k_times_g(k):
+        return affine_of(lsa.batch_exp("g1", G1, curve.fr_mont(k).reshape(1, 4))[0])
+
+    def sum_over_ranks(k):
+        if world == 1:
+            return k
+        parts = [None] * world
+        dist.all_gather_object(parts, int(k))
+        return sum(parts) % curve.R
+
+    class Workload:
+        """Rank-local slice [lo, hi) of an MSM over n_total pairs: bases P_i = (a + i*b)*G,
+        scalars uniform in [0, r); `cplink` zeroes the first scalar (w[0] = 0, commit.h:152)."""
+
+        def __init__(self, n_total, lo, hi, cplink=False):
+            rng = synth.Xoshiro256ss(seed=synth.SEED)           # the same a, b on every rank
+            self.a, self.b = rng.fr_int(), rng.fr_int()
+            srng = synth.Xoshiro256ss(seed=synth.SEED + 1 + rank)
+            self.n = hi - lo
+            self.x = synth.arith_fr_mont(self.a + lo * self.b, self.b, self.n)
+            self.s = srng.uniform_fr(self.n)
+            if cplink and lo == 0 and self.n:
+                self.s[0] = 0
+            t0 = time.perf_counter()
+            self.bases_jac = lsa.batch_exp("g1", G1, to_dev(self.x))      # un-normalised Jacobian (random Z)
+            self.B = lsa.Bases("g1", self.bases_jac, on_device=True)
+            lsa.synchronize()
+            self.setup_s = time.perf_counter() - t0
+            self.d_s = to_dev(self.s)
+            self.outs = torch.zeros((4, 12), dtype=torch.int64, device=dev)
+            self.calls = 0
+            self.job = None
+            if world > 1 and comm_kind == "torch":
+                from legosnark_amd import sharded
+                self.job = sharded.make_gpu_sharded(lsa, "g1", self.B, world, rank, dist=dist)
+            torch.cuda.synchronize()
+
+        def step(self):
+            if self.job is not None:
+                return self.job.run(self.d_s)
+            out = self.outs[self.calls % 4]
+            self.calls += 1
+            if world > 1:
+                self.B.msm_sharded_async(self.d_s, out)
+            else:
+                self.B.msm_async(self.d_s, out)
+            return out
+
+        def finish(self):
+            if self.job is not None:
+                self.job.side.synchronize()
+            elif world > 1:
+                lsa.comm_join()
+            lsa.synchronize()
+
+        def expected(self):
+            return k_times_g(sum_over_ranks(synth.fr_dot_mont(self.s, self.x)))
+
+        def timed(self, steps, warmup, profile=False):
+            for _ in range(warmup):
+                self.step()
+            self.finish()
+            barrier()
+            if profile:
+                lsa.profile_enable(True)     # per-stage HIP events on the library stream; no host sync
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                res = self.step()
+            self.finish()
+            barrier()
+            elapsed = time.perf_counter() - t0
+            stages = lsa.profile_last_msm() if profile else None
+            if profile:
+                lsa.profile_enable(False)
+            if world > 1:
+                tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                elapsed = float(tmax.item())
+            got = affine_of(res.cpu().numpy().view(np.uint64))
+            return elapsed, stages, bool(np.array_equal(got, self.expected()))
+
+    strong = args.total_log2n > 0
+    if strong:
+        n_total = (1 << args.total_log2n) + 2
+        lo, hi = lsa.shard_range(n_total, world, rank)
+        wl = Workload(n_total, lo, hi, cplink=True)
+    else:
+        n = 1 << args.log2n
+        n_total = world * n
+        wl = Workload(n_total, rank * n, (rank + 1) * n)
+    elapsed, stages, checked = wl.timed(args.steps, args.warmup, profile=True)
+    value = n_total * args.steps / elapsed
+    n_local = wl.n
+
     # single-call latency (no overlap with a following call), for the record
     lat = []
     for _ in range(5):
         barrier()
         tl = time.perf_counter()
-        job.run(d_scalars)
-        lsa.synchronize()
+        wl.step()
+        wl.finish()
         lat.append(time.perf_counter() - tl)
     latency_ms = sorted(lat)[len(lat) // 2] * 1e3
-    # the second half of BASELINE.json's metric, "CPlink prover ms": SubspaceSnark::prove
+
+    extra = {}
+    if world == 1 and not strong:
+        # second run of SURVEY 8(d): the same bases normalised (Z = 1) must give the same point
+        z1 = lsa.normalize("g1", wl.bases_jac.cpu().numpy().view(np.uint64))
+        B1 = lsa.Bases("g1", z1)
+        r_z1 = affine_of(B1.msm(wl.d_s))
+        r_rz = affine_of(wl.B.msm(wl.d_s))
+        extra["normalised_bases_run_matches"] = bool(np.array_equal(r_z1, r_rz))
+        B1.close()
+        del z1
+
+    # "CPlink prover ms" (the second half of BASELINE.json's metric): SubspaceSnark::prove
     # (src/gadgets/subspace.cc:78-85) is ONE multiExpMA over the N+2 meaningful CRS points with
-    # w = (0, rF, u) (src/examples/cplink.cc:107-108); timed as a blocking lsa_msm_run call on a
-    # resident CRS, host result included.
+    # w = (0, rF, u) (src/examples/cplink.cc:107-108).
     cplink_ms = None
-    if world == 1:
-        npl = n + 2
-        crs = lsa.Bases("g1", lsa.batch_exp("g1", curve.generator("g1"), random_fr(npl)), on_device=True)
-        w_vec = random_fr(npl)
+    host_path = None
+    if world == 1 and not strong:
+        N = 1 << args.log2n
+        npl = N + 2
+        rng = synth.Xoshiro256ss(seed=synth.SEED ^ 0xC9)
+        a, b = rng.fr_int(), rng.fr_int()
+        x = synth.arith_fr_mont(a, b, npl)
+        w_vec = rng.uniform_fr(npl)
         w_vec[0] = 0
+        want = k_times_g(synth.fr_dot_mont(w_vec, x))
+        crs_dev = lsa.batch_exp("g1", G1, to_dev(x))
+        # (i) resident CRS handle + device-resident witness: what a prover integrated through
+        #     lsa_g1_bases_create / lsa_msm_run sees
+        crs = lsa.Bases("g1", crs_dev, on_device=True)
+        d_w = to_dev(w_vec)
         torch.cuda.synchronize()
-        crs.msm(w_vec)
+        got = affine_of(crs.msm(d_w))
         tl = []
         for _ in range(5):
             t_ = time.perf_counter()
-            crs.msm(w_vec)
+            crs.msm(d_w)
             tl.append(time.perf_counter() - t_)
         cplink_ms = sorted(tl)[len(tl) // 2] * 1e3
+        extra["cplink_prover_checked"] = bool(np.array_equal(got, want))
         crs.close()
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    value = world * n * args.steps / elapsed
+        if not args.no_host_path:
+            # (ii) exactly what the unchanged reference delivers: multiExpMA(crs->P, w) with host
+            #      std::vectors (src/utils/globl.h:74-77) -> lsa_g1_msm on pageable host memory.
+            #      P has 2N+2 entries, the trailing N are infinity; n = min(|P|, |w|) = N+2.
+            P_host = np.zeros((2 * N + 2, 12), dtype=np.uint64)
+            P_host[:npl] = crs_dev.cpu().numpy().view(np.uint64)
+            P_host[npl:, 4:8] = curve.fq_mont(1)
+            del crs_dev
+            lsa.crs_cache_clear()
+            runs = []
+            for i in range(6):
+                t_ = time.perf_counter()
+                r_ = lsa.msm("g1", P_host, w_vec)
+                dt = (time.perf_counter() - t_) * 1e3
+                st = lsa.msm_host_stats()
+                runs.append((dt, st, bool(np.array_equal(affine_of(r_), want))))
+            warm = sorted(runs[2:], key=lambda t: t[0])[len(runs[2:]) // 2]
+            host_path = {
+                "call": "lsa_g1_msm(host P[2N+2], host w[N+2]) = multiExpMA(crs->P, w), N=2^%d, pageable memory" % args.log2n,
+                "cold_ms": runs[0][0], "second_ms": runs[1][0], "warm_ms": warm[0],
+                "cold": {k: runs[0][1][k] for k in ("cache_hit", "table", "h2d_scalars_ms", "fingerprint_wait_ms", "bases_prepare_ms", "msm_ms")},
+                "second": {k: runs[1][1][k] for k in ("cache_hit", "table", "h2d_scalars_ms", "fingerprint_wait_ms", "bases_prepare_ms", "msm_ms")},
+                "warm": {k: warm[1][k] for k in ("cache_hit", "table", "h2d_scalars_ms", "fingerprint_wait_ms", "bases_prepare_ms", "msm_ms")},
+                "all_results_checked": all(t[2] for t in runs),
+                "note": "cold = upload 96 B/point + normalise + MSM; second = first re-use, builds the pre-shifted window "
+                        "copies; warm = CRS resident, every byte of P re-fingerprinted on the host while w uploads",
+            }
+            lsa.crs_cache_clear()
+            del P_host
+
+    # BASELINE.json configs[3] shape whenever there is more than one rank: one 2^24+2 CPlink MSM
+    cplink_sharded = None
+    if world > 1 and not strong:
+        T = int(os.environ.get("LSA_BENCH_TOTAL_LOG2N", "24"))
+        nt = (1 << T) + 2
+        lo, hi = lsa.shard_range(nt, world, rank)
+        wl.B.close()
+        del wl
+        w4 = Workload(nt, lo, hi, cplink=True)
+        el4, _, ok4 = w4.timed(10, 2)
+        cplink_sharded = {"workload": "CPlink prover MSM n=2^%d+2 split over %d GPUs (lsa_shard_range), 1 RCCL all-gather of 96-B partials" % (T, world),
+                          "ms_per_prove": el4 / 10 * 1e3, "pairs_per_s": nt * 10 / el4, "result_checked": ok4, "steps": 10}
 
     out = None
     if rank == 0:
         acc_ms = stages["accumulate"]
-        achieved = n * ALG_BYTES_PER_PAIR / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_accumulate.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        fmuls_per_pair = lsa.msm_field_mults_per_pair(n_local) if hasattr(lsa, "msm_field_mults_per_pair") else 16 * 10 + 8
+        achieved = n_local * ALG_BYTES_PER_PAIR / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+        gf = n_local * fmuls_per_pair / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
+        if strong:
+            metric = "alt_bn128 G1 MSM point-scalar pairs/s, CPlink prover n=2^%d+2" % args.total_log2n
+            workload = "CPlink prover at n=2^%d (+2), MSM sharded across %d GPU(s), RCCL all-gather of Jacobian partials" % (args.total_log2n, world)
+        else:
+            metric = "alt_bn128 G1 MSM point-scalar pairs/s at n=2^%d" % args.log2n
+            workload = "alt_bn128 G1 Pippenger MSM, n=2^%d random scalars per GPU" % args.log2n
         out = {
-            "metric": "alt_bn128 G1 MSM point-scalar pairs/s at n=2^%d" % args.log2n,
+            "metric": metric,
             "value": value, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "u32 limbs (254-bit Montgomery integers)", "data": "synthetic",
-            "config": {"workload": "alt_bn128 G1 Pippenger MSM, n=2^%d random scalars per GPU" % args.log2n,
-                       "window_bits": lsa.msm_window_bits(n), "glv": True, "sharding": "index ranges, 1 RCCL all-gather of 96-B partials"
+            "config": {"workload": workload,
+                       "inputs": "scalars uniform in [0,r), xoshiro256** seed 0x4C45474F534E4152; bases (a+i*b)*G1, un-normalised Jacobian",
+                       "window_bits": lsa.msm_window_bits(n_local),
+                       "sharding": ("index ranges (libff chunk split), 1 RCCL all-gather of 96-B partials via "
+                                    + ("lsa_msm_run_sharded_async (C-ABI, csrc/comm.hip)" if comm_kind == "capi" else "torch.distributed + lsa_g1_sum_on"))
                        if world > 1 else "single GPU"},
+            "result_checked_by_identity": checked,
             "roofline": {"kernel": "k_accumulate<CurveG1>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel_ms": acc_ms, "calls_averaged": stages["calls"],
-                         "valu": {"achieved_Gfmul_s": n * FMULS_PER_PAIR / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0,
-                                  "peak_Gfmul_s": FMUL_PEAK_G,
-                                  "frac": (n * FMULS_PER_PAIR / (acc_ms * 1e-3) / 1e9 / FMUL_PEAK_G) if acc_ms > 0 else 0.0,
+                         "valu": {"achieved_Gfmul_s": gf, "peak_Gfmul_s": FMUL_PEAK_G, "frac": gf / FMUL_PEAK_G,
+                                  "field_mults_per_pair": fmuls_per_pair,
                                   "note": "254-bit field multiplications/s in k_accumulate vs the microbenchmarked "
                                           "ceiling of the 9x29-bit Montgomery product on this chip"}},
             "stage_ms": {k: round(v, 4) for k, v in stages.items() if k not in ("calls", "reserved")},
             "single_call_latency_ms": latency_ms,
             "cplink_prover_ms": cplink_ms,
+            "cplink_prover_host_path_ms": host_path,
+            "cplink_sharded": cplink_sharded,
+            "host": {"cpu_model": cpu_model(), "nproc": os.cpu_count()},
             "pipelining": "the tail (reduce+fold) of step i runs on an internal stream and overlaps the front of "
                           "step i+1; stage_ms are measured under that overlap; LSA_NO_OVERLAP=1 serialises",
         }
-        if not args.no_cpu_baseline and world == 1:
+        out.update(extra)
+        if not args.no_cpu_baseline and world == 1 and not strong:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as o   # the checker, timed as the reported CPU baseline
             ns = 1 << min(args.cpu_sample_log2, args.log2n)
-            hb = bases_jac[:ns].cpu().numpy().view(np.uint64)
-            hs = d_scalars[:ns].cpu().numpy().view(np.uint64)
+            hb = wl.bases_jac[:ns].cpu().numpy().view(np.uint64)
+            hs = wl.s[:ns]
             tc = time.perf_counter()
             ref = o.multi_exp("g1", hb, hs, chunks=1, threads=0, mode="mixed")
             tc = time.perf_counter() - tc
-            got = B.msm(d_scalars[:ns], n=ns)
+            got = wl.B.msm(wl.d_s[:ns], n=ns)
             same = o.g1_canonical_affine(ref) == o.g1_canonical_affine(got)
             out["cpu_baseline"] = {
                 "value": ns / tc, "unit": "pairs/s", "cores": 1, "kind": "port",
                 "sample": "first 2^%d pairs of the same workload, libff-algorithm restatement "
-                          "(multi_exp_with_mixed_addition<BDLO12>, chunks=1, gcc -O3), %d host cores present"
-                          % (min(args.cpu_sample_log2, args.log2n), os.cpu_count()),
+                          "(multi_exp_with_mixed_addition<BDLO12>, chunks=1, gcc -O3), %d host cores present (%s)"
+                          % (min(args.cpu_sample_log2, args.log2n), os.cpu_count(), cpu_model()),
                 "seconds": tc, "gpu_result_matches_cpu": bool(same),
             }
             # libff's MULTICORE build: chunks = threads (src/utils/globl.h:67-69), here every host core
@@ -212,6 +388,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        if comm_kind == "capi":
+            lsa.comm_destroy()
         dist.destroy_process_group()
 
 

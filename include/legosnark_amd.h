@@ -72,6 +72,35 @@ int lsa_stream_join_to(void *stream);
 int lsa_g1_msm(const void *bases_jac, const void *scalars_mont, size_t n, size_t chunks, void *out_jac);
 int lsa_g2_msm(const void *bases_jac, const void *scalars_mont, size_t n, size_t chunks, void *out_jac);
 
+/* CRS cache behind lsa_g1_msm / lsa_g2_msm.  The reference passes the SAME std::vector<G> on
+ * every call of a prover (crs->P, src/gadgets/subspace.cc:82; g1s/g2s, src/prototools/commit.h:
+ * 154-155; prefixes of g1s, src/gadgets/poly.h:77-86), so vectors of >= 1024 points stay
+ * resident on the GPU in prepared form, keyed by host pointer and verified by content before
+ * every use.  mode 2 (default; env LSA_CRS_CACHE=full): every byte of the n points passed is
+ * fingerprinted (64-point units, host thread pool, overlapped with the scalar upload) -- a
+ * vector modified in place is a miss, never a stale result.  mode 1 (LSA_CRS_CACHE=sampled):
+ * ~3*log2(n) sampled points are compared; for callers that do not modify CRS vectors in place.
+ * mode 0 (LSA_CRS_CACHE=0): every call uploads and normalises its bases.  Entries are evicted
+ * least-recently-used beyond max_bytes of device memory (0 keeps the current budget; default
+ * min(1/4 of the device, 64 GiB), env LSA_CRS_CACHE_MB).  The first re-use of an entry of at
+ * least the table threshold also builds its pre-shifted window copies. */
+int lsa_crs_cache_configure(int mode, size_t max_bytes);
+void lsa_crs_cache_clear(void);
+int lsa_crs_cache_stats(uint64_t *hits, uint64_t *misses, uint64_t *resident_bytes, uint64_t *entries);
+/* Host-side wall-clock split of the most recent lsa_g1_msm / lsa_g2_msm call, as the caller of
+ * multiExpMA experiences it (SURVEY.md 8e "Host staging": H2D reported separately). */
+typedef struct {
+    size_t n;
+    int cache_hit;               /* 1: bases were resident */
+    int table;                   /* 1: the call used pre-shifted window copies */
+    double h2d_scalars_ms;       /* pageable host -> device copy of n x 32 B */
+    double fingerprint_wait_ms;  /* what was left of the fingerprint pass after that copy */
+    double bases_prepare_ms;     /* miss: upload + normalise (+ table on first re-use); hit: lookup */
+    double msm_ms;               /* kernels + 96/192-byte result copy */
+    double total_ms;
+} lsa_host_stats;
+int lsa_msm_host_stats(lsa_host_stats *out);
+
 /* ---- device-resident bases (CRS) ---------------------------------------------------- */
 /* The CRS vectors passed to multiExpMA are fixed per key (crs->P at
  * src/gadgets/subspace.cc:82, g1s/g2s at src/prototools/commit.h:154-155), so they are
@@ -214,6 +243,48 @@ int lsa_final_exponentiation(const void *in_fq12, size_t n, void *out_fq12, int 
  * reduced_pairing (src/gadgets/subspace.cc:88-102,123-124); the batched form is the CPhad /
  * CPsc verifier shape (BASELINE.json configs[4]).  Host pointers. */
 int lsa_pairing_product(const void *g1_jac, const void *g2_jac, size_t n, void *out_gt);
+
+/* ---- multi-GPU: one process per GPU, one exchange step per MSM (RCCL over xGMI) --------------- */
+/* libff's multi_exp splits [0, n) into `chunks` contiguous ranges, runs multi_exp_inner on each
+ * and sums the partials; multiExpMA forwards `chunks` (src/utils/globl.h:67-77).  Here a chunk is
+ * a GPU and a rank is a process: every rank runs the single-GPU pipeline on its slice and the
+ * 96-byte (G1) / 192-byte (G2) Jacobian partials are combined with ONE ncclAllGather + a sum in
+ * rank order (RCCL has no elliptic-curve reduce op).  Every rank ends up with the same point.
+ *
+ * lsa_comm_unique_id: rank 0 fills 128 bytes (an ncclUniqueId) that the caller distributes to
+ * the other ranks over its own transport (MPI, a torch.distributed broadcast, a file ...).
+ * lsa_comm_init: collective over all ranks; binds the communicator to the device of lsa_init.
+ * lsa_comm_init_file: single-node bootstrap without a transport: rank 0 writes the id to `path`,
+ * the others poll for it (timeout_s <= 0: 60 s).  The file must not exist beforehand. */
+#define LSA_COMM_ID_BYTES 128
+int lsa_comm_unique_id(void *out_id128);
+int lsa_comm_init(int rank, int world, const void *id128);
+int lsa_comm_init_file(int rank, int world, const char *path, int timeout_s);
+void lsa_comm_destroy(void);
+int lsa_comm_rank(void);    /* 0 without a communicator */
+int lsa_comm_world(void);   /* 1 without a communicator */
+/* libff's chunk split: one = n / world, the last rank takes the remainder (n < world: rank 0
+ * takes everything).  The range of (base, scalar) pairs rank `rank` owns. */
+void lsa_shard_range(size_t n, int world, int rank, size_t *lo, size_t *hi);
+/* This rank's part of a sharded MSM over its resident bases[first .. first+n) (device scalars),
+ * then the exchange step on an internal side stream; d_out_jac (DEVICE) receives the sum over
+ * all ranks.  Asynchronous: lsa_stream() may start the next call's front meanwhile;
+ * lsa_comm_join() orders every exchange issued so far on lsa_stream(). */
+int lsa_msm_run_sharded_async(const lsa_bases *bases, size_t first, const void *d_scalars_mont, size_t n, void *d_out_jac);
+int lsa_comm_join(void);
+/* The same, blocking, result in a HOST buffer. */
+int lsa_msm_run_sharded(const lsa_bases *bases, size_t first, const void *d_scalars_mont, size_t n, void *out_jac);
+/* multiExpMA for an SPMD prover: every rank passes ITS slice of the vectors (host buffers, the
+ * range lsa_shard_range gives it; the CRS cache applies) and receives the sum over all ranks.
+ * Without a communicator (world 1) identical to lsa_g1_msm / lsa_g2_msm. */
+int lsa_g1_msm_sharded(const void *bases_jac, const void *scalars_mont, size_t n_local, void *out_jac);
+int lsa_g2_msm_sharded(const void *bases_jac, const void *scalars_mont, size_t n_local, void *out_jac);
+/* final_exponentiation(prod over all ranks' pairs): per-rank Miller product, all-gather of the
+ * 384-byte Fq12 partials, product in rank order, one final exponentiation on every rank. */
+int lsa_pairing_product_sharded(const void *g1_jac, const void *g2_jac, size_t n_local, void *out_gt);
+/* Building block: all-gather of one device-resident partial per rank (kind 1: G1 point, 2: G2
+ * point, 12: Fq12) into d_gathered (world x the same), ordered on lsa_stream(). */
+int lsa_comm_all_gather(const void *d_partial, void *d_gathered, int kind);
 
 /* ---- point helpers ------------------------------------------------------------------- */
 /* Jacobian -> libff "special" form (affine with Z = 1, or (0,1,0)), n points, host

@@ -26,6 +26,13 @@ class LsaError(RuntimeError):
     pass
 
 
+class HostStats(C.Structure):
+    """lsa_host_stats: host-side wall-clock split of the latest lsa_g1_msm / lsa_g2_msm call."""
+    _fields_ = [("n", C.c_size_t), ("cache_hit", C.c_int), ("table", C.c_int), ("h2d_scalars_ms", C.c_double),
+                ("fingerprint_wait_ms", C.c_double), ("bases_prepare_ms", C.c_double), ("msm_ms", C.c_double),
+                ("total_ms", C.c_double)]
+
+
 def build(verbose=False):
     """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
     cmd = ["make", "-C", os.path.join(_PKG, "csrc"), "-j4"]
@@ -91,6 +98,21 @@ def lib():
         L.lsa_pairing_product.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.lsa_fq12_product.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.lsa_final_exponentiation.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.lsa_comm_unique_id.argtypes = [C.c_void_p]
+        L.lsa_comm_init.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.lsa_comm_init_file.argtypes = [C.c_int, C.c_int, C.c_char_p, C.c_int]
+        L.lsa_comm_destroy.restype = None
+        L.lsa_shard_range.argtypes = [C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.lsa_shard_range.restype = None
+        for name in ("lsa_msm_run_sharded", "lsa_msm_run_sharded_async"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        for name in ("lsa_g1_msm_sharded", "lsa_g2_msm_sharded", "lsa_pairing_product_sharded"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.lsa_comm_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.lsa_crs_cache_configure.argtypes = [C.c_int, C.c_size_t]
+        L.lsa_crs_cache_clear.restype = None
+        L.lsa_crs_cache_stats.argtypes = [C.POINTER(C.c_uint64)] * 4
+        L.lsa_msm_host_stats.argtypes = [C.POINTER(HostStats)]
         _lib = L
     return _lib
 
@@ -191,6 +213,95 @@ def msm(group, bases, scalars, chunks=1):
     return out
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128-byte ncclUniqueId (rank 0 creates it and distributes it to the other ranks)."""
+    buf = (C.c_ubyte * COMM_ID_BYTES)()
+    _check(lib().lsa_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_init(rank, world, unique_id):
+    """Collective: RCCL communicator over `world` processes, one GPU each."""
+    if len(unique_id) != COMM_ID_BYTES:
+        raise ValueError("unique id must be %d bytes" % COMM_ID_BYTES)
+    buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id)
+    _check(lib().lsa_comm_init(int(rank), int(world), buf))
+
+
+def comm_init_file(rank, world, path, timeout_s=60):
+    _check(lib().lsa_comm_init_file(int(rank), int(world), os.fsencode(path), int(timeout_s)))
+
+
+def comm_destroy():
+    lib().lsa_comm_destroy()
+
+
+def comm_rank():
+    return lib().lsa_comm_rank()
+
+
+def comm_world():
+    return lib().lsa_comm_world()
+
+
+def comm_join():
+    _check(lib().lsa_comm_join())
+
+
+def shard_range(n, world, rank):
+    """libff multi_exp chunk split (the last rank takes the remainder) -- lsa_shard_range."""
+    lo, hi = C.c_size_t(), C.c_size_t()
+    lib().lsa_shard_range(int(n), int(world), int(rank), C.byref(lo), C.byref(hi))
+    return int(lo.value), int(hi.value)
+
+
+def msm_sharded(group, bases, scalars):
+    """SPMD multiExpMA: this rank's slice in (host buffers), the sum over all ranks out."""
+    w = _group_width(group)
+    bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, w)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    n = min(len(bases), len(scalars))
+    out = np.zeros(w, dtype=np.uint64)
+    fn = lib().lsa_g1_msm_sharded if group == "g1" else lib().lsa_g2_msm_sharded
+    _check(fn(_host_ptr(bases), _host_ptr(scalars), n, _host_ptr(out)))
+    return out
+
+
+def pairing_product_sharded(g1, g2):
+    """final_exponentiation(prod over all ranks' (P_i, Q_i)); this rank's slice in."""
+    g1, g2 = _pairs(g1, g2)
+    out = np.zeros(48, dtype=np.uint64)
+    _check(lib().lsa_pairing_product_sharded(_host_ptr(g1), _host_ptr(g2), len(g1), _host_ptr(out)))
+    return out
+
+
+CRS_CACHE_OFF, CRS_CACHE_SAMPLED, CRS_CACHE_FULL = 0, 1, 2
+
+
+def crs_cache_configure(mode, max_bytes=0):
+    """Verification mode (CRS_CACHE_*) and device-memory budget of the cache behind msm()."""
+    _check(lib().lsa_crs_cache_configure(int(mode), int(max_bytes)))
+
+
+def crs_cache_clear():
+    lib().lsa_crs_cache_clear()
+
+
+def crs_cache_stats():
+    v = [C.c_uint64() for _ in range(4)]
+    lib().lsa_crs_cache_stats(*[C.byref(x) for x in v])
+    return dict(zip(("hits", "misses", "resident_bytes", "entries"), [int(x.value) for x in v]))
+
+
+def msm_host_stats():
+    st = HostStats()
+    _check(lib().lsa_msm_host_stats(C.byref(st)))
+    return {k: getattr(st, k) for k, _ in HostStats._fields_}
+
+
 class Bases:
     """Device-resident, affine-normalised CRS vector (lsa_bases handle)."""
 
@@ -225,6 +336,22 @@ class Bases:
             n = self.n - first
         _after_torch(d_scalars, d_out)
         _check(lib().lsa_msm_run_async(self.handle, first, _ptr(d_scalars), n, _ptr(d_out)))
+
+    def msm_sharded_async(self, d_scalars, d_out, n=None, first=0):
+        """This rank's slice of a sharded MSM + the RCCL exchange step; d_out (device) receives the
+        sum over all ranks.  Needs comm_init(); order results with comm_join() / synchronize()."""
+        if n is None:
+            n = self.n - first
+        _after_torch(d_scalars, d_out)
+        _check(lib().lsa_msm_run_sharded_async(self.handle, first, _ptr(d_scalars), n, _ptr(d_out)))
+
+    def msm_sharded(self, d_scalars, n=None, first=0):
+        if n is None:
+            n = self.n - first
+        out = np.zeros(self.w, dtype=np.uint64)
+        _after_torch(d_scalars)
+        _check(lib().lsa_msm_run_sharded(self.handle, first, _ptr(d_scalars), n, _host_ptr(out)))
+        return out
 
     def device_ptr(self):
         return lib().lsa_bases_device_ptr(self.handle)

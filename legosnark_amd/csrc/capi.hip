@@ -4,10 +4,17 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
-#include "msm.h"
+#include "capi_internal.h"
 #include "tower.h"
 
 namespace lsa {
@@ -20,25 +27,9 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-struct State {
-    bool ready = false;
-    int device = -1;
-    hipStream_t stream = nullptr;
-    void *d_result = nullptr;      // 192-byte device slot for MSM results
-    void *h_result = nullptr;      // pinned host mirror
-};
-static State g;
+State g;
 
-#define HIPCHK(x)                                                                      \
-    do {                                                                               \
-        hipError_t e_ = (x);                                                           \
-        if (e_ != hipSuccess) {                                                        \
-            set_error("%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return LSA_ERR_HIP;                                                        \
-        }                                                                              \
-    } while (0)
-
-static int require_ready() {
+int require_ready() {
     if (!g.ready) {
         set_error("legosnark_amd: no initialised gfx950 device (call lsa_init first; there is no CPU fallback)");
         return LSA_ERR_NO_DEVICE;
@@ -51,13 +42,7 @@ static int require_ready() {
 using namespace lsa;
 
 static void release_stage_buffers();
-
-struct lsa_bases {
-    void *d_aff = nullptr;   // prepared bases (msm_base_bytes(group) each); with a table: window-major copies
-    size_t n = 0;
-    int group = 1;           // 1 = G1, 2 = G2
-    size_t table_stride = 0; // n when the pre-shifted windows 2^(16k)*P are resident, else 0
-};
+static void crs_cache_clear();
 
 extern "C" {
 
@@ -99,6 +84,8 @@ int lsa_init(int device) {
 void lsa_shutdown(void) {
     if (!g.ready) return;
     (void)hipStreamSynchronize(g.stream);
+    comm_release();
+    crs_cache_clear();
     msm_release_workspace();
     release_stage_buffers();
     (void)hipFree(g.d_result);
@@ -132,7 +119,7 @@ int lsa_profile_last_msm(float ms[LSA_MSM_STAGES]) { return msm_profile_last(ms)
 // ---------------------------------------------------------------- bases
 }  // extern "C"
 template <class F>
-static int bases_create(const void *bases_jac, size_t n, int src_on_device, int group, lsa_bases **out) {
+static int bases_create(const void *bases_jac, size_t n, int src_on_device, int group, lsa_bases **out, bool allow_table = true) {
     int rc = require_ready();
     if (rc) return rc;
     if (!out || (n && !bases_jac)) { set_error("bases_create: null argument"); return LSA_ERR_INVALID; }
@@ -146,7 +133,7 @@ static int bases_create(const void *bases_jac, size_t n, int src_on_device, int 
         // windows"): nwin x the memory, no Horner fold per MSM.  LSA_PRECOMPUTE=0 opts out; a
         // table that does not fit falls back to the plain layout.
         const char *pe = getenv("LSA_PRECOMPUTE");
-        bool table = n >= msm_merge_min() && !(pe && pe[0] == '0');
+        bool table = allow_table && n >= msm_merge_min() && !(pe && pe[0] == '0');
         const size_t tw = msm_table_windows(group);
         if (table && (uint64_t)n * tw >= (1u << 30)) table = false;
         if (table && hipMalloc(&b->d_aff, tw * n * msm_base_bytes(group)) != hipSuccess) { (void)hipGetLastError(); b->d_aff = nullptr; table = false; }
@@ -242,36 +229,397 @@ struct StageBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
-StageBuf g_stage_jac, g_stage_bases, g_stage_scalars;
+StageBuf g_stage_jac, g_stage_bases, g_stage_scalars, g_stage_gather;
 StageBuf g_pair_p, g_pair_q, g_pair_f, g_pair_s, g_pair_o;     // pairing host path: points, Miller values, product scratch, result
 }  // namespace
 static void release_stage_buffers() {
-    g_stage_jac.release(); g_stage_bases.release(); g_stage_scalars.release();
+    g_stage_jac.release(); g_stage_bases.release(); g_stage_scalars.release(); g_stage_gather.release();
     g_pair_p.release(); g_pair_q.release(); g_pair_f.release(); g_pair_s.release(); g_pair_o.release();
 }
 
+// ---------------------------------------------------------------- CRS cache behind lsa_g1_msm / lsa_g2_msm
+// multiExpMA hands libff the same std::vector<G> on every call of a prover: crs->P in
+// SubspaceSnark::prove (src/gadgets/subspace.cc:82), g1s/g2s in CommScheme::commit
+// (src/prototools/commit.h:154-155), prefixes of g1s in CPPoly::prove (src/gadgets/poly.h:77-86).
+// Uploading 96 B/point over PCIe and normalising it each time costs more than the MSM, so the
+// host-buffer entry points keep the prepared (affine, packed; after the first re-use also the
+// pre-shifted window copies) bases of recently seen vectors resident, keyed by host pointer and
+// VERIFIED by content before every use:
+//   mode 2 "full" (default): a 64-bit fingerprint of every 64-point unit, computed by a small
+//          host thread pool while the caller thread uploads the scalars; any change of any byte
+//          of the vector is a miss (a single changed word always changes its unit's fingerprint).
+//          Never reads past the n points the caller passed.
+//   mode 1 "sampled": only ~3*log2(n) sampled points are compared -- for callers that promise
+//          not to modify a CRS vector in place.
+//   mode 0: off.  Env LSA_CRS_CACHE = full | sampled | 0, LSA_CRS_CACHE_MB = budget (LRU by bytes).
+// A request (ptr, n) also hits an entry (ptr, n' > n) when n is a multiple of 64: the prefix is
+// verified unit-wise (CPPoly::prove's ladder of prefixes 2^k of g1s).
+namespace {
+
+constexpr size_t CRS_UNIT_POINTS = 64;          // fingerprint granularity (a prefix of k units can be verified against a longer entry)
+constexpr size_t CRS_TASK_UNITS = 64;           // units per hashing task (4096 points)
+constexpr size_t CRS_MIN_POINTS = 1024;         // smaller vectors are cheaper to re-upload than to look up
+
+inline uint64_t hash_words(const uint64_t *w, size_t nwords) {
+    // four independent multiply-xor lanes ((h ^ w) * K is a bijection in w and in h: one changed
+    // word always changes its lane), folded at the end
+    uint64_t h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull, h2 = 0xA4093822299F31D0ull, h3 = 0x082EFA98EC4E6C89ull;
+    const uint64_t K = 0x9E3779B97F4A7C15ull;
+    size_t i = 0;
+    for (; i + 4 <= nwords; i += 4) {
+        h0 = (h0 ^ w[i]) * K; h1 = (h1 ^ w[i + 1]) * K; h2 = (h2 ^ w[i + 2]) * K; h3 = (h3 ^ w[i + 3]) * K;
+    }
+    for (; i < nwords; i++) h0 = (h0 ^ w[i]) * K;
+    auto rotl = [](uint64_t x, int k) { return (x << k) | (x >> (64 - k)); };
+    uint64_t h = h0 ^ rotl(h1, 17) ^ rotl(h2, 31) ^ rotl(h3, 47);
+    h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
+    return h;
+}
+
+// persistent workers hashing the chunks of one vector; the caller thread joins in at finish()
+class HashPool {
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, cv_done_;
+    const uint8_t *base_ = nullptr;
+    size_t unit_bytes_ = 0, units_per_task_ = 1, total_bytes_ = 0, nunits_ = 0, ntasks_ = 0;
+    uint64_t *out_ = nullptr;
+    std::atomic<size_t> next_{0};
+    size_t active_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+
+    void work() {
+        for (;;) {
+            size_t t = next_.fetch_add(1);
+            if (t >= ntasks_) break;
+            size_t u1 = (t + 1) * units_per_task_ < nunits_ ? (t + 1) * units_per_task_ : nunits_;
+            for (size_t u = t * units_per_task_; u < u1; u++) {
+                size_t lo = u * unit_bytes_, hi = lo + unit_bytes_ < total_bytes_ ? lo + unit_bytes_ : total_bytes_;
+                out_[u] = hash_words(reinterpret_cast<const uint64_t *>(base_ + lo), (hi - lo) / 8);   // never past total_bytes_
+            }
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            work();
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--active_ == 0) cv_done_.notify_all();
+            }
+        }
+    }
+
+  public:
+    ~HashPool() { stop(); }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) if (t.joinable()) t.join();
+        th_.clear();
+        stop_ = false;
+    }
+    // starts hashing `bytes` bytes (a multiple of 8) in units of unit_bytes (the last one may be
+    // short); out: one u64 per unit; a task = units_per_task consecutive units
+    void begin(const void *p, size_t bytes, size_t unit_bytes, size_t units_per_task, uint64_t *out) {
+        base_ = (const uint8_t *)p; total_bytes_ = bytes; unit_bytes_ = unit_bytes; units_per_task_ = units_per_task; out_ = out;
+        nunits_ = (bytes + unit_bytes - 1) / unit_bytes;
+        ntasks_ = (nunits_ + units_per_task - 1) / units_per_task;
+        next_.store(0);
+        if (ntasks_ < 8) return;                     // small: the caller does it alone in finish()
+        if (th_.empty()) {
+            unsigned hw = std::thread::hardware_concurrency();
+            const char *e = getenv("LSA_HASH_THREADS");
+            unsigned want = e ? (unsigned)atoi(e) : (hw > 16 ? 15 : (hw > 1 ? hw - 1 : 0));
+            for (unsigned i = 0; i < want; i++) th_.emplace_back([this] { loop(); });
+        }
+        if (th_.empty()) return;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            active_ = th_.size();
+            gen_++;
+        }
+        cv_.notify_all();
+    }
+    void finish() {
+        work();
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] { return active_ == 0; });
+    }
+};
+
+struct CrsEntry {
+    const void *ptr = nullptr;
+    size_t n = 0;
+    int group = 1;
+    std::vector<uint64_t> unit_fp;                  // mode 2: one fingerprint per 64-point unit (the last may be short)
+    std::vector<size_t> sample_pos;                 // mode 1
+    std::vector<uint8_t> sample;
+    lsa_bases *b = nullptr;
+    size_t bytes = 0;
+    uint64_t tick = 0;
+    unsigned hits = 0;
+};
+
+struct CrsCache {
+    int mode = -1;                                  // -1: read the environment on first use
+    size_t budget = 0, bytes = 0;
+    uint64_t tick = 0, hits = 0, misses = 0;
+    std::vector<CrsEntry> entries;
+    HashPool pool;
+    std::vector<uint64_t> scratch_fp;
+} g_crs;
+
+lsa_host_stats g_host_stats = {};
+
+void crs_configure_from_env() {
+    if (g_crs.mode >= 0) return;
+    const char *e = getenv("LSA_CRS_CACHE");
+    g_crs.mode = 2;
+    if (e) {
+        if (e[0] == '0' || !strcmp(e, "off")) g_crs.mode = 0;
+        else if (!strcmp(e, "sampled") || e[0] == '1') g_crs.mode = 1;
+    }
+    const char *mb = getenv("LSA_CRS_CACHE_MB");
+    if (mb && atoll(mb) > 0) g_crs.budget = (size_t)atoll(mb) << 20;
+    if (g_crs.budget == 0) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) tot = (size_t)64 << 30;
+        g_crs.budget = std::min<size_t>(tot / 4, (size_t)64 << 30);
+    }
+}
+
+size_t bases_device_bytes(const lsa_bases *b) {
+    size_t per = msm_base_bytes(b->group);
+    return b->n * per * (b->table_stride ? msm_table_windows(b->group) : 1);
+}
+
+void crs_evict_to(size_t budget) {
+    while (g_crs.bytes > budget && !g_crs.entries.empty()) {
+        size_t victim = 0;
+        for (size_t i = 1; i < g_crs.entries.size(); i++) if (g_crs.entries[i].tick < g_crs.entries[victim].tick) victim = i;
+        (void)msm_join(g.stream);
+        (void)hipStreamSynchronize(g.stream);       // no MSM may still read the victim
+        g_crs.bytes -= g_crs.entries[victim].bytes;
+        lsa_bases_destroy(g_crs.entries[victim].b);
+        g_crs.entries.erase(g_crs.entries.begin() + victim);
+    }
+}
+
+// evicts least-recently-used entries beyond the budget, never the entry with tick `keep`
+void crs_trim(uint64_t keep) {
+    while (g_crs.bytes > g_crs.budget && g_crs.entries.size() > 1) {
+        size_t victim = g_crs.entries.size();
+        for (size_t i = 0; i < g_crs.entries.size(); i++) {
+            if (g_crs.entries[i].tick == keep) continue;
+            if (victim == g_crs.entries.size() || g_crs.entries[i].tick < g_crs.entries[victim].tick) victim = i;
+        }
+        if (victim == g_crs.entries.size()) break;
+        (void)msm_join(g.stream);
+        (void)hipStreamSynchronize(g.stream);       // no MSM may still read the victim
+        g_crs.bytes -= g_crs.entries[victim].bytes;
+        lsa_bases_destroy(g_crs.entries[victim].b);
+        g_crs.entries.erase(g_crs.entries.begin() + victim);
+    }
+}
+
+std::vector<size_t> sample_positions(size_t n) {
+    std::vector<size_t> pos;
+    for (size_t i = 0; i < 8 && i < n; i++) pos.push_back(i);
+    for (size_t k = 8; k < n; k <<= 1) {
+        pos.push_back(k - 1);
+        pos.push_back(k);
+        if (k + k / 2 < n) pos.push_back(k + k / 2);
+    }
+    if (n) pos.push_back(n - 1);
+    return pos;
+}
+
+}  // namespace
+
+static void crs_cache_clear() {
+    crs_evict_to(0);
+    g_crs.pool.stop();
+    g_crs.bytes = 0;
+}
+
+// adds the pre-shifted window copies to a handle that was created without them
 template <class F>
-static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *out_jac, int group) {
+static int bases_add_table(lsa_bases *b) {
+    const char *pe = getenv("LSA_PRECOMPUTE");
+    if (b->table_stride || b->n < msm_merge_min() || (pe && pe[0] == '0')) return LSA_OK;
+    const size_t tw = msm_table_windows(b->group), per = msm_base_bytes(b->group);
+    if ((uint64_t)b->n * tw >= (1u << 30)) return LSA_OK;
+    void *big = nullptr;
+    if (hipMalloc(&big, tw * b->n * per) != hipSuccess) { (void)hipGetLastError(); return LSA_OK; }   // stays a plain handle
+    int rc = msm_join(g.stream);
+    if (rc) { (void)hipFree(big); return rc; }
+    HIPCHK(hipMemcpyAsync(big, b->d_aff, b->n * per, hipMemcpyDeviceToDevice, g.stream));
+    rc = precompute_windows<F>(big, b->n, g.stream);   // synchronises the stream
+    if (rc) { (void)hipFree(big); return rc; }
+    (void)hipFree(b->d_aff);
+    b->d_aff = big;
+    b->table_stride = b->n;
+    return LSA_OK;
+}
+
+template <class F>
+static int crs_lookup_or_insert(const void *bases_jac, size_t n, int group, const std::vector<uint64_t> &fp, lsa_bases **out, bool *hit) {
+    const size_t psz = sizeof(Jac<F>);
+    const size_t nun = (n + CRS_UNIT_POINTS - 1) / CRS_UNIT_POINTS;
+    *hit = false;
+    for (auto &e : g_crs.entries) {
+        if (e.ptr != bases_jac || e.group != group || e.n < n) continue;
+        bool same = true;
+        if (g_crs.mode == 2) {
+            // comparable only when the request's units cover the same byte ranges as the entry's
+            if (e.n != n && n % CRS_UNIT_POINTS != 0) continue;
+            for (size_t u = 0; u < nun && same; u++) same = fp[u] == e.unit_fp[u];
+        } else {
+            for (size_t k = 0; k < e.sample_pos.size() && same; k++) {
+                size_t i = e.sample_pos[k];
+                if (i >= n) continue;
+                same = memcmp((const uint8_t *)bases_jac + i * psz, e.sample.data() + k * psz, psz) == 0;
+            }
+        }
+        if (!same) continue;
+        e.tick = ++g_crs.tick;
+        e.hits++;
+        g_crs.hits++;
+        if (!e.b->table_stride) {                     // second use: worth the pre-shifted copies
+            size_t before = bases_device_bytes(e.b);
+            int rc = bases_add_table<F>(e.b);
+            if (rc) return rc;
+            size_t after = bases_device_bytes(e.b);
+            e.bytes += after - before;
+            g_crs.bytes += after - before;
+        }
+        lsa_bases *found = e.b;
+        const uint64_t keep = e.tick;
+        crs_trim(keep);                               // (invalidates `e`)
+        *out = found;
+        *hit = true;
+        return LSA_OK;
+    }
+    // miss: drop stale entries for this pointer, upload + normalise (no table yet), insert
+    for (size_t i = 0; i < g_crs.entries.size();) {
+        if (g_crs.entries[i].ptr == bases_jac && g_crs.entries[i].group == group && g_crs.entries[i].n <= n) {
+            (void)msm_join(g.stream);
+            (void)hipStreamSynchronize(g.stream);
+            g_crs.bytes -= g_crs.entries[i].bytes;
+            lsa_bases_destroy(g_crs.entries[i].b);
+            g_crs.entries.erase(g_crs.entries.begin() + i);
+        } else i++;
+    }
+    g_crs.misses++;
+    CrsEntry e;
+    e.ptr = bases_jac; e.n = n; e.group = group;
+    int rc = bases_create<F>(bases_jac, n, 0, group, &e.b, false);
+    if (rc) return rc;
+    if (g_crs.mode == 2) e.unit_fp.assign(fp.begin(), fp.begin() + nun);
+    else {
+        e.sample_pos = sample_positions(n);
+        e.sample.resize(e.sample_pos.size() * psz);
+        for (size_t k = 0; k < e.sample_pos.size(); k++) memcpy(e.sample.data() + k * psz, (const uint8_t *)bases_jac + e.sample_pos[k] * psz, psz);
+    }
+    e.bytes = bases_device_bytes(e.b);
+    e.tick = ++g_crs.tick;
+    g_crs.bytes += e.bytes;
+    *out = e.b;
+    g_crs.entries.push_back(std::move(e));
+    const uint64_t keep = g_crs.entries.back().tick;
+    crs_trim(keep);
+    for (auto &x : g_crs.entries) if (x.tick == keep) *out = x.b;
+    return LSA_OK;
+}
+
+static inline double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+template <class F>
+static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *out_jac, int group, bool sharded = false) {
     int rc = require_ready();
     if (rc) return rc;
+    if (sharded && lsa_comm_world() <= 1) sharded = false;
     if (!out_jac || (n && (!bases_jac || !scalars))) { set_error("msm: null argument"); return LSA_ERR_INVALID; }
-    if (g_stage_jac.ensure(n * sizeof(Jac<F>)) || g_stage_bases.ensure(n * msm_base_bytes(group)) || g_stage_scalars.ensure(n * sizeof(Fr))) {
-        set_error("msm: staging allocation failed");
-        return LSA_ERR_NOMEM;
-    }
-    if (n) {
-        HIPCHK(hipMemcpyAsync(g_stage_jac.p, bases_jac, n * sizeof(Jac<F>), hipMemcpyHostToDevice, g.stream));
+    const auto t_all = std::chrono::steady_clock::now();
+    lsa_host_stats st = {};
+    st.n = n;
+    crs_configure_from_env();
+    const bool cached = g_crs.mode != 0 && n >= CRS_MIN_POINTS;
+    if (g_stage_scalars.ensure(n * sizeof(Fr))) { set_error("msm: staging allocation failed"); return LSA_ERR_NOMEM; }
+    const void *d_bases = nullptr;
+    size_t table_stride = 0;
+    if (cached) {
+        // the fingerprint of the bases is computed by the pool while this thread uploads the scalars
+        if (g_crs.mode == 2) {
+            g_crs.scratch_fp.resize((n + CRS_UNIT_POINTS - 1) / CRS_UNIT_POINTS);
+            g_crs.pool.begin(bases_jac, n * sizeof(Jac<F>), CRS_UNIT_POINTS * sizeof(Jac<F>), CRS_TASK_UNITS, g_crs.scratch_fp.data());
+        }
+        auto t0 = std::chrono::steady_clock::now();
         HIPCHK(hipMemcpyAsync(g_stage_scalars.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-        rc = prepare_bases<F>((const Jac<F> *)g_stage_jac.p, g_stage_bases.p, n, g.stream);
+        st.h2d_scalars_ms = ms_since(t0);
+        t0 = std::chrono::steady_clock::now();
+        if (g_crs.mode == 2) g_crs.pool.finish();
+        st.fingerprint_wait_ms = ms_since(t0);
+        t0 = std::chrono::steady_clock::now();
+        lsa_bases *b = nullptr;
+        bool hit = false;
+        rc = crs_lookup_or_insert<F>(bases_jac, n, group, g_crs.scratch_fp, &b, &hit);
         if (rc) return rc;
+        st.bases_prepare_ms = ms_since(t0);
+        st.cache_hit = hit ? 1 : 0;
+        st.table = b->table_stride ? 1 : 0;
+        d_bases = b->d_aff;
+        table_stride = b->table_stride;
+    } else {
+        if (g_stage_jac.ensure(n * sizeof(Jac<F>)) || g_stage_bases.ensure(n * msm_base_bytes(group))) {
+            set_error("msm: staging allocation failed");
+            return LSA_ERR_NOMEM;
+        }
+        if (n) {
+            auto t0 = std::chrono::steady_clock::now();
+            HIPCHK(hipMemcpyAsync(g_stage_jac.p, bases_jac, n * sizeof(Jac<F>), hipMemcpyHostToDevice, g.stream));
+            st.bases_prepare_ms = ms_since(t0);
+            t0 = std::chrono::steady_clock::now();
+            HIPCHK(hipMemcpyAsync(g_stage_scalars.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+            st.h2d_scalars_ms = ms_since(t0);
+            rc = prepare_bases<F>((const Jac<F> *)g_stage_jac.p, g_stage_bases.p, n, g.stream);
+            if (rc) return rc;
+        }
+        d_bases = g_stage_bases.p;
     }
-    rc = msm_device<F>(g_stage_bases.p, 0, (const Fr *)g_stage_scalars.p, n, (Jac<F> *)g.d_result, g.stream);
+    auto t0 = std::chrono::steady_clock::now();
+    rc = msm_device<F>(d_bases, 0, (const Fr *)g_stage_scalars.p, n, (Jac<F> *)g.d_result, g.stream, table_stride);
     if (rc) return rc;
     rc = msm_join(g.stream);
     if (rc) return rc;
+    if (sharded) {
+        // this rank's slice is one libff chunk: all-gather the partials, sum them in rank order
+        const size_t world = (size_t)lsa_comm_world();
+        if (g_stage_gather.ensure(world * sizeof(Jac<F>))) { set_error("msm: staging allocation failed"); return LSA_ERR_NOMEM; }
+        rc = lsa_comm_all_gather(g.d_result, g_stage_gather.p, group);
+        if (rc) return rc;
+        rc = sum_points_device<F>((const Jac<F> *)g_stage_gather.p, world, (Jac<F> *)g.d_result, g.stream);
+        if (rc) return rc;
+    }
     HIPCHK(hipMemcpyAsync(g.h_result, g.d_result, sizeof(Jac<F>), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     memcpy(out_jac, g.h_result, sizeof(Jac<F>));
+    st.msm_ms = ms_since(t0);
+    st.total_ms = ms_since(t_all);
+    g_host_stats = st;
     return LSA_OK;
 }
 
@@ -283,6 +631,36 @@ int lsa_g1_msm(const void *bases_jac, const void *scalars, size_t n, size_t chun
 int lsa_g2_msm(const void *bases_jac, const void *scalars, size_t n, size_t chunks, void *out_jac) {
     (void)chunks;
     return msm_host<Fq2>(bases_jac, scalars, n, out_jac, 2);
+}
+int lsa_g1_msm_sharded(const void *bases_jac, const void *scalars, size_t n_local, void *out_jac) {
+    return msm_host<Fq>(bases_jac, scalars, n_local, out_jac, 1, true);
+}
+int lsa_g2_msm_sharded(const void *bases_jac, const void *scalars, size_t n_local, void *out_jac) {
+    return msm_host<Fq2>(bases_jac, scalars, n_local, out_jac, 2, true);
+}
+int lsa_crs_cache_configure(int mode, size_t max_bytes) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (mode < 0 || mode > 2) { set_error("crs_cache_configure: mode must be 0 (off), 1 (sampled) or 2 (full)"); return LSA_ERR_INVALID; }
+    crs_configure_from_env();
+    if (mode != g_crs.mode) crs_evict_to(0);          // fingerprints of the two modes are not comparable
+    g_crs.mode = mode;
+    if (max_bytes) g_crs.budget = max_bytes;
+    crs_evict_to(g_crs.budget);
+    return LSA_OK;
+}
+void lsa_crs_cache_clear(void) { if (g.ready) crs_evict_to(0); }
+int lsa_crs_cache_stats(uint64_t *hits, uint64_t *misses, uint64_t *resident_bytes, uint64_t *entries) {
+    if (hits) *hits = g_crs.hits;
+    if (misses) *misses = g_crs.misses;
+    if (resident_bytes) *resident_bytes = g_crs.bytes;
+    if (entries) *entries = g_crs.entries.size();
+    return LSA_OK;
+}
+int lsa_msm_host_stats(lsa_host_stats *out) {
+    if (!out) return LSA_ERR_INVALID;
+    *out = g_host_stats;
+    return LSA_OK;
 }
 
 // ---------------------------------------------------------------- normalisation
@@ -618,11 +996,44 @@ int miller_upload_run(const void *g1, const void *g2, size_t n) {
     return miller_device(g_pair_p.p, g_pair_q.p, n, g_pair_f.p, g.stream);
 }
 
-int miller_product_host(const void *g1, const void *g2, size_t n, void *out, bool final_exp) {
+int miller_product_host(const void *g1, const void *g2, size_t n, void *out, bool final_exp, bool sharded = false) {
     int rc = require_ready();
     if (rc) return rc;
     if (!out || (n && (!g1 || !g2))) { set_error("pairing: null argument"); return LSA_ERR_INVALID; }
     void *res = nullptr;
+    if (sharded && lsa_comm_world() > 1) {
+        // per-rank Miller product (1 for an empty slice), all-gather of the Fq12 partials, product
+        // in rank order, one final exponentiation on every rank (SURVEY.md 8e "Pairings")
+        const size_t world = (size_t)lsa_comm_world();
+        if (g_pair_o.ensure(fq12_bytes()) || g_stage_gather.ensure(world * fq12_bytes()) || g_pair_s.ensure(((std::max(n, world) + 7) / 8) * fq12_bytes())) {
+            set_error("pairing: hipMalloc failed");
+            return LSA_ERR_NOMEM;
+        }
+        if (n == 0) {
+            Fq12 one = Fq12::one();
+            HIPCHK(hipMemcpyAsync(g_pair_o.p, &one, sizeof one, hipMemcpyHostToDevice, g.stream));
+            HIPCHK(hipStreamSynchronize(g.stream));
+        } else {
+            rc = miller_upload_run(g1, g2, n);
+            if (rc) return rc;
+            rc = fq12_product_device(g_pair_f.p, g_pair_s.p, n, &res, g.stream);
+            if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(g_pair_o.p, res, fq12_bytes(), hipMemcpyDeviceToDevice, g.stream));
+        }
+        rc = lsa_comm_all_gather(g_pair_o.p, g_stage_gather.p, 12);
+        if (rc) return rc;
+        rc = fq12_product_device(g_stage_gather.p, g_pair_s.p, world, &res, g.stream);
+        if (rc) return rc;
+        if (final_exp) {
+            rc = final_exp_device(res, 1, g_pair_o.p, g.stream);
+            if (rc) return rc;
+            res = g_pair_o.p;
+        }
+        HIPCHK(hipMemcpyAsync(g.h_result, res, fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        memcpy(out, g.h_result, fq12_bytes());
+        return LSA_OK;
+    }
     if (n == 0) {
         // empty product = 1; final_exponentiation(1) = 1
         Fq12 one = Fq12::one();
@@ -664,6 +1075,9 @@ int lsa_miller_loop_product(const void *g1, const void *g2, size_t n, void *out)
 }
 int lsa_pairing_product(const void *g1, const void *g2, size_t n, void *out) {
     return miller_product_host(g1, g2, n, out, true);
+}
+int lsa_pairing_product_sharded(const void *g1, const void *g2, size_t n_local, void *out) {
+    return miller_product_host(g1, g2, n_local, out, true, true);
 }
 int lsa_fq12_product(const void *in, size_t n, void *out) {
     int rc = require_ready();

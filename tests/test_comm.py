@@ -1,0 +1,82 @@
+"""The C-ABI multi-GPU step (legosnark_amd/csrc/comm.hip): host-side logic and linkage on CPU,
+a one-rank communicator on the GPU (RCCL refuses two ranks on one device, so world > 1 runs only
+on the driver's multi-GPU node; the partition / gather / fold logic for world = 2 is covered by
+tests/test_sharded_cpu.py under gloo and by the two-rank stand-in tests)."""
+import ctypes
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import legosnark_amd
+from legosnark_amd import sharded
+
+
+def test_shard_range_is_libffs_chunk_split():
+    rng = random.Random(5)
+    cases = [(0, 1, 0), (5, 8, 0), (5, 8, 7), (8, 8, 3), ((1 << 24) + 2, 8, 7), ((1 << 24) + 2, 8, 0)]
+    cases += [(rng.randrange(0, 1 << 26), w, r) for w in (1, 2, 3, 4, 8) for r in range(w) for _ in range(3)]
+    for n, world, rank in cases:
+        assert legosnark_amd.shard_range(n, world, rank) == sharded.shard_range(n, world, rank), (n, world, rank)
+    # the ranges tile [0, n)
+    for n, world in ((1 << 24) + 2, 8), (1000, 7), (3, 8):
+        edges = [legosnark_amd.shard_range(n, world, r) for r in range(world)]
+        covered = sorted(x for lo, hi in edges for x in ((lo, hi),) if hi > lo)
+        assert covered[0][0] == 0 and covered[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+
+
+def test_library_links_rccl_and_rccl_has_the_collectives():
+    out = subprocess.check_output(["readelf", "-d", legosnark_amd.LIB_PATH], text=True)
+    assert "librccl.so" in out, "liblegosnark_amd.so must link RCCL (comm.hip)"
+    rccl = ctypes.CDLL("librccl.so.1") if os.path.exists("/opt/rocm/lib/librccl.so.1") else ctypes.CDLL("librccl.so")
+    for sym in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclCommDestroy", "ncclGetErrorString"):
+        assert hasattr(rccl, sym), sym
+
+
+def test_comm_entry_points_fail_loudly_without_device_or_communicator():
+    if legosnark_amd.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(legosnark_amd.LsaError):
+        legosnark_amd.comm_init(0, 1, b"\0" * 128)
+    with pytest.raises(legosnark_amd.LsaError):
+        legosnark_amd.comm_join()
+    assert legosnark_amd.comm_world() == 1 and legosnark_amd.comm_rank() == 0
+
+
+@pytest.mark.gpu
+def test_one_rank_communicator_matches_single_gpu_entry_points(lsa, tmp_path):
+    import torch
+    import oracle_lib as o
+    with pytest.raises(legosnark_amd.LsaError):
+        lsa.comm_join()                                       # no communicator yet
+    lsa.comm_init(0, 1, lsa.comm_unique_id())
+    try:
+        assert (lsa.comm_world(), lsa.comm_rank()) == (1, 0)
+        n = 6000
+        bases = o.arith_bases("g1", 5, 7, n)
+        sc, _ = o.random_scalars(n, seed=1)
+        want = o.g1_canonical_affine(o.multi_exp("g1", bases, sc, mode="mixed"))
+        B = lsa.Bases("g1", bases)
+        d_s = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        assert o.g1_canonical_affine(B.msm_sharded(d_s)) == want
+        outs = torch.zeros((6, 12), dtype=torch.int64, device="cuda:0")
+        for i in range(6):                                    # more calls than rotating buffer sets
+            B.msm_sharded_async(d_s, outs[i])
+        lsa.comm_join()
+        lsa.synchronize()
+        for i in range(6):
+            assert o.g1_canonical_affine(outs[i].cpu().numpy().view(np.uint64)) == want
+        assert o.g1_canonical_affine(lsa.msm_sharded("g1", bases, sc)) == want
+        q = o.arith_bases("g2", 3, 11, 5)
+        p = o.arith_bases("g1", 9, 2, 5)
+        assert np.array_equal(lsa.pairing_product_sharded(p, q), lsa.pairing_product(p, q))
+        B.close()
+    finally:
+        lsa.comm_destroy()
+    # file bootstrap (what a C++ SPMD prover without its own transport uses)
+    lsa.comm_init_file(0, 1, str(tmp_path / "lsa_comm.id"))
+    assert lsa.comm_world() == 1
+    lsa.comm_destroy()

@@ -1,0 +1,141 @@
+"""The CRS cache behind lsa_g1_msm / lsa_g2_msm (the host-vector path multiExpMA takes,
+/root/reference/src/utils/globl.h:74-77): hits on an unchanged vector, never a stale result."""
+import numpy as np
+import pytest
+
+import oracle_lib as o
+
+pytestmark = pytest.mark.gpu
+
+
+def canon(group, pt):
+    return o.g1_canonical_affine(pt) if group == "g1" else o.g2_canonical_affine(pt)
+
+
+@pytest.fixture()
+def fresh_cache(lsa):
+    lsa.crs_cache_configure(lsa.CRS_CACHE_FULL, 8 << 30)
+    lsa.crs_cache_clear()
+    yield lsa
+    lsa.crs_cache_configure(lsa.CRS_CACHE_FULL, 8 << 30)
+    lsa.crs_cache_clear()
+    lsa.set_table_threshold(0)
+
+
+def delta(lsa, before):
+    now = lsa.crs_cache_stats()
+    return now["hits"] - before["hits"], now["misses"] - before["misses"]
+
+
+@pytest.mark.parametrize("group,n", [("g1", 5000), ("g2", 1500)])
+def test_hit_on_same_vector_miss_on_any_mutation(fresh_cache, group, n):
+    lsa = fresh_cache
+    bases = np.ascontiguousarray(o.arith_bases(group, 31337, 17, n))
+    sc, _ = o.random_scalars(n, seed=5)
+    want = canon(group, o.multi_exp(group, bases, sc, mode="mixed"))
+    s0 = lsa.crs_cache_stats()
+    assert canon(group, lsa.msm(group, bases, sc)) == want
+    assert delta(lsa, s0) == (0, 1) and lsa.msm_host_stats()["cache_hit"] == 0
+    assert canon(group, lsa.msm(group, bases, sc)) == want
+    assert delta(lsa, s0) == (1, 1) and lsa.msm_host_stats()["cache_hit"] == 1
+    # other scalars, same bases: hit
+    sc2, _ = o.random_scalars(n, seed=6)
+    assert canon(group, lsa.msm(group, bases, sc2)) == canon(group, o.multi_exp(group, bases, sc2, mode="mixed"))
+    assert delta(lsa, s0) == (2, 1)
+    # mutate ONE point in place, at a position no sampling scheme would look at: miss + right answer
+    i = 2917 % n
+    bases[i] = o.arith_bases(group, 999, 1, 1)[0]
+    want2 = canon(group, o.multi_exp(group, bases, sc, mode="mixed"))
+    assert want2 != want
+    assert canon(group, lsa.msm(group, bases, sc)) == want2
+    assert delta(lsa, s0) == (2, 2)
+    # flip a single bit of a single limb (another representative's low bit): still a miss
+    bases[i + 1, 0] ^= np.uint64(1)
+    s1 = lsa.crs_cache_stats()
+    lsa.msm(group, bases, sc)
+    assert delta(lsa, s1) == (0, 1)
+    # equal content at another address: its own entry
+    other = bases.copy()
+    s1 = lsa.crs_cache_stats()
+    assert canon(group, lsa.msm(group, other, sc)) == canon(group, o.multi_exp(group, bases, sc, mode="mixed"))
+    assert delta(lsa, s1) == (0, 1)
+
+
+def test_prefix_requests_cppoly_ladder_shape(fresh_cache):
+    """CPPoly::prove passes g1s with shorter and shorter scalar vectors (poly.h:77-86):
+    multiExpMA truncates to the prefix (globl.h:66).  Prefixes that are multiples of the
+    fingerprint unit hit the long entry; others are verified as their own entry."""
+    lsa = fresh_cache
+    n = 8192
+    bases = np.ascontiguousarray(o.arith_bases("g1", 4242, 7, n))
+    sc, _ = o.random_scalars(n, seed=11)
+    lsa.msm("g1", bases, sc)
+    s0 = lsa.crs_cache_stats()
+    for m in (4096, 2048, 1024):
+        got = lsa.msm("g1", bases, sc[:m])
+        assert canon("g1", got) == canon("g1", o.multi_exp("g1", bases[:m], sc[:m], mode="mixed")), m
+    assert delta(lsa, s0) == (3, 0)
+    m = 3001                                              # not a multiple of 64: separate entry, still right
+    got = lsa.msm("g1", bases, sc[:m])
+    assert canon("g1", got) == canon("g1", o.multi_exp("g1", bases[:m], sc[:m], mode="mixed"))
+    assert delta(lsa, s0) == (3, 1)
+    # a mutation beyond the prefix does not disturb the prefix; inside it does
+    bases[5000] = bases[1]
+    s1 = lsa.crs_cache_stats()
+    lsa.msm("g1", bases, sc[:4096])
+    assert delta(lsa, s1) == (1, 0)
+    bases[100] = bases[1]
+    got = lsa.msm("g1", bases, sc[:4096])
+    assert canon("g1", got) == canon("g1", o.multi_exp("g1", bases[:4096], sc[:4096], mode="mixed"))
+    assert delta(lsa, s1) == (1, 1)
+    # small vectors bypass the cache
+    s1 = lsa.crs_cache_stats()
+    lsa.msm("g1", bases, sc[:100])
+    assert delta(lsa, s1) == (0, 0)
+
+
+def test_table_built_on_first_reuse_and_lru_eviction(fresh_cache):
+    lsa = fresh_cache
+    lsa.set_table_threshold(2048)
+    n = 4096
+    sc, _ = o.random_scalars(n, seed=3)
+    vecs = [np.ascontiguousarray(o.arith_bases("g1", 100 + k, 3, n)) for k in range(3)]
+    wants = [canon("g1", o.multi_exp("g1", v, sc, mode="mixed")) for v in vecs]
+    assert canon("g1", lsa.msm("g1", vecs[0], sc)) == wants[0]
+    assert lsa.msm_host_stats()["table"] == 0             # cold: plain layout
+    assert canon("g1", lsa.msm("g1", vecs[0], sc)) == wants[0]
+    st = lsa.msm_host_stats()
+    assert st["cache_hit"] == 1 and st["table"] == 1      # first re-use: pre-shifted copies built
+    one = lsa.crs_cache_stats()["resident_bytes"]
+    assert one == n * 64 * 8
+    # budget for two such entries: the least recently used one goes
+    lsa.crs_cache_configure(lsa.CRS_CACHE_FULL, 2 * one + 1024)
+    for k in (1, 2):
+        for _ in range(2):
+            assert canon("g1", lsa.msm("g1", vecs[k], sc)) == wants[k]
+    st = lsa.crs_cache_stats()
+    assert st["entries"] == 2 and st["resident_bytes"] <= 2 * one + 1024
+    s0 = lsa.crs_cache_stats()
+    assert canon("g1", lsa.msm("g1", vecs[0], sc)) == wants[0]          # evicted: miss, right answer
+    assert delta(lsa, s0) == (0, 1)
+
+
+def test_sampled_mode_and_off(fresh_cache):
+    lsa = fresh_cache
+    n = 3000
+    bases = np.ascontiguousarray(o.arith_bases("g1", 77, 5, n))
+    sc, _ = o.random_scalars(n, seed=9)
+    want = canon("g1", o.multi_exp("g1", bases, sc, mode="mixed"))
+    lsa.crs_cache_configure(lsa.CRS_CACHE_SAMPLED)
+    s0 = lsa.crs_cache_stats()
+    assert canon("g1", lsa.msm("g1", bases, sc)) == want
+    assert canon("g1", lsa.msm("g1", bases, sc)) == want
+    assert delta(lsa, s0) == (1, 1)
+    bases[n - 1] = bases[0]                               # the last point is always sampled
+    assert canon("g1", lsa.msm("g1", bases, sc)) == canon("g1", o.multi_exp("g1", bases, sc, mode="mixed"))
+    assert delta(lsa, s0) == (1, 2)
+    lsa.crs_cache_configure(lsa.CRS_CACHE_OFF)
+    s0 = lsa.crs_cache_stats()
+    for _ in range(2):
+        assert canon("g1", lsa.msm("g1", bases, sc)) == canon("g1", o.multi_exp("g1", bases, sc, mode="mixed"))
+    assert delta(lsa, s0) == (0, 0) and lsa.crs_cache_stats()["entries"] == 0
