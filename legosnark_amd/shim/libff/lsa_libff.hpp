@@ -22,6 +22,9 @@
 #include <iostream>
 #include <random>
 #include <stdexcept>
+#include <cerrno>
+#include <sys/random.h>
+#include <sys/types.h>
 #include <string>
 #include <vector>
 
@@ -72,14 +75,35 @@ struct bigint {
     bool operator!=(const bigint &o) const { return !(*this == o); }
 };
 
-inline std::mt19937_64 &lsa_rng() {
+// Randomness of random_element(): trapdoors, blinding factors and published challenges of the
+// gadgets come from here (src/gadgets/subspace.cc:47, src/examples/cplink.cc:70,
+// src/gadgets/sigma.cc:11, src/gadgets/sumcheck.cc:47), so every draw reads the operating
+// system's CSPRNG (getrandom(2); std::random_device as the fallback) -- libff's
+// bigint::randomize() reads std::random_device for every limb [upstream, recalled].  A
+// reproducible stream exists only under the explicit test-only macro LSA_SHIM_TEST_SEED
+// (then env LSA_SEED seeds a Mersenne twister): never define it in a production build.
+inline void lsa_random_bytes(void *buf, size_t len) {
+#ifdef LSA_SHIM_TEST_SEED
     static std::mt19937_64 g = []() {
         const char *s = getenv("LSA_SEED");
-        if (s) return std::mt19937_64(strtoull(s, nullptr, 0));
-        std::random_device rd;
-        return std::mt19937_64(((uint64_t)rd() << 32) ^ rd());
+        return std::mt19937_64(s ? strtoull(s, nullptr, 0) : 0x4C45474F534E4152ull);
     }();
-    return g;
+    unsigned char *p = (unsigned char *)buf;
+    for (size_t i = 0; i < len; i += 8) { uint64_t r = g(); memcpy(p + i, &r, len - i < 8 ? len - i : 8); }
+#else
+    unsigned char *p = (unsigned char *)buf;
+    size_t got = 0;
+    while (got < len) {
+        ssize_t r = getrandom(p + got, len - got, 0);
+        if (r > 0) { got += (size_t)r; continue; }
+        if (r < 0 && errno == EINTR) continue;
+        break;                                     // ENOSYS etc.: fall back below
+    }
+    if (got < len) {
+        std::random_device rd;
+        for (; got < len; got++) p[got] = (unsigned char)rd();
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- prime fields
@@ -121,7 +145,7 @@ public:
     static Fp_shim random_element() {
         for (;;) {
             uint32_t l[8];
-            for (int i = 0; i < 4; i++) { uint64_t r = lsa_rng()(); l[2 * i] = (uint32_t)r; l[2 * i + 1] = (uint32_t)(r >> 32); }
+            lsa_random_bytes(l, sizeof l);
             l[7] &= 0x3fffffffu;
             bool lt = false;   // l < MOD ?
             for (int i = 7; i >= 0; --i) { if (l[i] != P::MOD[i]) { lt = l[i] < P::MOD[i]; break; } }
@@ -159,10 +183,25 @@ public:
     }
     unsigned long as_ulong() const { return as_bigint().as_ulong(); }
     void print() const { std::cout << *this << "\n"; }
-    // text I/O: canonical value in decimal (libff without BINARY_OUTPUT / MONTGOMERY_OUTPUT)
-    friend std::ostream &operator<<(std::ostream &os, const Fp_shim &a) {
-        bigint<4> b = a.as_bigint();
-        // 256-bit -> decimal
+    // libff Fp_model::sqrt for p = 3 mod 4 (Fq; used by point decompression): a^((p+1)/4)
+    Fp_shim sqrt() const {
+        bigint<4> e;
+        uint64_t m[4];
+        for (int i = 0; i < 4; i++) m[i] = (uint64_t)P::MOD[2 * i] | ((uint64_t)P::MOD[2 * i + 1] << 32);
+        m[0] += 1;                                              // p + 1 (no carry: p ends in ...47)
+        for (int i = 0; i < 4; i++) e.data[i] = (m[i] >> 2) | (i < 3 ? (m[i + 1] << 62) : 0);
+        return *this ^ e;
+    }
+    // Serialisation = libff's operator<< / operator>> for Fp_model (fp.tcc) and bigint
+    // (bigint.tcc) [upstream, recalled], under the same macros libff's build defines:
+    //   default            canonical value, decimal text
+    //   MONTGOMERY_OUTPUT  the Montgomery representation instead of the canonical value
+    //   BINARY_OUTPUT      the 32 raw little-endian bytes instead of decimal text
+    // (/root/reference/src/utils/util.h:56-96 streams vectors of these with `<<` / `>>`.)
+    static void write_bigint(std::ostream &os, const bigint<4> &b) {
+#ifdef BINARY_OUTPUT
+        os.write(reinterpret_cast<const char *>(b.data), sizeof b.data);
+#else
         uint32_t w[8];
         for (int i = 0; i < 4; i++) { w[2 * i] = (uint32_t)b.data[i]; w[2 * i + 1] = (uint32_t)(b.data[i] >> 32); }
         std::string s;
@@ -173,12 +212,67 @@ public:
             s.push_back((char)('0' + rem));
         }
         for (size_t i = 0; i < s.size() / 2; i++) std::swap(s[i], s[s.size() - 1 - i]);
-        return os << s;
+        os << s;
+#endif
+    }
+    static bool read_bigint(std::istream &is, bigint<4> &b) {
+#ifdef BINARY_OUTPUT
+        is.read(reinterpret_cast<char *>(b.data), sizeof b.data);
+        return (bool)is;
+#else
+        std::string s;
+        is >> s;
+        if (s.empty()) return false;
+        uint32_t w[8] = {0};
+        for (char c : s) {
+            if (c < '0' || c > '9') { is.setstate(std::ios::failbit); return false; }
+            uint64_t carry = (uint64_t)(c - '0');
+            for (int i = 0; i < 8; i++) { uint64_t cur = (uint64_t)w[i] * 10 + carry; w[i] = (uint32_t)cur; carry = cur >> 32; }
+        }
+        for (int i = 0; i < 4; i++) b.data[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+        return true;
+#endif
+    }
+    friend std::ostream &operator<<(std::ostream &os, const Fp_shim &a) {
+#ifdef MONTGOMERY_OUTPUT
+        bigint<4> b;
+        for (int i = 0; i < 4; i++) b.data[i] = (uint64_t)a.v.l[2 * i] | ((uint64_t)a.v.l[2 * i + 1] << 32);
+        write_bigint(os, b);
+#else
+        write_bigint(os, a.as_bigint());
+#endif
+        return os;
     }
     friend std::istream &operator>>(std::istream &is, Fp_shim &a) {
-        std::string s; is >> s; a = Fp_shim(s.c_str()); return is;
+        bigint<4> b;
+        if (!read_bigint(is, b)) return is;
+#ifdef MONTGOMERY_OUTPUT
+        for (int i = 0; i < 4; i++) { a.v.l[2 * i] = (uint32_t)b.data[i]; a.v.l[2 * i + 1] = (uint32_t)(b.data[i] >> 32); }
+#else
+        a = Fp_shim(b);
+#endif
+        return is;
     }
 };
+
+// libff serialization.hpp: separators are empty in binary mode
+#ifdef BINARY_OUTPUT
+#define LSA_OUTPUT_SEPARATOR ""
+#define LSA_OUTPUT_NEWLINE ""
+#else
+#define LSA_OUTPUT_SEPARATOR " "
+#define LSA_OUTPUT_NEWLINE "\n"
+#endif
+inline void consume_OUTPUT_SEPARATOR(std::istream &in) {
+#ifndef BINARY_OUTPUT
+    char c;
+    in.read(&c, 1);
+#else
+    (void)in;
+#endif
+}
+inline void consume_OUTPUT_NEWLINE(std::istream &in) { consume_OUTPUT_SEPARATOR(in); }
+inline void consume_newline(std::istream &in) { char c; in.read(&c, 1); }
 
 template <class P>
 const Fp_shim<P> Fp_shim<P>::multiplicative_generator = Fp_shim<P>(5L);
@@ -215,6 +309,45 @@ public:
     static alt_bn128_Fq2 zero() { return alt_bn128_Fq2(); }
     static alt_bn128_Fq2 one() { return alt_bn128_Fq2(lsa::Fq2::one()); }
     bool operator==(const alt_bn128_Fq2 &o) const { return v == o.v; }
+    bool operator!=(const alt_bn128_Fq2 &o) const { return !(v == o.v); }
+    alt_bn128_Fq2 operator*(const alt_bn128_Fq2 &o) const { return alt_bn128_Fq2(v * o.v); }
+    alt_bn128_Fq2 operator+(const alt_bn128_Fq2 &o) const { return alt_bn128_Fq2(v + o.v); }
+    alt_bn128_Fq2 operator-() const { return alt_bn128_Fq2(v.neg()); }
+    alt_bn128_Fq2 squared() const { return alt_bn128_Fq2(v.sqr()); }
+    // a square root in Fq[u]/(u^2+1) by the norm method; libff uses Tonelli-Shanks in Fq2 --
+    // either root serves point decompression, which fixes the sign by the parity of c0.
+    // Returns false when the element is not a square.
+    bool sqrt(alt_bn128_Fq2 &out) const {
+        const alt_bn128_Fq a0(v.c0), a1(v.c1);
+        if (a1.is_zero()) {
+            alt_bn128_Fq r = a0.sqrt();
+            if (r.squared() == a0) { out.v = lsa::Fq2{r.v, lsa::Fq::zero()}; return true; }
+            alt_bn128_Fq r2 = (-a0).sqrt();                       // a0 = -(r2^2) = (r2 u)^2
+            if (r2.squared() != -a0) return false;
+            out.v = lsa::Fq2{lsa::Fq::zero(), r2.v};
+            return true;
+        }
+        const alt_bn128_Fq norm = a0.squared() + a1.squared();
+        const alt_bn128_Fq sn = norm.sqrt();
+        if (sn.squared() != norm) return false;
+        const alt_bn128_Fq half = alt_bn128_Fq(2L).inverse();
+        alt_bn128_Fq x0sq = (a0 + sn) * half;
+        alt_bn128_Fq x0 = x0sq.sqrt();
+        if (x0.squared() != x0sq) { x0sq = (a0 - sn) * half; x0 = x0sq.sqrt(); if (x0.squared() != x0sq) return false; }
+        const alt_bn128_Fq x1 = a1 * (x0 + x0).inverse();
+        out.v = lsa::Fq2{x0.v, x1.v};
+        return true;
+    }
+    // libff Fp2_model operator<< / >>: c0 SEP c1
+    friend std::ostream &operator<<(std::ostream &os, const alt_bn128_Fq2 &a) {
+        return os << alt_bn128_Fq(a.v.c0) << LSA_OUTPUT_SEPARATOR << alt_bn128_Fq(a.v.c1);
+    }
+    friend std::istream &operator>>(std::istream &is, alt_bn128_Fq2 &a) {
+        alt_bn128_Fq c0, c1;
+        is >> c0 >> c1;
+        a.v = lsa::Fq2{c0.v, c1.v};
+        return is;
+    }
 };
 
 class alt_bn128_Fq12 {
@@ -236,11 +369,18 @@ public:
         for (long i = 255; i >= 0; --i) { acc = acc.squared(); if (e.test_bit(i)) acc *= *this; }
         return acc;
     }
-    void print() const { printf("<Fq12>\n"); }
+    void print() const { std::cout << *this << "\n"; }
+    // libff Fp12_2over3over2 / Fp6_3over2 operator<< / >>: c0 SEP c1 (SEP c2) recursively, i.e.
+    // the twelve Fq coefficients in tower order separated by OUTPUT_SEPARATOR
     friend std::ostream &operator<<(std::ostream &os, const alt_bn128_Fq12 &a) {
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(&a.v);
-        for (size_t i = 0; i < sizeof(lsa::Fq12) / 4; i++) os << w[i] << (i + 1 < sizeof(lsa::Fq12) / 4 ? " " : "");
+        const lsa::Fq2 *c = reinterpret_cast<const lsa::Fq2 *>(&a.v);      // c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2
+        for (int i = 0; i < 6; i++) os << alt_bn128_Fq2(c[i]) << (i < 5 ? LSA_OUTPUT_SEPARATOR : "");
         return os;
+    }
+    friend std::istream &operator>>(std::istream &is, alt_bn128_Fq12 &a) {
+        lsa::Fq2 *c = reinterpret_cast<lsa::Fq2 *>(&a.v);
+        for (int i = 0; i < 6; i++) { alt_bn128_Fq2 t; is >> t; c[i] = t.v; }
+        return is;
     }
 };
 static_assert(sizeof(alt_bn128_Fq12) == 384, "GT layout");
@@ -279,7 +419,12 @@ public:
     G_shim dbl() const { return G_shim(lsa::jac_dbl(jac())); }
     void to_affine_coordinates() { *this = G_shim(lsa::jac_normalize(jac())); }
     void to_special() { to_affine_coordinates(); }
-    bool is_well_formed() const { return true; }
+    // libff is_well_formed(): the Jacobian curve equation Y^2 = X^3 + b Z^6 (infinity is fine)
+    bool is_well_formed() const {
+        if (is_zero()) return true;
+        const F z2 = Z.sqr(), z6 = (z2.sqr()) * z2;
+        return Y.sqr() == X.sqr() * X + curve_b() * z6;
+    }
     void print() const { std::cout << *this << "\n"; }
     // libff "scalar * point": MSB-first double-and-add on the canonical scalar (cold path)
     friend G_shim operator*(const alt_bn128_Fr &k, const G_shim &p) {
@@ -292,18 +437,64 @@ public:
         }
         return G_shim(res);
     }
-    // text I/O: affine coordinates as raw 32-bit words (round-trips within this library)
+    // libff alt_bn128_G1 / alt_bn128_G2 operator<< / operator>> (alt_bn128_g1.cpp, alt_bn128_g2.cpp)
+    // [upstream, recalled]: affine coordinates after to_affine_coordinates();
+    //   "<is_zero> SEP X SEP <lsb of Y>"   default (point compression; G2 takes the lsb of Y.c0)
+    //   "<is_zero> SEP X SEP Y"            with NO_PT_COMPRESSION
+    // field elements in the Fp format above (the same BINARY_OUTPUT / MONTGOMERY_OUTPUT macros).
+    using FieldIO = typename std::conditional<GROUP == 1, alt_bn128_Fq, alt_bn128_Fq2>::type;
+    static unsigned y_parity(const F &y) {
+        if constexpr (GROUP == 1) return (unsigned)(alt_bn128_Fq(y).as_bigint().data[0] & 1);
+        else return (unsigned)(alt_bn128_Fq(y.c0).as_bigint().data[0] & 1);
+    }
     friend std::ostream &operator<<(std::ostream &os, const G_shim &p) {
-        G_shim a = p; a.to_affine_coordinates();
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(&a);
-        const size_t nw = sizeof(G_shim) / 4;
-        for (size_t i = 0; i < nw; i++) os << w[i] << (i + 1 < nw ? " " : "");
+        G_shim a = p;
+        a.to_affine_coordinates();
+        os << (a.is_zero() ? 1 : 0) << LSA_OUTPUT_SEPARATOR;
+#ifdef NO_PT_COMPRESSION
+        os << FieldIO(a.X) << LSA_OUTPUT_SEPARATOR << FieldIO(a.Y);
+#else
+        os << FieldIO(a.X) << LSA_OUTPUT_SEPARATOR << y_parity(a.Y);
+#endif
         return os;
     }
     friend std::istream &operator>>(std::istream &is, G_shim &p) {
-        uint32_t *w = reinterpret_cast<uint32_t *>(&p);
-        for (size_t i = 0; i < sizeof(G_shim) / 4; i++) is >> w[i];
+        char is_zero;
+        FieldIO tX, tY;
+#ifdef NO_PT_COMPRESSION
+        is >> is_zero >> tX >> tY;
+        is_zero -= '0';
+#else
+#ifndef BINARY_OUTPUT
+        is >> std::ws;                                 // vectors are streamed one element per line
+#endif
+        is.read(&is_zero, 1);
+        is_zero -= '0';
+        consume_OUTPUT_SEPARATOR(is);
+        unsigned char y_lsb;
+        is >> tX;
+        consume_OUTPUT_SEPARATOR(is);
+        is.read(reinterpret_cast<char *>(&y_lsb), 1);
+        y_lsb -= '0';
+        if (!is_zero) {                                // y = +/- sqrt(x^3 + b)
+            FieldIO rhs = tX.squared() * tX + FieldIO(curve_b());
+            if constexpr (GROUP == 1) { tY = rhs.sqrt(); if (tY.squared() != rhs) is.setstate(std::ios::failbit); }
+            else { if (!rhs.sqrt(tY)) is.setstate(std::ios::failbit); }
+            if (y_parity(tY.v) != y_lsb) tY = -tY;
+        }
+#endif
+        if (!is_zero) p = G_shim(tX.v, tY.v, F::one());
+        else p = zero();
         return is;
+    }
+    // curve coefficient: b = 3 (G1), b' = 3 / (9 + u) (G2, the sextic twist)
+    static F curve_b() {
+        if constexpr (GROUP == 1) return lsa::Fq::from_u32(3);
+        else {
+            lsa::Fq2 xi{lsa::Fq::from_u32(9), lsa::Fq::from_u32(1)};
+            lsa::Fq2 three{lsa::Fq::from_u32(3), lsa::Fq::zero()};
+            return three * xi.inverse();
+        }
     }
 };
 using alt_bn128_G1 = G_shim<lsa::Fq, 1>;

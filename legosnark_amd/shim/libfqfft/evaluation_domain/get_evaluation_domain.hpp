@@ -59,9 +59,17 @@ public:
 
 template <typename FieldT>
 std::shared_ptr<evaluation_domain<FieldT>> get_evaluation_domain(const size_t min_size) {
-    size_t m = 1;
-    while (m < min_size) m <<= 1;
-    return std::make_shared<evaluation_domain<FieldT>>(m);
+    // libfqfft picks basic_radix2 for a power of two and extended / step / arithmetic-sequence
+    // domains (a different m, omega and Lagrange basis) otherwise.  Only the basic radix-2 domain
+    // exists here; every size the built examples request is a power of two
+    // (src/prototools/interp.h:62, src/gadgets/lipmaa.cc:102 with n = 2^d).  Rounding another
+    // size up would silently produce keys and proofs that differ from a libfqfft build, so it is
+    // refused instead.
+    if (min_size == 0 || (min_size & (min_size - 1)) != 0)
+        throw std::invalid_argument("get_evaluation_domain: only power-of-two sizes (basic radix-2 domain) are supported; "
+                                    "libfqfft would select an extended/step/arithmetic domain for this size");
+    if (min_size > (size_t(1) << 28)) throw std::invalid_argument("get_evaluation_domain: size exceeds the 2-adicity of Fr (2^28)");
+    return std::make_shared<evaluation_domain<FieldT>>(min_size);
 }
 
 }  // namespace libfqfft
