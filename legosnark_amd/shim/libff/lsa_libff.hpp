@@ -592,6 +592,15 @@ T msm_forward(typename std::vector<T>::const_iterator vec_start, typename std::v
     T out;
     const void *b = n ? (const void *)&*vec_start : nullptr;
     const void *s = n ? (const void *)&*scalar_start : nullptr;
+    // SPMD provers (one process per GPU, lsa_comm_init done): every rank passes ITS chunk of the
+    // vectors -- the contiguous range lsa_shard_range() gives it, i.e. libff's own `chunks` split
+    // with chunks = world -- and receives the sum over all ranks (one RCCL all-gather of the
+    // Jacobian partials).  Without a communicator this is the single-GPU call.
+    if (lsa_comm_world() > 1) {
+        if (group_id<T>::value == 1) lsa_require(lsa_g1_msm_sharded(b, s, n, &out), "multi_exp<G1> (sharded)");
+        else lsa_require(lsa_g2_msm_sharded(b, s, n, &out), "multi_exp<G2> (sharded)");
+        return out;
+    }
     if (group_id<T>::value == 1) lsa_require(lsa_g1_msm(b, s, n, chunks, &out), "multi_exp<G1>");
     else lsa_require(lsa_g2_msm(b, s, n, chunks, &out), "multi_exp<G2>");
     return out;

@@ -13,8 +13,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "build", "reference")
 
 
-def run(name, *args, seed="7"):
-    exe = os.path.join(BIN, name)
+CMAKE_BIN = os.path.join(ROOT, "build", "reference_cmake", "src", "examples")
+
+
+def run(name, *args, seed="7", bindir=BIN):
+    exe = os.path.join(bindir, name)
     if not os.path.exists(exe):
         # the binaries are built from the reference's sources, which exist only in the dev
         # container (build/ travels with the snapshot); nothing to run if they were not shipped
@@ -46,3 +49,13 @@ def test_keygen_matrix_batched_call_equals_reference_column_loop():
     r = run("keygen_check", "10", "128")
     assert r.returncode == 0, r.stdout[-2000:]
     assert '"mismatches": 0' in r.stdout
+
+
+def test_cplink_built_by_the_references_own_cmake_verifies():
+    """The reference's unchanged CMakeLists.txt with depends/libsnark and depends/fmt replaced by
+    legosnark_amd/shim/cmake (targets snark, ff, fmt::fmt-header-only)."""
+    r = run("cplink", bindir=CMAKE_BIN)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "NCHUNKS : 1" in r.stdout and "Error!" not in r.stdout
+    r = run("hadamard", "4", bindir=CMAKE_BIN)
+    assert r.returncode == 0, r.stdout[-2000:]
