@@ -217,6 +217,8 @@ def main():
     elapsed, stages, checked = wl.timed(args.steps, args.warmup, profile=True)
     value = n_total * args.steps / elapsed
     n_local = wl.n
+    fm_per_pair = wl.B.field_mults_per_pair(wl.n)
+    table_windows = wl.B.table_windows()
 
     # single-call latency (no overlap with a following call), for the record
     lat = []
@@ -314,7 +316,7 @@ def main():
     out = None
     if rank == 0:
         acc_ms = stages["accumulate"]
-        fmuls_per_pair = lsa.msm_field_mults_per_pair(n_local) if hasattr(lsa, "msm_field_mults_per_pair") else 16 * 10 + 8
+        fmuls_per_pair = fm_per_pair
         achieved = n_local * ALG_BYTES_PER_PAIR / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         gf = n_local * fmuls_per_pair / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         if strong:
@@ -330,7 +332,9 @@ def main():
             "vs_baseline": None, "dtype": "u32 limbs (254-bit Montgomery integers)", "data": "synthetic",
             "config": {"workload": workload,
                        "inputs": "scalars uniform in [0,r), xoshiro256** seed 0x4C45474F534E4152; bases (a+i*b)*G1, un-normalised Jacobian",
-                       "window_bits": lsa.msm_window_bits(n_local),
+                       "windows": table_windows if table_windows else None,
+                       "pipeline": ("wide windows over pre-shifted resident bases: %d bucket additions per pair, one shared bucket space" % table_windows)
+                       if table_windows else "signed 16-bit windows + GLV",
                        "sharding": ("index ranges (libff chunk split), 1 RCCL all-gather of 96-B partials via "
                                     + ("lsa_msm_run_sharded_async (C-ABI, csrc/comm.hip)" if comm_kind == "capi" else "torch.distributed + lsa_g1_sum_on"))
                        if world > 1 else "single GPU"},

@@ -112,12 +112,20 @@ int lsa_g2_bases_create(const void *bases_jac, size_t n, int src_on_device, lsa_
 void lsa_bases_destroy(lsa_bases *b);
 size_t lsa_bases_size(const lsa_bases *b);
 /* Resident vectors of at least `threshold` points (default 2^19; env LSA_PRECOMPUTE_MIN) also keep
- * the pre-shifted copies 2^(16k)*P_i of every 16-bit window (G1: 8 x 64 B, G2: 16 x 128 B per
- * point; LSA_PRECOMPUTE=0 disables), which removes the per-MSM Horner fold.  MSMs of at least
- * `threshold` pairs on such a handle use them.  lsa_msm_set_table_threshold(0) restores the
- * default; lsa_bases_has_table() tells whether a handle carries the copies. */
+ * pre-shifted copies 2^(s_k)*P_i, one per window of a decomposition of the 255 scalar bits into
+ * 13 (n < 6*2^20) or 12 windows of at most 20 / 22 bits (G1: 13 x 64 B, G2: 13 x 128 B per point;
+ * LSA_PRECOMPUTE=0 disables).  MSMs of at least `threshold` pairs on such a handle then run over
+ * ONE bucket space shared by all windows: 13 bucket additions per pair instead of 16, no GLV
+ * beta-multiplications, one bucket reduction, no Horner fold.  lsa_msm_set_table_threshold(0)
+ * restores the default; lsa_bases_has_table() tells whether a handle carries the copies. */
 void lsa_msm_set_table_threshold(size_t threshold);
 int lsa_bases_has_table(const lsa_bases *b);
+unsigned lsa_bases_table_windows(const lsa_bases *b);   /* 0 without the copies */
+/* Field multiplications per point-scalar pair in the bucket-accumulation kernel for an MSM of n
+ * pairs on this handle (NULL: host-buffer path) -- the operation count behind bench.py's
+ * integer-throughput roofline: 10 per bucket addition (XYZZ mixed add, 8M + 2S), plus one
+ * beta-multiplication per GLV half on the plain path. */
+unsigned lsa_msm_field_mults_per_pair(const lsa_bases *b, size_t n);
 /* Device pointer to the normalised affine array (n x 64 B / 128 B), for inspection. */
 const void *lsa_bases_device_ptr(const lsa_bases *b);
 

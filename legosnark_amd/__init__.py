@@ -64,6 +64,10 @@ def lib():
         L.lsa_bases_device_ptr.restype = C.c_void_p
         L.lsa_bases_device_ptr.argtypes = [C.c_void_p]
         L.lsa_bases_has_table.argtypes = [C.c_void_p]
+        L.lsa_bases_table_windows.argtypes = [C.c_void_p]
+        L.lsa_bases_table_windows.restype = C.c_uint
+        L.lsa_msm_field_mults_per_pair.argtypes = [C.c_void_p, C.c_size_t]
+        L.lsa_msm_field_mults_per_pair.restype = C.c_uint
         L.lsa_msm_set_table_threshold.argtypes = [C.c_size_t]
         L.lsa_msm_set_table_threshold.restype = None
         L.lsa_bases_destroy.argtypes = [C.c_void_p]
@@ -358,6 +362,12 @@ class Bases:
 
     def has_table(self):
         return bool(lib().lsa_bases_has_table(self.handle))
+
+    def table_windows(self):
+        return int(lib().lsa_bases_table_windows(self.handle))
+
+    def field_mults_per_pair(self, n=None):
+        return int(lib().lsa_msm_field_mults_per_pair(self.handle, self.n if n is None else n))
 
     def close(self):
         if self.handle:

