@@ -142,8 +142,9 @@ unsigned lsa_msm_window_bits(size_t n);
 
 /* ---- per-stage timing (HIP events on lsa_stream()) ----------------------------------- */
 #define LSA_MSM_STAGES 8
-/* 0 digits+histogram, 1 scan, 2 scatter, 3 bucket accumulate (dominant), 4 bucket
- * reduce, 5 window fold, 6 reserved, 7 total */
+/* 0 digits+histogram, 1 scan, 2 scatter (+ fine sort), 3 bucket accumulate (dominant; the
+ * accumulate kernels alone), 4 bucket reduce, 5 window fold, 6 ordering of the buckets by
+ * population (between scatter and accumulate), 7 total */
 int lsa_profile_enable(int on);   /* also resets the recorded-call counter */
 /* Average milliseconds per stage over the MSM calls (at most 64) recorded since
  * lsa_profile_enable(1); synchronises on their events; returns the number of calls. */

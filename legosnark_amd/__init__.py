@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_PKG, "liblegosnark_amd.so")
 _lib = None
 
 MSM_STAGES = 8
-STAGE_NAMES = ("digits", "scan", "scatter", "accumulate", "reduce", "fold", "reserved", "total")
+STAGE_NAMES = ("digits", "scan", "scatter", "accumulate", "reduce", "fold", "order", "total")
 
 
 class LsaError(RuntimeError):

@@ -286,6 +286,33 @@ __global__ __launch_bounds__(1024) void k_scatter(const int32_t *__restrict__ di
     }
 }
 
+// Wide path: R = nwin * ntiles rows share ONE bin space of Bc bins; R is a few hundred, so a
+// workgroup of 16 wavefronts takes 64 bins (one per lane, coalesced row reads) and splits the rows
+// 16 ways: partial sums per wavefront, exclusive prefix across the wavefronts through LDS, then a
+// second pass writes every row's base.
+__global__ __launch_bounds__(1024) void k_tile_scan_rows(const uint16_t *__restrict__ tile_hist, uint32_t Bc, uint32_t R,
+                                                         uint32_t *__restrict__ tile_base, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t part[16][64];
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t b = blockIdx.x * 64 + lane;
+    const uint32_t per = (R + 15) / 16, r0 = wv * per, r1 = r0 + per < R ? r0 + per : R;
+    uint32_t sum = 0;
+    if (b < Bc) for (uint32_t r = r0; r < r1; r++) sum += tile_hist[(size_t)r * Bc + b];
+    part[wv][lane] = sum;
+    __syncthreads();
+    uint32_t run = 0, tot = 0;
+#pragma unroll
+    for (unsigned w = 0; w < 16; w++) { uint32_t x = part[w][lane]; if (w < wv) run += x; tot += x; }
+    if (b < Bc) {
+        for (uint32_t r = r0; r < r1; r++) {
+            const size_t idx = (size_t)r * Bc + b;
+            tile_base[idx] = run;
+            run += tile_hist[idx];
+        }
+        if (wv == 0) hist[b] = tot;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Wide-window path (resident bases with pre-shifted copies, see "Wide windows" below).
 // The bucket index has up to 21 bits -- too many for an LDS histogram -- so the sort runs in two
@@ -830,7 +857,7 @@ int msm_join_to(hipStream_t other) {
 // Per-stage HIP events on the library stream.  A ring of EV_POOL call slots so that
 // profiling never synchronises inside the timed loop; msm_profile_last() harvests.
 static constexpr int EV_POOL = 64;
-static constexpr int EV_MARKS = 7;
+static constexpr int EV_MARKS = 8;   // 0..3 sort stage (caller's stream), 4..5 accumulate kernels (internal stream), 6..7 tail
 static hipEvent_t g_ev[EV_POOL][EV_MARKS];
 static bool g_ev_ready = false;
 static bool g_profile = false;
@@ -857,7 +884,10 @@ int msm_profile_last(float ms[LSA_MSM_STAGES]) {
     if (!g_ev_ready || cnt == 0) return 0;
     for (int c = 0; c < cnt; c++) {
         if (hipEventSynchronize(g_ev[c][EV_MARKS - 1]) != hipSuccess) return 0;
-        for (int s = 0; s < 6; s++) { float t = 0.f; (void)hipEventElapsedTime(&t, g_ev[c][s], g_ev[c][s + 1]); ms[s] += t; }
+        // stage -> (from mark, to mark); stage 6 = hand-over from the sort to the accumulate kernel
+        // (waiting for the previous call's accumulate + ordering the buckets by population)
+        static const int span[7][2] = {{0, 1}, {1, 2}, {2, 3}, {4, 5}, {5, 6}, {6, 7}, {3, 4}};
+        for (int s = 0; s < 7; s++) { float t = 0.f; (void)hipEventElapsedTime(&t, g_ev[c][span[s][0]], g_ev[c][span[s][1]]); ms[s] += t; }
         float t = 0.f; (void)hipEventElapsedTime(&t, g_ev[c][0], g_ev[c][EV_MARKS - 1]); ms[7] += t;
     }
     for (int s = 0; s < LSA_MSM_STAGES; s++) ms[s] /= (float)cnt;
@@ -1021,7 +1051,8 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     const uint32_t nb = wide ? B : nwin * B;                                 // wide: one bucket space for all windows
     const uint32_t Bc = wide ? B >> WIDE_FINE_BITS : B;                      // bins of the LDS-ranked sort pass
     const size_t ne = nv * nwin;
-    const uint32_t split = wide ? 1u : 2u;                                   // lanes per bucket in k_accumulate
+    static const uint32_t wide_split = getenv("LSA_WIDE_SPLIT") ? (uint32_t)atoi(getenv("LSA_WIDE_SPLIT")) : 1u;
+    const uint32_t split = wide ? (wide_split == 2 ? 2u : 1u) : 2u;        // lanes per bucket in k_accumulate
     // first reduction level: plain = quads over L buckets (latency), wide = lanes over Lw buckets (throughput)
     const uint32_t L = wide ? std::max<uint32_t>(1, B / 65536) : (B > 4096 ? B / 4096 : 1);
     uint32_t logL = 0;
@@ -1046,19 +1077,19 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     size_t o_offs = carve((size_t)nb * 4);
     const uint32_t nscan = wide ? Bc : nb;           // counters the generic scan runs over
     const uint32_t scan_blocks = (nscan + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;   // <= 1024 since nscan <= 2^20
-    size_t o_bsum = carve((size_t)scan_blocks * 4);
     const uint32_t ngroups = 1;
     size_t o_bins = carve((size_t)3 * ngroups * SIZE_BINS * 4);   // bin_count | bin_start | bin_cursor
     size_t o_perm = carve((size_t)nb * 4);
+    size_t o_entries = carve(ne * 4);
+    size_t o_heavy = carve((size_t)max_heavy * 4);
+    size_t o_choff = carve((size_t)(max_heavy + 1) * 4);
+    size_t o_hpart = carve(max_chunks * sizeof(A));
+    size_t o_bsum = carve((size_t)scan_blocks * 4);
     const uint32_t ntiles = (uint32_t)((nv + SORT_TILE - 1) / SORT_TILE);
     size_t o_digits = carve(ne * 4);
     size_t o_rank = carve(ne * 2);
     size_t o_thist = carve((size_t)nwin * Bc * ntiles * 2);
     size_t o_tbase = carve((size_t)nwin * Bc * ntiles * 4);
-    size_t o_entries = carve(ne * 4);
-    size_t o_heavy = carve((size_t)max_heavy * 4);
-    size_t o_choff = carve((size_t)(max_heavy + 1) * 4);
-    size_t o_hpart = carve(max_chunks * sizeof(A));
     size_t o_recs = carve(wide ? ne * 8 : 0);        // coarse-sorted 64-bit records
     size_t o_chist = carve(wide ? (size_t)Bc * 4 : 0);
     size_t o_coffs = carve(wide ? (size_t)Bc * 4 : 0);
@@ -1072,6 +1103,11 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         }
         HIPCHK(hipEventCreateWithFlags(&g_front_done, hipEventDisableTiming));
     }
+    // (Running the sort of call i+1 beside the accumulate of call i on a third stream was measured
+    // and rejected: with enough hardware queues for real concurrency both kernels slow each other
+    // down by more than the overlap gains -- 1.87 ms per step against 1.70 -- because the
+    // accumulate kernel alone already fills every SIMD's issue slots and register file.)
+    hipStream_t acc = st;
     TailBuf &tb = g_tail[g_slot];
     TailBuf &prev = g_tail[(g_slot + NTAIL - 1) % NTAIL];
     hipStream_t tail = g_overlap ? tb.stream : st;
@@ -1088,27 +1124,28 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         if (t.pending) HIPCHK(hipEventSynchronize(t.done));            // about to reallocate: the old tail must be finished
         if (t.ws.ensure(toff) != 0) { set_error("msm: tail workspace allocation of %zu bytes failed", toff); return LSA_ERR_NOMEM; }
     }
-    if (tb.pending) HIPCHK(hipStreamWaitEvent(st, tb.done, 0));        // the front may not overwrite buckets a tail still reads
+    if (tb.pending) HIPCHK(hipStreamWaitEvent(acc, tb.done, 0));       // the accumulate stage may not overwrite buckets a tail still reads
     char *tws = (char *)tb.ws.ptr;
     char *ws = (char *)g_ws.ptr;
+    char *ws1 = ws;
     uint32_t *hist = (uint32_t *)(ws + o_hist);
     uint32_t *heavy_count = hist + nb;
     uint32_t *offs = (uint32_t *)(ws + o_offs);
-    uint32_t *bsum = (uint32_t *)(ws + o_bsum);
+    uint32_t *bsum = (uint32_t *)(ws1 + o_bsum);
     uint32_t *bin_count = (uint32_t *)(ws + o_bins), *bin_start = bin_count + ngroups * SIZE_BINS, *bin_cursor = bin_start + ngroups * SIZE_BINS;
     uint32_t *perm = (uint32_t *)(ws + o_perm);
-    int32_t *digits = (int32_t *)(ws + o_digits);
-    uint16_t *rank = (uint16_t *)(ws + o_rank);
-    uint16_t *tile_hist = (uint16_t *)(ws + o_thist);
-    uint32_t *tile_base = (uint32_t *)(ws + o_tbase);
+    int32_t *digits = (int32_t *)(ws1 + o_digits);
+    uint16_t *rank = (uint16_t *)(ws1 + o_rank);
+    uint16_t *tile_hist = (uint16_t *)(ws1 + o_thist);
+    uint32_t *tile_base = (uint32_t *)(ws1 + o_tbase);
     uint32_t *entries = (uint32_t *)(ws + o_entries);
     A *buckets = (A *)(tws + o_buckets);
     uint32_t *heavy_list = (uint32_t *)(ws + o_heavy);
     uint32_t *chunk_off = (uint32_t *)(ws + o_choff);
     A *hpart = (A *)(ws + o_hpart);
-    uint64_t *recs = (uint64_t *)(ws + o_recs);
-    uint32_t *hist_c = (uint32_t *)(ws + o_chist);
-    uint32_t *offs_c = (uint32_t *)(ws + o_coffs);
+    uint64_t *recs = (uint64_t *)(ws1 + o_recs);
+    uint32_t *hist_c = (uint32_t *)(ws1 + o_chist);
+    uint32_t *offs_c = (uint32_t *)(ws1 + o_coffs);
     A *wave_out = (A *)(tws + o_wave);
     A *window_sums = (A *)(tws + o_win);
 
@@ -1121,8 +1158,6 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     auto mark = [&](hipStream_t s_) { if (g_profile) (void)hipEventRecord(g_ev[evslot][evi++], s_); };
 
     mark(st);  // 0
-    HIPCHK(hipMemsetAsync(heavy_count, 0, 4, st));
-    HIPCHK(hipMemsetAsync(bin_count, 0, (size_t)3 * ngroups * SIZE_BINS * 4, st));
     static bool lds_attr_set = false;
     if (!lds_attr_set) {   // > 64 KiB of dynamic LDS needs an explicit opt-in
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
@@ -1133,7 +1168,7 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     if (wide) {
         hipLaunchKernelGGL(k_digits_wide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, pl, digits);
         hipLaunchKernelGGL(k_rank, dim3(ntiles, nwin), dim3(1024), (size_t)Bc * 2, st, digits, nv, Bc, ntiles, rank, tile_hist, WIDE_FINE_BITS);
-        hipLaunchKernelGGL(k_tile_scan, dim3((Bc + 255) / 256), dim3(256), 0, st, tile_hist, Bc, nwin * ntiles, Bc, tile_base, hist_c);
+        hipLaunchKernelGGL(k_tile_scan_rows, dim3((Bc + 63) / 64), dim3(1024), 0, st, tile_hist, Bc, nwin * ntiles, tile_base, hist_c);
         mark(st);  // 1
         hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(256), 0, st, hist_c, Bc, bsum);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bsum, scan_blocks);
@@ -1154,24 +1189,28 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         hipLaunchKernelGGL(k_scatter, dim3(ntiles, nwin), dim3(1024), (size_t)B * 4, st, digits, rank, offs, tile_base, nv, n, B, ntiles, entries, 0u);
         mark(st);  // 3
     }
+    // ---- accumulate stage: bucket order, accumulation, heavy buckets
+    HIPCHK(hipMemsetAsync(heavy_count, 0, 4, acc));
+    HIPCHK(hipMemsetAsync(bin_count, 0, (size_t)3 * ngroups * SIZE_BINS * 4, acc));
     {
         const unsigned sb = (nb + 2047) / 2048;
         const uint32_t gsz = 0u;
-        hipLaunchKernelGGL((k_size_hist<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_count, gsz, bin_shift);
-        hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(256), 0, st, bin_count, bin_start, ngroups);
-        hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets, gsz, bin_shift, split);
+        hipLaunchKernelGGL((k_size_hist<C>), dim3(sb), dim3(256), 0, acc, hist, nb, heavy_threshold, bin_count, gsz, bin_shift);
+        hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(256), 0, acc, bin_count, bin_start, ngroups);
+        hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, acc, hist, nb, heavy_threshold, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets, gsz, bin_shift, split);
     }
-    if (wide)
-        hipLaunchKernelGGL((k_accumulate<C, 1u>), dim3((nb + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
+    mark(acc);  // 4
+    if (wide && split == 1)
+        hipLaunchKernelGGL((k_accumulate<C, 1u>), dim3((nb + 255) / 256), dim3(256), 0, acc, d_bases, entries, offs, hist, perm, bin_start, buckets);
     else
-        hipLaunchKernelGGL((k_accumulate<C, 2u>), dim3((nb * 2 + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
-    hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(256), 0, st, hist, heavy_list, heavy_count, chunk_off);
-    hipLaunchKernelGGL((k_accumulate_heavy<C>), dim3(4096), dim3(64), 0, st, d_bases, entries, offs, hist,
+        hipLaunchKernelGGL((k_accumulate<C, 2u>), dim3((nb * 2 + 255) / 256), dim3(256), 0, acc, d_bases, entries, offs, hist, perm, bin_start, buckets);
+    hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(256), 0, acc, hist, heavy_list, heavy_count, chunk_off);
+    hipLaunchKernelGGL((k_accumulate_heavy<C>), dim3(4096), dim3(64), 0, acc, d_bases, entries, offs, hist,
                        heavy_list, heavy_count, chunk_off, hpart);
-    hipLaunchKernelGGL((k_heavy_finish<C>), dim3(256), dim3(64), 0, st, heavy_list, heavy_count, chunk_off, hpart, buckets, split);
-    mark(st);  // 4
-    if (tail != st) {
-        HIPCHK(hipEventRecord(g_front_done, st));
+    hipLaunchKernelGGL((k_heavy_finish<C>), dim3(256), dim3(64), 0, acc, heavy_list, heavy_count, chunk_off, hpart, buckets, split);
+    mark(acc);  // 5
+    if (tail != acc) {
+        HIPCHK(hipEventRecord(g_front_done, acc));
         HIPCHK(hipStreamWaitEvent(tail, g_front_done, 0));
     }
     if (wide)
@@ -1180,14 +1219,14 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         hipLaunchKernelGGL((k_reduce1<C>), dim3(kw * wpw), dim3(64), 0, tail, buckets, B, L, logL, wpw, split, wave_out);
     A *lvl_in = wave_out, *lvl_out = window_sums;
     uint32_t m = wpw, lm = wide ? logL : logL + 4;   // m pairs per window, each covering 2^lm buckets
-    while (m > 1 || lvl_in == wave_out) {            // at least one k_reduce2 level (it leaves the sum in slot 0)
+    do {                                             // at least one k_reduce2 level (it leaves the sum in slot 0)
         const uint32_t m_out = (m + 15) / 16;
         hipLaunchKernelGGL((k_reduce2<C>), dim3(kw * m_out), dim3(64), 0, tail, lvl_in, m, m_out, lm, lvl_out);
         std::swap(lvl_in, lvl_out);
         m = m_out;
         lm += 4;
-    }
-    mark(tail);  // 5
+    } while (m > 1);
+    mark(tail);  // 6
     // lvl_in[2*k] = sum of window k (pairs of (ACC,RUN): stride 2)
     Jac<F> *res = tail != st ? (Jac<F> *)(tws + o_res) : d_out;
     if constexpr (std::is_same<C, CurveG1>::value)
@@ -1199,7 +1238,7 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         static_assert(sizeof(Jac<F>) / 4 <= 64, "one wavefront publishes the result");
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, tail, (const uint32_t *)res, (uint32_t *)d_out, (unsigned)(sizeof(Jac<F>) / 4));
     }
-    mark(tail);  // 6
+    mark(tail);  // 7
     HIPCHK(hipEventRecord(tb.done, tail));
     tb.pending = true;
     tb.unjoined = (tail != st);
