@@ -111,13 +111,14 @@ int lsa_g1_bases_create(const void *bases_jac, size_t n, int src_on_device, lsa_
 int lsa_g2_bases_create(const void *bases_jac, size_t n, int src_on_device, lsa_bases **out);
 void lsa_bases_destroy(lsa_bases *b);
 size_t lsa_bases_size(const lsa_bases *b);
-/* Resident vectors of at least `threshold` points (default 2^19; env LSA_PRECOMPUTE_MIN) also keep
- * pre-shifted copies 2^(s_k)*P_i, one per window of a decomposition of the 255 scalar bits into
- * 13 (n < 6*2^20) or 12 windows of at most 20 / 22 bits (G1: 13 x 64 B, G2: 13 x 128 B per point;
- * LSA_PRECOMPUTE=0 disables).  MSMs of at least `threshold` pairs on such a handle then run over
- * ONE bucket space shared by all windows: 13 bucket additions per pair instead of 16, no GLV
- * beta-multiplications, one bucket reduction, no Horner fold.  lsa_msm_set_table_threshold(0)
- * restores the default; lsa_bases_has_table() tells whether a handle carries the copies. */
+/* Resident vectors of at least 2^19 points (env LSA_PRECOMPUTE_MIN) also keep pre-shifted copies
+ * 2^(10j)*P_i, j < 26 (2^(11j), j < 24, from 6*2^20 points on; G1 64 B, G2 128 B per point and copy;
+ * LSA_PRECOMPUTE=0 disables).  Every MSM on such a handle then runs over ONE bucket space shared by
+ * all windows: 13 (12) bucket additions per pair instead of 16 and no GLV beta-multiplications for
+ * n >= 2^16, 26 narrow digits and only 512 buckets to reduce below; one bucket reduction, no
+ * Horner fold.  lsa_msm_set_table_threshold(t), t != 0: vectors of at least t points get the
+ * copies and only MSMs of at least t pairs use them (tests); 0 restores the defaults.
+ * lsa_bases_has_table() tells whether a handle carries the copies. */
 void lsa_msm_set_table_threshold(size_t threshold);
 int lsa_bases_has_table(const lsa_bases *b);
 unsigned lsa_bases_table_windows(const lsa_bases *b);   /* 0 without the copies */
@@ -136,6 +137,19 @@ int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars_mont
 /* Same, asynchronous: result is written to the DEVICE buffer d_out_jac; it is ordered on
  * lsa_stream() after lsa_stream_join() (or any synchronous call). */
 int lsa_msm_run_async(const lsa_bases *bases, size_t first, const void *d_scalars_mont, size_t n, void *d_out_jac);
+
+/* Several independent MSMs over PREFIXES of the same resident bases in one pass -- the ladder
+ * of CPPoly::prove (src/gadgets/poly.h:77-86: witness[i] = multiExpMA(g1s, w[start_i ..
+ * start_i + 2^(d-1-i))), whose scalar slices are consecutive in one array):
+ *   d_out_jac[j] = sum_i d_scalars[seg_offsets[j] + i] * bases[first + i],
+ *                  i < seg_offsets[j+1] - seg_offsets[j],      j < nseg <= 64.
+ * seg_offsets: HOST array of nseg + 1 non-decreasing element offsets into d_scalars_mont (device).
+ * d_out_jac: DEVICE, nseg points (infinity for an empty segment).  The bases must carry the
+ * pre-shifted copies (lsa_bases_has_table).  Meant for segments of up to about 2^16 pairs (each
+ * is cut into 26 ten-bit digits over 512 buckets of its own); longer ones are better issued
+ * through lsa_msm_run_async.  Asynchronous like lsa_msm_run_async. */
+int lsa_msm_run_segments_async(const lsa_bases *bases, size_t first, const void *d_scalars_mont, const uint64_t *seg_offsets, size_t nseg,
+                               void *d_out_jac);
 
 /* Window width (bits) the MSM uses for n pairs -- exposed for DESIGN.md / tests. */
 unsigned lsa_msm_window_bits(size_t n);

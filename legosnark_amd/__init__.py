@@ -78,6 +78,7 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         for name in ("lsa_g1_msm", "lsa_g2_msm"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+        L.lsa_msm_run_segments_async.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         for name in ("lsa_msm_run", "lsa_msm_run_async"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
         for name in ("lsa_g1_normalize", "lsa_g2_normalize"):
@@ -340,6 +341,14 @@ class Bases:
             n = self.n - first
         _after_torch(d_scalars, d_out)
         _check(lib().lsa_msm_run_async(self.handle, first, _ptr(d_scalars), n, _ptr(d_out)))
+
+    def msm_segments_async(self, d_scalars, offsets, d_outs, first=0):
+        """len(offsets) - 1 independent MSMs in one pass: result j = sum_i d_scalars[offsets[j] + i] *
+        bases[first + i] (prefixes of these bases; CPPoly::prove's ladder).  d_outs: device tensor of
+        len(offsets) - 1 points.  Needs has_table()."""
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _after_torch(d_scalars, d_outs)
+        _check(lib().lsa_msm_run_segments_async(self.handle, first, _ptr(d_scalars), _host_ptr(off), len(off) - 1, _ptr(d_outs)))
 
     def msm_sharded_async(self, d_scalars, d_out, n=None, first=0):
         """This rank's slice of a sharded MSM + the RCCL exchange step; d_out (device) receives the

@@ -201,6 +201,23 @@ int lsa_msm_run_async(const lsa_bases *bases, size_t first, const void *d_scalar
     return msm_device<Fq2>(bases->d_aff, first, (const Fr *)d_scalars, n, (Jac<Fq2> *)d_out_jac, g.stream, bases->table_stride);
 }
 
+int lsa_msm_run_segments_async(const lsa_bases *bases, size_t first, const void *d_scalars, const uint64_t *seg_offsets, size_t nseg,
+                               void *d_out_jac) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (nseg == 0) return LSA_OK;
+    if (!bases || !d_out_jac || !seg_offsets || !d_scalars) { set_error("msm_run_segments: null argument"); return LSA_ERR_INVALID; }
+    if (!bases->table_stride) { set_error("msm_run_segments: the bases carry no pre-shifted copies (lsa_bases_has_table)"); return LSA_ERR_INVALID; }
+    for (size_t j = 0; j < nseg; j++) {
+        if (seg_offsets[j + 1] < seg_offsets[j]) { set_error("msm_run_segments: offsets must not decrease"); return LSA_ERR_INVALID; }
+        const size_t len = seg_offsets[j + 1] - seg_offsets[j];
+        if (first > bases->n || len > bases->n - first) { set_error("msm_run_segments: segment %zu of %zu pairs exceeds the %zu bases", j, len, bases->n); return LSA_ERR_INVALID; }
+    }
+    if (bases->group == 1)
+        return msm_segments_device<Fq>(bases->d_aff, first, (const Fr *)d_scalars, seg_offsets, nseg, (Jac<Fq> *)d_out_jac, g.stream, bases->table_stride);
+    return msm_segments_device<Fq2>(bases->d_aff, first, (const Fr *)d_scalars, seg_offsets, nseg, (Jac<Fq2> *)d_out_jac, g.stream, bases->table_stride);
+}
+
 int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars, size_t n, void *out_jac) {
     int rc = lsa_msm_run_async(bases, first, d_scalars, n, g.d_result);
     if (rc) return rc;

@@ -31,6 +31,11 @@ size_t msm_base_bytes(int group);
 // when n >= msm_merge_min() ("wide windows", msm.hip).
 template <class F>
 int msm_device(const void *d_bases, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride = 0);
+// nseg independent MSMs over prefixes of the same table-carrying bases in one pass (msm.hip):
+// result j = sum_i d_scalars[seg_off[j] + i] * bases[first + i], i < seg_off[j+1] - seg_off[j].
+template <class F>
+int msm_segments_device(const void *d_bases, size_t first, const Fr *d_scalars, const uint64_t *seg_off, size_t nseg, Jac<F> *d_out,
+                        hipStream_t st, size_t table_stride);
 unsigned msm_table_windows(int group, size_t n);
 unsigned msm_field_mults_per_pair(size_t n, size_t table_n);
 size_t msm_merge_min();

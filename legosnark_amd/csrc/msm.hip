@@ -292,68 +292,110 @@ __global__ __launch_bounds__(1024) void k_scatter(const int32_t *__restrict__ di
 // second pass writes every row's base.
 __global__ __launch_bounds__(1024) void k_tile_scan_rows(const uint16_t *__restrict__ tile_hist, uint32_t Bc, uint32_t R,
                                                          uint32_t *__restrict__ tile_base, uint32_t *__restrict__ hist) {
-    __shared__ uint32_t part[16][64];
+    // 32 bins x 32 row groups per workgroup: lane -> (bin = lane & 31, group = 2 * wavefront + (lane >> 5))
+    __shared__ uint32_t part[32][33];
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t b = blockIdx.x * 64 + lane;
-    const uint32_t per = (R + 15) / 16, r0 = wv * per, r1 = r0 + per < R ? r0 + per : R;
+    const unsigned bl = lane & 31, grp = 2 * wv + (lane >> 5);
+    const uint32_t b = blockIdx.x * 32 + bl;
+    const uint32_t per = (R + 31) / 32, r0 = grp * per, r1 = r0 + per < R ? r0 + per : R;
+    constexpr uint32_t MAXPER = 16;                  // rows held in registers (R <= 512: n <= 2^20 at 13 windows)
+    uint32_t v[MAXPER];
     uint32_t sum = 0;
-    if (b < Bc) for (uint32_t r = r0; r < r1; r++) sum += tile_hist[(size_t)r * Bc + b];
-    part[wv][lane] = sum;
+    const bool in_regs = per <= MAXPER;
+    if (in_regs) {
+#pragma unroll
+        for (uint32_t j = 0; j < MAXPER; j++) {
+            const uint32_t r = r0 + j;
+            v[j] = (b < Bc && r < r1) ? tile_hist[(size_t)r * Bc + b] : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < MAXPER; j++) sum += v[j];
+    } else if (b < Bc) {
+        for (uint32_t r = r0; r < r1; r++) sum += tile_hist[(size_t)r * Bc + b];
+    }
+    part[grp][bl] = sum;
     __syncthreads();
     uint32_t run = 0, tot = 0;
 #pragma unroll
-    for (unsigned w = 0; w < 16; w++) { uint32_t x = part[w][lane]; if (w < wv) run += x; tot += x; }
+    for (unsigned g2 = 0; g2 < 32; g2++) { uint32_t x = part[g2][bl]; if (g2 < grp) run += x; tot += x; }
     if (b < Bc) {
-        for (uint32_t r = r0; r < r1; r++) {
-            const size_t idx = (size_t)r * Bc + b;
-            tile_base[idx] = run;
-            run += tile_hist[idx];
+        if (in_regs) {
+#pragma unroll
+            for (uint32_t j = 0; j < MAXPER; j++) {
+                const uint32_t r = r0 + j;
+                if (r < r1) { tile_base[(size_t)r * Bc + b] = run; run += v[j]; }
+            }
+        } else {
+            for (uint32_t r = r0; r < r1; r++) {
+                const size_t idx = (size_t)r * Bc + b;
+                tile_base[idx] = run;
+                run += tile_hist[idx];
+            }
         }
-        if (wv == 0) hist[b] = tot;
+        if (grp == 0) hist[b] = tot;
     }
 }
 
 // ------------------------------------------------------------------------------------
 // Wide-window path (resident bases with pre-shifted copies, see "Wide windows" below).
-// The bucket index has up to 21 bits -- too many for an LDS histogram -- so the sort runs in two
-// passes: (A) k_rank / k_tile_scan / k_scatter_wide partition all nwin*n entries by the COARSE
-// bin (bucket >> 7; 4096 or 16384 bins, a tile's histogram fits LDS) into 64-bit records
-// (fine bits | entry); (B) k_fine_sort, one workgroup per coarse bin, counts its 128 fine
-// buckets in LDS and places the 32-bit entries, writing the per-bucket populations and offsets.
+// Every entry is (bin, point reference): bin = segment * B + bucket.  With B = 2^(c-1) up to 2^21
+// the bin space can be too large for an LDS histogram; then the sort runs in two passes:
+// (A) k_rank / k_tile_scan_rows / k_scatter_wide<true> partition all entries by the COARSE bin
+// (bin >> 7; a tile's histogram fits LDS) into 64-bit records (fine bits | entry); (B)
+// k_fine_sort, one workgroup per coarse bin, counts its 128 fine bins in LDS and places the
+// 32-bit entries, writing the per-bin populations and offsets.  With at most 32768 bins (the
+// narrow digits used for small inputs and for segmented calls) pass A alone sorts completely.
 // ------------------------------------------------------------------------------------
 #define WIDE_FINE_BITS 7u
+#define MSM_MAX_SEGMENTS 64u
 struct WidePlan {
-    unsigned nwin, cmax;
-    unsigned c[32];       // window widths (sum = 255)
-    unsigned s[32];       // window start bits
+    unsigned nwin;        // digits per scalar
+    unsigned c;           // window width: window k covers bits [c*k, min(c*k + c, 255))
+    unsigned copy_step;   // window k gathers from table copy k * copy_step
+    unsigned g;           // granularity of the table: copy j holds 2^(g*j) * P
+};
+// scalar slices of a segmented call: segment j = scalars[off[j] .. off[j+1]) against bases[0 .. len_j)
+struct SegList {
+    uint32_t nseg;
+    uint32_t off[MSM_MAX_SEGMENTS + 1];
 };
 
-__global__ __launch_bounds__(256) void k_digits_wide(const Fr *__restrict__ scalars, size_t n, WidePlan pl, int32_t *__restrict__ digits) {
+// digits[k][i] = +-(segment * B + |digit|), 0 for a zero digit; local_idx[i] = index inside the segment
+__global__ __launch_bounds__(256) void k_digits_wide(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B,
+                                                     int32_t *__restrict__ digits, uint32_t *__restrict__ local_idx) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    uint32_t seg = 0;
+    for (uint32_t j = 1; j < segs.nseg; j++) if (i >= segs.off[j]) seg = j;
+    if (local_idx) local_idx[i] = (uint32_t)i - segs.off[seg];
     uint32_t s[8];
     scalars[i].to_canonical(s);
     uint32_t carry = 0;
+    const unsigned c = pl.c;
     for (unsigned k = 0; k < pl.nwin; k++) {
-        const unsigned bit = pl.s[k], c = pl.c[k];
+        const unsigned bit = c * k;
+        const unsigned width = bit + c <= 255 ? c : 255 - bit;
         const int w = (int)(bit >> 5);
         const unsigned sh = bit & 31;
         uint64_t two = (uint64_t)(w < 8 ? s[w] : 0) | ((uint64_t)(w + 1 < 8 ? s[w + 1] : 0) << 32);
-        uint32_t d = (uint32_t)(two >> sh) & ((1u << c) - 1);
+        uint32_t d = (uint32_t)(two >> sh) & ((1u << width) - 1);
         d += carry;
         int32_t sd;
         // the top window is never recoded: scalars are < 2^254 and the windows cover 255 bits, so
-        // its raw value is < 2^(c-1) and the carry keeps it <= 2^(c-1)
+        // its raw value is < 2^(width-1) and the carry keeps it <= 2^(width-1) <= B
         if (k + 1 < pl.nwin && d >= (1u << (c - 1))) { sd = (int32_t)d - (int32_t)(1u << c); carry = 1; }
         else { sd = (int32_t)d; carry = 0; }
+        if (sd != 0) { const int32_t m = (int32_t)(seg * B) + (sd < 0 ? -sd : sd); sd = sd < 0 ? -m : m; }
         digits[(size_t)k * n + i] = sd;
     }
 }
 
+// FINE: 64-bit records (fine bits | entry) ordered by coarse bin; else the final 32-bit entries
+template <bool FINE>
 __global__ __launch_bounds__(1024) void k_scatter_wide(const int32_t *__restrict__ digits, const uint16_t *__restrict__ rank,
                                                        const uint32_t *__restrict__ offs, const uint32_t *__restrict__ tile_base,
-                                                       size_t n, uint32_t Bc, uint32_t ntiles, uint64_t *__restrict__ recs,
-                                                       uint32_t win_stride) {
+                                                       const uint32_t *__restrict__ local_idx, size_t n, uint32_t Bc, uint32_t ntiles,
+                                                       void *__restrict__ out, uint32_t win_stride) {
     extern __shared__ __attribute__((aligned(16))) uint32_t base[];   // Bc words
     const uint32_t t = blockIdx.x, k = blockIdx.y;
     const uint32_t *tb = tile_base + ((size_t)k * ntiles + t) * Bc;
@@ -366,9 +408,11 @@ __global__ __launch_bounds__(1024) void k_scatter_wide(const int32_t *__restrict
     for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
         int32_t sd = dg[i];
         if (sd != 0) {
-            uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
-            uint32_t ent = ((uint32_t)i + k * win_stride) | (sd < 0 ? 0x80000000u : 0u);   // window k reads its own copy of the bases
-            recs[base[b >> WIDE_FINE_BITS] + rk[i]] = ((uint64_t)(b & ((1u << WIDE_FINE_BITS) - 1)) << 32) | ent;
+            const uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
+            const uint32_t j = local_idx ? local_idx[i] : (uint32_t)i;
+            const uint32_t ent = (j + k * win_stride) | (sd < 0 ? 0x80000000u : 0u);   // window k reads its own copy of the bases
+            if (FINE) ((uint64_t *)out)[base[b >> WIDE_FINE_BITS] + rk[i]] = ((uint64_t)(b & ((1u << WIDE_FINE_BITS) - 1)) << 32) | ent;
+            else ((uint32_t *)out)[base[b] + rk[i]] = ent;
         }
     }
 }
@@ -769,10 +813,21 @@ __global__ __launch_bounds__(64) void k_fold_quad_g2(const XYZZ29x2 *__restrict_
     fold_quad_body(window_sums, nwin, c, out);
 }
 
-// publishes a slot's result into the caller's buffer (a 96/192-byte hipMemcpyAsync costs ~30 us
-// as a runtime copy kernel; this is one wavefront)
-__global__ __launch_bounds__(64) void k_publish(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, unsigned words) {
-    if (threadIdx.x < words) dst[threadIdx.x] = src[threadIdx.x];
+// segmented calls: window j's sum (slot 2j of the last reduction level) -> result j
+template <class A, class J>
+__device__ __forceinline__ void emit_body(const A *__restrict__ window_sums, J *__restrict__ out) {
+    if (threadIdx.x != 0) return;
+    A r = window_sums[2 * (size_t)blockIdx.x];
+    if constexpr (std::is_same<A, XYZZ29>::value) out[blockIdx.x] = xyzz29_to_jac(r);
+    else out[blockIdx.x] = g2_to_jac(r);
+}
+__global__ __launch_bounds__(64) void k_emit_g1(const XYZZ29 *__restrict__ window_sums, Jac<Fq> *__restrict__ out) { emit_body(window_sums, out); }
+__global__ __launch_bounds__(64) void k_emit_g2(const XYZZ29x2 *__restrict__ window_sums, Jac<Fq2> *__restrict__ out) { emit_body(window_sums, out); }
+
+// publishes a slot's result(s) into the caller's buffer (a 96/192-byte hipMemcpyAsync costs ~30 us
+// as a runtime copy kernel; this is one small workgroup)
+__global__ __launch_bounds__(256) void k_publish(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, unsigned words) {
+    for (unsigned i = threadIdx.x; i < words; i += 256) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------------------------
@@ -939,43 +994,45 @@ template int normalize_to_affine<Fq2>(const Jac<Fq2> *, Aff<Fq2> *, size_t, hipS
 
 // ------------------------------------------------------------------------------------
 // Wide windows over pre-shifted bases.  A resident CRS can carry, next to P_i, the multiples
-// 2^(s_k) * P_i for every window k of a decomposition into nwin windows of c_k <= cmax bits
-// (window-major: entry k*N + i).  Window k then gathers from its own copy, so a digit d of ANY
-// window is "add d * (its copy's point)": all windows share ONE bucket space in which bucket b has
-// weight b+1.  Consequences:
-//   * c is no longer tied to the per-window bucket count: cmax = 20 (n < 6*2^20) or 22 gives 13 or
-//     12 digits per scalar instead of 16 -- 13 mixed additions per pair, and no GLV (its only
-//     gain, fewer windows to reduce and fold, is moot), so no beta-multiplications either:
-//     130 field products per pair instead of 168.
-//   * one reduction over 2^(cmax-1) buckets instead of nwin reductions, and no Horner fold
+// 2^(g*j) * P_i, j < ceil(255/g) (window-major: entry j*N + i; g = 10, or 11 for very large
+// vectors).  A digit of width c = g or 2g at bit position c*k then gathers from copy k*(c/g), so
+// a digit d of ANY window is "add d * (its copy's point)": all windows share ONE bucket space in
+// which bucket b has weight b+1.  Consequences:
+//   * c is no longer tied to the per-window bucket count.  Large inputs (n >= 2^16) use c = 2g:
+//     13 (12) digits per scalar instead of 16 -- 13 mixed additions per pair -- and no GLV (its only
+//     gain, fewer windows to reduce and fold, is moot), so no beta-multiplications either: 130
+//     field products per pair instead of 168.  Smaller inputs use c = g: 26 digits, but only
+//     2^(g-1) buckets to reduce.
+//   * one reduction over 2^(c-1) buckets instead of nwin reductions, and no Horner fold
 //     (c*(nwin-1) sequential doublings: 0.3 ms G1 / 1.8 ms G2 of pure latency).
-// Price: nwin x the base memory (G1 13 x 64 B, G2 13 x 128 B per point) and one pass of
-// sum(c_k) doublings + nwin batch normalisations per key.
+//   * several independent MSMs over prefixes of the same bases (CPPoly::prove's ladder,
+//     /root/reference/src/gadgets/poly.h:77-86) run as ONE pass: segment j owns the bins
+//     [j*B, (j+1)*B) of one sorted entry array (msm_segments_device).
+// Price: 26 (24) x the base memory (G1 64 B, G2 128 B per point and copy) and one pass of 255
+// doublings + 26 batch normalisations per key.
 // ------------------------------------------------------------------------------------
-static WidePlan wide_plan(size_t n_table) {
-    static const int forced = getenv("LSA_WIDE_C") ? atoi(getenv("LSA_WIDE_C")) : 0;
-    unsigned lg = 0;
-    while ((size_t(1) << (lg + 1)) <= n_table) lg++;
-    unsigned cmax = n_table >= (size_t)6 << 20 ? 22 : (lg > 20 ? 20 : lg);
-    if (cmax < 12) cmax = 12;                       // tables forced on tiny vectors (tests)
-    if (forced >= 9 && forced <= 24) cmax = (unsigned)forced;
+static unsigned table_granularity(size_t n_table) { return n_table >= ((size_t)6 << 20) ? 11u : 10u; }
+static unsigned table_copies(size_t n_table) { const unsigned g = table_granularity(n_table); return (255 + g - 1) / g; }
+static size_t wide_big_min() {
+    static const size_t v = getenv("LSA_WIDE_BIG_MIN") ? (size_t)atoll(getenv("LSA_WIDE_BIG_MIN")) : (size_t)1 << 16;
+    return v;
+}
+static WidePlan wide_plan(size_t n_table, size_t n_call, unsigned nseg) {
     WidePlan pl;
-    pl.cmax = cmax;
-    pl.nwin = (255 + cmax - 1) / cmax;
-    const unsigned base = 255 / pl.nwin, rem = 255 % pl.nwin;
-    unsigned bit = 0;
-    for (unsigned k = 0; k < 32; k++) {
-        pl.c[k] = k < pl.nwin ? base + (k < rem ? 1u : 0u) : 0u;
-        pl.s[k] = bit;
-        bit += pl.c[k];
-    }
-    pl.cmax = pl.c[0];                              // widest window (base + 1 when rem != 0)
+    pl.g = table_granularity(n_table);
+    const bool big = nseg == 1 && n_call >= wide_big_min();
+    pl.c = big ? 2 * pl.g : pl.g;
+    pl.copy_step = pl.c / pl.g;
+    pl.nwin = (255 + pl.c - 1) / pl.c;
     return pl;
 }
-unsigned msm_table_windows(int /*group*/, size_t n) { return wide_plan(n).nwin; }
+unsigned msm_table_windows(int /*group*/, size_t n) { return table_copies(n); }
 
 static size_t g_merge_min = 0;
-void msm_set_merge_min(size_t n) { g_merge_min = n; }     // 0: back to LSA_PRECOMPUTE_MIN / the default
+static bool g_merge_min_explicit = false;
+// n != 0: vectors of at least n points get the copies and MSMs of at least n pairs use them;
+// 0: defaults (copies from LSA_PRECOMPUTE_MIN / 2^19 points on, used by MSMs of every size)
+void msm_set_merge_min(size_t n) { g_merge_min = n; g_merge_min_explicit = n != 0; }
 size_t msm_merge_min() {
     if (g_merge_min == 0) {
         const char *e = getenv("LSA_PRECOMPUTE_MIN");
@@ -983,6 +1040,7 @@ size_t msm_merge_min() {
     }
     return g_merge_min;
 }
+static size_t table_use_min() { return g_merge_min_explicit ? msm_merge_min() : 1; }
 
 template <class C>
 __global__ __launch_bounds__(256) void k_shift_window(const typename C::Base *__restrict__ prev, Jac<typename C::Field> *__restrict__ out,
@@ -994,18 +1052,18 @@ __global__ __launch_bounds__(256) void k_shift_window(const typename C::Base *__
     out[i] = C::to_jac(p);
 }
 
-// d_table: msm_table_windows(group, n) * n entries, window 0 (= the bases) already filled.
+// d_table: msm_table_windows(group, n) * n entries, copy 0 (= the bases) already filled.
 template <class F>
 int precompute_windows(void *d_table, size_t n, hipStream_t st) {
     using C = typename CurveOf<F>::type;
     if (n == 0) return LSA_OK;
-    const WidePlan pl = wide_plan(n);
+    const unsigned g = table_granularity(n), copies = table_copies(n);
     Jac<F> *tmp = nullptr;
     if (hipMalloc(&tmp, n * sizeof(Jac<F>)) != hipSuccess) { set_error("precompute_windows: hipMalloc failed"); return LSA_ERR_NOMEM; }
     typename C::Base *tbl = (typename C::Base *)d_table;
     int rc = LSA_OK;
-    for (unsigned k = 1; k < pl.nwin && !rc; k++) {
-        hipLaunchKernelGGL((k_shift_window<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tbl + (size_t)(k - 1) * n, tmp, n, pl.c[k - 1]);
+    for (unsigned k = 1; k < copies && !rc; k++) {
+        hipLaunchKernelGGL((k_shift_window<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tbl + (size_t)(k - 1) * n, tmp, n, g);
         rc = prepare_bases<F>(tmp, tbl + (size_t)k * n, n, st);
     }
     hipError_t e = hipStreamSynchronize(st);
@@ -1019,52 +1077,55 @@ template int precompute_windows<Fq2>(void *, size_t, hipStream_t);
 
 // field multiplications per point-scalar pair in the accumulate kernel (bench.py's VALU roofline)
 unsigned msm_field_mults_per_pair(size_t n, size_t table_n) {
-    if (table_n && n >= msm_merge_min()) return wide_plan(table_n).nwin * 10;       // mixed XYZZ addition: 8M + 2S
-    return 16 * 10 + 8;                                                              // 16 additions + 8 beta-multiplications (GLV)
+    if (table_n && n >= table_use_min()) return wide_plan(table_n, n, 1).nwin * 10;   // mixed XYZZ addition: 8M + 2S
+    return 16 * 10 + 8;                                                                // 16 additions + 8 beta-multiplications (GLV)
 }
 
+// The whole pipeline.  segs.nseg == 1: one MSM over n = segs.off[1] pairs.  segs.nseg > 1 (wide path
+// only): segment j multiplies scalars[off[j] .. off[j+1]) with bases[first .. first + len_j) and
+// d_out receives nseg points.
 template <class F>
-int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride) {
+static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars, const SegList &segs, Jac<F> *d_out, hipStream_t st,
+                        size_t table_stride) {
     using C = typename CurveOf<F>::type;
     using A = typename C::Acc;
     const typename C::Base *d_bases = (const typename C::Base *)d_bases_v + first;
-    if (n == 0) {
-        int jr = msm_join(st);
-        if (jr) return jr;
-        Jac<F> inf = Jac<F>::inf();
-        HIPCHK(hipMemcpyAsync(d_out, &inf, sizeof inf, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
-        return LSA_OK;
-    }
+    const uint32_t nseg = segs.nseg;
+    const size_t n = segs.off[nseg];
     if (n >= (size_t(1) << 27)) { set_error("msm: n too large (%zu)", n); return LSA_ERR_INVALID; }
-    const bool wide = table_stride != 0 && n >= msm_merge_min();
+    const bool wide = table_stride != 0 && (nseg > 1 || n >= table_use_min());
+    if (nseg > 1 && !wide) { set_error("msm: segmented calls need bases with pre-shifted copies"); return LSA_ERR_INVALID; }
     WidePlan pl = {};
     if (wide) {
-        pl = wide_plan(table_stride);
-        if ((uint64_t)table_stride * pl.nwin >= (1u << 30)) { set_error("msm: base table too large for 30-bit entries"); return LSA_ERR_INVALID; }
+        pl = wide_plan(table_stride, n, nseg);
+        if ((uint64_t)table_stride * table_copies(table_stride) >= (1u << 30)) { set_error("msm: base table too large for 30-bit entries"); return LSA_ERR_INVALID; }
     }
     const bool glv = C::GLV && !wide;
-    const unsigned c = wide ? pl.cmax : msm_window_bits(glv ? 2 * n : n);    // plain path: sized by the virtual scalars
+    const unsigned c = wide ? pl.c : msm_window_bits(glv ? 2 * n : n);       // plain path: sized by the virtual scalars
     const unsigned nwin = wide ? pl.nwin : (glv ? (128 + c - 1) / c : num_windows(c));   // |k1|,|k2| < 2^127 (glv.h)
     const size_t nv = glv ? 2 * n : n;                                       // virtual scalars
     const uint32_t B = 1u << (c - 1);
-    const uint32_t nb = wide ? B : nwin * B;                                 // wide: one bucket space for all windows
-    const uint32_t Bc = wide ? B >> WIDE_FINE_BITS : B;                      // bins of the LDS-ranked sort pass
+    const uint32_t nb = wide ? nseg * B : nwin * B;                          // wide: one bucket space per segment, shared by all windows
+    if (wide && (uint64_t)nseg * B > (1u << 21)) { set_error("msm: %u segments of %u buckets exceed the bin space", nseg, B); return LSA_ERR_INVALID; }
+    const bool fine = wide && nb > 32768;                                    // two-pass sort
+    const uint32_t Bc = !wide ? B : (fine ? nb >> WIDE_FINE_BITS : nb);      // bins of the LDS-ranked sort pass
     const size_t ne = nv * nwin;
+    const bool big = wide && B > 4096;                                       // throughput-shaped reduction
     static const uint32_t wide_split = getenv("LSA_WIDE_SPLIT") ? (uint32_t)atoi(getenv("LSA_WIDE_SPLIT")) : 1u;
     const uint32_t split = wide ? (wide_split == 2 ? 2u : 1u) : 2u;        // lanes per bucket in k_accumulate
-    // first reduction level: plain = quads over L buckets (latency), wide = lanes over Lw buckets (throughput)
-    const uint32_t L = wide ? std::max<uint32_t>(1, B / 65536) : (B > 4096 ? B / 4096 : 1);
+    // first reduction level: quads over L buckets (latency) or, for 2^19+ buckets, lanes over L buckets (throughput)
+    const uint32_t L = big ? std::max<uint32_t>(1, B / 65536) : (B > 4096 ? B / 4096 : 1);
     uint32_t logL = 0;
     while ((1u << logL) < L) logL++;
     const uint32_t T = B / L;                        // first-level segments per window
-    const uint32_t wpw = wide ? T : (T + 15) / 16;   // (ACC,RUN) pairs per window leaving level 1
-    const uint32_t kw = wide ? 1 : nwin;             // windows leaving the reduction
-    // Buckets far above the average population (skewed scalars; the partly filled top window
-    // when c does not divide the scalar length) are split across workgroups instead of being
-    // walked by their owner lanes.
+    const uint32_t wpw = big ? T : (T + 15) / 16;    // (ACC,RUN) pairs per window leaving level 1
+    const uint32_t kw = wide ? nseg : nwin;          // bucket spaces ("windows") entering the reduction
+    // Buckets far above the average population (skewed scalars; the partly filled top window)
+    // are split across workgroups instead of being walked by their owner lanes.  With narrow
+    // digits every bucket is long (26*n/512 entries), and the point of that path is latency:
+    // anything above 32 entries is cut into chunks summed by a wavefront each.
     const uint32_t avg_pop = (uint32_t)(ne / nb + 1);
-    const uint32_t heavy_threshold = std::max<uint32_t>(64, 2 * avg_pop + 32);
+    const uint32_t heavy_threshold = (wide && !big) ? 32u : std::max<uint32_t>(64, 2 * avg_pop + 32);
     uint32_t bin_shift = 0;                          // populations above 1024 share bins (the order only balances wavefronts)
     while (((heavy_threshold - 1) >> bin_shift) + 1 > SIZE_BINS - 1) bin_shift++;
     const uint32_t max_heavy = (uint32_t)std::min<size_t>(nb, ne / heavy_threshold + 1);
@@ -1077,22 +1138,23 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     size_t o_offs = carve((size_t)nb * 4);
     const uint32_t nscan = wide ? Bc : nb;           // counters the generic scan runs over
     const uint32_t scan_blocks = (nscan + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;   // <= 1024 since nscan <= 2^20
+    size_t o_bsum = carve((size_t)scan_blocks * 4);
     const uint32_t ngroups = 1;
     size_t o_bins = carve((size_t)3 * ngroups * SIZE_BINS * 4);   // bin_count | bin_start | bin_cursor
     size_t o_perm = carve((size_t)nb * 4);
-    size_t o_entries = carve(ne * 4);
-    size_t o_heavy = carve((size_t)max_heavy * 4);
-    size_t o_choff = carve((size_t)(max_heavy + 1) * 4);
-    size_t o_hpart = carve(max_chunks * sizeof(A));
-    size_t o_bsum = carve((size_t)scan_blocks * 4);
     const uint32_t ntiles = (uint32_t)((nv + SORT_TILE - 1) / SORT_TILE);
     size_t o_digits = carve(ne * 4);
     size_t o_rank = carve(ne * 2);
     size_t o_thist = carve((size_t)nwin * Bc * ntiles * 2);
     size_t o_tbase = carve((size_t)nwin * Bc * ntiles * 4);
-    size_t o_recs = carve(wide ? ne * 8 : 0);        // coarse-sorted 64-bit records
-    size_t o_chist = carve(wide ? (size_t)Bc * 4 : 0);
-    size_t o_coffs = carve(wide ? (size_t)Bc * 4 : 0);
+    size_t o_entries = carve(ne * 4);
+    size_t o_heavy = carve((size_t)max_heavy * 4);
+    size_t o_choff = carve((size_t)(max_heavy + 1) * 4);
+    size_t o_hpart = carve(max_chunks * sizeof(A));
+    size_t o_recs = carve(fine ? ne * 8 : 0);        // coarse-sorted 64-bit records
+    size_t o_chist = carve(fine ? (size_t)Bc * 4 : 0);
+    size_t o_coffs = carve(fine ? (size_t)Bc * 4 : 0);
+    size_t o_lidx = carve(nseg > 1 ? n * 4 : 0);     // index of every scalar inside its segment
     if (g_ws.ensure(off) != 0) { set_error("msm: workspace allocation of %zu bytes failed", off); return LSA_ERR_NOMEM; }
     // tail buffers of this call parity
     if (g_overlap < 0) g_overlap = getenv("LSA_NO_OVERLAP") ? 0 : 1;
@@ -1107,7 +1169,6 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     // and rejected: with enough hardware queues for real concurrency both kernels slow each other
     // down by more than the overlap gains -- 1.87 ms per step against 1.70 -- because the
     // accumulate kernel alone already fills every SIMD's issue slots and register file.)
-    hipStream_t acc = st;
     TailBuf &tb = g_tail[g_slot];
     TailBuf &prev = g_tail[(g_slot + NTAIL - 1) % NTAIL];
     hipStream_t tail = g_overlap ? tb.stream : st;
@@ -1116,7 +1177,7 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     size_t o_buckets = tcarve((size_t)nb * split * sizeof(A));
     size_t o_wave = tcarve((size_t)kw * wpw * 2 * sizeof(A));
     size_t o_win = tcarve((size_t)kw * ((wpw + 15) / 16) * 2 * sizeof(A));   // reduction levels ping-pong between the two
-    size_t o_res = tcarve(sizeof(Jac<F>));                                     // this call's result before it is published
+    size_t o_res = tcarve((size_t)nseg * sizeof(Jac<F>));                      // this call's result(s) before they are published
     // all slots grow together, so that a new problem size pays its allocations in one call
     // instead of once per slot
     for (auto &t : g_tail) {
@@ -1124,28 +1185,28 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         if (t.pending) HIPCHK(hipEventSynchronize(t.done));            // about to reallocate: the old tail must be finished
         if (t.ws.ensure(toff) != 0) { set_error("msm: tail workspace allocation of %zu bytes failed", toff); return LSA_ERR_NOMEM; }
     }
-    if (tb.pending) HIPCHK(hipStreamWaitEvent(acc, tb.done, 0));       // the accumulate stage may not overwrite buckets a tail still reads
+    if (tb.pending) HIPCHK(hipStreamWaitEvent(st, tb.done, 0));        // the front may not overwrite buckets a tail still reads
     char *tws = (char *)tb.ws.ptr;
     char *ws = (char *)g_ws.ptr;
-    char *ws1 = ws;
     uint32_t *hist = (uint32_t *)(ws + o_hist);
     uint32_t *heavy_count = hist + nb;
     uint32_t *offs = (uint32_t *)(ws + o_offs);
-    uint32_t *bsum = (uint32_t *)(ws1 + o_bsum);
+    uint32_t *bsum = (uint32_t *)(ws + o_bsum);
     uint32_t *bin_count = (uint32_t *)(ws + o_bins), *bin_start = bin_count + ngroups * SIZE_BINS, *bin_cursor = bin_start + ngroups * SIZE_BINS;
     uint32_t *perm = (uint32_t *)(ws + o_perm);
-    int32_t *digits = (int32_t *)(ws1 + o_digits);
-    uint16_t *rank = (uint16_t *)(ws1 + o_rank);
-    uint16_t *tile_hist = (uint16_t *)(ws1 + o_thist);
-    uint32_t *tile_base = (uint32_t *)(ws1 + o_tbase);
+    int32_t *digits = (int32_t *)(ws + o_digits);
+    uint16_t *rank = (uint16_t *)(ws + o_rank);
+    uint16_t *tile_hist = (uint16_t *)(ws + o_thist);
+    uint32_t *tile_base = (uint32_t *)(ws + o_tbase);
     uint32_t *entries = (uint32_t *)(ws + o_entries);
     A *buckets = (A *)(tws + o_buckets);
     uint32_t *heavy_list = (uint32_t *)(ws + o_heavy);
     uint32_t *chunk_off = (uint32_t *)(ws + o_choff);
     A *hpart = (A *)(ws + o_hpart);
-    uint64_t *recs = (uint64_t *)(ws1 + o_recs);
-    uint32_t *hist_c = (uint32_t *)(ws1 + o_chist);
-    uint32_t *offs_c = (uint32_t *)(ws1 + o_coffs);
+    uint64_t *recs = (uint64_t *)(ws + o_recs);
+    uint32_t *hist_c = fine ? (uint32_t *)(ws + o_chist) : hist;       // one pass: the bins ARE the buckets
+    uint32_t *offs_c = fine ? (uint32_t *)(ws + o_coffs) : offs;
+    uint32_t *local_idx = nseg > 1 ? (uint32_t *)(ws + o_lidx) : nullptr;
     A *wave_out = (A *)(tws + o_wave);
     A *window_sums = (A *)(tws + o_win);
 
@@ -1161,21 +1222,27 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     static bool lds_attr_set = false;
     if (!lds_attr_set) {   // > 64 KiB of dynamic LDS needs an explicit opt-in
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         lds_attr_set = true;
     }
     if (wide) {
-        hipLaunchKernelGGL(k_digits_wide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, pl, digits);
-        hipLaunchKernelGGL(k_rank, dim3(ntiles, nwin), dim3(1024), (size_t)Bc * 2, st, digits, nv, Bc, ntiles, rank, tile_hist, WIDE_FINE_BITS);
-        hipLaunchKernelGGL(k_tile_scan_rows, dim3((Bc + 63) / 64), dim3(1024), 0, st, tile_hist, Bc, nwin * ntiles, tile_base, hist_c);
+        const uint32_t win_stride = (uint32_t)(table_stride * pl.copy_step);
+        hipLaunchKernelGGL(k_digits_wide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, segs, pl, B, digits, local_idx);
+        hipLaunchKernelGGL(k_rank, dim3(ntiles, nwin), dim3(1024), (size_t)Bc * 2, st, digits, nv, Bc, ntiles, rank, tile_hist, fine ? WIDE_FINE_BITS : 0u);
+        hipLaunchKernelGGL(k_tile_scan_rows, dim3((Bc + 31) / 32), dim3(1024), 0, st, tile_hist, Bc, nwin * ntiles, tile_base, hist_c);
         mark(st);  // 1
         hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(256), 0, st, hist_c, Bc, bsum);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bsum, scan_blocks);
         hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, hist_c, bsum, Bc, offs_c);
         mark(st);  // 2
-        hipLaunchKernelGGL(k_scatter_wide, dim3(ntiles, nwin), dim3(1024), (size_t)Bc * 4, st, digits, rank, offs_c, tile_base, nv, Bc, ntiles, recs, (uint32_t)table_stride);
-        hipLaunchKernelGGL(k_fine_sort, dim3(Bc), dim3(1024), 0, st, recs, offs_c, hist_c, entries, hist, offs);
+        if (fine) {
+            hipLaunchKernelGGL(k_scatter_wide<true>, dim3(ntiles, nwin), dim3(1024), (size_t)Bc * 4, st, digits, rank, offs_c, tile_base, local_idx, nv, Bc, ntiles, (void *)recs, win_stride);
+            hipLaunchKernelGGL(k_fine_sort, dim3(Bc), dim3(1024), 0, st, recs, offs_c, hist_c, entries, hist, offs);
+        } else {
+            hipLaunchKernelGGL(k_scatter_wide<false>, dim3(ntiles, nwin), dim3(1024), (size_t)Bc * 4, st, digits, rank, offs_c, tile_base, local_idx, nv, Bc, ntiles, (void *)entries, win_stride);
+        }
         mark(st);  // 3
     } else {
         hipLaunchKernelGGL((k_digits<C::GLV>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, c, nwin, digits);
@@ -1190,35 +1257,35 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         mark(st);  // 3
     }
     // ---- accumulate stage: bucket order, accumulation, heavy buckets
-    HIPCHK(hipMemsetAsync(heavy_count, 0, 4, acc));
-    HIPCHK(hipMemsetAsync(bin_count, 0, (size_t)3 * ngroups * SIZE_BINS * 4, acc));
+    HIPCHK(hipMemsetAsync(heavy_count, 0, 4, st));
+    HIPCHK(hipMemsetAsync(bin_count, 0, (size_t)3 * ngroups * SIZE_BINS * 4, st));
     {
         const unsigned sb = (nb + 2047) / 2048;
         const uint32_t gsz = 0u;
-        hipLaunchKernelGGL((k_size_hist<C>), dim3(sb), dim3(256), 0, acc, hist, nb, heavy_threshold, bin_count, gsz, bin_shift);
-        hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(256), 0, acc, bin_count, bin_start, ngroups);
-        hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, acc, hist, nb, heavy_threshold, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets, gsz, bin_shift, split);
+        hipLaunchKernelGGL((k_size_hist<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_count, gsz, bin_shift);
+        hipLaunchKernelGGL(k_size_scan, dim3(1), dim3(256), 0, st, bin_count, bin_start, ngroups);
+        hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets, gsz, bin_shift, split);
     }
-    mark(acc);  // 4
-    if (wide && split == 1)
-        hipLaunchKernelGGL((k_accumulate<C, 1u>), dim3((nb + 255) / 256), dim3(256), 0, acc, d_bases, entries, offs, hist, perm, bin_start, buckets);
+    mark(st);  // 4
+    if (split == 1)
+        hipLaunchKernelGGL((k_accumulate<C, 1u>), dim3((nb + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
     else
-        hipLaunchKernelGGL((k_accumulate<C, 2u>), dim3((nb * 2 + 255) / 256), dim3(256), 0, acc, d_bases, entries, offs, hist, perm, bin_start, buckets);
-    hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(256), 0, acc, hist, heavy_list, heavy_count, chunk_off);
-    hipLaunchKernelGGL((k_accumulate_heavy<C>), dim3(4096), dim3(64), 0, acc, d_bases, entries, offs, hist,
+        hipLaunchKernelGGL((k_accumulate<C, 2u>), dim3((nb * 2 + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
+    hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(256), 0, st, hist, heavy_list, heavy_count, chunk_off);
+    hipLaunchKernelGGL((k_accumulate_heavy<C>), dim3(4096), dim3(64), 0, st, d_bases, entries, offs, hist,
                        heavy_list, heavy_count, chunk_off, hpart);
-    hipLaunchKernelGGL((k_heavy_finish<C>), dim3(256), dim3(64), 0, acc, heavy_list, heavy_count, chunk_off, hpart, buckets, split);
-    mark(acc);  // 5
-    if (tail != acc) {
-        HIPCHK(hipEventRecord(g_front_done, acc));
+    hipLaunchKernelGGL((k_heavy_finish<C>), dim3(256), dim3(64), 0, st, heavy_list, heavy_count, chunk_off, hpart, buckets, split);
+    mark(st);  // 5
+    if (tail != st) {
+        HIPCHK(hipEventRecord(g_front_done, st));
         HIPCHK(hipStreamWaitEvent(tail, g_front_done, 0));
     }
-    if (wide)
-        hipLaunchKernelGGL((k_reduce1_lane<C>), dim3((T + 63) / 64), dim3(64), 0, tail, buckets, B, L, split, wave_out);
+    if (big)
+        hipLaunchKernelGGL((k_reduce1_lane<C>), dim3(kw * ((T + 63) / 64)), dim3(64), 0, tail, buckets, B, L, split, wave_out);
     else
         hipLaunchKernelGGL((k_reduce1<C>), dim3(kw * wpw), dim3(64), 0, tail, buckets, B, L, logL, wpw, split, wave_out);
     A *lvl_in = wave_out, *lvl_out = window_sums;
-    uint32_t m = wpw, lm = wide ? logL : logL + 4;   // m pairs per window, each covering 2^lm buckets
+    uint32_t m = wpw, lm = big ? logL : logL + 4;    // m pairs per window, each covering 2^lm buckets
     do {                                             // at least one k_reduce2 level (it leaves the sum in slot 0)
         const uint32_t m_out = (m + 15) / 16;
         hipLaunchKernelGGL((k_reduce2<C>), dim3(kw * m_out), dim3(64), 0, tail, lvl_in, m, m_out, lm, lvl_out);
@@ -1229,14 +1296,17 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     mark(tail);  // 6
     // lvl_in[2*k] = sum of window k (pairs of (ACC,RUN): stride 2)
     Jac<F> *res = tail != st ? (Jac<F> *)(tws + o_res) : d_out;
-    if constexpr (std::is_same<C, CurveG1>::value)
+    if (wide) {           // every bucket space is a finished sum: convert
+        if constexpr (std::is_same<C, CurveG1>::value) hipLaunchKernelGGL(k_emit_g1, dim3(nseg), dim3(64), 0, tail, lvl_in, res);
+        else hipLaunchKernelGGL(k_emit_g2, dim3(nseg), dim3(64), 0, tail, lvl_in, res);
+    } else if constexpr (std::is_same<C, CurveG1>::value) {
         hipLaunchKernelGGL(k_fold_quad, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, res);
-    else
+    } else {
         hipLaunchKernelGGL(k_fold_quad_g2, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, res);
+    }
     if (tail != st) {
         if (prev.pending && &prev != &tb) HIPCHK(hipStreamWaitEvent(tail, prev.done, 0));   // publish in call order
-        static_assert(sizeof(Jac<F>) / 4 <= 64, "one wavefront publishes the result");
-        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, tail, (const uint32_t *)res, (uint32_t *)d_out, (unsigned)(sizeof(Jac<F>) / 4));
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, tail, (const uint32_t *)res, (uint32_t *)d_out, (unsigned)(nseg * sizeof(Jac<F>) / 4));
     }
     mark(tail);  // 7
     HIPCHK(hipEventRecord(tb.done, tail));
@@ -1247,6 +1317,51 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
     if (g_profile) g_ev_calls++;
     return LSA_OK;
 }
+
+template <class F>
+int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride) {
+    if (n == 0) {
+        int jr = msm_join(st);
+        if (jr) return jr;
+        Jac<F> inf = Jac<F>::inf();
+        HIPCHK(hipMemcpyAsync(d_out, &inf, sizeof inf, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return LSA_OK;
+    }
+    SegList segs;
+    segs.nseg = 1;
+    segs.off[0] = 0;
+    segs.off[1] = (uint32_t)n;
+    return msm_pipeline<F>(d_bases_v, first, d_scalars, segs, d_out, st, table_stride);
+}
+
+// nseg independent MSMs in one pass: result j = sum_i scalars[off[j] + i] * bases[first + i],
+// i < off[j+1] - off[j] (every segment multiplies a PREFIX of the same bases).  Needs the
+// pre-shifted copies; at most MSM_MAX_SEGMENTS segments; empty segments give infinity.
+template <class F>
+int msm_segments_device(const void *d_bases_v, size_t first, const Fr *d_scalars, const uint64_t *seg_off, size_t nseg, Jac<F> *d_out,
+                        hipStream_t st, size_t table_stride) {
+    if (nseg == 0) return LSA_OK;
+    if (nseg > MSM_MAX_SEGMENTS) { set_error("msm_segments: at most %u segments per call", MSM_MAX_SEGMENTS); return LSA_ERR_INVALID; }
+    SegList segs;
+    segs.nseg = (uint32_t)nseg;
+    for (size_t j = 0; j <= nseg; j++) {
+        if (seg_off[j] >= (uint64_t(1) << 27) || (j && seg_off[j] < seg_off[j - 1])) { set_error("msm_segments: bad offsets"); return LSA_ERR_INVALID; }
+        segs.off[j] = (uint32_t)(seg_off[j] - seg_off[0]);
+    }
+    if (segs.off[nseg] == 0) {          // nothing but empty segments
+        int jr = msm_join(st);
+        if (jr) return jr;
+        std::vector<Jac<F>> inf(nseg, Jac<F>::inf());
+        HIPCHK(hipMemcpyAsync(d_out, inf.data(), nseg * sizeof(Jac<F>), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return LSA_OK;
+    }
+    return msm_pipeline<F>(d_bases_v, first, d_scalars + seg_off[0], segs, d_out, st, table_stride);
+}
+template int msm_segments_device<Fq>(const void *, size_t, const Fr *, const uint64_t *, size_t, Jac<Fq> *, hipStream_t, size_t);
+template int msm_segments_device<Fq2>(const void *, size_t, const Fr *, const uint64_t *, size_t, Jac<Fq2> *, hipStream_t, size_t);
+
 template int msm_device<Fq>(const void *, size_t, const Fr *, size_t, Jac<Fq> *, hipStream_t, size_t);
 template int msm_device<Fq2>(const void *, size_t, const Fr *, size_t, Jac<Fq2> *, hipStream_t, size_t);
 

@@ -119,6 +119,21 @@ def test_cppoly_d20_commit_and_ladder(lsa):
     assert len(calls) == 39
     for slot, st, m in calls:
         assert canon("g1", res[slot]) == k_times_gen("g1", synth.fr_sum_mont(w[st:st + m])), (slot, st, m)
+    # the same ladder as an integrator would issue it: rungs of up to 2^15 pairs in ONE segmented
+    # call over consecutive slices of w (witnessa[i] is the same sum as witness[i]), the longer
+    # rungs one call each
+    if B1.has_table():
+        starts = np.concatenate([[0], np.cumsum([1 << (d - 1 - i) for i in range(d)])])
+        first_small = next(i for i in range(d) if (1 << (d - 1 - i)) <= (1 << 15))
+        seg_outs = torch.zeros((d - first_small, 12), dtype=torch.int64, device="cuda:0")
+        big_outs = torch.zeros((first_small, 12), dtype=torch.int64, device="cuda:0")
+        for i in range(first_small):
+            B1.msm_async(d_w[int(starts[i]):int(starts[i + 1])], big_outs[i], n=1 << (d - 1 - i))
+        B1.msm_segments_async(d_w, starts[first_small:], seg_outs)
+        lsa.synchronize()
+        both = np.concatenate([to_host(big_outs), to_host(seg_outs)])
+        for i in range(d):
+            assert canon("g1", both[i]) == canon("g1", res[2 * i]), i
     B1.close(); B2.close()
 
 

@@ -317,3 +317,46 @@ def test_msm_random_sweep_vs_oracle(lsa):
         got = lsa.msm(group, bases, sc)
         want = o.multi_exp(group, bases, sc, mode="mixed")
         assert canon(group, got) == canon(group, want), (case, group, n, bits)
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_segmented_msm_over_prefixes_vs_oracle(lsa, group):
+    """lsa_msm_run_segments_async: several MSMs over prefixes of one table-carrying handle in one
+    pass (CPPoly::prove's ladder shape, src/gadgets/poly.h:77-86), every segment against the
+    oracle; empty segments, a one-element segment, zeros / ones / r-1 among the scalars, an
+    infinity among the bases, a non-zero `first`."""
+    import torch
+    n = 3000 if group == "g1" else 600
+    lsa.set_table_threshold(1)
+    try:
+        bases = o.arith_bases(group, 9001, 77, n)
+        bases[11] = 0                                            # infinity
+        B = lsa.Bases(group, bases)
+        assert B.has_table() == TABLES_ENABLED
+        if not TABLES_ENABLED:
+            pytest.skip("tables disabled")
+        lens = [n, n // 2, 0, 1, 37, 0, n // 4, 5, 64, n - 1]
+        offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        sc, _ = o.random_scalars(int(offs[-1]), seed=4242)
+        sc[0] = o.fr_mont(0); sc[1] = o.fr_mont(1); sc[2] = o.fr_mont(o.R - 1); sc[n] = o.fr_mont(0)
+        d_s = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        w = 12 if group == "g1" else 24
+        outs = torch.zeros((len(lens), w), dtype=torch.int64, device="cuda:0")
+        for first in (0, 3):
+            ok_lens = [min(m, n - first) for m in lens]
+            offs2 = np.concatenate([[0], np.cumsum(ok_lens)]).astype(np.uint64)
+            B.msm_segments_async(d_s, offs2, outs, first=first)
+            lsa.synchronize()
+            got = outs.cpu().numpy().view(np.uint64)
+            for j, m in enumerate(ok_lens):
+                lo = int(offs2[j])
+                want = o.multi_exp(group, bases[first:first + m], sc[lo:lo + m], mode="mixed")
+                assert canon(group, got[j]) == canon(group, want), (first, j, m)
+        # the same slices one call at a time (narrow digits, one segment) must agree as well
+        for j, m in enumerate(lens):
+            if m:
+                lo = int(offs[j])
+                assert canon(group, B.msm(d_s[lo:lo + m], n=m)) == canon(group, o.multi_exp(group, bases[:m], sc[lo:lo + m], mode="mixed"))
+        B.close()
+    finally:
+        lsa.set_table_threshold(0)

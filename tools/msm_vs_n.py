@@ -1,26 +1,38 @@
-"""Dev helper: G1 MSM latency vs n (random bases and n copies of the generator)."""
-import sys, os, time
+#!/usr/bin/env python3
+"""MSM time vs n on one resident 2^20-point handle (CPPoly::prove's ladder shape: prefixes of g1s):
+single blocking call (latency) and 8 back-to-back asynchronous calls (throughput), every result
+checked against k*G through the fixed-base kernel.  Run on the GPU box."""
+import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
 import legosnark_amd as lsa
-from legosnark_amd import curve
+from legosnark_amd import curve, synth
 lsa.init(0)
 dev = torch.device("cuda:0")
-gen = torch.Generator(device=dev); gen.manual_seed(1)
-def rfr(c):
-    t = torch.randint(-(1 << 63), (1 << 63) - 1, (c, 4), dtype=torch.int64, device=dev, generator=gen); t[:, 3] &= (1 << 60) - 1; return t.contiguous()
+G1 = curve.generator("g1")
 N = 1 << 20
-Brand = lsa.Bases("g1", lsa.batch_exp("g1", curve.generator("g1"), rfr(N)), on_device=True)
-Bgen = lsa.Bases("g1", torch.from_numpy(np.tile(curve.generator("g1").view(np.int64), (N, 1))).to(dev), on_device=True)
-s = rfr(N); out = torch.zeros(12, dtype=torch.int64, device=dev)
-for k in range(0, 21, 2):
+rng = synth.Xoshiro256ss(seed=77)
+x = synth.arith_fr_mont(rng.fr_int(), rng.fr_int(), N)
+B = lsa.Bases("g1", lsa.batch_exp("g1", G1, torch.from_numpy(x.view(np.int64)).to(dev)), on_device=True)
+s = rng.uniform_fr(N)
+d_s = torch.from_numpy(s.view(np.int64)).to(dev)
+outs = torch.zeros((8, 12), dtype=torch.int64, device=dev)
+torch.cuda.synchronize()
+print("%8s %12s %14s %8s" % ("log2 n", "latency_ms", "pipelined_ms", "check"))
+for k in range(0, 21):
     n = 1 << k
-    res = []
-    for B in (Brand, Bgen):
-        B.msm_async(s[:n], out, n=n); lsa.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(5): B.msm_async(s[:n], out, n=n)
-        lsa.synchronize(); res.append((time.perf_counter() - t0) / 5 * 1e3)
-    lsa.profile_enable(True); Brand.msm_async(s[:n], out, n=n); st = lsa.profile_last_msm(); lsa.profile_enable(False)
-    print("n=2^%-2d c=%2d random %.3f ms  generator-copies %.3f ms  stages %s" % (k, lsa.msm_window_bits(n), res[0], res[1], {a: round(b, 3) for a, b in st.items() if a in ("digits","scatter","accumulate","reduce","fold")}))
+    B.msm(d_s, n=n)
+    lat = []
+    for _ in range(3):
+        t0 = time.perf_counter(); r = B.msm(d_s, n=n); lat.append(time.perf_counter() - t0)
+    want = lsa.normalize("g1", lsa.batch_exp("g1", G1, curve.fr_mont(synth.fr_dot_mont(s[:n], x[:n])).reshape(1, 4)))[0]
+    ok = np.array_equal(lsa.normalize("g1", r.reshape(1, 12))[0], want)
+    lsa.synchronize()
+    t0 = time.perf_counter()
+    for rep in range(3):
+        for j in range(8):
+            B.msm_async(d_s, outs[j], n=n)
+    lsa.synchronize()
+    thr = (time.perf_counter() - t0) / 24
+    print("%8d %12.3f %14.3f %8s" % (k, sorted(lat)[1] * 1e3, thr * 1e3, "ok" if ok else "MISMATCH"), flush=True)
