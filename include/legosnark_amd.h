@@ -111,9 +111,9 @@ int lsa_g1_bases_create(const void *bases_jac, size_t n, int src_on_device, lsa_
 int lsa_g2_bases_create(const void *bases_jac, size_t n, int src_on_device, lsa_bases **out);
 void lsa_bases_destroy(lsa_bases *b);
 size_t lsa_bases_size(const lsa_bases *b);
-/* Resident vectors of at least 2^19 points (env LSA_PRECOMPUTE_MIN) also keep pre-shifted copies
- * 2^(10j)*P_i, j < 26 (2^(11j), j < 24, from 6*2^20 points on; G1 64 B, G2 128 B per point and copy;
- * LSA_PRECOMPUTE=0 disables).  Every MSM on such a handle then runs over ONE bucket space shared by
+/* Resident vectors of at least 2^19 points (env LSA_PRECOMPUTE_MIN) also keep 26 pre-shifted
+ * copies 2^(pos_j)*P_i at bit positions about 10 apart (24 copies about 11 apart from 6*2^20
+ * points on; G1 64 B, G2 128 B per point and copy; LSA_PRECOMPUTE=0 disables).  Every MSM on such a handle then runs over ONE bucket space shared by
  * all windows: 13 (12) bucket additions per pair instead of 16 and no GLV beta-multiplications for
  * n >= 2^16, 26 narrow digits and only 512 buckets to reduce below; one bucket reduction, no
  * Horner fold.  lsa_msm_set_table_threshold(t), t != 0: vectors of at least t points get the

@@ -350,9 +350,10 @@ __global__ __launch_bounds__(1024) void k_tile_scan_rows(const uint16_t *__restr
 #define MSM_MAX_SEGMENTS 64u
 struct WidePlan {
     unsigned nwin;        // digits per scalar
-    unsigned c;           // window width: window k covers bits [c*k, min(c*k + c, 255))
+    unsigned c;           // widest window: 2^(c-1) buckets
     unsigned copy_step;   // window k gathers from table copy k * copy_step
-    unsigned g;           // granularity of the table: copy j holds 2^(g*j) * P
+    unsigned start[32];   // window k covers bits [start[k], start[k] + width[k])
+    unsigned width[32];
 };
 // scalar slices of a segmented call: segment j = scalars[off[j] .. off[j+1]) against bases[0 .. len_j)
 struct SegList {
@@ -371,10 +372,8 @@ __global__ __launch_bounds__(256) void k_digits_wide(const Fr *__restrict__ scal
     uint32_t s[8];
     scalars[i].to_canonical(s);
     uint32_t carry = 0;
-    const unsigned c = pl.c;
     for (unsigned k = 0; k < pl.nwin; k++) {
-        const unsigned bit = c * k;
-        const unsigned width = bit + c <= 255 ? c : 255 - bit;
+        const unsigned bit = pl.start[k], width = pl.width[k];
         const int w = (int)(bit >> 5);
         const unsigned sh = bit & 31;
         uint64_t two = (uint64_t)(w < 8 ? s[w] : 0) | ((uint64_t)(w + 1 < 8 ? s[w + 1] : 0) << 32);
@@ -383,7 +382,7 @@ __global__ __launch_bounds__(256) void k_digits_wide(const Fr *__restrict__ scal
         int32_t sd;
         // the top window is never recoded: scalars are < 2^254 and the windows cover 255 bits, so
         // its raw value is < 2^(width-1) and the carry keeps it <= 2^(width-1) <= B
-        if (k + 1 < pl.nwin && d >= (1u << (c - 1))) { sd = (int32_t)d - (int32_t)(1u << c); carry = 1; }
+        if (k + 1 < pl.nwin && d >= (1u << (width - 1))) { sd = (int32_t)d - (int32_t)(1u << width); carry = 1; }
         else { sd = (int32_t)d; carry = 0; }
         if (sd != 0) { const int32_t m = (int32_t)(seg * B) + (sd < 0 ? -sd : sd); sd = sd < 0 ? -m : m; }
         digits[(size_t)k * n + i] = sd;
@@ -994,36 +993,64 @@ template int normalize_to_affine<Fq2>(const Jac<Fq2> *, Aff<Fq2> *, size_t, hipS
 
 // ------------------------------------------------------------------------------------
 // Wide windows over pre-shifted bases.  A resident CRS can carry, next to P_i, the multiples
-// 2^(g*j) * P_i, j < ceil(255/g) (window-major: entry j*N + i; g = 10, or 11 for very large
-// vectors).  A digit of width c = g or 2g at bit position c*k then gathers from copy k*(c/g), so
-// a digit d of ANY window is "add d * (its copy's point)": all windows share ONE bucket space in
-// which bucket b has weight b+1.  Consequences:
-//   * c is no longer tied to the per-window bucket count.  Large inputs (n >= 2^16) use c = 2g:
-//     13 (12) digits per scalar instead of 16 -- 13 mixed additions per pair -- and no GLV (its only
-//     gain, fewer windows to reduce and fold, is moot), so no beta-multiplications either: 130
-//     field products per pair instead of 168.  Smaller inputs use c = g: 26 digits, but only
-//     2^(g-1) buckets to reduce.
+// 2^(pos_j) * P_i for 26 (24) bit positions pos_j (window-major: entry j*N + i; table_grid()).
+// A digit that starts at pos_j gathers from copy j, so a digit d of ANY window is "add d * (its
+// copy's point)": all windows share ONE bucket space in which bucket b has weight b+1.
+// Consequences:
+//   * the digit width is no longer tied to the per-window bucket count.  Large inputs
+//     (n >= 2^16) use every other position: 13 (12) digits of 20/19 (22/21) bits per scalar instead
+//     of 16 -- 13 mixed additions per pair -- and no GLV (its only gain, fewer windows to reduce
+//     and fold, is moot), so no beta-multiplications either: 130 field products per pair instead
+//     of 168.  Smaller inputs use every position: 26 digits, but only 512 (1024) buckets to reduce.
 //   * one reduction over 2^(c-1) buckets instead of nwin reductions, and no Horner fold
 //     (c*(nwin-1) sequential doublings: 0.3 ms G1 / 1.8 ms G2 of pure latency).
 //   * several independent MSMs over prefixes of the same bases (CPPoly::prove's ladder,
 //     /root/reference/src/gadgets/poly.h:77-86) run as ONE pass: segment j owns the bins
 //     [j*B, (j+1)*B) of one sorted entry array (msm_segments_device).
 // Price: 26 (24) x the base memory (G1 64 B, G2 128 B per point and copy) and one pass of 255
-// doublings + 26 batch normalisations per key.
+// doublings + 25 batch normalisations per key.
 // ------------------------------------------------------------------------------------
-static unsigned table_granularity(size_t n_table) { return n_table >= ((size_t)6 << 20) ? 11u : 10u; }
-static unsigned table_copies(size_t n_table) { const unsigned g = table_granularity(n_table); return (255 + g - 1) / g; }
+// Copy j of the table holds 2^(pos[j]) * P.  The positions are the starts of 13 (12 from 6*2^20
+// points on) wide windows that split the 255 scalar bits as evenly as possible (8 x 20 + 5 x 19
+// bits; 3 x 22 + 9 x 21) plus the midpoint of each: wide digits use every other copy, narrow
+// digits (10 or 9 bits; 11 or 10) all of them.  Even widths matter: a short window concentrates
+// its digits on few buckets, and the longest bucket list bounds the accumulate kernel.
+struct TableGrid {
+    unsigned ncopies;
+    unsigned pos[33];     // pos[ncopies] = 255
+};
+static TableGrid table_grid(size_t n_table) {
+    TableGrid t;
+    const unsigned nbig = n_table >= ((size_t)6 << 20) ? 12u : 13u;
+    const unsigned base = 255 / nbig, rem = 255 % nbig;
+    unsigned bit = 0;
+    for (unsigned k = 0; k < nbig; k++) {
+        const unsigned w = base + (k < rem ? 1u : 0u);
+        t.pos[2 * k] = bit;
+        t.pos[2 * k + 1] = bit + (w + 1) / 2;
+        bit += w;
+    }
+    t.ncopies = 2 * nbig;
+    t.pos[t.ncopies] = 255;
+    return t;
+}
+static unsigned table_copies(size_t n_table) { return table_grid(n_table).ncopies; }
 static size_t wide_big_min() {
     static const size_t v = getenv("LSA_WIDE_BIG_MIN") ? (size_t)atoll(getenv("LSA_WIDE_BIG_MIN")) : (size_t)1 << 16;
     return v;
 }
 static WidePlan wide_plan(size_t n_table, size_t n_call, unsigned nseg) {
-    WidePlan pl;
-    pl.g = table_granularity(n_table);
+    const TableGrid t = table_grid(n_table);
+    WidePlan pl = {};
     const bool big = nseg == 1 && n_call >= wide_big_min();
-    pl.c = big ? 2 * pl.g : pl.g;
-    pl.copy_step = pl.c / pl.g;
-    pl.nwin = (255 + pl.c - 1) / pl.c;
+    pl.copy_step = big ? 2 : 1;
+    pl.nwin = t.ncopies / pl.copy_step;
+    pl.c = 0;
+    for (unsigned k = 0; k < pl.nwin; k++) {
+        pl.start[k] = t.pos[k * pl.copy_step];
+        pl.width[k] = t.pos[(k + 1) * pl.copy_step] - pl.start[k];
+        if (pl.width[k] > pl.c) pl.c = pl.width[k];
+    }
     return pl;
 }
 unsigned msm_table_windows(int /*group*/, size_t n) { return table_copies(n); }
@@ -1057,13 +1084,13 @@ template <class F>
 int precompute_windows(void *d_table, size_t n, hipStream_t st) {
     using C = typename CurveOf<F>::type;
     if (n == 0) return LSA_OK;
-    const unsigned g = table_granularity(n), copies = table_copies(n);
+    const TableGrid grid = table_grid(n);
     Jac<F> *tmp = nullptr;
     if (hipMalloc(&tmp, n * sizeof(Jac<F>)) != hipSuccess) { set_error("precompute_windows: hipMalloc failed"); return LSA_ERR_NOMEM; }
     typename C::Base *tbl = (typename C::Base *)d_table;
     int rc = LSA_OK;
-    for (unsigned k = 1; k < copies && !rc; k++) {
-        hipLaunchKernelGGL((k_shift_window<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tbl + (size_t)(k - 1) * n, tmp, n, g);
+    for (unsigned k = 1; k < grid.ncopies && !rc; k++) {
+        hipLaunchKernelGGL((k_shift_window<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tbl + (size_t)(k - 1) * n, tmp, n, grid.pos[k] - grid.pos[k - 1]);
         rc = prepare_bases<F>(tmp, tbl + (size_t)k * n, n, st);
     }
     hipError_t e = hipStreamSynchronize(st);
@@ -1114,6 +1141,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     static const uint32_t wide_split = getenv("LSA_WIDE_SPLIT") ? (uint32_t)atoi(getenv("LSA_WIDE_SPLIT")) : 1u;
     const uint32_t split = wide ? (wide_split == 2 ? 2u : 1u) : 2u;        // lanes per bucket in k_accumulate
     // first reduction level: quads over L buckets (latency) or, for 2^19+ buckets, lanes over L buckets (throughput)
+    // (a quad-shared first level over 2^19 buckets was measured too: 0.69 - 1.27 ms against 0.63 ms)
     const uint32_t L = big ? std::max<uint32_t>(1, B / 65536) : (B > 4096 ? B / 4096 : 1);
     uint32_t logL = 0;
     while ((1u << logL) < L) logL++;
@@ -1123,9 +1151,12 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     // Buckets far above the average population (skewed scalars; the partly filled top window)
     // are split across workgroups instead of being walked by their owner lanes.  With narrow
     // digits every bucket is long (26*n/512 entries), and the point of that path is latency:
-    // anything above 32 entries is cut into chunks summed by a wavefront each.
+    // anything above 4 entries is cut into chunks summed by a wavefront each.
     const uint32_t avg_pop = (uint32_t)(ne / nb + 1);
-    const uint32_t heavy_threshold = (wide && !big) ? 32u : std::max<uint32_t>(64, 2 * avg_pop + 32);
+    // (Wide digits: the top window covers only 255 - 20*12 = 15 bits, so 2^14 buckets carry n/2^14
+    // extra entries -- 88 against the average 26 at n = 2^20; the population order copes with
+    // that, so the threshold sits well above it.)
+    const uint32_t heavy_threshold = (wide && !big) ? 4u : (wide ? std::max<uint32_t>(64, 4 * avg_pop + 64) : std::max<uint32_t>(64, 2 * avg_pop + 32));
     uint32_t bin_shift = 0;                          // populations above 1024 share bins (the order only balances wavefronts)
     while (((heavy_threshold - 1) >> bin_shift) + 1 > SIZE_BINS - 1) bin_shift++;
     const uint32_t max_heavy = (uint32_t)std::min<size_t>(nb, ne / heavy_threshold + 1);
