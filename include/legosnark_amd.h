@@ -309,6 +309,16 @@ int lsa_pairing_product_sharded(const void *g1_jac, const void *g2_jac, size_t n
  * point, 12: Fq12) into d_gathered (world x the same), ordered on lsa_stream(). */
 int lsa_comm_all_gather(const void *d_partial, void *d_gathered, int kind);
 
+/* Many independent pairing products in one pass -- a verifier's shape (CPPoly::verify,
+ * src/gadgets/poly.h:105-122: d products of two or three Miller values, each followed by a final
+ * exponentiation; CPhad verify at d = 20: 181 Miller loops in 62 products):
+ *   out[j] = [final_exponentiation] ( prod_{i = seg_offsets[j]}^{seg_offsets[j+1]-1} miller_loop(P_i, Q_i) ),  j < nseg
+ * (Fq12 one for an empty segment).  seg_offsets: nseg + 1 non-decreasing offsets, the first 0.
+ * One upload, one Miller launch over all pairs, one product workgroup per segment, one batched
+ * final exponentiation, one download.  final_exp == 0 leaves the Miller products
+ * (double_miller_loop values).  Host pointers. */
+int lsa_pairing_product_segments(const void *g1_jac, const void *g2_jac, const uint64_t *seg_offsets, size_t nseg, void *out_gt, int final_exp);
+
 /* ---- point helpers ------------------------------------------------------------------- */
 /* Jacobian -> libff "special" form (affine with Z = 1, or (0,1,0)), n points, host
  * buffers; replaces G::to_affine_coordinates()/batch_to_special on result vectors. */

@@ -114,6 +114,7 @@ def lib():
         for name in ("lsa_g1_msm_sharded", "lsa_g2_msm_sharded", "lsa_pairing_product_sharded"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.lsa_comm_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.lsa_pairing_product_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.lsa_crs_cache_configure.argtypes = [C.c_int, C.c_size_t]
         L.lsa_crs_cache_clear.restype = None
         L.lsa_crs_cache_stats.argtypes = [C.POINTER(C.c_uint64)] * 4
@@ -603,6 +604,19 @@ def pairing_product(g1, g2):
     g1, g2 = _pairs(g1, g2)
     out = np.zeros(48, dtype=np.uint64)
     _check(lib().lsa_pairing_product(_host_ptr(g1), _host_ptr(g2), len(g1), _host_ptr(out)))
+    return out
+
+
+def pairing_product_segments(g1, g2, offsets, final_exp=True):
+    """out[j] = final_exponentiation(prod_{i in [offsets[j], offsets[j+1])} miller_loop(P_i, Q_i)) for
+    many independent products in one pass (a verifier's shape) -> (nseg, 48) uint64."""
+    g1, g2 = _pairs(g1, g2)
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    if len(off) < 1 or int(off[-1]) != len(g1):
+        raise ValueError("offsets must end at the number of pairs")
+    out = np.zeros((len(off) - 1, 48), dtype=np.uint64)
+    _check(lib().lsa_pairing_product_segments(_host_ptr(g1), _host_ptr(g2), _host_ptr(off), len(off) - 1, _host_ptr(out),
+                                              1 if final_exp else 0))
     return out
 
 

@@ -1095,6 +1095,40 @@ int lsa_miller_loop_product(const void *g1, const void *g2, size_t n, void *out)
 int lsa_pairing_product(const void *g1, const void *g2, size_t n, void *out) {
     return miller_product_host(g1, g2, n, out, true);
 }
+// many independent products in one pass: one upload, one Miller launch over all pairs, one
+// product workgroup per segment, one batched final exponentiation, one download
+int lsa_pairing_product_segments(const void *g1, const void *g2, const uint64_t *seg_offsets, size_t nseg, void *out_gt, int final_exp) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (nseg == 0) return LSA_OK;
+    if (!seg_offsets || !out_gt) { set_error("pairing_product_segments: null argument"); return LSA_ERR_INVALID; }
+    if (seg_offsets[0] != 0) { set_error("pairing_product_segments: offsets must start at 0"); return LSA_ERR_INVALID; }
+    for (size_t j = 0; j < nseg; j++)
+        if (seg_offsets[j + 1] < seg_offsets[j]) { set_error("pairing_product_segments: offsets must not decrease"); return LSA_ERR_INVALID; }
+    const size_t n = seg_offsets[nseg];
+    if (n && (!g1 || !g2)) { set_error("pairing_product_segments: null argument"); return LSA_ERR_INVALID; }
+    if (g_pair_s.ensure(nseg * fq12_bytes()) || g_pair_o.ensure(nseg * fq12_bytes()) || g_stage_gather.ensure((nseg + 1) * sizeof(uint64_t)) ||
+        g_pair_f.ensure((n ? n : 1) * fq12_bytes())) {
+        set_error("pairing: hipMalloc failed");
+        return LSA_ERR_NOMEM;
+    }
+    if (n) {
+        rc = miller_upload_run(g1, g2, n);
+        if (rc) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(g_stage_gather.p, seg_offsets, (nseg + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+    rc = fq12_segment_products_device(g_pair_f.p, (const uint64_t *)g_stage_gather.p, nseg, g_pair_s.p, g.stream);
+    if (rc) return rc;
+    void *res = g_pair_s.p;
+    if (final_exp) {
+        rc = final_exp_device(g_pair_s.p, nseg, g_pair_o.p, g.stream);
+        if (rc) return rc;
+        res = g_pair_o.p;
+    }
+    HIPCHK(hipMemcpyAsync(out_gt, res, nseg * fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return LSA_OK;
+}
 int lsa_pairing_product_sharded(const void *g1, const void *g2, size_t n_local, void *out) {
     return miller_product_host(g1, g2, n_local, out, true, true);
 }

@@ -74,6 +74,7 @@ int sum_points_device(const Jac<F> *d_in, size_t n, Jac<F> *d_out, hipStream_t s
 int miller_device(const void *d_g1_jac, const void *d_g2_jac, size_t n, void *d_out_fq12, hipStream_t st);
 int final_exp_device(const void *d_in_fq12, size_t n, void *d_out_fq12, hipStream_t st);
 int fq12_product_device(void *d_buf, void *d_scratch, size_t n, void **result, hipStream_t st);
+int fq12_segment_products_device(const void *d_in, const uint64_t *d_off, size_t nseg, void *d_out, hipStream_t st);
 size_t fq12_bytes();
 
 // Orders the results of earlier msm_device calls (whose tails run on an internal stream) on `st`.

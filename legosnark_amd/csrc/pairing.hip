@@ -164,6 +164,29 @@ __global__ __launch_bounds__(128) void k_fq12_prod8_wave(const Fq12 *__restrict_
     if (lane < 12) reinterpret_cast<Fq *>(&out[blockIdx.x])[lane] = w12_fq_ref(w.slot(0), lane)->to_mont256();
 }
 
+// out[j] = prod in[off[j] .. off[j+1]) (1 for an empty segment), one workgroup per segment: the
+// verifiers' many short products (CPPoly::verify multiplies 2-3 Miller values per final
+// exponentiation, /root/reference/src/gadgets/poly.h:105-122)
+__global__ __launch_bounds__(128) void k_fq12_prod_seg_wave(const Fq12 *__restrict__ in, const uint64_t *__restrict__ off, Fq12 *__restrict__ out) {
+    __shared__ Fq2S lds[W12_LDS_FQ2];
+    const size_t lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
+    const unsigned lane = threadIdx.x;
+    WaveExec ex;
+    W12<WaveExec> w{ex, lds, lds + 6 * W12_SLOTS};
+    if (lane < 12) {
+        Fs v = (lane == 0) ? Fs::one() : Fs::zero();
+        if (lo < hi) v = Fs::from_mont256(reinterpret_cast<const Fq *>(&in[lo])[lane]);
+        *w12_fq_ref(w.slot(0), lane) = v;
+    }
+    __syncthreads();
+    for (size_t e = lo + 1; e < hi; e++) {
+        if (lane < 12) *w12_fq_ref(w.slot(1), lane) = Fs::from_mont256(reinterpret_cast<const Fq *>(&in[e])[lane]);
+        __syncthreads();
+        w.mul(0, 0, 1);
+    }
+    if (lane < 12) reinterpret_cast<Fq *>(&out[blockIdx.x])[lane] = w12_fq_ref(w.slot(0), lane)->to_mont256();
+}
+
 // out[i] = prod in[8i .. 8i+7]
 __global__ __launch_bounds__(64) void k_fq12_prod8(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -227,6 +250,14 @@ int fq12_product_device(void *d_buf, void *d_scratch, size_t n, void **result, h
     }
     HIPCHK(hipGetLastError());
     *result = a;
+    return LSA_OK;
+}
+
+// d_out[j] = prod d_in[off[j] .. off[j+1]), j < nseg; d_off: nseg + 1 offsets on the device
+int fq12_segment_products_device(const void *d_in, const uint64_t *d_off, size_t nseg, void *d_out, hipStream_t st) {
+    if (nseg == 0) return LSA_OK;
+    hipLaunchKernelGGL(k_fq12_prod_seg_wave, dim3((unsigned)nseg), dim3(128), 0, st, (const Fq12 *)d_in, d_off, (Fq12 *)d_out);
+    HIPCHK(hipGetLastError());
     return LSA_OK;
 }
 

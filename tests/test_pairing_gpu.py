@@ -167,3 +167,21 @@ def test_large_batch_takes_the_grouped_kernel_and_matches(lsa):
     for i in (0, 9, 10, 1234, n - 1):
         assert np.array_equal(f[i], o.miller_loop_batch(ps[i:i + 1], qs[i:i + 1])[0]), i
     assert np.array_equal(lsa.pairing_product(ps, qs), o.fq12_one())
+
+
+def test_segmented_pairing_products_vs_oracle(lsa):
+    """lsa_pairing_product_segments: a verifier's many short products (CPPoly::verify multiplies two
+    or three Miller values per final exponentiation, src/gadgets/poly.h:105-122) in one pass, every
+    segment byte for byte against the oracle; empty segments give one."""
+    lens = [3, 2, 0, 1, 4, 0, 3, 7]
+    n = sum(lens)
+    ps = o.arith_bases("g1", 2024, 9, n)
+    qs = o.arith_bases("g2", 77, 13, n)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    got = lsa.pairing_product_segments(ps, qs, offs)
+    raw = lsa.pairing_product_segments(ps, qs, offs, final_exp=False)
+    f = o.miller_loop_batch(ps, qs)
+    for j, m in enumerate(lens):
+        lo = int(offs[j])
+        assert np.array_equal(raw[j], o.fq12_product(f[lo:lo + m])), j
+        assert np.array_equal(got[j], o.pairing_product(ps[lo:lo + m], qs[lo:lo + m]) if m else o.fq12_one()), j

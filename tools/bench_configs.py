@@ -227,16 +227,14 @@ def main():
         edges = np.cumsum([0] + sizes)
 
         def run():
-            f = lsa.miller_loop(ps, qs)
-            prods = np.stack([lsa.fq12_product(f[edges[i]:edges[i + 1]]) for i in range(len(sizes))])
-            return lsa.final_exponentiation(prods)
+            return lsa.pairing_product_segments(ps, qs, edges)
         res = run()
         best = 1e9
         for _ in range(max(2, args.reps)):
             t0 = time.perf_counter()
             res = run()
             best = min(best, (time.perf_counter() - t0) * 1e3)
-        emit("CPhad verifier pairing shape d=%d: %d Miller loops, %d final exponentiations (host buffers)" % (d, len(ps), len(sizes)),
+        emit("CPhad verifier pairing shape d=%d: %d Miller loops, %d final exponentiations (lsa_pairing_product_segments, host buffers)" % (d, len(ps), len(sizes)),
              all(np.array_equal(r_, fq12_one) for r_ in res), {"ms": best})
 
 
