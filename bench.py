@@ -53,6 +53,53 @@ def cpu_model():
     return "unknown"
 
 
+def pmc_traffic(kernel_substr="k_accumulate", exclude="heavy", timeout_s=150):
+    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC counters, collected as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc
+    passes (they do not fit one pass), each over a short child run of this same script; both
+    counters are KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads, so
+    bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (the factor is calibrated on streaming reads,
+    not on this kernel's 64-byte gathers: the raw sum is reported next to it).  Returns a dict or
+    None when rocprofv3 is unavailable / fails -- the bench line then carries traffic = null."""
+    import glob
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="lsa_pmc_")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            cmd = [exe, "--pmc", ctr, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-host-path", "--no-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            if r.returncode != 0 or not dbs:
+                return None
+            db = sqlite3.connect(dbs[0])
+            rows = db.execute("select kernel_name, count(*), avg(value), avg(duration) from counters_collection "
+                              "where counter_name = ? group by kernel_name", (ctr,)).fetchall()
+            rows = [x for x in rows if kernel_substr in x[0] and exclude not in x[0]]
+            if not rows:
+                return None
+            rows.sort(key=lambda x: -x[1])
+            vals[ctr] = {"kib_mean": rows[0][2], "launches": rows[0][1], "kernel_us": rows[0][3] / 1e3, "kernel": rows[0][0][:60]}
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    f, w = vals["FETCH_SIZE"]["kib_mean"], vals["WRITE_SIZE"]["kib_mean"]
+    return {"bytes_per_launch": 2 * f * 1024 + w * 1024, "raw_bytes_per_launch": (f + w) * 1024,
+            "fetch_size_kib": f, "write_size_kib": w, "launches_sampled": [vals["FETCH_SIZE"]["launches"], vals["WRITE_SIZE"]["launches"]],
+            "kernel_us_under_pmc": [vals["FETCH_SIZE"]["kernel_us"], vals["WRITE_SIZE"]["kernel_us"]],
+            "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate child runs of bench.py; "
+                      "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 half-count correction, calibrated on streaming reads)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -65,7 +112,14 @@ def main():
                     help="pairs of the same workload timed on the host CPU (2^k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
     args = ap.parse_args()
+
+    # roofline.traffic: two short profiled child runs of this script, before this process
+    # initialises the GPU (or even imports torch)
+    traffic = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_pmc and not args.total_log2n and args.log2n == 20:
+        traffic = pmc_traffic()
 
     import numpy as np
     import torch
@@ -340,7 +394,9 @@ def main():
                        if world > 1 else "single GPU"},
             "result_checked_by_identity": checked,
             "roofline": {"kernel": "k_accumulate<CurveG1>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
+                         "algorithmic_bytes_per_launch": n_local * ALG_BYTES_PER_PAIR,
                          "kernel_ms": acc_ms, "calls_averaged": stages["calls"],
                          "valu": {"achieved_Gfmul_s": gf, "peak_Gfmul_s": FMUL_PEAK_G, "frac": gf / FMUL_PEAK_G,
                                   "field_mults_per_pair": fmuls_per_pair,
