@@ -133,11 +133,20 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # debug hooks to exercise the multi-process path on a one-GPU box: every rank on cuda:0 and
+    # gloo collectives (RCCL refuses two ranks on one device); default: one rank per GPU, RCCL
+    if os.environ.get("LSA_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
+    backend = os.environ.get("LSA_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     lsa.init(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 and backend != "nccl":
+        import torch.distributed as dist
+        dist.init_process_group(backend)
+        comm_kind = "torch"
+    elif world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
         # the library's own RCCL communicator: rank 0 creates the id, torch broadcasts the 128 bytes
@@ -253,7 +262,7 @@ def main():
             if profile:
                 lsa.profile_enable(False)
             if world > 1:
-                tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+                tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 elapsed = float(tmax.item())
             got = affine_of(res.cpu().numpy().view(np.uint64))
@@ -386,9 +395,10 @@ def main():
             "vs_baseline": None, "dtype": "u32 limbs (254-bit Montgomery integers)", "data": "synthetic",
             "config": {"workload": workload,
                        "inputs": "scalars uniform in [0,r), xoshiro256** seed 0x4C45474F534E4152; bases (a+i*b)*G1, un-normalised Jacobian",
-                       "windows": table_windows if table_windows else None,
-                       "pipeline": ("wide windows over pre-shifted resident bases: %d bucket additions per pair, one shared bucket space" % table_windows)
-                       if table_windows else "signed 16-bit windows + GLV",
+                       "digits_per_scalar": fm_per_pair // 10 if table_windows else None,
+                       "pre_shifted_copies": table_windows if table_windows else None,
+                       "pipeline": ("wide windows over %d pre-shifted copies of the resident bases: %d bucket additions per pair, one shared bucket space"
+                                    % (table_windows, fm_per_pair // 10)) if table_windows else "signed 16-bit windows + GLV",
                        "sharding": ("index ranges (libff chunk split), 1 RCCL all-gather of 96-B partials via "
                                     + ("lsa_msm_run_sharded_async (C-ABI, csrc/comm.hip)" if comm_kind == "capi" else "torch.distributed + lsa_g1_sum_on"))
                        if world > 1 else "single GPU"},

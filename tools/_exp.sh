@@ -1,1 +1,2 @@
-for v in "LSA_WIDE_SPLIT=1" "LSA_WIDE_SPLIT=2"; do echo "== $v"; env $v python bench.py --no-cpu-baseline --no-host-path | python -c "import json,sys; d=json.load(sys.stdin); print(d['value'], d['ms_per_step'], d['stage_ms'], d['single_call_latency_ms'], d['result_checked_by_identity'], d['cplink_prover_ms'])"; done
+export LSA_BENCH_SINGLE_DEVICE=1 LSA_BENCH_BACKEND=gloo
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 10 --warmup 2 2>&1 | grep -v "amdgpu.ids\|W1002\|^\*\*\*\|OMP_NUM" | tail -5
