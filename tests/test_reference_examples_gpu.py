@@ -59,3 +59,17 @@ def test_cplink_built_by_the_references_own_cmake_verifies():
     assert "NCHUNKS : 1" in r.stdout and "Error!" not in r.stdout
     r = run("hadamard", "4", bindir=CMAKE_BIN)
     assert r.returncode == 0, r.stdout[-2000:]
+
+
+def test_multiexpma_on_a_chunk_per_process_from_cpp(tmp_path):
+    """legosnark_amd/shim/checks/spmd_prover_check.cc: the reference's unchanged multiExpMA called
+    on this rank's chunk with a communicator set (file bootstrap) returns the whole sum -- the
+    C++ route to more than one GPU.  One rank here (RCCL wants one device per rank); the same
+    binary runs with WORLD_SIZE = N, RANK = r, LSA_DEVICE = r on an N-GPU node."""
+    exe = os.path.join(BIN, "spmd_prover_check")
+    if not os.path.exists(exe):
+        pytest.skip("%s missing" % exe)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LSA_COMM_FILE=str(tmp_path / "comm.id"))
+    r = subprocess.run([exe, "12"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert '"matches_single_gpu": true' in r.stdout
