@@ -398,6 +398,35 @@ LSA_HD Fq2S g6_coeff_full(int k, const Fq2S *A, const Fq2S *B) {
     }
     return g6_finish(lo, hi);
 }
+// The unordered index pairs {t, u} behind coefficient k of a SQUARE: t + u = k (plain) or k + 6
+// (wrapped, times xi).  k even: 4 pairs (two of them squares), k odd: 3 -- instead of the 6
+// ordered pairs of a general product.  j-th pair of coefficient k:
+LSA_HD void sqr_pair(int k, int j, int &t, int &u, bool &wrap) {
+    const int hk = k >> 1;
+    if (j <= hk) { t = j; u = k - j; wrap = false; }
+    else { t = k + j - hk; u = k + 6 - t; wrap = true; }
+}
+LSA_HD int sqr_pair_count(int k) { return 4 - (k & 1); }
+// coefficient k of a*a: 4 or 3 Fq2 products instead of 6 (the same canonical value)
+LSA_HD Fq2S g6_coeff_square(int k, const Fq2S *A) {
+    F29x2 lo = F29x2::zero(), hi = F29x2::zero();
+    const int cnt = sqr_pair_count(k);
+    for (int j = 0; j < 4; j++) {
+        if (j >= cnt) break;
+        int t, u;
+        bool wr;
+        sqr_pair(k, j, t, u, wr);
+        const uint32_t wrap = 0u - (uint32_t)wr;
+        const uint32_t sh = t == u ? 0u : 1u;                    // off-diagonal pairs count twice
+        const Fq2S p = w12_fq2_mul(A[t], A[u]);
+#pragma unroll
+        for (int l = 0; l < 9; l++) {
+            lo.c0.l[l] += (p.c0.v.l[l] << sh) & ~wrap; lo.c1.l[l] += (p.c1.v.l[l] << sh) & ~wrap;
+            hi.c0.l[l] += (p.c0.v.l[l] << sh) & wrap;  hi.c1.l[l] += (p.c1.v.l[l] << sh) & wrap;
+        }
+    }
+    return g6_finish(lo, hi);
+}
 // coefficient k of a * (l0 + l3 w^3 + l4 w^4): L = {l0, l3, l4}
 LSA_HD Fq2S g6_coeff_sparse(int k, const Fq2S *A, const Fq2S *L) {
     F29x2 lo = F29x2::zero(), hi = F29x2::zero();
@@ -430,7 +459,7 @@ struct G6Miller {
             const unsigned g = lane / 6, k = lane % 6;
             if (g >= (unsigned)G6_GROUPS) return;
             Fq2S *base = m + g * G6_STRIDE;
-            if (mode == 1) base[G6_T + k] = g6_coeff_full((int)k, base + G6_F, base + G6_F);
+            if (mode == 1) base[G6_T + k] = g6_coeff_square((int)k, base + G6_F);
             else if (mode == 2) base[G6_T + k] = g6_coeff_sparse((int)k, base + G6_F, base + G6_L);
             if ((int)k < sd.n) base[G6_G + k] = w12_fq2_mul(base[G6_V + sd.a[k]], base[G6_V + sd.b[k]]);
         });
@@ -586,21 +615,30 @@ struct G12Miller {
             const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
             if (g >= (unsigned)G12_GROUPS) return;
             Fq2S *base = m + g * G12_STRIDE;
-            if (mode) {
-                const int terms = mode == 1 ? 6 : 3;
+            if (mode == 1) {
+                // F*F is a square: the 4 (k even) or 3 (k odd) unordered pairs of sqr_pair()
+                // instead of 6 ordered ones; off-diagonal pairs count twice (same total weight 6)
+                const int cnt = sqr_pair_count((int)k);
                 F29 sum = F29::zero();
-                for (int t = 0; t < terms; t++) {
-                    // mode 1: a index t, b = F[k - t];  mode 2: b = L[t] (w^0, w^3, w^4), a index k - {0,3,4}
-                    int ai = mode == 1 ? t : (int)k - (t == 0 ? 0 : t + 2);
-                    int bi = mode == 1 ? (int)k - t : t;
+                for (int j = 0; j < 4; j++) {
+                    if (j >= cnt) break;
+                    int t, u;
                     bool wrap;
-                    if (mode == 1) { wrap = bi < 0; if (wrap) bi += 6; }
-                    else { wrap = ai < 0; if (wrap) ai += 6; }
-                    const Fq2S &a = base[(wrap ? G12_XF : G12_F) + ai];
-                    const Fq2S &b = base[(mode == 1 ? G12_F : G12_L) + bi];
-                    sum = add_lazy(sum, g12_comp_mul<2>(part, a, b));
+                    sqr_pair((int)k, j, t, u, wrap);
+                    const F29 x1 = g12_comp_mul<2>(part, base[(wrap ? G12_XF : G12_F) + t], base[G12_F + u]);
+                    sum = add_lazy(sum, t == u ? x1 : add_lazy(x1, x1));
                 }
                 g12_part(base[G12_T + k], part) = Fs{mul(w12_norm_u(sum), F29::one())};     // < 12p -> < 2p
+            } else if (mode) {
+                F29 sum = F29::zero();
+                for (int t = 0; t < 3; t++) {
+                    // b = L[t] (w^0, w^3, w^4), a index k - {0,3,4}
+                    int ai = (int)k - (t == 0 ? 0 : t + 2);
+                    const bool wrap = ai < 0;
+                    if (wrap) ai += 6;
+                    sum = add_lazy(sum, g12_comp_mul<2>(part, base[(wrap ? G12_XF : G12_F) + ai], base[G12_L + t]));
+                }
+                g12_part(base[G12_T + k], part) = Fs{mul(w12_norm_u(sum), F29::one())};     // < 6p -> < 2p
             }
             if ((int)k < sd.n) g12_part(base[G12_G + k], part) = Fs{g12_comp_mul<20>(part, base[G12_V + sd.a[k]], base[G12_V + sd.b[k]])};
         });

@@ -208,12 +208,17 @@ __global__ __launch_bounds__(64) void k_fq12_prod8(const Fq12 *__restrict__ in, 
 
 int miller_device(const void *d_g1, const void *d_g2, size_t n, void *d_out, hipStream_t st) {
     if (n == 0) return LSA_OK;
-    // up to ~1 wavefront per SIMD the one-pairing-per-wavefront kernel has the shorter chain
-    // (1.3 ms); then five pairings per wavefront (twelve lanes each) while that still leaves at
-    // most one wavefront per SIMD, then ten per wavefront (2.9 ms flat up to ~10^4 pairings,
-    // throughput-bound beyond); from 2^16 on one lane per pairing does the least total work.
+    // Measured inside lsa_pairing_product calls (tools/pairing_sweep.py: every Miller kernel starts
+    // on a chip that idled through the previous final exponentiation): up to one wavefront per
+    // SIMD (1024 pairings) the one-pairing-per-wavefront kernel is as fast as any (2.9-3.1 ms per
+    // call); five pairings per wavefront (twelve lanes each) hold 3.2 ms up to 3072 pairings but
+    // jump to 4.4 ms once their wavefronts cover more than ~3/4 of the SIMDs -- the same kernel
+    // takes 1.8 ms at 4096 pairings in a back-to-back loop (tools/miller_sweep.py), so this is the
+    // chip ramping up, not work; ten pairings per wavefront (six lanes each, 4 or 3 products per
+    // coefficient of f^2 since the squaring uses unordered pairs) stay at 3.6-3.9 ms from 3073 to
+    // 8192 pairings and win from there on; from 2^16 on one lane per pairing does the least work.
     static const int force = getenv("LSA_MILLER_KERNEL") ? atoi(getenv("LSA_MILLER_KERNEL")) : 0;   // 1: wave, 2: g6, 3: lane, 4: g12
-    const int pick = force ? force : (n <= 1536 ? 1 : (n <= 5120 ? 4 : (n < 65536 ? 2 : 3)));
+    const int pick = force ? force : (n <= 1024 ? 1 : (n <= 3072 ? 4 : (n < 65536 ? 2 : 3)));
     if (pick == 1)
         hipLaunchKernelGGL(k_miller_wave, dim3((unsigned)n), dim3(64), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, n, (Fq12 *)d_out);
     else if (pick == 4)

@@ -149,7 +149,7 @@ def test_gpu_miller_values_up_to_subfield_factor(lsa, vec):
     pins = vec["miller_pins"]
     base_p = np.concatenate([pairs_from_hex(p["pair"])[0] for p in pins])
     base_q = np.concatenate([pairs_from_hex(p["pair"])[1] for p in pins])
-    for n in (2000, 6000, 20000):
+    for n in (2000, 6000, 70000):
         reps = (n + len(pins) - 1) // len(pins)
         f = lsa.miller_loop(np.tile(base_p, (reps, 1))[:n], np.tile(base_q, (reps, 1))[:n])
         for i in (0, n // 2 + 3, n - 1):
