@@ -361,58 +361,102 @@ struct SegList {
     uint32_t off[MSM_MAX_SEGMENTS + 1];
 };
 
-// digits[k][i] = +-(segment * B + |digit|), 0 for a zero digit; local_idx[i] = index inside the segment
-__global__ __launch_bounds__(256) void k_digits_wide(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B,
-                                                     int32_t *__restrict__ digits, uint32_t *__restrict__ local_idx) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t seg = 0;
-    for (uint32_t j = 1; j < segs.nseg; j++) if (i >= segs.off[j]) seg = j;
-    if (local_idx) local_idx[i] = (uint32_t)i - segs.off[seg];
+// Signed digits of one scalar, produced one window at a time (the carry chain is sequential) and
+// handed to `use(k, sd)` with sd = +-(segment * B + |digit|), 0 for a zero digit -- no digit
+// array: the ranking pass and the scatter pass both recompute them from the scalar (a Montgomery
+// reduction and a few shifts per scalar) instead of writing 4 B per digit to HBM and reading
+// them back twice.
+template <class Use>
+__device__ __forceinline__ void wide_digits(const Fr &scalar, const WidePlan &pl, uint32_t seg_base, Use use) {
     uint32_t s[8];
-    scalars[i].to_canonical(s);
+    scalar.to_canonical(s);
+    // consume the limbs through a 64-bit bit buffer (static limb index: no register-array indexing)
+    uint64_t buf = 0;
+    unsigned have = 0, k = 0;
     uint32_t carry = 0;
-    for (unsigned k = 0; k < pl.nwin; k++) {
-        const unsigned bit = pl.start[k], width = pl.width[k];
-        const int w = (int)(bit >> 5);
-        const unsigned sh = bit & 31;
-        uint64_t two = (uint64_t)(w < 8 ? s[w] : 0) | ((uint64_t)(w + 1 < 8 ? s[w + 1] : 0) << 32);
-        uint32_t d = (uint32_t)(two >> sh) & ((1u << width) - 1);
-        d += carry;
-        int32_t sd;
-        // the top window is never recoded: scalars are < 2^254 and the windows cover 255 bits, so
-        // its raw value is < 2^(width-1) and the carry keeps it <= 2^(width-1) <= B
-        if (k + 1 < pl.nwin && d >= (1u << (width - 1))) { sd = (int32_t)d - (int32_t)(1u << width); carry = 1; }
-        else { sd = (int32_t)d; carry = 0; }
-        if (sd != 0) { const int32_t m = (int32_t)(seg * B) + (sd < 0 ? -sd : sd); sd = sd < 0 ? -m : m; }
-        digits[(size_t)k * n + i] = sd;
+#pragma unroll
+    for (int limb = 0; limb < 8; limb++) {
+        buf |= (uint64_t)s[limb] << have;
+        have += 32;
+        while (k < pl.nwin && (have >= pl.width[k] || limb == 7)) {
+            const unsigned width = pl.width[k];
+            uint32_t d = (uint32_t)buf & ((1u << width) - 1);
+            buf >>= width;
+            have = have >= width ? have - width : 0;
+            d += carry;
+            int32_t sd;
+            // the top window is never recoded: scalars are < 2^254 and the windows cover 255 bits, so
+            // its raw value is < 2^(width-1) and the carry keeps it <= 2^(width-1) <= B
+            if (k + 1 < pl.nwin && d >= (1u << (width - 1))) { sd = (int32_t)d - (int32_t)(1u << width); carry = 1; }
+            else { sd = (int32_t)d; carry = 0; }
+            if (sd != 0) { const int32_t m = (int32_t)seg_base + (sd < 0 ? -sd : sd); sd = sd < 0 ? -m : m; }
+            use(k, sd);
+            k++;
+        }
     }
 }
 
-// FINE: 64-bit records (fine bits | entry) ordered by coarse bin; else the final 32-bit entries
+#define WIDE_TILE 4096u            // scalars per workgroup of the wide path's ranking / scatter passes
+__device__ __forceinline__ uint32_t segment_of(const SegList &segs, uint32_t i) {
+    uint32_t seg = 0;
+    for (uint32_t j = 1; j < segs.nseg; j++) if (i >= segs.off[j]) seg = j;
+    return seg;
+}
+
+// One workgroup per tile of WIDE_TILE scalars, ALL windows: a histogram of the (coarse) bins in LDS
+// (u16 pairs) ranks every entry of the tile with one ds_add_rtn_u32.  rank[k][i] and the tile's
+// histogram row go to HBM.
+__global__ __launch_bounds__(1024) void k_rank_wide(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B,
+                                                    uint32_t Bc, uint32_t shift, uint16_t *__restrict__ rank, uint16_t *__restrict__ tile_hist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t cnt2[];   // Bc/2 words: two u16 counters each
+    for (uint32_t x = threadIdx.x; x < (Bc + 1) / 2; x += 1024) cnt2[x] = 0;
+    __syncthreads();
+    const size_t lo = (size_t)blockIdx.x * WIDE_TILE;
+    for (uint32_t j = 0; j < WIDE_TILE / 1024; j++) {
+        const size_t i = lo + threadIdx.x + j * 1024;
+        if (i >= n) break;
+        const uint32_t seg = segment_of(segs, (uint32_t)i);
+        wide_digits(scalars[i], pl, seg * B, [&](unsigned k, int32_t sd) {
+            if (sd != 0) {
+                const uint32_t b = ((uint32_t)(sd < 0 ? -sd : sd) - 1) >> shift;
+                const uint32_t sh = (b & 1) * 16;
+                const uint32_t old = atomicAdd(&cnt2[b >> 1], 1u << sh);      // ds_add_rtn_u32
+                rank[(size_t)k * n + i] = (uint16_t)(old >> sh);
+            }
+        });
+    }
+    __syncthreads();
+    uint16_t *th = tile_hist + (size_t)blockIdx.x * Bc;
+    const uint16_t *c16 = reinterpret_cast<const uint16_t *>(cnt2);
+    for (uint32_t x = threadIdx.x; x < Bc; x += 1024) th[x] = c16[x];
+}
+
+// The same tiles again: base[bin] = offs[bin] + tile_base[tile][bin] in LDS, every entry written
+// at base + rank.  FINE: 64-bit records (fine bits | entry) ordered by coarse bin; else the final
+// 32-bit entries.  Entry = index inside the segment + copy * win_stride | sign << 31.
 template <bool FINE>
-__global__ __launch_bounds__(1024) void k_scatter_wide(const int32_t *__restrict__ digits, const uint16_t *__restrict__ rank,
-                                                       const uint32_t *__restrict__ offs, const uint32_t *__restrict__ tile_base,
-                                                       const uint32_t *__restrict__ local_idx, size_t n, uint32_t Bc, uint32_t ntiles,
-                                                       void *__restrict__ out, uint32_t win_stride) {
+__global__ __launch_bounds__(1024) void k_scatter_wide(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B,
+                                                       uint32_t Bc, const uint16_t *__restrict__ rank, const uint32_t *__restrict__ offs,
+                                                       const uint32_t *__restrict__ tile_base, void *__restrict__ out, uint32_t win_stride) {
     extern __shared__ __attribute__((aligned(16))) uint32_t base[];   // Bc words
-    const uint32_t t = blockIdx.x, k = blockIdx.y;
-    const uint32_t *tb = tile_base + ((size_t)k * ntiles + t) * Bc;
+    const uint32_t *tb = tile_base + (size_t)blockIdx.x * Bc;
     for (uint32_t x = threadIdx.x; x < Bc; x += 1024) base[x] = offs[x] + tb[x];
     __syncthreads();
-    const size_t lo = (size_t)t * SORT_TILE;
-    const size_t hi = lo + SORT_TILE < n ? lo + SORT_TILE : n;
-    const int32_t *dg = digits + (size_t)k * n;
-    const uint16_t *rk = rank + (size_t)k * n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
-        int32_t sd = dg[i];
-        if (sd != 0) {
-            const uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
-            const uint32_t j = local_idx ? local_idx[i] : (uint32_t)i;
-            const uint32_t ent = (j + k * win_stride) | (sd < 0 ? 0x80000000u : 0u);   // window k reads its own copy of the bases
-            if (FINE) ((uint64_t *)out)[base[b >> WIDE_FINE_BITS] + rk[i]] = ((uint64_t)(b & ((1u << WIDE_FINE_BITS) - 1)) << 32) | ent;
-            else ((uint32_t *)out)[base[b] + rk[i]] = ent;
-        }
+    const size_t lo = (size_t)blockIdx.x * WIDE_TILE;
+    for (uint32_t j = 0; j < WIDE_TILE / 1024; j++) {
+        const size_t i = lo + threadIdx.x + j * 1024;
+        if (i >= n) break;
+        const uint32_t seg = segment_of(segs, (uint32_t)i);
+        const uint32_t local = (uint32_t)i - segs.off[seg];
+        wide_digits(scalars[i], pl, seg * B, [&](unsigned k, int32_t sd) {
+            if (sd != 0) {
+                const uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
+                const uint32_t ent = (local + k * win_stride) | (sd < 0 ? 0x80000000u : 0u);   // window k reads its own copy of the bases
+                const uint32_t r = rank[(size_t)k * n + i];
+                if (FINE) ((uint64_t *)out)[base[b >> WIDE_FINE_BITS] + r] = ((uint64_t)(b & ((1u << WIDE_FINE_BITS) - 1)) << 32) | ent;
+                else ((uint32_t *)out)[base[b] + r] = ent;
+            }
+        });
     }
 }
 
@@ -1174,10 +1218,12 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     size_t o_bins = carve((size_t)3 * ngroups * SIZE_BINS * 4);   // bin_count | bin_start | bin_cursor
     size_t o_perm = carve((size_t)nb * 4);
     const uint32_t ntiles = (uint32_t)((nv + SORT_TILE - 1) / SORT_TILE);
-    size_t o_digits = carve(ne * 4);
+    const uint32_t wtiles = (uint32_t)((n + WIDE_TILE - 1) / WIDE_TILE);     // wide path: one row per tile (all windows)
+    const size_t rows = wide ? wtiles : (size_t)nwin * ntiles;
+    size_t o_digits = carve(wide ? 0 : ne * 4);
     size_t o_rank = carve(ne * 2);
-    size_t o_thist = carve((size_t)nwin * Bc * ntiles * 2);
-    size_t o_tbase = carve((size_t)nwin * Bc * ntiles * 4);
+    size_t o_thist = carve(rows * Bc * 2);
+    size_t o_tbase = carve(rows * Bc * 4);
     size_t o_entries = carve(ne * 4);
     size_t o_heavy = carve((size_t)max_heavy * 4);
     size_t o_choff = carve((size_t)(max_heavy + 1) * 4);
@@ -1185,7 +1231,6 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     size_t o_recs = carve(fine ? ne * 8 : 0);        // coarse-sorted 64-bit records
     size_t o_chist = carve(fine ? (size_t)Bc * 4 : 0);
     size_t o_coffs = carve(fine ? (size_t)Bc * 4 : 0);
-    size_t o_lidx = carve(nseg > 1 ? n * 4 : 0);     // index of every scalar inside its segment
     if (g_ws.ensure(off) != 0) { set_error("msm: workspace allocation of %zu bytes failed", off); return LSA_ERR_NOMEM; }
     // tail buffers of this call parity
     if (g_overlap < 0) g_overlap = getenv("LSA_NO_OVERLAP") ? 0 : 1;
@@ -1237,7 +1282,6 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     uint64_t *recs = (uint64_t *)(ws + o_recs);
     uint32_t *hist_c = fine ? (uint32_t *)(ws + o_chist) : hist;       // one pass: the bins ARE the buckets
     uint32_t *offs_c = fine ? (uint32_t *)(ws + o_coffs) : offs;
-    uint32_t *local_idx = nseg > 1 ? (uint32_t *)(ws + o_lidx) : nullptr;
     A *wave_out = (A *)(tws + o_wave);
     A *window_sums = (A *)(tws + o_win);
 
@@ -1256,23 +1300,24 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         lds_attr_set = true;
     }
     if (wide) {
         const uint32_t win_stride = (uint32_t)(table_stride * pl.copy_step);
-        hipLaunchKernelGGL(k_digits_wide, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_scalars, n, segs, pl, B, digits, local_idx);
-        hipLaunchKernelGGL(k_rank, dim3(ntiles, nwin), dim3(1024), (size_t)Bc * 2, st, digits, nv, Bc, ntiles, rank, tile_hist, fine ? WIDE_FINE_BITS : 0u);
-        hipLaunchKernelGGL(k_tile_scan_rows, dim3((Bc + 31) / 32), dim3(1024), 0, st, tile_hist, Bc, nwin * ntiles, tile_base, hist_c);
+        const uint32_t shift = fine ? WIDE_FINE_BITS : 0u;
+        hipLaunchKernelGGL(k_rank_wide, dim3(wtiles), dim3(1024), (size_t)((Bc + 1) / 2) * 4, st, d_scalars, n, segs, pl, B, Bc, shift, rank, tile_hist);
+        hipLaunchKernelGGL(k_tile_scan_rows, dim3((Bc + 31) / 32), dim3(1024), 0, st, tile_hist, Bc, wtiles, tile_base, hist_c);
         mark(st);  // 1
         hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(256), 0, st, hist_c, Bc, bsum);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bsum, scan_blocks);
         hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, hist_c, bsum, Bc, offs_c);
         mark(st);  // 2
         if (fine) {
-            hipLaunchKernelGGL(k_scatter_wide<true>, dim3(ntiles, nwin), dim3(1024), (size_t)Bc * 4, st, digits, rank, offs_c, tile_base, local_idx, nv, Bc, ntiles, (void *)recs, win_stride);
+            hipLaunchKernelGGL(k_scatter_wide<true>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, rank, offs_c, tile_base, (void *)recs, win_stride);
             hipLaunchKernelGGL(k_fine_sort, dim3(Bc), dim3(1024), 0, st, recs, offs_c, hist_c, entries, hist, offs);
         } else {
-            hipLaunchKernelGGL(k_scatter_wide<false>, dim3(ntiles, nwin), dim3(1024), (size_t)Bc * 4, st, digits, rank, offs_c, tile_base, local_idx, nv, Bc, ntiles, (void *)entries, win_stride);
+            hipLaunchKernelGGL(k_scatter_wide<false>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, rank, offs_c, tile_base, (void *)entries, win_stride);
         }
         mark(st);  // 3
     } else {
