@@ -290,7 +290,11 @@ __global__ __launch_bounds__(1024) void k_scatter(const int32_t *__restrict__ di
 // workgroup of 16 wavefronts takes 64 bins (one per lane, coalesced row reads) and splits the rows
 // 16 ways: partial sums per wavefront, exclusive prefix across the wavefronts through LDS, then a
 // second pass writes every row's base.
-__global__ __launch_bounds__(1024) void k_tile_scan_rows(const uint16_t *__restrict__ tile_hist, uint32_t Bc, uint32_t R,
+// Rows are `pitch` elements apart, pitch = Bc + 96, so that the rows of one bin are not a power of
+// two apart.  (The kernel takes ~80 us for 2 MB whatever its shape -- one thread per bin over all
+// rows, 64 bins x 16 row groups, this version, padded or not: it inherits the write-back of the
+// 27 MB of ranks the preceding kernel left dirty in the L2s.)
+__global__ __launch_bounds__(1024) void k_tile_scan_rows(const uint16_t *__restrict__ tile_hist, uint32_t Bc, uint32_t R, uint32_t pitch,
                                                          uint32_t *__restrict__ tile_base, uint32_t *__restrict__ hist) {
     // 32 bins x 32 row groups per workgroup: lane -> (bin = lane & 31, group = 2 * wavefront + (lane >> 5))
     __shared__ uint32_t part[32][33];
@@ -306,12 +310,12 @@ __global__ __launch_bounds__(1024) void k_tile_scan_rows(const uint16_t *__restr
 #pragma unroll
         for (uint32_t j = 0; j < MAXPER; j++) {
             const uint32_t r = r0 + j;
-            v[j] = (b < Bc && r < r1) ? tile_hist[(size_t)r * Bc + b] : 0u;
+            v[j] = (b < Bc && r < r1) ? tile_hist[(size_t)r * pitch + b] : 0u;
         }
 #pragma unroll
         for (uint32_t j = 0; j < MAXPER; j++) sum += v[j];
     } else if (b < Bc) {
-        for (uint32_t r = r0; r < r1; r++) sum += tile_hist[(size_t)r * Bc + b];
+        for (uint32_t r = r0; r < r1; r++) sum += tile_hist[(size_t)r * pitch + b];
     }
     part[grp][bl] = sum;
     __syncthreads();
@@ -323,11 +327,11 @@ __global__ __launch_bounds__(1024) void k_tile_scan_rows(const uint16_t *__restr
 #pragma unroll
             for (uint32_t j = 0; j < MAXPER; j++) {
                 const uint32_t r = r0 + j;
-                if (r < r1) { tile_base[(size_t)r * Bc + b] = run; run += v[j]; }
+                if (r < r1) { tile_base[(size_t)r * pitch + b] = run; run += v[j]; }
             }
         } else {
             for (uint32_t r = r0; r < r1; r++) {
-                const size_t idx = (size_t)r * Bc + b;
+                const size_t idx = (size_t)r * pitch + b;
                 tile_base[idx] = run;
                 run += tile_hist[idx];
             }
@@ -407,7 +411,8 @@ __device__ __forceinline__ uint32_t segment_of(const SegList &segs, uint32_t i) 
 // (u16 pairs) ranks every entry of the tile with one ds_add_rtn_u32.  rank[k][i] and the tile's
 // histogram row go to HBM.
 __global__ __launch_bounds__(1024) void k_rank_wide(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B,
-                                                    uint32_t Bc, uint32_t shift, uint16_t *__restrict__ rank, uint16_t *__restrict__ tile_hist) {
+                                                    uint32_t Bc, uint32_t shift, uint32_t pitch, uint16_t *__restrict__ rank,
+                                                    uint16_t *__restrict__ tile_hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cnt2[];   // Bc/2 words: two u16 counters each
     for (uint32_t x = threadIdx.x; x < (Bc + 1) / 2; x += 1024) cnt2[x] = 0;
     __syncthreads();
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(1024) void k_rank_wide(const Fr *__restrict__ scala
         });
     }
     __syncthreads();
-    uint16_t *th = tile_hist + (size_t)blockIdx.x * Bc;
+    uint16_t *th = tile_hist + (size_t)blockIdx.x * pitch;
     const uint16_t *c16 = reinterpret_cast<const uint16_t *>(cnt2);
     for (uint32_t x = threadIdx.x; x < Bc; x += 1024) th[x] = c16[x];
 }
@@ -436,10 +441,11 @@ __global__ __launch_bounds__(1024) void k_rank_wide(const Fr *__restrict__ scala
 // 32-bit entries.  Entry = index inside the segment + copy * win_stride | sign << 31.
 template <bool FINE>
 __global__ __launch_bounds__(1024) void k_scatter_wide(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B,
-                                                       uint32_t Bc, const uint16_t *__restrict__ rank, const uint32_t *__restrict__ offs,
-                                                       const uint32_t *__restrict__ tile_base, void *__restrict__ out, uint32_t win_stride) {
+                                                       uint32_t Bc, uint32_t pitch, const uint16_t *__restrict__ rank,
+                                                       const uint32_t *__restrict__ offs, const uint32_t *__restrict__ tile_base,
+                                                       void *__restrict__ out, uint32_t win_stride) {
     extern __shared__ __attribute__((aligned(16))) uint32_t base[];   // Bc words
-    const uint32_t *tb = tile_base + (size_t)blockIdx.x * Bc;
+    const uint32_t *tb = tile_base + (size_t)blockIdx.x * pitch;
     for (uint32_t x = threadIdx.x; x < Bc; x += 1024) base[x] = offs[x] + tb[x];
     __syncthreads();
     const size_t lo = (size_t)blockIdx.x * WIDE_TILE;
@@ -1222,8 +1228,9 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     const size_t rows = wide ? wtiles : (size_t)nwin * ntiles;
     size_t o_digits = carve(wide ? 0 : ne * 4);
     size_t o_rank = carve(ne * 2);
-    size_t o_thist = carve(rows * Bc * 2);
-    size_t o_tbase = carve(rows * Bc * 4);
+    const uint32_t pitch = wide ? Bc + 96 : Bc;      // elements between rows of the tile arrays (see k_tile_scan_rows)
+    size_t o_thist = carve(rows * pitch * 2);
+    size_t o_tbase = carve(rows * pitch * 4);
     size_t o_entries = carve(ne * 4);
     size_t o_heavy = carve((size_t)max_heavy * 4);
     size_t o_choff = carve((size_t)(max_heavy + 1) * 4);
@@ -1306,18 +1313,18 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     if (wide) {
         const uint32_t win_stride = (uint32_t)(table_stride * pl.copy_step);
         const uint32_t shift = fine ? WIDE_FINE_BITS : 0u;
-        hipLaunchKernelGGL(k_rank_wide, dim3(wtiles), dim3(1024), (size_t)((Bc + 1) / 2) * 4, st, d_scalars, n, segs, pl, B, Bc, shift, rank, tile_hist);
-        hipLaunchKernelGGL(k_tile_scan_rows, dim3((Bc + 31) / 32), dim3(1024), 0, st, tile_hist, Bc, wtiles, tile_base, hist_c);
+        hipLaunchKernelGGL(k_rank_wide, dim3(wtiles), dim3(1024), (size_t)((Bc + 1) / 2) * 4, st, d_scalars, n, segs, pl, B, Bc, shift, pitch, rank, tile_hist);
+        hipLaunchKernelGGL(k_tile_scan_rows, dim3((Bc + 31) / 32), dim3(1024), 0, st, tile_hist, Bc, wtiles, pitch, tile_base, hist_c);
         mark(st);  // 1
         hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(256), 0, st, hist_c, Bc, bsum);
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bsum, scan_blocks);
         hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, hist_c, bsum, Bc, offs_c);
         mark(st);  // 2
         if (fine) {
-            hipLaunchKernelGGL(k_scatter_wide<true>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, rank, offs_c, tile_base, (void *)recs, win_stride);
+            hipLaunchKernelGGL(k_scatter_wide<true>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, rank, offs_c, tile_base, (void *)recs, win_stride);
             hipLaunchKernelGGL(k_fine_sort, dim3(Bc), dim3(1024), 0, st, recs, offs_c, hist_c, entries, hist, offs);
         } else {
-            hipLaunchKernelGGL(k_scatter_wide<false>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, rank, offs_c, tile_base, (void *)entries, win_stride);
+            hipLaunchKernelGGL(k_scatter_wide<false>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, rank, offs_c, tile_base, (void *)entries, win_stride);
         }
         mark(st);  // 3
     } else {
