@@ -587,10 +587,11 @@ static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *
             g_crs.pool.begin(bases_jac, n * sizeof(Jac<F>), CRS_UNIT_POINTS * sizeof(Jac<F>), CRS_TASK_UNITS, g_crs.scratch_fp.data());
         }
         auto t0 = std::chrono::steady_clock::now();
-        HIPCHK(hipMemcpyAsync(g_stage_scalars.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+        const hipError_t ce = hipMemcpyAsync(g_stage_scalars.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream);
         st.h2d_scalars_ms = ms_since(t0);
         t0 = std::chrono::steady_clock::now();
-        if (g_crs.mode == 2) g_crs.pool.finish();
+        if (g_crs.mode == 2) g_crs.pool.finish();       // also on the error path: the workers read the caller's buffer
+        HIPCHK(ce);
         st.fingerprint_wait_ms = ms_since(t0);
         t0 = std::chrono::steady_clock::now();
         lsa_bases *b = nullptr;

@@ -400,7 +400,10 @@ __device__ __forceinline__ void wide_digits(const Fr &scalar, const WidePlan &pl
     }
 }
 
-#define WIDE_TILE 4096u            // scalars per workgroup of the wide path's ranking / scatter passes
+// Scalars per workgroup of the wide path's ranking / scatter passes: a tile's entries (nwin per
+// scalar) must fit the u16 counters even when every one of them lands in the same bin
+// (all scalars equal, all their digits equal): 13 x 4096 or 26 x 2048 = 53248 < 65536.
+static inline uint32_t wide_tile(uint32_t nwin) { return nwin > 15 ? 2048u : 4096u; }
 __device__ __forceinline__ uint32_t segment_of(const SegList &segs, uint32_t i) {
     uint32_t seg = 0;
     for (uint32_t j = 1; j < segs.nseg; j++) if (i >= segs.off[j]) seg = j;
@@ -411,13 +414,13 @@ __device__ __forceinline__ uint32_t segment_of(const SegList &segs, uint32_t i) 
 // (u16 pairs) ranks every entry of the tile with one ds_add_rtn_u32.  rank[k][i] and the tile's
 // histogram row go to HBM.
 __global__ __launch_bounds__(1024) void k_rank_wide(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B,
-                                                    uint32_t Bc, uint32_t shift, uint32_t pitch, uint16_t *__restrict__ rank,
+                                                    uint32_t Bc, uint32_t shift, uint32_t pitch, uint32_t tile, uint16_t *__restrict__ rank,
                                                     uint16_t *__restrict__ tile_hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cnt2[];   // Bc/2 words: two u16 counters each
     for (uint32_t x = threadIdx.x; x < (Bc + 1) / 2; x += 1024) cnt2[x] = 0;
     __syncthreads();
-    const size_t lo = (size_t)blockIdx.x * WIDE_TILE;
-    for (uint32_t j = 0; j < WIDE_TILE / 1024; j++) {
+    const size_t lo = (size_t)blockIdx.x * tile;
+    for (uint32_t j = 0; j < tile / 1024; j++) {
         const size_t i = lo + threadIdx.x + j * 1024;
         if (i >= n) break;
         const uint32_t seg = segment_of(segs, (uint32_t)i);
@@ -441,15 +444,15 @@ __global__ __launch_bounds__(1024) void k_rank_wide(const Fr *__restrict__ scala
 // 32-bit entries.  Entry = index inside the segment + copy * win_stride | sign << 31.
 template <bool FINE>
 __global__ __launch_bounds__(1024) void k_scatter_wide(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B,
-                                                       uint32_t Bc, uint32_t pitch, const uint16_t *__restrict__ rank,
+                                                       uint32_t Bc, uint32_t pitch, uint32_t tile, const uint16_t *__restrict__ rank,
                                                        const uint32_t *__restrict__ offs, const uint32_t *__restrict__ tile_base,
                                                        void *__restrict__ out, uint32_t win_stride) {
     extern __shared__ __attribute__((aligned(16))) uint32_t base[];   // Bc words
     const uint32_t *tb = tile_base + (size_t)blockIdx.x * pitch;
     for (uint32_t x = threadIdx.x; x < Bc; x += 1024) base[x] = offs[x] + tb[x];
     __syncthreads();
-    const size_t lo = (size_t)blockIdx.x * WIDE_TILE;
-    for (uint32_t j = 0; j < WIDE_TILE / 1024; j++) {
+    const size_t lo = (size_t)blockIdx.x * tile;
+    for (uint32_t j = 0; j < tile / 1024; j++) {
         const size_t i = lo + threadIdx.x + j * 1024;
         if (i >= n) break;
         const uint32_t seg = segment_of(segs, (uint32_t)i);
@@ -1224,7 +1227,8 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     size_t o_bins = carve((size_t)3 * ngroups * SIZE_BINS * 4);   // bin_count | bin_start | bin_cursor
     size_t o_perm = carve((size_t)nb * 4);
     const uint32_t ntiles = (uint32_t)((nv + SORT_TILE - 1) / SORT_TILE);
-    const uint32_t wtiles = (uint32_t)((n + WIDE_TILE - 1) / WIDE_TILE);     // wide path: one row per tile (all windows)
+    const uint32_t wtile = wide_tile(nwin);
+    const uint32_t wtiles = (uint32_t)((n + wtile - 1) / wtile);             // wide path: one row per tile (all windows)
     const size_t rows = wide ? wtiles : (size_t)nwin * ntiles;
     size_t o_digits = carve(wide ? 0 : ne * 4);
     size_t o_rank = carve(ne * 2);
@@ -1313,7 +1317,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     if (wide) {
         const uint32_t win_stride = (uint32_t)(table_stride * pl.copy_step);
         const uint32_t shift = fine ? WIDE_FINE_BITS : 0u;
-        hipLaunchKernelGGL(k_rank_wide, dim3(wtiles), dim3(1024), (size_t)((Bc + 1) / 2) * 4, st, d_scalars, n, segs, pl, B, Bc, shift, pitch, rank, tile_hist);
+        hipLaunchKernelGGL(k_rank_wide, dim3(wtiles), dim3(1024), (size_t)((Bc + 1) / 2) * 4, st, d_scalars, n, segs, pl, B, Bc, shift, pitch, wtile, rank, tile_hist);
         hipLaunchKernelGGL(k_tile_scan_rows, dim3((Bc + 31) / 32), dim3(1024), 0, st, tile_hist, Bc, wtiles, pitch, tile_base, hist_c);
         mark(st);  // 1
         hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(256), 0, st, hist_c, Bc, bsum);
@@ -1321,10 +1325,10 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
         hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, hist_c, bsum, Bc, offs_c);
         mark(st);  // 2
         if (fine) {
-            hipLaunchKernelGGL(k_scatter_wide<true>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, rank, offs_c, tile_base, (void *)recs, win_stride);
+            hipLaunchKernelGGL(k_scatter_wide<true>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, wtile, rank, offs_c, tile_base, (void *)recs, win_stride);
             hipLaunchKernelGGL(k_fine_sort, dim3(Bc), dim3(1024), 0, st, recs, offs_c, hist_c, entries, hist, offs);
         } else {
-            hipLaunchKernelGGL(k_scatter_wide<false>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, rank, offs_c, tile_base, (void *)entries, win_stride);
+            hipLaunchKernelGGL(k_scatter_wide<false>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, wtile, rank, offs_c, tile_base, (void *)entries, win_stride);
         }
         mark(st);  // 3
     } else {

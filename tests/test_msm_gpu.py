@@ -360,3 +360,39 @@ def test_segmented_msm_over_prefixes_vs_oracle(lsa, group):
         B.close()
     finally:
         lsa.set_table_threshold(0)
+
+
+def _table_positions(n_table):
+    """Bit positions of the pre-shifted copies (mirror of table_grid() in csrc/msm.hip)."""
+    nbig = 12 if n_table >= 6 << 20 else 13
+    base, rem = divmod(255, nbig)
+    pos, bit = [], 0
+    for k in range(nbig):
+        w = base + (1 if k < rem else 0)
+        pos += [bit, bit + (w + 1) // 2]
+        bit += w
+    return pos
+
+
+@pytest.mark.parametrize("n,step", [(6000, 1), (70000, 2)])
+def test_every_scalar_and_every_digit_equal(lsa, n, step):
+    """The worst case for the sort's u16 counters: all n scalars are the same value AND all of its
+    digits (26 narrow ones at n < 2^16, 13 wide ones above) are equal, so every entry of a tile lands
+    in ONE bin -- 26 x 2048 or 13 x 4096 = 53248 per tile.  Plus the heavy-bucket path end to end."""
+    import torch
+    lsa.set_table_threshold(1)
+    try:
+        bases = o.arith_bases("g1", 31, 7, n)
+        B = lsa.Bases("g1", bases)
+        if not B.has_table():
+            pytest.skip("tables disabled")
+        pos = _table_positions(n)[::step]
+        for d in (5, 1):
+            s = sum(d << p for p in pos) % R
+            sc = np.tile(o.fr_mont(s), (n, 1))
+            got = B.msm(torch.from_numpy(sc.view(np.int64)).to("cuda:0"))
+            k = s * sum(31 + 7 * i for i in range(n)) % R
+            assert canon("g1", got) == canon("g1", o.g1_mul(o.generator("g1"), o.fr_mont(k))), (n, d)
+        B.close()
+    finally:
+        lsa.set_table_threshold(0)
