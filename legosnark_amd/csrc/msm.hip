@@ -1383,10 +1383,10 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     mark(tail);  // 6
     // lvl_in[2*k] = sum of window k (pairs of (ACC,RUN): stride 2)
     Jac<F> *res = tail != st ? (Jac<F> *)(tws + o_res) : d_out;
-    if (wide) {           // every bucket space is a finished sum: convert
+    if (wide && nseg > 1) {   // every segment's bucket space is a finished sum: convert
         if constexpr (std::is_same<C, CurveG1>::value) hipLaunchKernelGGL(k_emit_g1, dim3(nseg), dim3(64), 0, tail, lvl_in, res);
         else hipLaunchKernelGGL(k_emit_g2, dim3(nseg), dim3(64), 0, tail, lvl_in, res);
-    } else if constexpr (std::is_same<C, CurveG1>::value) {
+    } else if constexpr (std::is_same<C, CurveG1>::value) {   // (wide, one segment: kw = 1, the fold only converts -- with a quad of lanes)
         hipLaunchKernelGGL(k_fold_quad, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, res);
     } else {
         hipLaunchKernelGGL(k_fold_quad_g2, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, res);
