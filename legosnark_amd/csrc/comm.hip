@@ -39,7 +39,27 @@ struct Comm {
     hipEvent_t done[DEPTH] = {};
     bool used[DEPTH] = {};
     unsigned calls = 0;
+    // test hook (env LSA_COMM_LOOPBACK=W with a one-rank communicator): behave as rank 0 of W ranks
+    // whose peers all contribute THIS rank's partial -- the collective becomes W device copies, so the
+    // whole multi-rank step (side stream, rotating buffers, events, fold) runs on one GPU, where RCCL
+    // itself refuses more than one rank; the result is W times the local one
+    int loopback = 0;
 } c;
+
+// all-gather of `bytes` per rank on `stream` (ncclAllGather of u64 words, or the loopback copies)
+int gather_all(const void *send, void *recv, size_t bytes, hipStream_t stream) {
+    if (c.loopback) {
+        for (int r = 0; r < c.world; r++)
+            if (hipMemcpyAsync((char *)recv + (size_t)r * bytes, send, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+                set_error("comm loopback copy failed");
+                return LSA_ERR_HIP;
+            }
+        return LSA_OK;
+    }
+    ncclResult_t r_ = ncclAllGather(send, recv, bytes / 8, ncclUint64, c.comm, stream);
+    if (r_ != ncclSuccess) { set_error("ncclAllGather failed: %s", ncclGetErrorString(r_)); return LSA_ERR_HIP; }
+    return LSA_OK;
+}
 
 #define NCCLCHK(x)                                                                      \
     do {                                                                                \
@@ -96,7 +116,8 @@ static int msm_sharded_async(const lsa_bases *b, size_t first, const void *d_sca
     if (rc) return rc;
     rc = side_after_main_and_tails();
     if (rc) return rc;
-    NCCLCHK(ncclAllGather(c.partial[j], c.gathered[j], sizeof(Jac<F>) / 8, ncclUint64, c.comm, c.side));
+    rc = gather_all(c.partial[j], c.gathered[j], sizeof(Jac<F>), c.side);
+    if (rc) return rc;
     rc = sum_points_device<F>((const Jac<F> *)c.gathered[j], (size_t)c.world, (Jac<F> *)d_out, c.side);
     if (rc) return rc;
     HIPCHK(hipEventRecord(c.done[j], c.side));
@@ -126,11 +147,13 @@ int lsa_comm_init(int rank, int world, const void *id128) {
     NCCLCHK(ncclCommInitRank(&c.comm, world, id, rank));
     c.rank = rank;
     c.world = world;
+    const char *lb = getenv("LSA_COMM_LOOPBACK");
+    if (world == 1 && lb && atoi(lb) > 1 && atoi(lb) <= 64) { c.loopback = atoi(lb); c.world = c.loopback; }
     HIPCHK(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c.front, hipEventDisableTiming));
     for (int j = 0; j < DEPTH; j++) {
         HIPCHK(hipMalloc(&c.partial[j], 384));
-        HIPCHK(hipMalloc(&c.gathered[j], (size_t)world * 384));
+        HIPCHK(hipMalloc(&c.gathered[j], (size_t)c.world * 384));
         HIPCHK(hipEventCreateWithFlags(&c.done[j], hipEventDisableTiming));
     }
     c.active = true;
@@ -234,8 +257,7 @@ int lsa_comm_all_gather(const void *d_partial, void *d_gathered, int kind) {
         HIPCHK(hipMemcpyAsync(d_gathered, d_partial, words * 8, hipMemcpyDeviceToDevice, g.stream));
         return LSA_OK;
     }
-    NCCLCHK(ncclAllGather(d_partial, d_gathered, words, ncclUint64, c.comm, g.stream));
-    return LSA_OK;
+    return gather_all(d_partial, d_gathered, words * 8, g.stream);
 }
 
 }  // extern "C"
