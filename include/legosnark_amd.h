@@ -151,6 +151,16 @@ int lsa_msm_run_async(const lsa_bases *bases, size_t first, const void *d_scalar
 int lsa_msm_run_segments_async(const lsa_bases *bases, size_t first, const void *d_scalars_mont, const uint64_t *seg_offsets, size_t nseg,
                                void *d_out_jac);
 
+/* CommScheme::commit (src/prototools/commit.h:149-158; CPPoly::commitPoly, src/gadgets/poly.h:30-32):
+ *   c = multiExpMA<LG1>(g1s, v),   kc = multiExpMA<LG2>(g2s, v)
+ * -- a G1 and a G2 MSM over the SAME scalar vector.  The scalar sort (digits, ranks, scatter) does
+ * not depend on the bases, so it runs once for both when the two handles carry pre-shifted copies
+ * over the same number of points (otherwise this is two lsa_msm_run_async calls).  bases[0 .. n)
+ * of both handles; d_scalars_mont, d_out_g1 (96 B), d_out_g2 (192 B): DEVICE.  Asynchronous like
+ * lsa_msm_run_async. */
+int lsa_commit_run_async(const lsa_bases *g1_bases, const lsa_bases *g2_bases, const void *d_scalars_mont, size_t n, void *d_out_g1,
+                         void *d_out_g2);
+
 /* Window width (bits) the MSM uses for n pairs -- exposed for DESIGN.md / tests. */
 unsigned lsa_msm_window_bits(size_t n);
 

@@ -78,6 +78,7 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_void_p)]
         for name in ("lsa_g1_msm", "lsa_g2_msm"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+        L.lsa_commit_run_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.lsa_msm_run_segments_async.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         for name in ("lsa_msm_run", "lsa_msm_run_async"):
             getattr(L, name).argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -389,6 +390,16 @@ class Bases:
             self.close()
         except Exception:
             pass
+
+
+def commit_async(g1_bases, g2_bases, d_scalars, d_out_g1, d_out_g2, n=None):
+    """CommScheme::commit's pair of MSMs (commit.h:154-155) over one device-resident scalar vector:
+    d_out_g1 = sum s_i * g1_bases[i], d_out_g2 = sum s_i * g2_bases[i]; one shared scalar sort when
+    both handles carry copies over the same number of points."""
+    if n is None:
+        n = min(g1_bases.n, g2_bases.n)
+    _after_torch(d_scalars, d_out_g1, d_out_g2)
+    _check(lib().lsa_commit_run_async(g1_bases.handle, g2_bases.handle, _ptr(d_scalars), n, _ptr(d_out_g1), _ptr(d_out_g2)))
 
 
 def normalize(group, pts):

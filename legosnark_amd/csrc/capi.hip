@@ -218,6 +218,21 @@ int lsa_msm_run_segments_async(const lsa_bases *bases, size_t first, const void 
     return msm_segments_device<Fq2>(bases->d_aff, first, (const Fr *)d_scalars, seg_offsets, nseg, (Jac<Fq2> *)d_out_jac, g.stream, bases->table_stride);
 }
 
+int lsa_commit_run_async(const lsa_bases *g1_bases, const lsa_bases *g2_bases, const void *d_scalars, size_t n, void *d_out_g1, void *d_out_g2) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (!g1_bases || !g2_bases || !d_out_g1 || !d_out_g2 || (n && !d_scalars)) { set_error("commit_run: null argument"); return LSA_ERR_INVALID; }
+    if (g1_bases->group != 1 || g2_bases->group != 2) { set_error("commit_run: needs a G1 and a G2 handle, in that order"); return LSA_ERR_INVALID; }
+    if (n > g1_bases->n || n > g2_bases->n) { set_error("commit_run: %zu pairs exceed the bases (%zu, %zu)", n, g1_bases->n, g2_bases->n); return LSA_ERR_INVALID; }
+    // one shared sort when both handles carry copies over the same number of points; else two calls
+    if (n && g1_bases->table_stride && g1_bases->table_stride == g2_bases->table_stride)
+        return msm_commit_pair_device(g1_bases->d_aff, g2_bases->d_aff, (const Fr *)d_scalars, n, (Jac<Fq> *)d_out_g1, (Jac<Fq2> *)d_out_g2, g.stream,
+                                      g1_bases->table_stride);
+    rc = msm_device<Fq>(g1_bases->d_aff, 0, (const Fr *)d_scalars, n, (Jac<Fq> *)d_out_g1, g.stream, g1_bases->table_stride);
+    if (rc) return rc;
+    return msm_device<Fq2>(g2_bases->d_aff, 0, (const Fr *)d_scalars, n, (Jac<Fq2> *)d_out_g2, g.stream, g2_bases->table_stride);
+}
+
 int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars, size_t n, void *out_jac) {
     int rc = lsa_msm_run_async(bases, first, d_scalars, n, g.d_result);
     if (rc) return rc;

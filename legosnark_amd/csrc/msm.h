@@ -36,6 +36,10 @@ int msm_device(const void *d_bases, size_t first, const Fr *d_scalars, size_t n,
 template <class F>
 int msm_segments_device(const void *d_bases, size_t first, const Fr *d_scalars, const uint64_t *seg_off, size_t nseg, Jac<F> *d_out,
                         hipStream_t st, size_t table_stride);
+// G1 and G2 MSM over the same n scalars with ONE shared sort (CommScheme::commit); both base tables
+// carry the copies and have table_stride points
+int msm_commit_pair_device(const void *d_g1_bases, const void *d_g2_bases, const Fr *d_scalars, size_t n, Jac<Fq> *d_out1,
+                           Jac<Fq2> *d_out2, hipStream_t st, size_t table_stride);
 unsigned msm_table_windows(int group, size_t n);
 unsigned msm_field_mults_per_pair(size_t n, size_t table_n);
 size_t msm_merge_min();

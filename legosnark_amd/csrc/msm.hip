@@ -1166,7 +1166,7 @@ unsigned msm_field_mults_per_pair(size_t n, size_t table_n) {
 // d_out receives nseg points.
 template <class F>
 static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars, const SegList &segs, Jac<F> *d_out, hipStream_t st,
-                        size_t table_stride) {
+                        size_t table_stride, bool reuse_sort = false) {
     using C = typename CurveOf<F>::type;
     using A = typename C::Acc;
     const typename C::Base *d_bases = (const typename C::Base *)d_bases_v + first;
@@ -1314,7 +1314,13 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         lds_attr_set = true;
     }
-    if (wide) {
+    if (reuse_sort) {
+        // second MSM of a commitment pair: the entries, populations and offsets of the call just
+        // issued on this stream (same scalars, same digit plan, same table stride) are still in the
+        // workspace -- the sort does not depend on the bases
+        if (!wide) { set_error("msm: a shared sort needs bases with pre-shifted copies"); return LSA_ERR_INVALID; }
+        mark(st); mark(st); mark(st);  // 1..3
+    } else if (wide) {
         const uint32_t win_stride = (uint32_t)(table_stride * pl.copy_step);
         const uint32_t shift = fine ? WIDE_FINE_BITS : 0u;
         hipLaunchKernelGGL(k_rank_wide, dim3(wtiles), dim3(1024), (size_t)((Bc + 1) / 2) * 4, st, d_scalars, n, segs, pl, B, Bc, shift, pitch, wtile, rank, tile_hist);
@@ -1446,6 +1452,22 @@ int msm_segments_device(const void *d_bases_v, size_t first, const Fr *d_scalars
     }
     return msm_pipeline<F>(d_bases_v, first, d_scalars + seg_off[0], segs, d_out, st, table_stride);
 }
+// CommScheme::commit (/root/reference/src/prototools/commit.h:154-155): a G1 and a G2 MSM over the
+// SAME scalar vector.  The sort (digits, ranks, scatter, fine sort: a third of a G1 call) depends on
+// the scalars and the digit plan only, so it runs once: the G2 pipeline goes first (its workspace
+// is the larger one), the G1 pipeline re-uses the sorted entries.  Both tables must have the same
+// number of points (the same plan and copy stride); the caller checks that.
+int msm_commit_pair_device(const void *d_g1_bases, const void *d_g2_bases, const Fr *d_scalars, size_t n, Jac<Fq> *d_out1,
+                           Jac<Fq2> *d_out2, hipStream_t st, size_t table_stride) {
+    SegList segs;
+    segs.nseg = 1;
+    segs.off[0] = 0;
+    segs.off[1] = (uint32_t)n;
+    int rc = msm_pipeline<Fq2>(d_g2_bases, 0, d_scalars, segs, d_out2, st, table_stride, false);
+    if (rc) return rc;
+    return msm_pipeline<Fq>(d_g1_bases, 0, d_scalars, segs, d_out1, st, table_stride, true);
+}
+
 template int msm_segments_device<Fq>(const void *, size_t, const Fr *, const uint64_t *, size_t, Jac<Fq> *, hipStream_t, size_t);
 template int msm_segments_device<Fq2>(const void *, size_t, const Fr *, const uint64_t *, size_t, Jac<Fq2> *, hipStream_t, size_t);
 

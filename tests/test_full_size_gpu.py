@@ -98,6 +98,12 @@ def test_cppoly_d20_commit_and_ladder(lsa):
     vsum = synth.fr_sum_mont(v)
     assert canon("g1", B1.msm(d_v)) == k_times_gen("g1", vsum)
     assert canon("g2", B2.msm(d_v)) == k_times_gen("g2", vsum)
+    c1 = torch.zeros(12, dtype=torch.int64, device="cuda:0")
+    c2 = torch.zeros(24, dtype=torch.int64, device="cuda:0")
+    lsa.commit_async(B1, B2, d_v, c1, c2)                        # the pair with one shared scalar sort
+    lsa.synchronize()
+    assert canon("g1", to_host(c1)) == k_times_gen("g1", vsum)
+    assert canon("g2", to_host(c2)) == k_times_gen("g2", vsum)
     # prove: witness recursion on the device, bit-exact vs the oracle's restatement of poly.h:55-67
     d_w = lsa.cppoly_witness(d_v, d_r)
     lsa.synchronize()

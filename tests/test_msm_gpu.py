@@ -396,3 +396,39 @@ def test_every_scalar_and_every_digit_equal(lsa, n, step):
         B.close()
     finally:
         lsa.set_table_threshold(0)
+
+
+@pytest.mark.parametrize("n", [2500, 70000])
+def test_commitment_pair_shares_the_sort(lsa, n):
+    """lsa_commit_run_async = CommScheme::commit's G1 + G2 MSM over one scalar vector
+    (src/prototools/commit.h:154-155) with one shared scalar sort: both results against the oracle
+    (narrow digits at n = 2500, wide digits at n = 70000), then again through handles without
+    copies (two independent calls inside)."""
+    import torch
+    b1 = o.arith_bases("g1", 5, 3, n)
+    b2 = o.arith_bases("g2", 7, 11, n)
+    sc, ints = o.random_scalars(n, seed=n)
+    d_s = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+    k1 = sum(s * (5 + 3 * i) for i, s in enumerate(ints)) % R
+    k2 = sum(s * (7 + 11 * i) for i, s in enumerate(ints)) % R
+    want1 = canon("g1", o.g1_mul(o.generator("g1"), o.fr_mont(k1)))
+    want2 = canon("g2", o.g2_mul(o.generator("g2"), o.fr_mont(k2)))
+    for thr in (1, 1 << 30):
+        lsa.set_table_threshold(thr)
+        try:
+            B1, B2 = lsa.Bases("g1", b1), lsa.Bases("g2", b2)
+            o1 = torch.zeros(12, dtype=torch.int64, device="cuda:0")
+            o2 = torch.zeros(24, dtype=torch.int64, device="cuda:0")
+            for _ in range(3):                                   # back to back: tails overlap the next pair
+                lsa.commit_async(B1, B2, d_s, o1, o2)
+            lsa.synchronize()
+            assert canon("g1", o1.cpu().numpy().view(np.uint64)) == want1, thr
+            assert canon("g2", o2.cpu().numpy().view(np.uint64)) == want2, thr
+            m = n - 37                                           # a prefix
+            lsa.commit_async(B1, B2, d_s, o1, o2, n=m)
+            lsa.synchronize()
+            assert canon("g1", o1.cpu().numpy().view(np.uint64)) == canon("g1", o.multi_exp("g1", b1[:m], sc[:m], mode="mixed"))
+            assert canon("g2", o2.cpu().numpy().view(np.uint64)) == canon("g2", o.multi_exp("g2", b2[:m], sc[:m], mode="mixed"))
+            B1.close(); B2.close()
+        finally:
+            lsa.set_table_threshold(0)
