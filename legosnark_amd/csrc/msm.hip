@@ -440,9 +440,12 @@ __global__ __launch_bounds__(1024) void k_rank_wide(const Fr *__restrict__ scala
 }
 
 // The same tiles again: base[bin] = offs[bin] + tile_base[tile][bin] in LDS, every entry written
-// at base + rank.  FINE: 64-bit records (fine bits | entry) ordered by coarse bin; else the final
-// 32-bit entries.  Entry = index inside the segment + copy * win_stride | sign << 31.
-template <bool FINE>
+// at base + rank.  REC 0: the final 32-bit entries (one pass sorts completely); REC 1: 64-bit
+// records (7 fine bits << 32 | entry) ordered by coarse bin; REC 2: 32-bit records
+// (sign | 6 fine bits | 25-bit point reference) when every point reference fits 25 bits (tables of
+// up to 2^20 points): half the bytes through the scatter and the fine sort.
+// Entry = index inside the segment + copy * win_stride | sign << 31.
+template <int REC>
 __global__ __launch_bounds__(1024) void k_scatter_wide(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B,
                                                        uint32_t Bc, uint32_t pitch, uint32_t tile, const uint16_t *__restrict__ rank,
                                                        const uint32_t *__restrict__ offs, const uint32_t *__restrict__ tile_base,
@@ -462,44 +465,65 @@ __global__ __launch_bounds__(1024) void k_scatter_wide(const Fr *__restrict__ sc
                 const uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
                 const uint32_t ent = (local + k * win_stride) | (sd < 0 ? 0x80000000u : 0u);   // window k reads its own copy of the bases
                 const uint32_t r = rank[(size_t)k * n + i];
-                if (FINE) ((uint64_t *)out)[base[b >> WIDE_FINE_BITS] + r] = ((uint64_t)(b & ((1u << WIDE_FINE_BITS) - 1)) << 32) | ent;
+                if (REC == 1) ((uint64_t *)out)[base[b >> 7] + r] = ((uint64_t)(b & 127u) << 32) | ent;
+                else if (REC == 2) ((uint32_t *)out)[base[b >> 6] + r] = (ent & 0x81ffffffu) | ((b & 63u) << 25);
                 else ((uint32_t *)out)[base[b] + r] = ent;
             }
         });
     }
 }
 
-__global__ __launch_bounds__(1024) void k_fine_sort(const uint64_t *__restrict__ recs, const uint32_t *__restrict__ offs_c,
+template <class Rec>
+struct RecOps;
+template <>
+struct RecOps<uint64_t> {          // 7 fine bits above a 32-bit entry
+    static constexpr uint32_t NF = 128;
+    static __device__ __forceinline__ uint32_t fine(uint64_t r) { return (uint32_t)(r >> 32); }
+    static __device__ __forceinline__ uint32_t entry(uint64_t r) { return (uint32_t)r; }
+};
+template <>
+struct RecOps<uint32_t> {          // sign | 6 fine bits | 25-bit point reference
+    static constexpr uint32_t NF = 64;
+    static __device__ __forceinline__ uint32_t fine(uint32_t r) { return (r >> 25) & 63u; }
+    static __device__ __forceinline__ uint32_t entry(uint32_t r) { return r & 0x81ffffffu; }
+};
+template <class Rec>
+__global__ __launch_bounds__(1024) void k_fine_sort(const Rec *__restrict__ recs, const uint32_t *__restrict__ offs_c,
                                                     const uint32_t *__restrict__ hist_c, uint32_t *__restrict__ entries,
                                                     uint32_t *__restrict__ hist, uint32_t *__restrict__ offs) {
-    constexpr uint32_t NF = 1u << WIDE_FINE_BITS;
+    using O = RecOps<Rec>;
+    constexpr uint32_t NF = O::NF;
     __shared__ uint32_t cnt[NF], cur[NF];
     const uint32_t bin = blockIdx.x, lo = offs_c[bin], n = hist_c[bin];
     if (threadIdx.x < NF) cnt[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t j = threadIdx.x; j < n; j += 1024) atomicAdd(&cnt[(uint32_t)(recs[lo + j] >> 32)], 1u);
+    for (uint32_t j = threadIdx.x; j < n; j += 1024) atomicAdd(&cnt[O::fine(recs[lo + j])], 1u);
     __syncthreads();
-    if (threadIdx.x < 64) {          // exclusive scan of the 128 counters by the first wavefront, two per lane
-        const uint32_t c0 = cnt[2 * threadIdx.x], c1 = cnt[2 * threadIdx.x + 1];
-        uint32_t incl = c0 + c1;
+    if (threadIdx.x < 64) {          // exclusive scan of the NF counters by the first wavefront, NF/64 per lane
+        constexpr uint32_t PER = NF / 64;
+        uint32_t c[PER], tot = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) { c[q] = cnt[PER * threadIdx.x + q]; tot += c[q]; }
+        uint32_t incl = tot;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             uint32_t t = __shfl_up(incl, d, 64);
             if ((int)threadIdx.x >= d) incl += t;
         }
-        const uint32_t ex = incl - (c0 + c1);
-        cur[2 * threadIdx.x] = ex;
-        cur[2 * threadIdx.x + 1] = ex + c0;
-        hist[(size_t)bin * NF + 2 * threadIdx.x] = c0;
-        hist[(size_t)bin * NF + 2 * threadIdx.x + 1] = c1;
-        offs[(size_t)bin * NF + 2 * threadIdx.x] = lo + ex;
-        offs[(size_t)bin * NF + 2 * threadIdx.x + 1] = lo + ex + c0;
+        uint32_t ex = incl - tot;
+#pragma unroll
+        for (uint32_t q = 0; q < PER; q++) {
+            cur[PER * threadIdx.x + q] = ex;
+            hist[(size_t)bin * NF + PER * threadIdx.x + q] = c[q];
+            offs[(size_t)bin * NF + PER * threadIdx.x + q] = lo + ex;
+            ex += c[q];
+        }
     }
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < n; j += 1024) {
-        const uint64_t r = recs[lo + j];
-        const uint32_t pos = atomicAdd(&cur[(uint32_t)(r >> 32)], 1u);
-        entries[lo + pos] = (uint32_t)r;
+        const Rec r = recs[lo + j];
+        const uint32_t pos = atomicAdd(&cur[O::fine(r)], 1u);
+        entries[lo + pos] = O::entry(r);
     }
 }
 
@@ -1188,7 +1212,11 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     const uint32_t nb = wide ? nseg * B : nwin * B;                          // wide: one bucket space per segment, shared by all windows
     if (wide && (uint64_t)nseg * B > (1u << 21)) { set_error("msm: %u segments of %u buckets exceed the bin space", nseg, B); return LSA_ERR_INVALID; }
     const bool fine = wide && nb > 32768;                                    // two-pass sort
-    const uint32_t Bc = !wide ? B : (fine ? nb >> WIDE_FINE_BITS : nb);      // bins of the LDS-ranked sort pass
+    // 32-bit records (6 fine bits) when every point reference fits 25 bits, else 64-bit ones (7 fine bits)
+    static const bool allow_rec32 = getenv("LSA_NO_REC32") == nullptr;
+    const bool rec32 = fine && allow_rec32 && (uint64_t)table_stride * table_copies(table_stride) < (1u << 25) && (nb >> 6) <= 32768;
+    const uint32_t fine_bits = rec32 ? 6u : WIDE_FINE_BITS;
+    const uint32_t Bc = !wide ? B : (fine ? nb >> fine_bits : nb);           // bins of the LDS-ranked sort pass
     const size_t ne = nv * nwin;
     const bool big = wide && B > 4096;                                       // throughput-shaped reduction
     static const uint32_t wide_split = getenv("LSA_WIDE_SPLIT") ? (uint32_t)atoi(getenv("LSA_WIDE_SPLIT")) : 1u;
@@ -1308,8 +1336,9 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     static bool lds_attr_set = false;
     if (!lds_attr_set) {   // > 64 KiB of dynamic LDS needs an explicit opt-in
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         lds_attr_set = true;
@@ -1322,7 +1351,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
         mark(st); mark(st); mark(st);  // 1..3
     } else if (wide) {
         const uint32_t win_stride = (uint32_t)(table_stride * pl.copy_step);
-        const uint32_t shift = fine ? WIDE_FINE_BITS : 0u;
+        const uint32_t shift = fine ? fine_bits : 0u;
         hipLaunchKernelGGL(k_rank_wide, dim3(wtiles), dim3(1024), (size_t)((Bc + 1) / 2) * 4, st, d_scalars, n, segs, pl, B, Bc, shift, pitch, wtile, rank, tile_hist);
         hipLaunchKernelGGL(k_tile_scan_rows, dim3((Bc + 31) / 32), dim3(1024), 0, st, tile_hist, Bc, wtiles, pitch, tile_base, hist_c);
         mark(st);  // 1
@@ -1330,11 +1359,14 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
         hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bsum, scan_blocks);
         hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, hist_c, bsum, Bc, offs_c);
         mark(st);  // 2
-        if (fine) {
-            hipLaunchKernelGGL(k_scatter_wide<true>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, wtile, rank, offs_c, tile_base, (void *)recs, win_stride);
-            hipLaunchKernelGGL(k_fine_sort, dim3(Bc), dim3(1024), 0, st, recs, offs_c, hist_c, entries, hist, offs);
+        if (rec32) {
+            hipLaunchKernelGGL(k_scatter_wide<2>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, wtile, rank, offs_c, tile_base, (void *)recs, win_stride);
+            hipLaunchKernelGGL(k_fine_sort<uint32_t>, dim3(Bc), dim3(1024), 0, st, (const uint32_t *)recs, offs_c, hist_c, entries, hist, offs);
+        } else if (fine) {
+            hipLaunchKernelGGL(k_scatter_wide<1>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, wtile, rank, offs_c, tile_base, (void *)recs, win_stride);
+            hipLaunchKernelGGL(k_fine_sort<uint64_t>, dim3(Bc), dim3(1024), 0, st, (const uint64_t *)recs, offs_c, hist_c, entries, hist, offs);
         } else {
-            hipLaunchKernelGGL(k_scatter_wide<false>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, wtile, rank, offs_c, tile_base, (void *)entries, win_stride);
+            hipLaunchKernelGGL(k_scatter_wide<0>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, wtile, rank, offs_c, tile_base, (void *)entries, win_stride);
         }
         mark(st);  // 3
     } else {
