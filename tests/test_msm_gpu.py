@@ -432,3 +432,53 @@ def test_commitment_pair_shares_the_sort(lsa, n):
             B1.close(); B2.close()
         finally:
             lsa.set_table_threshold(0)
+
+
+def test_table_handle_size_boundaries_and_random_segments(lsa):
+    """One table-carrying handle of 70000 points: prefixes at the tile (2048 / 4096 scalars) and
+    narrow/wide (2^16) boundaries with uniform, 31-bit and all-ones scalars, then randomly cut
+    segment lists -- all by the discrete-log identity (bases (a + i*b)*G)."""
+    import torch
+    rng = random.Random(77)
+    N = 70000
+    a, b = 0x1234567 << 100 | 5, 0x7654321 << 64 | 9
+    bases = o.arith_bases("g1", a, b, N)
+    lsa.set_table_threshold(1)
+    try:
+        B = lsa.Bases("g1", bases)
+        if not B.has_table():
+            pytest.skip("tables disabled")
+        sc, ints = o.random_scalars(N, seed=5)
+        small = [rng.randrange(1 << 31) for _ in range(N)]
+        ones = [1] * N
+        g = o.generator("g1")
+
+        def want(vals, lo, m):
+            return canon("g1", o.g1_mul(g, o.fr_mont(sum(v * (a + i * b) for i, v in enumerate(vals[lo:lo + m])) % R)))
+
+        for vals, arr in ((ints, sc), (small, o.fr_mont_array(small)), (ones, o.fr_mont_array(ones))):
+            d = torch.from_numpy(arr.view(np.int64)).to("cuda:0")
+            for m in (1023, 1024, 2047, 2048, 2049, 4095, 4096, 4097, 65535, 65536, 65537, N):
+                assert canon("g1", B.msm(d[:m], n=m)) == want(vals, 0, m), m
+        d = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+        for _ in range(4):
+            nseg = rng.randrange(1, 40)
+            lens = [rng.choice([0, 1, 2, 63, 64, 65, rng.randrange(1, 3000)]) for _ in range(nseg)]
+            offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+            outs = torch.zeros((nseg, 12), dtype=torch.int64, device="cuda:0")
+            B.msm_segments_async(d, offs, outs)
+            lsa.synchronize()
+            got = outs.cpu().numpy().view(np.uint64)
+            for j, m in enumerate(lens):
+                lo = int(offs[j])
+                k = sum(ints[lo + i] * (a + i * b) for i in range(m)) % R
+                assert canon("g1", got[j]) == canon("g1", o.g1_mul(g, o.fr_mont(k))), (nseg, j, m)
+        # a handle without copies refuses segmented calls loudly
+        lsa.set_table_threshold(1 << 30)
+        B2 = lsa.Bases("g1", bases[:100])
+        with pytest.raises(lsa.LsaError):
+            B2.msm_segments_async(d, np.array([0, 10, 20], dtype=np.uint64), torch.zeros((2, 12), dtype=torch.int64, device="cuda:0"))
+        B2.close()
+        B.close()
+    finally:
+        lsa.set_table_threshold(0)
