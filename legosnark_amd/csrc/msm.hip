@@ -634,10 +634,10 @@ __global__ __launch_bounds__(256) void k_size_scatter(const uint32_t *__restrict
 // ~2 us gather latency hides under ~2300 VALU instructions of arithmetic.
 // ------------------------------------------------------------------------------------
 template <class C, uint32_t ACC_SPLIT>
-__global__ __launch_bounds__(256) void k_accumulate(const typename C::Base *__restrict__ bases, const uint32_t *__restrict__ entries,
-                                                    const uint32_t *__restrict__ offs, const uint32_t *__restrict__ hist,
-                                                    const uint32_t *__restrict__ perm, const uint32_t *__restrict__ nperm,
-                                                    typename C::Acc *__restrict__ buckets) {
+__device__ __forceinline__ void accumulate_body(const typename C::Base *__restrict__ bases, const uint32_t *__restrict__ entries,
+                                                const uint32_t *__restrict__ offs, const uint32_t *__restrict__ hist,
+                                                const uint32_t *__restrict__ perm, const uint32_t *__restrict__ nperm,
+                                                typename C::Acc *__restrict__ buckets) {
     // ACC_SPLIT lanes per bucket take interleaved parts of its entry list; the parts are summed
     // when the bucket reduction loads them.
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -659,6 +659,21 @@ __global__ __launch_bounds__(256) void k_accumulate(const typename C::Base *__re
         }
     }
     buckets[(size_t)g * ACC_SPLIT + part] = acc;
+}
+template <class C, uint32_t ACC_SPLIT>
+__global__ __launch_bounds__(256) void k_accumulate(const typename C::Base *__restrict__ bases, const uint32_t *__restrict__ entries,
+                                                    const uint32_t *__restrict__ offs, const uint32_t *__restrict__ hist,
+                                                    const uint32_t *__restrict__ perm, const uint32_t *__restrict__ nperm,
+                                                    typename C::Acc *__restrict__ buckets) {
+    accumulate_body<C, ACC_SPLIT>(bases, entries, offs, hist, perm, nperm, buckets);
+}
+// The G2 kernel capped to the registers of two wavefronts per SIMD: 256 VGPRs + 316 B of scratch per
+// lane instead of 256 + 42 AGPRs at one wavefront per SIMD -- 3.35 -> 3.16 ms at n = 2^20 on the
+// wide path (the second wavefront hides the gathers the single one stalled on)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_accumulate_g2_occ2(
+    const CurveG2::Base *__restrict__ bases, const uint32_t *__restrict__ entries, const uint32_t *__restrict__ offs,
+    const uint32_t *__restrict__ hist, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ nperm, CurveG2::Acc *__restrict__ buckets) {
+    accumulate_body<CurveG2, 1u>(bases, entries, offs, hist, perm, nperm, buckets);
 }
 
 template <class A>
@@ -1392,10 +1407,18 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
         hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets, gsz, bin_shift, split);
     }
     mark(st);  // 4
+    static const bool g2_occ2 = getenv("LSA_G2_OCC1") == nullptr;
+    if constexpr (std::is_same<C, CurveG2>::value) {
+        if (split == 1 && g2_occ2) {
+            hipLaunchKernelGGL(k_accumulate_g2_occ2, dim3((nb + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
+            goto acc_done;
+        }
+    }
     if (split == 1)
         hipLaunchKernelGGL((k_accumulate<C, 1u>), dim3((nb + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
     else
         hipLaunchKernelGGL((k_accumulate<C, 2u>), dim3((nb * 2 + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
+acc_done:
     hipLaunchKernelGGL(k_heavy_plan, dim3(1), dim3(256), 0, st, hist, heavy_list, heavy_count, chunk_off);
     hipLaunchKernelGGL((k_accumulate_heavy<C>), dim3(4096), dim3(64), 0, st, d_bases, entries, offs, hist,
                        heavy_list, heavy_count, chunk_off, hpart);
