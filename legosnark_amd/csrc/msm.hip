@@ -676,6 +676,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     accumulate_body<CurveG2, 1u>(bases, entries, offs, hist, perm, nperm, buckets);
 }
 
+// (G1 capped to 128 VGPRs / four wavefronts per SIMD spills 208 B per lane and measured 2 % slower.)
 template <class A>
 __device__ __forceinline__ A shfl_down_acc(const A &p, unsigned delta) {
     A r;
