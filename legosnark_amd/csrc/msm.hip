@@ -295,7 +295,12 @@ __global__ __launch_bounds__(1024) void k_scatter(const int32_t *__restrict__ di
 // rows, 64 bins x 16 row groups, this version, padded or not: it inherits the write-back of the
 // 27 MB of ranks the preceding kernel left dirty in the L2s.)
 __global__ __launch_bounds__(1024) void k_tile_scan_rows(const uint16_t *__restrict__ tile_hist, uint32_t Bc, uint32_t R, uint32_t pitch,
-                                                         uint32_t *__restrict__ tile_base, uint32_t *__restrict__ hist) {
+                                                         uint32_t *__restrict__ tile_base, uint32_t *__restrict__ hist,
+                                                         uint32_t *__restrict__ zero1, uint32_t *__restrict__ zeron, uint32_t nzero) {
+    if (blockIdx.x == 0) {               // counters of the ordering stage (heavy_count; bin_count | bin_start | bin_cursor)
+        if (threadIdx.x == 0) *zero1 = 0;
+        for (uint32_t x = threadIdx.x; x < nzero; x += 1024) zeron[x] = 0;
+    }
     // 32 bins x 32 row groups per workgroup: lane -> (bin = lane & 31, group = 2 * wavefront + (lane >> 5))
     __shared__ uint32_t part[32][33];
     const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -410,51 +415,88 @@ __device__ __forceinline__ uint32_t segment_of(const SegList &segs, uint32_t i) 
     return seg;
 }
 
-// One workgroup per tile of WIDE_TILE scalars, ALL windows: a histogram of the (coarse) bins in LDS
-// (u16 pairs) ranks every entry of the tile with one ds_add_rtn_u32.  rank[k][i] and the tile's
-// histogram row go to HBM.
-__global__ __launch_bounds__(1024) void k_rank_wide(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B,
-                                                    uint32_t Bc, uint32_t shift, uint32_t pitch, uint32_t tile, uint16_t *__restrict__ rank,
+// Workgroup -> tile of the two wide-path passes.  Consecutive workgroup ids land on different
+// XCDs (round-robin over the 8 dies, each with its own L2); a coarse bin's region of the record
+// array is the concatenation of the tiles' runs in tile order, so giving every XCD a CONTIGUOUS
+// range of tiles makes the short runs (a few records per tile and bin) of neighbouring tiles meet
+// in the same L2 and leave it as whole lines instead of partial-line writes from eight dies.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t ntiles) {
+    const uint32_t q = ntiles >> 3, r = ntiles & 7u, x = bid & 7u, j = bid >> 3;
+    return x * q + (x < r ? x : r) + j;
+}
+
+// One workgroup per tile of WIDE_TILE scalars, ALL windows: the histogram of the (coarse) bins of
+// the tile's entries in LDS (u16 pairs, one ds_add_u32 per entry) -> the tile's row of tile_hist.
+__global__ __launch_bounds__(1024) void k_hist_wide(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B,
+                                                    uint32_t Bc, uint32_t shift, uint32_t pitch, uint32_t tile,
                                                     uint16_t *__restrict__ tile_hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cnt2[];   // Bc/2 words: two u16 counters each
     for (uint32_t x = threadIdx.x; x < (Bc + 1) / 2; x += 1024) cnt2[x] = 0;
     __syncthreads();
-    const size_t lo = (size_t)blockIdx.x * tile;
+    const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
+    const size_t lo = (size_t)t * tile;
     for (uint32_t j = 0; j < tile / 1024; j++) {
         const size_t i = lo + threadIdx.x + j * 1024;
         if (i >= n) break;
         const uint32_t seg = segment_of(segs, (uint32_t)i);
-        wide_digits(scalars[i], pl, seg * B, [&](unsigned k, int32_t sd) {
+        wide_digits(scalars[i], pl, seg * B, [&](unsigned, int32_t sd) {
             if (sd != 0) {
                 const uint32_t b = ((uint32_t)(sd < 0 ? -sd : sd) - 1) >> shift;
-                const uint32_t sh = (b & 1) * 16;
-                const uint32_t old = atomicAdd(&cnt2[b >> 1], 1u << sh);      // ds_add_rtn_u32
-                rank[(size_t)k * n + i] = (uint16_t)(old >> sh);
+                atomicAdd(&cnt2[b >> 1], 1u << ((b & 1) * 16));                 // ds_add_u32
             }
         });
     }
     __syncthreads();
-    uint16_t *th = tile_hist + (size_t)blockIdx.x * pitch;
+    uint16_t *th = tile_hist + (size_t)t * pitch;
     const uint16_t *c16 = reinterpret_cast<const uint16_t *>(cnt2);
     for (uint32_t x = threadIdx.x; x < Bc; x += 1024) th[x] = c16[x];
 }
 
-// The same tiles again: base[bin] = offs[bin] + tile_base[tile][bin] in LDS, every entry written
-// at base + rank.  REC 0: the final 32-bit entries (one pass sorts completely); REC 1: 64-bit
+// The same tiles again.  Every workgroup first rebuilds the exclusive prefix of the Bc bin
+// populations in LDS (a few KB out of L2: cheaper than three scan launches), adds its tile's row
+// of tile_base, and then hands out positions with one returning LDS atomic per entry: the order
+// of a (tile, bin) run's records is whatever the atomics give -- bucket sums do not depend on it
+// -- so no rank array travels between the passes.
+// REC 0: the final 32-bit entries (one pass sorts completely); REC 1: 64-bit
 // records (7 fine bits << 32 | entry) ordered by coarse bin; REC 2: 32-bit records
 // (sign | 6 fine bits | 25-bit point reference) when every point reference fits 25 bits (tables of
 // up to 2^20 points): half the bytes through the scatter and the fine sort.
 // Entry = index inside the segment + copy * win_stride | sign << 31.
 template <int REC>
 __global__ __launch_bounds__(1024) void k_scatter_wide(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B,
-                                                       uint32_t Bc, uint32_t pitch, uint32_t tile, const uint16_t *__restrict__ rank,
-                                                       const uint32_t *__restrict__ offs, const uint32_t *__restrict__ tile_base,
+                                                       uint32_t Bc, uint32_t pitch, uint32_t tile, const uint32_t *__restrict__ hist_c,
+                                                       uint32_t *__restrict__ offs, const uint32_t *__restrict__ tile_base,
                                                        void *__restrict__ out, uint32_t win_stride) {
     extern __shared__ __attribute__((aligned(16))) uint32_t base[];   // Bc words
-    const uint32_t *tb = tile_base + (size_t)blockIdx.x * pitch;
-    for (uint32_t x = threadIdx.x; x < Bc; x += 1024) base[x] = offs[x] + tb[x];
+    __shared__ uint32_t wsum[16];
+    const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
+    const uint32_t *tb = tile_base + (size_t)t * pitch;
+    {
+        // exclusive scan of hist_c[0 .. Bc): thread x owns `per` consecutive bins
+        const uint32_t per = (Bc + 1023) / 1024, b0 = threadIdx.x * per;
+        uint32_t sum = 0;
+        for (uint32_t q = 0; q < per; q++) if (b0 + q < Bc) sum += hist_c[b0 + q];
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t u = __shfl_up(incl, d, 64);
+            if ((int)(threadIdx.x & 63) >= d) incl += u;
+        }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) run += wsum[w];
+        for (uint32_t q = 0; q < per; q++) {
+            const uint32_t b = b0 + q;
+            if (b < Bc) {
+                if (blockIdx.x == 0) offs[b] = run;
+                base[b] = run + tb[b];
+                run += hist_c[b];
+            }
+        }
+    }
     __syncthreads();
-    const size_t lo = (size_t)blockIdx.x * tile;
+    const size_t lo = (size_t)t * tile;
     for (uint32_t j = 0; j < tile / 1024; j++) {
         const size_t i = lo + threadIdx.x + j * 1024;
         if (i >= n) break;
@@ -464,10 +506,9 @@ __global__ __launch_bounds__(1024) void k_scatter_wide(const Fr *__restrict__ sc
             if (sd != 0) {
                 const uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
                 const uint32_t ent = (local + k * win_stride) | (sd < 0 ? 0x80000000u : 0u);   // window k reads its own copy of the bases
-                const uint32_t r = rank[(size_t)k * n + i];
-                if (REC == 1) ((uint64_t *)out)[base[b >> 7] + r] = ((uint64_t)(b & 127u) << 32) | ent;
-                else if (REC == 2) ((uint32_t *)out)[base[b >> 6] + r] = (ent & 0x81ffffffu) | ((b & 63u) << 25);
-                else ((uint32_t *)out)[base[b] + r] = ent;
+                if (REC == 1) ((uint64_t *)out)[atomicAdd(&base[b >> 7], 1u)] = ((uint64_t)(b & 127u) << 32) | ent;
+                else if (REC == 2) ((uint32_t *)out)[atomicAdd(&base[b >> 6], 1u)] = (ent & 0x81ffffffu) | ((b & 63u) << 25);
+                else ((uint32_t *)out)[atomicAdd(&base[b], 1u)] = ent;
             }
         });
     }
@@ -798,6 +839,23 @@ __device__ __forceinline__ void quadwave_weighted(A &acc, A &run, unsigned log_m
 // own pre-shifted copy of the bases, so bucket b has weight b+1 whatever the window).  That many
 // buckets are throughput, not latency: one LANE per segment of L buckets with lane-private
 // additions, writing the (ACC, RUN) pair the quad levels (k_reduce2) continue from.
+// The kernel holds ONE inlined copy of the general addition (~40 KB of code with its doubling
+// and infinity paths): written with two call sites (RUN += bucket; ACC += RUN) the loop body was
+// 83 KB for G1 -- more than the 64-KB instruction cache two CUs share -- and every kernel that
+// ran beside it on another stream (the next call's first sort kernels) spent its time on
+// instruction fetches: k_hist_wide 35 -> 124 us, k_tile_scan_rows 6 -> 80 us.  The two additions of
+// a bucket are therefore two trips through the same call site; which operands a trip takes is
+// selected word by word with a mask the compiler cannot see through (it would unswitch the loop
+// into two copies again).
+template <class A>
+__device__ __forceinline__ A select_acc(uint32_t mask, const A &a, const A &b) {   // mask all ones: a, zero: b
+    A r;
+    const uint32_t *pa = reinterpret_cast<const uint32_t *>(&a), *pb = reinterpret_cast<const uint32_t *>(&b);
+    uint32_t *pr = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(A) / 4); i++) pr[i] = (pa[i] & mask) | (pb[i] & ~mask);
+    return r;
+}
 template <class C>
 __global__ __launch_bounds__(64) void k_reduce1_lane(const typename C::Acc *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t split,
                                                      typename C::Acc *__restrict__ out) {
@@ -806,9 +864,21 @@ __global__ __launch_bounds__(64) void k_reduce1_lane(const typename C::Acc *__re
     if ((uint64_t)t * L >= B) return;
     A acc = A::inf(), run = A::inf();
     const A *bk = buckets + (size_t)t * L * split;
+    // trips per bucket: `split` of "RUN += part h", then one of "ACC += RUN"
+    const uint32_t per = split + 1;
+#pragma unroll 1
     for (int i = (int)L - 1; i >= 0; i--) {
-        for (uint32_t h = 0; h < split; h++) run = C::add(run, bk[(size_t)i * split + h]);
-        acc = C::add(acc, run);
+#pragma unroll 1
+        for (uint32_t h = 0; h < per; h++) {
+            uint32_t m = h < split ? 0xffffffffu : 0u;       // all ones: RUN += bucket part
+            asm volatile("" : "+v"(m));
+            A rhs = run;
+            if (h < split) rhs = bk[(size_t)i * split + h];
+            const A lhs = select_acc(m, run, acc);
+            const A r = C::add(lhs, rhs);
+            run = select_acc(m, r, run);
+            acc = select_acc(m, acc, r);
+        }
     }
     out[2 * (size_t)t] = acc;
     out[2 * (size_t)t + 1] = run;
@@ -970,15 +1040,22 @@ static constexpr int NTAIL = 4;
 struct TailBuf {
     Workspace ws;
     hipEvent_t done = nullptr;     // recorded after the slot's result has been published
+    hipEvent_t front_done = nullptr;   // recorded on the caller's stream after the slot's accumulate stage
     hipStream_t stream = nullptr;
     bool pending = false;          // a tail has been issued on this slot
     bool unjoined = false;         // ... and the caller's stream has not waited for it yet
 };
 static TailBuf g_tail[NTAIL];
-static hipEvent_t g_front_done = nullptr;
 static unsigned g_slot = 0;
 static int g_overlap = -1;
 
+// (Measured and rejected: keeping the tail of call i back until call i+1 has issued its sort, so
+// that it runs beside the next accumulate kernel instead of the next sort.  The first sort kernels
+// are hit hard by a tail that starts beside them -- k_hist_wide 35 -> 110 us, k_tile_scan_rows
+// 6 -> 52 us next to k_reduce1_lane's 1024 long single-wavefront workgroups -- but the tail's ~0.12 ms
+// of multiplier work has to run somewhere: beside the accumulate kernel it stretches that one from
+// 0.97 to 1.14 ms and itself to 1.8 ms, and the step stays at 1.61 ms either way.  Stream
+// priorities and CU masks for the tail streams make every kernel slower: 1.95 - 3.7 ms per step.)
 int msm_join(hipStream_t st) {
     for (auto &t : g_tail) {
         if (!t.unjoined) continue;
@@ -1015,9 +1092,9 @@ void msm_release_workspace() {
         if (t.stream) { (void)hipStreamSynchronize(t.stream); (void)hipStreamDestroy(t.stream); t.stream = nullptr; }
         t.ws.release();
         if (t.done) (void)hipEventDestroy(t.done);
-        t.done = nullptr; t.pending = false; t.unjoined = false;
+        if (t.front_done) (void)hipEventDestroy(t.front_done);
+        t.done = nullptr; t.front_done = nullptr; t.pending = false; t.unjoined = false;
     }
-    if (g_front_done) { (void)hipEventDestroy(g_front_done); g_front_done = nullptr; }
     g_ws.release();
     g_prep_ws.release();
     if (g_ev_ready) { for (auto &row : g_ev) for (auto &e : row) (void)hipEventDestroy(e); g_ev_ready = false; }
@@ -1275,7 +1352,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     const uint32_t wtiles = (uint32_t)((n + wtile - 1) / wtile);             // wide path: one row per tile (all windows)
     const size_t rows = wide ? wtiles : (size_t)nwin * ntiles;
     size_t o_digits = carve(wide ? 0 : ne * 4);
-    size_t o_rank = carve(ne * 2);
+    size_t o_rank = carve(wide ? 0 : ne * 2);     // plain path only: the wide passes hand out positions with LDS atomics
     const uint32_t pitch = wide ? Bc + 96 : Bc;      // elements between rows of the tile arrays (see k_tile_scan_rows)
     size_t o_thist = carve(rows * pitch * 2);
     size_t o_tbase = carve(rows * pitch * 4);
@@ -1292,9 +1369,9 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     if (!g_tail[0].done) {
         for (auto &t : g_tail) {
             HIPCHK(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&t.front_done, hipEventDisableTiming));
             if (g_overlap) HIPCHK(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
         }
-        HIPCHK(hipEventCreateWithFlags(&g_front_done, hipEventDisableTiming));
     }
     // (Running the sort of call i+1 beside the accumulate of call i on a third stream was measured
     // and rejected: with enough hardware queues for real concurrency both kernels slow each other
@@ -1356,7 +1433,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         lds_attr_set = true;
     }
     if (reuse_sort) {
@@ -1368,21 +1445,20 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     } else if (wide) {
         const uint32_t win_stride = (uint32_t)(table_stride * pl.copy_step);
         const uint32_t shift = fine ? fine_bits : 0u;
-        hipLaunchKernelGGL(k_rank_wide, dim3(wtiles), dim3(1024), (size_t)((Bc + 1) / 2) * 4, st, d_scalars, n, segs, pl, B, Bc, shift, pitch, wtile, rank, tile_hist);
-        hipLaunchKernelGGL(k_tile_scan_rows, dim3((Bc + 31) / 32), dim3(1024), 0, st, tile_hist, Bc, wtiles, pitch, tile_base, hist_c);
+        hipLaunchKernelGGL(k_hist_wide, dim3(wtiles), dim3(1024), (size_t)((Bc + 1) / 2) * 4, st, d_scalars, n, segs, pl, B, Bc, shift, pitch, wtile, tile_hist);
         mark(st);  // 1
-        hipLaunchKernelGGL(k_scan_sums, dim3(scan_blocks), dim3(256), 0, st, hist_c, Bc, bsum);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(256), 0, st, bsum, scan_blocks);
-        hipLaunchKernelGGL(k_scan_final, dim3(scan_blocks), dim3(256), 0, st, hist_c, bsum, Bc, offs_c);
+        // (also clears the counters of the ordering stage: two memset launches less)
+        hipLaunchKernelGGL(k_tile_scan_rows, dim3((Bc + 31) / 32), dim3(1024), 0, st, tile_hist, Bc, wtiles, pitch, tile_base, hist_c, heavy_count, bin_count,
+                           (uint32_t)(3 * ngroups * SIZE_BINS));
         mark(st);  // 2
         if (rec32) {
-            hipLaunchKernelGGL(k_scatter_wide<2>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, wtile, rank, offs_c, tile_base, (void *)recs, win_stride);
+            hipLaunchKernelGGL(k_scatter_wide<2>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, wtile, hist_c, offs_c, tile_base, (void *)recs, win_stride);
             hipLaunchKernelGGL(k_fine_sort<uint32_t>, dim3(Bc), dim3(1024), 0, st, (const uint32_t *)recs, offs_c, hist_c, entries, hist, offs);
         } else if (fine) {
-            hipLaunchKernelGGL(k_scatter_wide<1>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, wtile, rank, offs_c, tile_base, (void *)recs, win_stride);
+            hipLaunchKernelGGL(k_scatter_wide<1>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, wtile, hist_c, offs_c, tile_base, (void *)recs, win_stride);
             hipLaunchKernelGGL(k_fine_sort<uint64_t>, dim3(Bc), dim3(1024), 0, st, (const uint64_t *)recs, offs_c, hist_c, entries, hist, offs);
         } else {
-            hipLaunchKernelGGL(k_scatter_wide<0>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, wtile, rank, offs_c, tile_base, (void *)entries, win_stride);
+            hipLaunchKernelGGL(k_scatter_wide<0>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, wtile, hist_c, offs_c, tile_base, (void *)entries, win_stride);
         }
         mark(st);  // 3
     } else {
@@ -1398,8 +1474,10 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
         mark(st);  // 3
     }
     // ---- accumulate stage: bucket order, accumulation, heavy buckets
-    HIPCHK(hipMemsetAsync(heavy_count, 0, 4, st));
-    HIPCHK(hipMemsetAsync(bin_count, 0, (size_t)3 * ngroups * SIZE_BINS * 4, st));
+    if (!wide || reuse_sort) {         // (the wide path's k_tile_scan_rows has cleared them)
+        HIPCHK(hipMemsetAsync(heavy_count, 0, 4, st));
+        HIPCHK(hipMemsetAsync(bin_count, 0, (size_t)3 * ngroups * SIZE_BINS * 4, st));
+    }
     {
         const unsigned sb = (nb + 2047) / 2048;
         const uint32_t gsz = 0u;
@@ -1425,40 +1503,43 @@ acc_done:
                        heavy_list, heavy_count, chunk_off, hpart);
     hipLaunchKernelGGL((k_heavy_finish<C>), dim3(256), dim3(64), 0, st, heavy_list, heavy_count, chunk_off, hpart, buckets, split);
     mark(st);  // 5
-    if (tail != st) {
-        HIPCHK(hipEventRecord(g_front_done, st));
-        HIPCHK(hipStreamWaitEvent(tail, g_front_done, 0));
+    if (tail != st) HIPCHK(hipEventRecord(tb.front_done, st));
+    const bool profile = g_profile;
+    hipEvent_t ev6 = profile ? g_ev[evslot][6] : nullptr, ev7 = profile ? g_ev[evslot][7] : nullptr;
+    const size_t res_off = o_res;
+    {
+        if (tail != st) HIPCHK(hipStreamWaitEvent(tail, tb.front_done, 0));
+        if (big)
+            hipLaunchKernelGGL((k_reduce1_lane<C>), dim3(kw * ((T + 63) / 64)), dim3(64), 0, tail, buckets, B, L, split, wave_out);
+        else
+            hipLaunchKernelGGL((k_reduce1<C>), dim3(kw * wpw), dim3(64), 0, tail, buckets, B, L, logL, wpw, split, wave_out);
+        A *lvl_in = wave_out, *lvl_out = window_sums;
+        uint32_t m = wpw, lm = big ? logL : logL + 4;    // m pairs per window, each covering 2^lm buckets
+        do {                                             // at least one k_reduce2 level (it leaves the sum in slot 0)
+            const uint32_t m_out = (m + 15) / 16;
+            hipLaunchKernelGGL((k_reduce2<C>), dim3(kw * m_out), dim3(64), 0, tail, lvl_in, m, m_out, lm, lvl_out);
+            std::swap(lvl_in, lvl_out);
+            m = m_out;
+            lm += 4;
+        } while (m > 1);
+        if (profile) (void)hipEventRecord(ev6, tail);  // 6
+        // lvl_in[2*k] = sum of window k (pairs of (ACC,RUN): stride 2)
+        Jac<F> *res = tail != st ? (Jac<F> *)(tws + res_off) : d_out;
+        if (wide && nseg > 1) {   // every segment's bucket space is a finished sum: convert
+            if constexpr (std::is_same<C, CurveG1>::value) hipLaunchKernelGGL(k_emit_g1, dim3(nseg), dim3(64), 0, tail, lvl_in, res);
+            else hipLaunchKernelGGL(k_emit_g2, dim3(nseg), dim3(64), 0, tail, lvl_in, res);
+        } else if constexpr (std::is_same<C, CurveG1>::value) {   // (wide, one segment: kw = 1, the fold only converts -- with a quad of lanes)
+            hipLaunchKernelGGL(k_fold_quad, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, res);
+        } else {
+            hipLaunchKernelGGL(k_fold_quad_g2, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, res);
+        }
+        if (tail != st) {
+            if (prev.pending && &prev != &tb) HIPCHK(hipStreamWaitEvent(tail, prev.done, 0));   // publish in call order
+            hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, tail, (const uint32_t *)res, (uint32_t *)d_out, (unsigned)(nseg * sizeof(Jac<F>) / 4));
+        }
+        if (profile) (void)hipEventRecord(ev7, tail);  // 7
+        HIPCHK(hipEventRecord(tb.done, tail));
     }
-    if (big)
-        hipLaunchKernelGGL((k_reduce1_lane<C>), dim3(kw * ((T + 63) / 64)), dim3(64), 0, tail, buckets, B, L, split, wave_out);
-    else
-        hipLaunchKernelGGL((k_reduce1<C>), dim3(kw * wpw), dim3(64), 0, tail, buckets, B, L, logL, wpw, split, wave_out);
-    A *lvl_in = wave_out, *lvl_out = window_sums;
-    uint32_t m = wpw, lm = big ? logL : logL + 4;    // m pairs per window, each covering 2^lm buckets
-    do {                                             // at least one k_reduce2 level (it leaves the sum in slot 0)
-        const uint32_t m_out = (m + 15) / 16;
-        hipLaunchKernelGGL((k_reduce2<C>), dim3(kw * m_out), dim3(64), 0, tail, lvl_in, m, m_out, lm, lvl_out);
-        std::swap(lvl_in, lvl_out);
-        m = m_out;
-        lm += 4;
-    } while (m > 1);
-    mark(tail);  // 6
-    // lvl_in[2*k] = sum of window k (pairs of (ACC,RUN): stride 2)
-    Jac<F> *res = tail != st ? (Jac<F> *)(tws + o_res) : d_out;
-    if (wide && nseg > 1) {   // every segment's bucket space is a finished sum: convert
-        if constexpr (std::is_same<C, CurveG1>::value) hipLaunchKernelGGL(k_emit_g1, dim3(nseg), dim3(64), 0, tail, lvl_in, res);
-        else hipLaunchKernelGGL(k_emit_g2, dim3(nseg), dim3(64), 0, tail, lvl_in, res);
-    } else if constexpr (std::is_same<C, CurveG1>::value) {   // (wide, one segment: kw = 1, the fold only converts -- with a quad of lanes)
-        hipLaunchKernelGGL(k_fold_quad, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, res);
-    } else {
-        hipLaunchKernelGGL(k_fold_quad_g2, dim3(1), dim3(64), 0, tail, lvl_in, kw, c, res);
-    }
-    if (tail != st) {
-        if (prev.pending && &prev != &tb) HIPCHK(hipStreamWaitEvent(tail, prev.done, 0));   // publish in call order
-        hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, tail, (const uint32_t *)res, (uint32_t *)d_out, (unsigned)(nseg * sizeof(Jac<F>) / 4));
-    }
-    mark(tail);  // 7
-    HIPCHK(hipEventRecord(tb.done, tail));
     tb.pending = true;
     tb.unjoined = (tail != st);
     g_slot = (g_slot + 1) % NTAIL;
