@@ -425,10 +425,24 @@ __device__ __forceinline__ uint32_t xcd_tile(uint32_t bid, uint32_t ntiles) {
     return x * q + (x < r ? x : r) + j;
 }
 
+// Bucket -> coarse bin of the first sort pass.  Windows of the widest width c reach all 2^(c-1)
+// buckets, windows one bit narrower (5 of the 13 at n = 2^20) only the lower half, so a bucket of
+// the lower half holds more than twice as many entries as one of the upper half (36 against 16):
+// bins of equal POPULATION take 2^sh_lo buckets below `half` and 2^sh_hi above.  half = 0 makes it a
+// plain shift by sh_hi.
+struct CoarseMap {
+    uint32_t half, sh_lo, sh_hi, nlo;      // nlo = half >> sh_lo bins below `half`
+    __device__ __forceinline__ uint32_t bin(uint32_t b) const { return b < half ? b >> sh_lo : nlo + ((b - half) >> sh_hi); }
+    __device__ __forceinline__ uint32_t fine(uint32_t b) const { return b < half ? b & ((1u << sh_lo) - 1) : (b - half) & ((1u << sh_hi) - 1); }
+    // bin -> its first bucket and its bucket count
+    __device__ __forceinline__ uint32_t first(uint32_t bin_) const { return bin_ < nlo ? bin_ << sh_lo : half + ((bin_ - nlo) << sh_hi); }
+    __device__ __forceinline__ uint32_t bits(uint32_t bin_) const { return bin_ < nlo ? sh_lo : sh_hi; }
+};
+
 // One workgroup per tile of WIDE_TILE scalars, ALL windows: the histogram of the (coarse) bins of
 // the tile's entries in LDS (u16 pairs, one ds_add_u32 per entry) -> the tile's row of tile_hist.
 __global__ __launch_bounds__(1024) void k_hist_wide(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B,
-                                                    uint32_t Bc, uint32_t shift, uint32_t pitch, uint32_t tile,
+                                                    uint32_t Bc, CoarseMap cm, uint32_t pitch, uint32_t tile,
                                                     uint16_t *__restrict__ tile_hist) {
     extern __shared__ __attribute__((aligned(16))) uint32_t cnt2[];   // Bc/2 words: two u16 counters each
     for (uint32_t x = threadIdx.x; x < (Bc + 1) / 2; x += 1024) cnt2[x] = 0;
@@ -441,7 +455,7 @@ __global__ __launch_bounds__(1024) void k_hist_wide(const Fr *__restrict__ scala
         const uint32_t seg = segment_of(segs, (uint32_t)i);
         wide_digits(scalars[i], pl, seg * B, [&](unsigned, int32_t sd) {
             if (sd != 0) {
-                const uint32_t b = ((uint32_t)(sd < 0 ? -sd : sd) - 1) >> shift;
+                const uint32_t b = cm.bin((uint32_t)(sd < 0 ? -sd : sd) - 1);
                 atomicAdd(&cnt2[b >> 1], 1u << ((b & 1) * 16));                 // ds_add_u32
             }
         });
@@ -511,6 +525,186 @@ __global__ __launch_bounds__(1024) void k_scatter_wide(const Fr *__restrict__ sc
                 else ((uint32_t *)out)[atomicAdd(&base[b], 1u)] = ent;
             }
         });
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Partitioned two-pass sort (the large single-MSM shape: 2^19 .. 2^21 buckets).  The scatter of
+// k_scatter_wide writes 13.6 M four-byte records at n = 2^20 in runs of ~6 (one run per tile and
+// coarse bin, 8192 bins): 183 us, against 35 us for the same tiles without the stores
+// (k_hist_wide).  Here the first pass cuts the bin space into only PART_SEGS = 256 segments and
+// stages a tile's records in LDS, so a tile leaves ~100-record runs behind (whole cache lines),
+// and the second pass -- one workgroup per segment, 2^11 .. 2^13 fine buckets counted in LDS -- does
+// its scattered stores inside the segment's own few hundred KB, which stay in one L2.
+// A record is 32 bits: low bits of the tile number | fine bucket (10 .. 13 bits) << 16 | window << 12 | sign << 11 |
+// index inside the tile; the rest of the tile number is implied by the record's position, because a
+// segment's region is the concatenation of the tiles' runs in tile order (tile_base column of the
+// segment): the second pass only has to find the block of 64 (.. 8) tiles a position falls into.
+// ------------------------------------------------------------------------------------
+#define PART_TILE 2048u
+#define PART_SEGS 768u       // at most: 512 bins of 2^9 buckets below B/2 and 256 of 2^10 above, at 2^19 buckets
+#define PART_STAGE 28672u     // records the second pass can stage in LDS (a segment holds 26624 +- 160 at n = 2^20)
+__global__ __launch_bounds__(1024) void k_partition(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B, uint32_t Bc,
+                                                    CoarseMap cm, uint32_t pitch, const uint16_t *__restrict__ tile_hist,
+                                                    const uint32_t *__restrict__ hist_c, uint32_t *__restrict__ offs_c,
+                                                    const uint32_t *__restrict__ tile_base, uint32_t *__restrict__ recs) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t stage[];      // nwin * PART_TILE records
+    __shared__ uint32_t lstart[PART_SEGS + 1], lcur[PART_SEGS], gdst[PART_SEGS], wtot[2][PART_SEGS / 64];
+    const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    {
+        // threads < Bc (<= 768: twelve wavefronts): exclusive prefix of the segment populations
+        // (global: where a segment starts) and of this tile's row (where its run starts in LDS)
+        uint32_t gv = 0, lv = 0;
+        if (threadIdx.x < Bc) { gv = hist_c[threadIdx.x]; lv = tile_hist[(size_t)t * pitch + threadIdx.x]; }
+        uint32_t gi = gv, li = lv;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t a = __shfl_up(gi, d, 64), b = __shfl_up(li, d, 64);
+            if ((int)lane >= d) { gi += a; li += b; }
+        }
+        if (wv < PART_SEGS / 64 && lane == 63) { wtot[0][wv] = gi; wtot[1][wv] = li; }
+        __syncthreads();
+        if (threadIdx.x < Bc) {
+            uint32_t gex = gi - gv, lex = li - lv;
+            for (unsigned w = 0; w < wv; w++) { gex += wtot[0][w]; lex += wtot[1][w]; }
+            lstart[threadIdx.x] = lex;
+            lcur[threadIdx.x] = lex;
+            gdst[threadIdx.x] = gex + tile_base[(size_t)t * pitch + threadIdx.x];
+            if (blockIdx.x == 0) offs_c[threadIdx.x] = gex;
+            if (threadIdx.x == Bc - 1) lstart[Bc] = lex + lv;
+        }
+    }
+    __syncthreads();
+    const size_t lo = (size_t)t * PART_TILE;
+    const uint32_t fine_bits = cm.sh_hi;                               // (sh_lo <= sh_hi: the fine field is sh_hi bits wide)
+    const uint32_t tlow = t & ((1u << (16 - fine_bits)) - 1);          // the record's spare high bits: low bits of the tile number
+    for (uint32_t j = 0; j < PART_TILE / 1024; j++) {
+        const uint32_t il = threadIdx.x + j * 1024;
+        const size_t i = lo + il;
+        if (i >= n) break;
+        const uint32_t seg = segment_of(segs, (uint32_t)i);
+        wide_digits(scalars[i], pl, seg * B, [&](unsigned k, int32_t sd) {
+            if (sd != 0) {
+                const uint32_t b = (uint32_t)(sd < 0 ? -sd : sd) - 1;
+                const uint32_t pos = atomicAdd(&lcur[cm.bin(b)], 1u);
+                stage[pos] = (tlow << (16 + fine_bits)) | (cm.fine(b) << 16) | (k << 12) | (sd < 0 ? 0x800u : 0u) | il;
+            }
+        });
+    }
+    __syncthreads();
+    // half a wavefront moves one run (~50 records): consecutive lanes, consecutive words
+    for (uint32_t sg = threadIdx.x >> 5; sg < Bc; sg += 32) {
+        const uint32_t a = lstart[sg], e = lstart[sg + 1], g = gdst[sg];
+        for (uint32_t x = a + (lane & 31); x < e; x += 32) recs[g + (x - a)] = stage[x];
+    }
+}
+
+// Second pass: one workgroup per segment.  LDS: cnt[F] | cur[F] | col[T + 1] | stage[PART_STAGE] (F =
+// 2^fine_bits fine buckets, T tiles; col[t] = start of tile t's run inside the segment).
+__global__ __launch_bounds__(1024) void k_fine_sort_part(const uint32_t *__restrict__ recs, const uint32_t *__restrict__ offs_c,
+                                                         const uint32_t *__restrict__ hist_c, const uint32_t *__restrict__ tile_base,
+                                                         uint32_t pitch, uint32_t T, CoarseMap cm, SegList segs, uint32_t win_stride, uint32_t stage_cap,
+                                                         uint32_t *__restrict__ entries, uint32_t *__restrict__ hist, uint32_t *__restrict__ offs) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
+    __shared__ uint32_t wsum[16];
+    const uint32_t sg = blockIdx.x, lo = offs_c[sg], ns = hist_c[sg];
+    const uint32_t fine_bits = cm.sh_hi, FM = 1u << fine_bits, fmask = FM - 1, tbits = 16 - fine_bits;   // record layout (tbits low bits of the tile number ride in it)
+    const uint32_t F = 1u << cm.bits(sg), bucket0 = cm.first(sg);      // this segment's buckets: [bucket0, bucket0 + F)
+    uint32_t *cnt = sm, *cur = sm + FM, *col = sm + 2 * FM, *stage = col + T + 1;
+    const unsigned lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (uint32_t x = threadIdx.x; x < F; x += 1024) cnt[x] = 0;
+    for (uint32_t x = threadIdx.x; x < T; x += 1024) col[x] = tile_base[(size_t)x * pitch + sg];
+    if (threadIdx.x == 0) col[T] = ns;
+    // exclusive scan of the F counters -> cur[], and this segment's slice of hist / offs
+    auto scan_counters = [&]() {
+        const uint32_t per = (F + 1023) >> 10, f0 = threadIdx.x * per;
+        uint32_t sum = 0;
+        for (uint32_t q = 0; q < per; q++) if (f0 + q < F) sum += cnt[f0 + q];
+        uint32_t incl = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t u = __shfl_up(incl, d, 64);
+            if ((int)lane >= d) incl += u;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t run = incl - sum;
+        for (unsigned w = 0; w < wv; w++) run += wsum[w];
+        for (uint32_t q = 0; q < per; q++) {
+            if (f0 + q >= F) break;
+            const uint32_t c = cnt[f0 + q];
+            cur[f0 + q] = run;
+            hist[(size_t)bucket0 + f0 + q] = c;
+            offs[(size_t)bucket0 + f0 + q] = lo + run;
+            run += c;
+        }
+    };
+    // record at position p2 of the segment -> entry: it belongs to tile t with col[t] <= p2 < col[t + 1]
+    // (runs may be empty): binary search for the last t with col[t] <= p2
+    auto entry_of = [&](uint32_t r, uint32_t p2) {
+        // block of 2^tbits tiles: the last j with col[j << tbits] <= p2 (few distinct addresses: cheap LDS reads)
+        uint32_t a = 0, e = (T + (1u << tbits) - 1) >> tbits;   // invariant: col[a << tbits] <= p2, and p2 < col[e << tbits] (or e is the end)
+        while (e - a > 1) {
+            const uint32_t m = (a + e) >> 1;
+            if (col[m << tbits] <= p2) a = m; else e = m;
+        }
+        const uint32_t i = ((a << tbits) | (r >> (16 + fine_bits))) * PART_TILE + (r & 0x7ffu);
+        const uint32_t local = i - segs.off[segment_of(segs, i)];
+        return (local + ((r >> 12) & 15u) * win_stride) | ((r & 0x800u) << 20);
+    };
+    if (ns <= stage_cap) {
+        // The usual case (every segment, with uniformly distributed digits at n <= 2^20): the
+        // segment's records are read ONCE, all loads of a thread in flight together, and stay in
+        // registers across the count and the placement; the entries are ordered in LDS and leave
+        // as one linear copy -- no scattered global stores at all.
+        constexpr uint32_t NR = PART_STAGE / 1024;
+        uint32_t r[NR];
+#pragma unroll
+        for (uint32_t u = 0; u < NR; u++) { const uint32_t p2 = threadIdx.x + u * 1024; r[u] = p2 < ns ? recs[lo + p2] : 0u; }
+        __syncthreads();
+        uint16_t rk[NR];                                     // rank inside the fine bucket, from the counting atomic
+#pragma unroll
+        for (uint32_t u = 0; u < NR; u++) {
+            rk[u] = 0;
+            if (threadIdx.x + u * 1024 < ns) rk[u] = (uint16_t)atomicAdd(&cnt[(r[u] >> 16) & fmask], 1u);
+        }
+        __syncthreads();
+        scan_counters();
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < NR; u++) {
+            const uint32_t p2 = threadIdx.x + u * 1024;
+            if (p2 < ns) stage[cur[(r[u] >> 16) & fmask] + rk[u]] = entry_of(r[u], p2);
+        }
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < ns; x += 1024) entries[lo + x] = stage[x];
+        return;
+    }
+    // A larger segment (skewed digits, or n > 2^20) is read twice and places its entries with
+    // scattered stores inside its own region.
+    __syncthreads();
+    constexpr uint32_t UNR = 8;
+    for (uint32_t p0 = threadIdx.x; p0 < ns; p0 += 1024 * UNR) {
+        uint32_t r[UNR];
+#pragma unroll
+        for (uint32_t u = 0; u < UNR; u++) { const uint32_t p2 = p0 + u * 1024; r[u] = p2 < ns ? recs[lo + p2] : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < UNR; u++) if (p0 + u * 1024 < ns) atomicAdd(&cnt[(r[u] >> 16) & fmask], 1u);
+    }
+    __syncthreads();
+    scan_counters();
+    __syncthreads();
+    for (uint32_t p0 = threadIdx.x; p0 < ns; p0 += 1024 * UNR) {
+        uint32_t r[UNR];
+#pragma unroll
+        for (uint32_t u = 0; u < UNR; u++) { const uint32_t p2 = p0 + u * 1024; r[u] = p2 < ns ? recs[lo + p2] : 0u; }
+#pragma unroll
+        for (uint32_t u = 0; u < UNR; u++) {
+            const uint32_t p2 = p0 + u * 1024;
+            if (p2 >= ns) break;
+            entries[lo + atomicAdd(&cur[(r[u] >> 16) & fmask], 1u)] = entry_of(r[u], p2);
+        }
     }
 }
 
@@ -816,22 +1010,43 @@ __global__ __launch_bounds__(64) void k_heavy_finish(const uint32_t *__restrict_
 // using an inclusive suffix scan of run over the quads (4 shuffle steps), then two tree sums.
 // ------------------------------------------------------------------------------------
 template <class A>
+__device__ __forceinline__ A select_acc(uint32_t mask, const A &a, const A &b) {   // mask all ones: a, zero: b
+    A r;
+    const uint32_t *pa = reinterpret_cast<const uint32_t *>(&a), *pb = reinterpret_cast<const uint32_t *>(&b);
+    uint32_t *pr = reinterpret_cast<uint32_t *>(&r);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(A) / 4); i++) pr[i] = (pa[i] & mask) | (pb[i] & ~mask);
+    return r;
+}
+// One call site of quad_add and one of quad_dbl for the whole helper (a loop of nine trips whose
+// operands are selected with opaque masks, as in k_reduce1_lane below): the kernels built on it
+// run ONE wavefront through their code once, so an unrolled version (13 inlined additions, 122 KB
+// for k_reduce2) spent more time fetching instructions than executing them.  Order of work: the
+// suffix scan of run (4 additions), then every quad scales its own suffix sum (log_mult
+// doublings, all quads side by side) and adds it to its acc, then ONE tree sum (4 additions):
+// 9 + log_mult sequential operations instead of 13 + log_mult.
+template <class A>
 __device__ __forceinline__ void quadwave_weighted(A &acc, A &run, unsigned log_mult, unsigned lane) {
     const unsigned q = lane & 3, qi = lane >> 2;
-    for (unsigned d = 1; d < 16; d <<= 1) {          // suffix scan: run_j <- sum_{i >= j} run_i
-        A t = shfl_down_acc(run, 4 * d);
-        if (qi + d < 16) run = quad_add(run, t, q);
-    }
-    A s = (qi == 0) ? A::inf() : run;                // sum_{k=1..15} Suf_k = sum_j j*run_j
-    for (unsigned d = 8; d >= 1; d >>= 1) {
-        A t = shfl_down_acc(s, 4 * d);
-        if (qi + d < 16) s = quad_add(s, t, q);
-        A u = shfl_down_acc(acc, 4 * d);
-        if (qi + d < 16) acc = quad_add(acc, u, q);
-    }
-    if (qi == 0) {
-        for (unsigned i = 0; i < log_mult; i++) s = quad_dbl(s, q);
-        acc = quad_add(acc, s, q);
+    A s = A::inf();
+#pragma unroll 1
+    for (unsigned step = 0; step < 9; step++) {
+        // steps 0-3: run_j <- run_j + run_(j+d), d = 1, 2, 4, 8 (suffix scan); step 4: acc_j <- acc_j +
+        // 2^log_mult * Suf_j (j >= 1); steps 5-8: acc_j <- acc_j + acc_(j+d), d = 8, 4, 2, 1
+        if (step == 4) {
+            s = (qi == 0) ? A::inf() : run;
+#pragma unroll 1
+            for (unsigned i = 0; i < log_mult; i++) s = quad_dbl(s, q);
+        }
+        uint32_t m_run = step < 4 ? 0xffffffffu : 0u, m_s = step == 4 ? 0xffffffffu : 0u;
+        asm volatile("" : "+v"(m_run), "+v"(m_s));
+        const unsigned d = step < 4 ? (1u << step) : (step == 4 ? 0u : (8u >> (step - 5)));
+        const A lhs = select_acc(m_run, run, acc);
+        const A rhs = select_acc(m_s, s, shfl_down_acc(lhs, 4 * d));
+        A r = lhs;
+        if (qi + d < 16) r = quad_add(lhs, rhs, q);
+        run = select_acc(m_run, r, run);
+        acc = select_acc(m_run, acc, r);
     }
 }
 
@@ -847,15 +1062,6 @@ __device__ __forceinline__ void quadwave_weighted(A &acc, A &run, unsigned log_m
 // a bucket are therefore two trips through the same call site; which operands a trip takes is
 // selected word by word with a mask the compiler cannot see through (it would unswitch the loop
 // into two copies again).
-template <class A>
-__device__ __forceinline__ A select_acc(uint32_t mask, const A &a, const A &b) {   // mask all ones: a, zero: b
-    A r;
-    const uint32_t *pa = reinterpret_cast<const uint32_t *>(&a), *pb = reinterpret_cast<const uint32_t *>(&b);
-    uint32_t *pr = reinterpret_cast<uint32_t *>(&r);
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(A) / 4); i++) pr[i] = (pa[i] & mask) | (pb[i] & ~mask);
-    return r;
-}
 template <class C>
 __global__ __launch_bounds__(64) void k_reduce1_lane(const typename C::Acc *__restrict__ buckets, uint32_t B, uint32_t L, uint32_t split,
                                                      typename C::Acc *__restrict__ out) {
@@ -897,9 +1103,20 @@ __global__ __launch_bounds__(64) void k_reduce1(const typename C::Acc *__restric
     A acc = A::inf(), run = A::inf();
     if ((uint64_t)t * L < B) {
         const A *bk = buckets + ((size_t)k * B + (size_t)t * L) * split;
+        const uint32_t per = split + 1;              // trips per bucket through ONE addition site (see k_reduce1_lane)
+#pragma unroll 1
         for (int i = (int)L - 1; i >= 0; i--) {
-            for (uint32_t h = 0; h < split; h++) run = quad_add(run, bk[(size_t)i * split + h], q);
-            acc = quad_add(acc, run, q);
+#pragma unroll 1
+            for (uint32_t h = 0; h < per; h++) {
+                uint32_t m = h < split ? 0xffffffffu : 0u;   // all ones: RUN += bucket part h; zero: ACC += RUN
+                asm volatile("" : "+v"(m));
+                A rhs = run;
+                if (h < split) rhs = bk[(size_t)i * split + h];
+                const A lhs = select_acc(m, run, acc);
+                const A r = quad_add(lhs, rhs, q);
+                run = select_acc(m, r, run);
+                acc = select_acc(m, acc, r);
+            }
         }
     }
     quadwave_weighted(acc, run, logL, lane);
@@ -1308,8 +1525,22 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     // 32-bit records (6 fine bits) when every point reference fits 25 bits, else 64-bit ones (7 fine bits)
     static const bool allow_rec32 = getenv("LSA_NO_REC32") == nullptr;
     const bool rec32 = fine && allow_rec32 && (uint64_t)table_stride * table_copies(table_stride) < (1u << 25) && (nb >> 6) <= 32768;
-    const uint32_t fine_bits = rec32 ? 6u : WIDE_FINE_BITS;
-    const uint32_t Bc = !wide ? B : (fine ? nb >> fine_bits : nb);           // bins of the LDS-ranked sort pass
+    // partitioned sort (k_partition / k_fine_sort_part): one large MSM whose tile count fits the second pass's LDS
+    static const bool allow_part = getenv("LSA_NO_PART") == nullptr;
+    const bool part = fine && allow_part && nseg == 1 && nwin <= 13 && n <= ((size_t)1 << 25) && (nb & (nb - 1)) == 0 && nb >= (1u << 19);
+    const uint32_t fine_bits = rec32 ? 6u : WIDE_FINE_BITS;                  // (of the k_scatter_wide / k_fine_sort path)
+    CoarseMap cm = {0u, 0u, fine ? fine_bits : 0u, 0u};
+    uint32_t Bc = !wide ? B : (fine ? nb >> fine_bits : nb);                 // bins of the first sort pass
+    if (part) {
+        // 512 bins below B/2 and 256 above when some windows are a bit narrower than the widest
+        // (they only reach the lower half of the buckets), 512 equal bins otherwise
+        bool narrower = false;
+        for (unsigned k = 0; k < nwin; k++) narrower |= pl.width[k] < c;
+        unsigned lg = 0;
+        while ((1u << lg) < B) lg++;
+        if (narrower) { cm.half = B >> 1; cm.sh_lo = lg - 1 - 9; cm.sh_hi = lg - 1 - 8; cm.nlo = 512; Bc = 768; }
+        else { cm.half = 0; cm.sh_lo = cm.sh_hi = lg - 9; cm.nlo = 0; Bc = 512; }
+    }
     const size_t ne = nv * nwin;
     const bool big = wide && B > 4096;                                       // throughput-shaped reduction
     static const uint32_t wide_split = getenv("LSA_WIDE_SPLIT") ? (uint32_t)atoi(getenv("LSA_WIDE_SPLIT")) : 1u;
@@ -1348,7 +1579,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     size_t o_bins = carve((size_t)3 * ngroups * SIZE_BINS * 4);   // bin_count | bin_start | bin_cursor
     size_t o_perm = carve((size_t)nb * 4);
     const uint32_t ntiles = (uint32_t)((nv + SORT_TILE - 1) / SORT_TILE);
-    const uint32_t wtile = wide_tile(nwin);
+    const uint32_t wtile = part ? PART_TILE : wide_tile(nwin);
     const uint32_t wtiles = (uint32_t)((n + wtile - 1) / wtile);             // wide path: one row per tile (all windows)
     const size_t rows = wide ? wtiles : (size_t)nwin * ntiles;
     size_t o_digits = carve(wide ? 0 : ne * 4);
@@ -1360,7 +1591,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     size_t o_heavy = carve((size_t)max_heavy * 4);
     size_t o_choff = carve((size_t)(max_heavy + 1) * 4);
     size_t o_hpart = carve(max_chunks * sizeof(A));
-    size_t o_recs = carve(fine ? ne * 8 : 0);        // coarse-sorted 64-bit records
+    size_t o_recs = carve(fine ? ne * (part || rec32 ? 4 : 8) : 0);   // coarse-sorted records
     size_t o_chist = carve(fine ? (size_t)Bc * 4 : 0);
     size_t o_coffs = carve(fine ? (size_t)Bc * 4 : 0);
     if (g_ws.ensure(off) != 0) { set_error("msm: workspace allocation of %zu bytes failed", off); return LSA_ERR_NOMEM; }
@@ -1434,6 +1665,8 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partition), hipFuncAttributeMaxDynamicSharedMemorySize, 13 * PART_TILE * 4));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fine_sort_part), hipFuncAttributeMaxDynamicSharedMemorySize, 155648));
         lds_attr_set = true;
     }
     if (reuse_sort) {
@@ -1444,14 +1677,20 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
         mark(st); mark(st); mark(st);  // 1..3
     } else if (wide) {
         const uint32_t win_stride = (uint32_t)(table_stride * pl.copy_step);
-        const uint32_t shift = fine ? fine_bits : 0u;
-        hipLaunchKernelGGL(k_hist_wide, dim3(wtiles), dim3(1024), (size_t)((Bc + 1) / 2) * 4, st, d_scalars, n, segs, pl, B, Bc, shift, pitch, wtile, tile_hist);
+        hipLaunchKernelGGL(k_hist_wide, dim3(wtiles), dim3(1024), (size_t)((Bc + 1) / 2) * 4, st, d_scalars, n, segs, pl, B, Bc, cm, pitch, wtile, tile_hist);
         mark(st);  // 1
         // (also clears the counters of the ordering stage: two memset launches less)
         hipLaunchKernelGGL(k_tile_scan_rows, dim3((Bc + 31) / 32), dim3(1024), 0, st, tile_hist, Bc, wtiles, pitch, tile_base, hist_c, heavy_count, bin_count,
                            (uint32_t)(3 * ngroups * SIZE_BINS));
         mark(st);  // 2
-        if (rec32) {
+        if (part) {
+            hipLaunchKernelGGL(k_partition, dim3(wtiles), dim3(1024), (size_t)nwin * PART_TILE * 4, st, d_scalars, n, segs, pl, B, Bc, cm, pitch,
+                               tile_hist, hist_c, offs_c, tile_base, (uint32_t *)recs);
+            const uint32_t fixed_words = 2 * (1u << cm.sh_hi) + wtiles + 1, budget_words = 155648 / 4;
+            const uint32_t stage_cap = fixed_words + PART_STAGE <= budget_words ? PART_STAGE : 0u;   // larger problems have larger segments anyway
+            hipLaunchKernelGGL(k_fine_sort_part, dim3(Bc), dim3(1024), (size_t)(fixed_words + stage_cap) * 4, st, (const uint32_t *)recs, offs_c, hist_c,
+                               tile_base, pitch, wtiles, cm, segs, win_stride, stage_cap, entries, hist, offs);
+        } else if (rec32) {
             hipLaunchKernelGGL(k_scatter_wide<2>, dim3(wtiles), dim3(1024), (size_t)Bc * 4, st, d_scalars, n, segs, pl, B, Bc, pitch, wtile, hist_c, offs_c, tile_base, (void *)recs, win_stride);
             hipLaunchKernelGGL(k_fine_sort<uint32_t>, dim3(Bc), dim3(1024), 0, st, (const uint32_t *)recs, offs_c, hist_c, entries, hist, offs);
         } else if (fine) {

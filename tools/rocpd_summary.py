@@ -34,6 +34,24 @@ def trace(db_path):
         print("%-72s %7d %12.1f %12.3f %6.2f%%" % (short(name), calls, total, avg, pct))
 
 
+
+def spread(db_path, needle=""):
+    """per-kernel min / median / max duration (us) from the `kernels` view"""
+    db = sqlite3.connect(db_path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    dur = "duration" if "duration" in cols else "(end - start)"
+    rows = db.execute("select name, %s from kernels" % dur).fetchall()
+    by = {}
+    for name, d in rows:
+        by.setdefault(short(name), []).append(d / 1e3)
+    print("%-60s %6s %10s %10s %10s" % ("kernel", "calls", "min_us", "median_us", "max_us"))
+    for name, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+        if needle and needle not in name:
+            continue
+        v.sort()
+        print("%-60s %6d %10.1f %10.1f %10.1f" % (name[:60], len(v), v[0], v[len(v) // 2], v[-1]))
+
+
 def pmc_means(db_path):
     db = sqlite3.connect(db_path)
     q = ("select kernel_name, counter_name, count(*), avg(value), avg(duration), max(vgpr_count), max(sgpr_count), "
@@ -71,7 +89,9 @@ def hbm(fetch_db, write_db, needle, out):
 
 if __name__ == "__main__":
     mode = sys.argv[1]
-    if mode == "trace":
+    if mode == "spread":
+        spread(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
+    elif mode == "trace":
         trace(sys.argv[2])
     elif mode == "pmc":
         pmc(sys.argv[2:])
