@@ -297,6 +297,7 @@ __global__ __launch_bounds__(1024) void k_scatter(const int32_t *__restrict__ di
 __global__ __launch_bounds__(1024) void k_tile_scan_rows(const uint16_t *__restrict__ tile_hist, uint32_t Bc, uint32_t R, uint32_t pitch,
                                                          uint32_t *__restrict__ tile_base, uint32_t *__restrict__ hist,
                                                          uint32_t *__restrict__ zero1, uint32_t *__restrict__ zeron, uint32_t nzero) {
+    __builtin_amdgcn_s_setprio(3);      // the sort runs beside the previous call's tail: do not starve behind its older wavefronts
     if (blockIdx.x == 0) {               // counters of the ordering stage (heavy_count; bin_count | bin_start | bin_cursor)
         if (threadIdx.x == 0) *zero1 = 0;
         for (uint32_t x = threadIdx.x; x < nzero; x += 1024) zeron[x] = 0;
@@ -444,13 +445,14 @@ struct CoarseMap {
 __global__ __launch_bounds__(1024) void k_hist_wide(const Fr *__restrict__ scalars, size_t n, SegList segs, WidePlan pl, uint32_t B,
                                                     uint32_t Bc, CoarseMap cm, uint32_t pitch, uint32_t tile,
                                                     uint16_t *__restrict__ tile_hist) {
+    __builtin_amdgcn_s_setprio(3);      // the sort runs beside the previous call's tail: do not starve behind its older wavefronts
     extern __shared__ __attribute__((aligned(16))) uint32_t cnt2[];   // Bc/2 words: two u16 counters each
-    for (uint32_t x = threadIdx.x; x < (Bc + 1) / 2; x += 1024) cnt2[x] = 0;
+    for (uint32_t x = threadIdx.x; x < (Bc + 1) / 2; x += blockDim.x) cnt2[x] = 0;
     __syncthreads();
     const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
     const size_t lo = (size_t)t * tile;
-    for (uint32_t j = 0; j < tile / 1024; j++) {
-        const size_t i = lo + threadIdx.x + j * 1024;
+    for (uint32_t j = 0; j < tile / blockDim.x; j++) {
+        const size_t i = lo + threadIdx.x + j * blockDim.x;
         if (i >= n) break;
         const uint32_t seg = segment_of(segs, (uint32_t)i);
         wide_digits(scalars[i], pl, seg * B, [&](unsigned, int32_t sd) {
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(1024) void k_hist_wide(const Fr *__restrict__ scala
     __syncthreads();
     uint16_t *th = tile_hist + (size_t)t * pitch;
     const uint16_t *c16 = reinterpret_cast<const uint16_t *>(cnt2);
-    for (uint32_t x = threadIdx.x; x < Bc; x += 1024) th[x] = c16[x];
+    for (uint32_t x = threadIdx.x; x < Bc; x += blockDim.x) th[x] = c16[x];
 }
 
 // The same tiles again.  Every workgroup first rebuilds the exclusive prefix of the Bc bin
@@ -548,6 +550,7 @@ __global__ __launch_bounds__(1024) void k_partition(const Fr *__restrict__ scala
                                                     CoarseMap cm, uint32_t pitch, const uint16_t *__restrict__ tile_hist,
                                                     const uint32_t *__restrict__ hist_c, uint32_t *__restrict__ offs_c,
                                                     const uint32_t *__restrict__ tile_base, uint32_t *__restrict__ recs) {
+    __builtin_amdgcn_s_setprio(3);      // the sort runs beside the previous call's tail: do not starve behind its older wavefronts
     extern __shared__ __attribute__((aligned(16))) uint32_t stage[];      // nwin * PART_TILE records
     __shared__ uint32_t lstart[PART_SEGS + 1], lcur[PART_SEGS], gdst[PART_SEGS], wtot[2][PART_SEGS / 64];
     const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
@@ -606,6 +609,7 @@ __global__ __launch_bounds__(1024) void k_fine_sort_part(const uint32_t *__restr
                                                          const uint32_t *__restrict__ hist_c, const uint32_t *__restrict__ tile_base,
                                                          uint32_t pitch, uint32_t T, CoarseMap cm, SegList segs, uint32_t win_stride, uint32_t stage_cap,
                                                          uint32_t *__restrict__ entries, uint32_t *__restrict__ hist, uint32_t *__restrict__ offs) {
+    __builtin_amdgcn_s_setprio(3);      // the sort runs beside the previous call's tail: do not starve behind its older wavefronts
     extern __shared__ __attribute__((aligned(16))) uint32_t sm[];
     __shared__ uint32_t wsum[16];
     const uint32_t sg = blockIdx.x, lo = offs_c[sg], ns = hist_c[sg];
