@@ -4,13 +4,17 @@
 // multiExpMA (/root/reference/src/utils/globl.h:63-78) and sparsemexp
 // (/root/reference/src/utils/sparsemexp.h:58,89).  Same sum, different schedule:
 //
-//   1 digits     scalars (Montgomery Fr, 32 B, read once, coalesced) -> canonical ->
-//                signed c-bit digits.  Then per (tile of 32768 scalars, window) a bucket
-//                histogram in LDS ranks every entry inside (tile, bucket) with one LDS
-//                atomic; a per-bucket prefix over tiles gives populations.  No global atomics.
-//   2 scan       exclusive prefix sum over the nwin*2^(c-1) bucket populations.
-//   3 scatter    entry (point index | sign) written to offs[bucket] + tile_base + rank,
-//                the base table of the (tile, window) held in LDS.
+//   1 digits     scalars (Montgomery Fr, 32 B, coalesced) -> canonical -> signed c-bit digits,
+//                recomputed by both sort passes instead of stored.  Resident bases with
+//                pre-shifted copies (the usual case, "wide" path below): per tile of 2048 scalars
+//                a histogram of 768 population-balanced bucket segments in LDS; plain path: per
+//                (tile of 32768 scalars, window) a bucket histogram in LDS that ranks every entry.
+//                A prefix over the tiles gives populations and run starts.  No global atomics.
+//   2/3 sort     wide path: k_partition stages a tile's records per segment in LDS and copies
+//                them out as whole runs; k_fine_sort_part (one workgroup per segment) orders a
+//                segment in LDS from registers and writes it out linearly, with the per-bucket
+//                populations and offsets.  Plain path: exclusive scan over the bucket populations,
+//                then entry (point index | sign) written to offs[bucket] + tile_base + rank.
 //   3b order     buckets ordered by population (largest first) so a wavefront's 64 lanes
 //                walk equally long lists.
 //   4 accumulate one lane per bucket walks its entry list, gathers 64-B affine points
