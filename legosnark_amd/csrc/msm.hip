@@ -413,7 +413,14 @@ __device__ __forceinline__ void wide_digits(const Fr &scalar, const WidePlan &pl
 // Scalars per workgroup of the wide path's ranking / scatter passes: a tile's entries (nwin per
 // scalar) must fit the u16 counters even when every one of them lands in the same bin
 // (all scalars equal, all their digits equal): 13 x 4096 or 26 x 2048 = 53248 < 65536.
-static inline uint32_t wide_tile(uint32_t nwin) { return nwin > 15 ? 2048u : 4096u; }
+// Small inputs get 256- or 1024-scalar tiles: a lone workgroup ranking
+// 26 digits of 1024 scalars keeps ONE CU's LDS busy for 13 + 17 us (hist + scatter); with more
+// tiles the LDS atomics of a call spread over several CUs.
+static inline uint32_t wide_tile(uint32_t nwin, size_t n) {
+    if (n <= 4096) return 256u;
+    if (n <= 16384) return 1024u;
+    return nwin > 15 ? 2048u : 4096u;
+}
 __device__ __forceinline__ uint32_t segment_of(const SegList &segs, uint32_t i) {
     uint32_t seg = 0;
     for (uint32_t j = 1; j < segs.nseg; j++) if (i >= segs.off[j]) seg = j;
@@ -455,8 +462,8 @@ __global__ __launch_bounds__(1024) void k_hist_wide(const Fr *__restrict__ scala
     __syncthreads();
     const uint32_t t = xcd_tile(blockIdx.x, gridDim.x);
     const size_t lo = (size_t)t * tile;
-    for (uint32_t j = 0; j < tile / blockDim.x; j++) {
-        const size_t i = lo + threadIdx.x + j * blockDim.x;
+    for (uint32_t il = threadIdx.x; il < tile; il += blockDim.x) {
+        const size_t i = lo + il;
         if (i >= n) break;
         const uint32_t seg = segment_of(segs, (uint32_t)i);
         wide_digits(scalars[i], pl, seg * B, [&](unsigned, int32_t sd) {
@@ -517,8 +524,8 @@ __global__ __launch_bounds__(1024) void k_scatter_wide(const Fr *__restrict__ sc
     }
     __syncthreads();
     const size_t lo = (size_t)t * tile;
-    for (uint32_t j = 0; j < tile / 1024; j++) {
-        const size_t i = lo + threadIdx.x + j * 1024;
+    for (uint32_t il = threadIdx.x; il < tile; il += 1024) {
+        const size_t i = lo + il;
         if (i >= n) break;
         const uint32_t seg = segment_of(segs, (uint32_t)i);
         const uint32_t local = (uint32_t)i - segs.off[seg];
@@ -1587,7 +1594,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     size_t o_bins = carve((size_t)3 * ngroups * SIZE_BINS * 4);   // bin_count | bin_start | bin_cursor
     size_t o_perm = carve((size_t)nb * 4);
     const uint32_t ntiles = (uint32_t)((nv + SORT_TILE - 1) / SORT_TILE);
-    const uint32_t wtile = part ? PART_TILE : wide_tile(nwin);
+    const uint32_t wtile = part ? PART_TILE : wide_tile(nwin, n);
     const uint32_t wtiles = (uint32_t)((n + wtile - 1) / wtile);             // wide path: one row per tile (all windows)
     const size_t rows = wide ? wtiles : (size_t)nwin * ntiles;
     size_t o_digits = carve(wide ? 0 : ne * 4);
