@@ -384,6 +384,27 @@ template <class Use>
 __device__ __forceinline__ void wide_digits(const Fr &scalar, const WidePlan &pl, uint32_t seg_base, Use use) {
     uint32_t s[8];
     scalar.to_canonical(s);
+    // balanced representative: s > (r-1)/2 is recoded as -(r - s), i.e. the digits of r - s with
+    // every sign flipped.  Same sum; "small negative" scalars (r - 1, r - 2, ...: ten of their
+    // thirteen digits would be the digits of r, the same ten buckets for every such scalar) become
+    // small digits, and the top window never exceeds a quarter of its range.
+    bool flip;
+    {
+        uint32_t t[8];
+        uint64_t br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {                  // t = r - s
+            const uint64_t x = (uint64_t)LSA_R[i] - s[i] - br;
+            t[i] = (uint32_t)x;
+            br = (x >> 32) & 1;
+        }
+        br = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) br = (((uint64_t)t[i] - s[i] - br) >> 32) & 1;      // borrow out <=> t < s <=> 2 s > r
+        flip = br != 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) s[i] = flip ? t[i] : s[i];
+    }
     // consume the limbs through a 64-bit bit buffer (static limb index: no register-array indexing)
     uint64_t buf = 0;
     unsigned have = 0, k = 0;
@@ -403,7 +424,7 @@ __device__ __forceinline__ void wide_digits(const Fr &scalar, const WidePlan &pl
             // its raw value is < 2^(width-1) and the carry keeps it <= 2^(width-1) <= B
             if (k + 1 < pl.nwin && d >= (1u << (width - 1))) { sd = (int32_t)d - (int32_t)(1u << width); carry = 1; }
             else { sd = (int32_t)d; carry = 0; }
-            if (sd != 0) { const int32_t m = (int32_t)seg_base + (sd < 0 ? -sd : sd); sd = sd < 0 ? -m : m; }
+            if (sd != 0) { const int32_t m = (int32_t)seg_base + (sd < 0 ? -sd : sd); sd = (sd < 0) != flip ? -m : m; }
             use(k, sd);
             k++;
         }
