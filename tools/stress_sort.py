@@ -35,6 +35,10 @@ def scalars(kind, n):
         return [vals[int(x)] for x in rng.integers(0, len(vals), size=n)]
     if kind == "pow2":
         return [1 << int(x) for x in rng.integers(0, 253, size=n)]
+    if kind == "bits":
+        return [int(x) for x in rng.integers(0, 2, size=n)]
+    if kind == "bytes":
+        return [int(x) for x in rng.integers(0, 256, size=n)]
     if kind == "runs":
         out, v = [], 0
         while len(out) < n:
@@ -45,7 +49,7 @@ def scalars(kind, n):
 
 
 bad = 0
-kinds = ["uniform", "small", "near_r", "few", "pow2", "runs"]
+kinds = ["uniform", "small", "near_r", "few", "pow2", "runs", "bits", "bytes"]
 for c in range(cases):
     kind = kinds[c % len(kinds)]
     n = int(rng.integers(1 << 15, n_table + 1)) if c % 5 else n_table
