@@ -575,6 +575,20 @@ __global__ __launch_bounds__(1024) void k_scatter_wide(const Fr *__restrict__ sc
 // segment's region is the concatenation of the tiles' runs in tile order (tile_base column of the
 // segment): the second pass only has to find the block of 64 (.. 8) tiles a position falls into.
 // ------------------------------------------------------------------------------------
+// counter[idx]++ for every active lane, returning the lane's own old value.  When all active lanes of the
+// wavefront name the SAME counter (few distinct scalar digits: every record of a segment in one
+// bucket) the wavefront issues one atomic instead of 64 serialised ones.
+__device__ __forceinline__ uint32_t lds_inc_rank(uint32_t *counters, uint32_t idx) {
+    const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+    const uint64_t active = __ballot(1), same = __ballot(idx == first);
+    if (same == active) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(active >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)active, 0u));
+        uint32_t base = 0;
+        if (rank == 0) base = atomicAdd(&counters[first], (uint32_t)__popcll(active));
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + rank;
+    }
+    return atomicAdd(&counters[idx], 1u);
+}
 #define PART_TILE 2048u
 #define PART_SEGS 768u       // at most: 512 bins of 2^9 buckets below B/2 and 256 of 2^10 above, at 2^19 buckets
 #define PART_STAGE 28672u     // records the second pass can stage in LDS (a segment holds 26624 +- 160 at n = 2^20)
@@ -726,7 +740,7 @@ __global__ __launch_bounds__(1024) void k_fine_sort_part(const uint32_t *__restr
 #pragma unroll
         for (uint32_t u = 0; u < UNR; u++) { const uint32_t p2 = p0 + u * 1024; r[u] = p2 < ns ? recs[lo + p2] : 0u; }
 #pragma unroll
-        for (uint32_t u = 0; u < UNR; u++) if (p0 + u * 1024 < ns) atomicAdd(&cnt[(r[u] >> 16) & fmask], 1u);
+        for (uint32_t u = 0; u < UNR; u++) if (p0 + u * 1024 < ns) (void)lds_inc_rank(cnt, (r[u] >> 16) & fmask);
     }
     __syncthreads();
     scan_counters();
@@ -739,7 +753,7 @@ __global__ __launch_bounds__(1024) void k_fine_sort_part(const uint32_t *__restr
         for (uint32_t u = 0; u < UNR; u++) {
             const uint32_t p2 = p0 + u * 1024;
             if (p2 >= ns) break;
-            entries[lo + atomicAdd(&cur[(r[u] >> 16) & fmask], 1u)] = entry_of(r[u], p2);
+            entries[lo + lds_inc_rank(cur, (r[u] >> 16) & fmask)] = entry_of(r[u], p2);
         }
     }
 }
@@ -975,20 +989,41 @@ __device__ __forceinline__ typename C::Acc wave_sum(typename C::Acc v, unsigned 
 // k_heavy_finish sums a bucket's chunk partials.  With uniformly random scalars and c | 128
 // there are no heavy buckets and all three exit at once.
 #define HEAVY_CHUNK 512u
+// Chunk size of this call: 512 entries, doubled (up to 4096) while that still leaves >= 2048 chunks.
+// A chunk costs 6 general additions per lane (the shuffle tree) on top of its mixed additions --
+// 8 per lane at 512 entries, i.e. 40 % overhead, which is right for a handful of heavy buckets
+// (many short chunks = parallelism) and wasteful when most of the input sits in heavy buckets
+// (few distinct scalars: 13.6 M heavy entries at n = 2^20, k_accumulate_heavy 2.0 -> 1.3 ms).
+// Stored behind the chunk offsets: chunk_off[nh + 1].
 __global__ __launch_bounds__(256) void k_heavy_plan(const uint32_t *__restrict__ hist, const uint32_t *__restrict__ heavy_list,
                                                     const uint32_t *__restrict__ heavy_count, uint32_t *__restrict__ chunk_off) {
     __shared__ uint32_t lds[4];
+    __shared__ uint32_t s_chunk;
     const uint32_t nh = *heavy_count;
     uint32_t carry = 0;
+    for (uint32_t base = 0; base < nh; base += 256) {           // total number of heavy entries
+        uint32_t h = base + threadIdx.x;
+        uint32_t tot;
+        (void)block_exclusive_scan_256(h < nh ? hist[heavy_list[h]] : 0, lds, &tot);
+        carry += tot;
+    }
+    if (threadIdx.x == 0) {
+        uint32_t chunk = HEAVY_CHUNK;
+        while (chunk < 4096u && carry / (2 * chunk) >= 2048u) chunk *= 2;
+        s_chunk = chunk;
+    }
+    __syncthreads();
+    const uint32_t chunk = s_chunk;
+    carry = 0;
     for (uint32_t base = 0; base < nh; base += 256) {
         uint32_t h = base + threadIdx.x;
-        uint32_t v = h < nh ? (hist[heavy_list[h]] + HEAVY_CHUNK - 1) / HEAVY_CHUNK : 0;
+        uint32_t v = h < nh ? (hist[heavy_list[h]] + chunk - 1) / chunk : 0;
         uint32_t tot;
         uint32_t ex = block_exclusive_scan_256(v, lds, &tot);
         if (h < nh) chunk_off[h] = carry + ex;
         carry += tot;
     }
-    if (threadIdx.x == 0) chunk_off[nh] = carry;      // total number of chunks
+    if (threadIdx.x == 0) { chunk_off[nh] = carry; chunk_off[nh + 1] = chunk; }      // total number of chunks; chunk size
 }
 
 template <class C>
@@ -998,15 +1033,15 @@ __global__ __launch_bounds__(64) void k_accumulate_heavy(const typename C::Base 
                                                          const uint32_t *__restrict__ chunk_off, typename C::Acc *__restrict__ partials) {
     const uint32_t nh = *heavy_count;
     if (nh == 0) return;
-    const uint32_t total = chunk_off[nh];
+    const uint32_t total = chunk_off[nh], chunk = chunk_off[nh + 1];
     const unsigned lane = threadIdx.x;
     for (uint32_t v = blockIdx.x; v < total; v += gridDim.x) {
         uint32_t lo = 0, hi = nh;                       // largest h with chunk_off[h] <= v
         while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (chunk_off[mid] <= v) lo = mid; else hi = mid; }
         const uint32_t g = heavy_list[lo];
         const uint32_t cnt = hist[g];
-        const uint32_t start = (v - chunk_off[lo]) * HEAVY_CHUNK;
-        const uint32_t end = start + HEAVY_CHUNK < cnt ? start + HEAVY_CHUNK : cnt;
+        const uint32_t start = (v - chunk_off[lo]) * chunk;
+        const uint32_t end = start + chunk < cnt ? start + chunk : cnt;
         const uint32_t *e = entries + offs[g];
         typename C::Acc acc = C::inf();
         for (uint32_t j = start + lane; j < end; j += 64) {
@@ -1625,7 +1660,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     size_t o_tbase = carve(rows * pitch * 4);
     size_t o_entries = carve(ne * 4);
     size_t o_heavy = carve((size_t)max_heavy * 4);
-    size_t o_choff = carve((size_t)(max_heavy + 1) * 4);
+    size_t o_choff = carve((size_t)(max_heavy + 2) * 4);    // chunk offsets, the chunk count, the chunk size
     size_t o_hpart = carve(max_chunks * sizeof(A));
     size_t o_recs = carve(fine ? ne * (part || rec32 ? 4 : 8) : 0);   // coarse-sorted records
     size_t o_chist = carve(fine ? (size_t)Bc * 4 : 0);
