@@ -189,6 +189,20 @@ struct W12 {
         W12 self = *this;
         x.par([=](unsigned lane) { if (lane == 0) self.store_tower(d, fq12_inverse(self.load_tower(a))); });
     }
+    // d = a^-1 for a in the subfield Fq6 = Fq2[w^2] (odd coefficients zero, whatever their residues'
+    // representatives say): the tower's Fq6 inversion on lane 0 (15 Fq2 products and one Fermat
+    // inversion in Fq).  The final exponentiation inverts f as conj(f) * (f * conj(f))^-1 with it:
+    // two products of the parallel engine instead of four Fq6 products on one lane.
+    LSA_HD void inverse6(int d, int a) {
+        Fq2S *A = slot(a), *D = slot(d);
+        x.par([=](unsigned lane) {
+            if (lane == 0) {
+                const Fq6T<Fs> r = fq6_inverse(Fq6T<Fs>{A[0], A[2], A[4]});
+                D[0] = r.c0; D[2] = r.c1; D[4] = r.c2;
+                D[1] = Fq2S::zero(); D[3] = Fq2S::zero(); D[5] = Fq2S::zero();
+            }
+        });
+    }
     // Frobenius map, one coefficient per lane: slot k is tower position (half k & 1, coefficient k >> 1),
     // so it becomes frob(a_k) * FROB6_C{k>>1} * FROB12_C1 (the factors the tower code applies, in the same
     // order: the same canonical value) -- at most two Fq2 products per lane instead of eleven on lane 0.
@@ -244,9 +258,11 @@ struct W12 {
     // pairing.hip).  Uses every slot.
     LSA_HD void final_exponentiation() {
         enum { ELT = 0, FIRST, A, B, C, D, E, F, G, T0, T1, T2 };
-        conj(A, ELT);
-        inverse(B, ELT);
-        mul(C, A, B);
+        conj(A, ELT);             // conj(f): f^(p^6)
+        mul(C, ELT, A);           // f * conj(f), an element of Fq6
+        inverse6(D, C);
+        mul(B, A, D);             // f^-1 = conj(f) / (f * conj(f))
+        mul(C, A, B);             // f^(p^6 - 1)
         frobenius<2>(D, C);
         mul(FIRST, D, C);
         exp_by_neg_z(A, FIRST, T0);
