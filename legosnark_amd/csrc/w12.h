@@ -38,6 +38,12 @@ LSA_HD Fq2S w12_fq2_mul(const Fq2S &a, const Fq2S &b) {
     return {Fs{r.c0}, Fs{r.c1}};
 }
 
+// component `part` (0: c0, 1: c1) of an Fq2 value in memory, by address: a select between the two
+// components costs 9 v_cndmask_b32 (each ~5x a plain VALU op on gfx950), an offset costs nothing
+LSA_HD const Fs &w12_comp(const Fq2S &v, unsigned part) { return (&v.c0)[part]; }
+LSA_HD Fs &w12_comp(Fq2S &v, unsigned part) { return (&v.c0)[part]; }
+static_assert(sizeof(Fq2S) == 2 * sizeof(Fs), "Fq2S is two consecutive Fs");
+
 // carry pass for limbs that are unsigned sums up to 2^32 - 8 (F29::norm takes signed limbs)
 LSA_HD F29 w12_norm_u(const F29 &a) {
     F29 r;
@@ -63,14 +69,11 @@ LSA_HD void w12_reduce_lane12(unsigned lane, const Fq2S *Pp, Fq2S *D) {
     const unsigned part = lane & 1;
     const uint32_t pm = 0u - part;                       // all ones for the c1 lanes
     F29 lo = F29::zero(), hm = F29::zero(), ho = F29::zero();
-    for (int i = 0; i <= k; i++) {
-        const Fq2S &t = Pp[i * 6 + (k - i)];
-        lo = add_lazy(lo, part ? t.c1.v : t.c0.v);
-    }
+    for (int i = 0; i <= k; i++) lo = add_lazy(lo, w12_comp(Pp[i * 6 + (k - i)], part).v);
     for (int i = k + 1; i <= 5; i++) {
         const Fq2S &t = Pp[i * 6 + (k + 6 - i)];
-        hm = add_lazy(hm, part ? t.c1.v : t.c0.v);       // the component that takes the factor 9
-        ho = add_lazy(ho, part ? t.c0.v : t.c1.v);       // the other one: -hi.c1 (part 0) / +hi.c0 (part 1)
+        hm = add_lazy(hm, w12_comp(t, part).v);          // the component that takes the factor 9
+        ho = add_lazy(ho, w12_comp(t, part ^ 1u).v);     // the other one: -hi.c1 (part 0) / +hi.c0 (part 1)
     }
     lo = w12_norm_u(lo);
     hm = w12_norm_u(hm);
@@ -85,7 +88,7 @@ LSA_HD void w12_reduce_lane12(unsigned lane, const Fq2S *Pp, Fq2S *D) {
     for (int i = 0; i < 9; i++) sel.l[i] = (ho.l[i] & pm) | (neg.l[i] & ~pm);
     F29 sum = w12_norm_u(add_lazy(add_lazy(add_lazy(h8, hm), lo), sel));   // < 112p
     Fs res = {mul(sum, F29::one())};
-    if (part) D[k].c1 = res; else D[k].c0 = res;
+    w12_comp(D[k], part) = res;
 }
 
 // xi * t for t < 2 (tight):  (9 t0 - t1 + 2p,  9 t1 + t0)   [< 20; tight]
@@ -149,19 +152,16 @@ struct W12 {
                     asel.c1.v.l[l] = (xa.c1.l[l] & wrap) | (ai.c1.v.l[l] & ~wrap);
                 }
                 const Fs r = {w12_comp_mul<2>(part, asel, B[j])};
-                if (part) Pp[i * 6 + j].c1 = r; else Pp[i * 6 + j].c0 = r;
+                w12_comp(Pp[i * 6 + j], part) = r;
             }
         });
         x.par([=](unsigned lane) {
             if (lane < 12) {
                 const unsigned k = lane >> 1, part = lane & 1;
                 F29 sum = F29::zero();
-                for (int i = 0; i < 6; i++) {
-                    const Fq2S &t = Pp[i * 6 + ((int)k - i + 6) % 6];
-                    sum = add_lazy(sum, part ? t.c1.v : t.c0.v);
-                }
+                for (int i = 0; i < 6; i++) sum = add_lazy(sum, w12_comp(Pp[i * 6 + ((int)k - i + 6) % 6], part).v);
                 const Fs r = {f29_mul(w12_norm_u(sum), F29::one())};          // < 12p -> < 2p
-                if (part) D[k].c1 = r; else D[k].c0 = r;
+                w12_comp(D[k], part) = r;
             }
         });
     }
