@@ -38,6 +38,14 @@ LSA_HD Fq2S w12_fq2_mul(const Fq2S &a, const Fq2S &b) {
     return {Fs{r.c0}, Fs{r.c1}};
 }
 
+// A lane mask (all ones / zero) the optimiser must not see through: it rewrites (a & m) | (b & ~m) with
+// m = -(condition) into v_cndmask_b32, which issues ~5x slower than the two bit operations on gfx950.
+LSA_HD uint32_t w12_mask(uint32_t m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(m));
+#endif
+    return m;
+}
 // component `part` (0: c0, 1: c1) of an Fq2 value in memory, by address: a select between the two
 // components costs 9 v_cndmask_b32 (each ~5x a plain VALU op on gfx950), an offset costs nothing
 LSA_HD const Fs &w12_comp(const Fq2S &v, unsigned part) { return (&v.c0)[part]; }
@@ -67,7 +75,7 @@ LSA_HD F29 w12_norm_u(const F29 &a) {
 LSA_HD void w12_reduce_lane12(unsigned lane, const Fq2S *Pp, Fq2S *D) {
     const int k = (int)(lane >> 1);
     const unsigned part = lane & 1;
-    const uint32_t pm = 0u - part;                       // all ones for the c1 lanes
+    const uint32_t pm = w12_mask(0u - part);             // all ones for the c1 lanes
     F29 lo = F29::zero(), hm = F29::zero(), ho = F29::zero();
     for (int i = 0; i <= k; i++) lo = add_lazy(lo, w12_comp(Pp[i * 6 + (k - i)], part).v);
     for (int i = k + 1; i <= 5; i++) {
@@ -104,7 +112,7 @@ LSA_HD F29x2 w12_xi_times(const F29x2 &t) {
 // < KB p and 2 * bound(a) * KB < 169.  [< 2p; tight]
 template <int KB>
 LSA_HD F29 w12_comp_mul(unsigned part, const Fq2S &a, const Fq2S &b) {
-    const uint32_t pm = 0u - part;
+    const uint32_t pm = w12_mask(0u - part);
     const F29 nb1 = sub_k<KB>(F29::zero(), b.c1.v);
     F29 y0, y1;
 #pragma unroll
@@ -144,7 +152,7 @@ struct W12 {
                 const unsigned i = t / 12, j = (t >> 1) % 6, part = t & 1;
                 const Fq2S ai = A[i];
                 const F29x2 xa = w12_xi_times(F29x2{ai.c0.v, ai.c1.v});        // [< 20]
-                const uint32_t wrap = 0u - (uint32_t)(i + j >= 6);
+                const uint32_t wrap = w12_mask(0u - (uint32_t)(i + j >= 6));
                 Fq2S asel;
 #pragma unroll
                 for (int l = 0; l < 9; l++) {
