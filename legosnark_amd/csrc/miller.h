@@ -387,7 +387,7 @@ LSA_HD Fq2S g6_coeff_full(int k, const Fq2S *A, const Fq2S *B) {
     F29x2 lo = F29x2::zero(), hi = F29x2::zero();
     for (int i = 0; i < 6; i++) {
         int j = k - i;
-        const uint32_t wrap = 0u - (uint32_t)(j < 0);
+        const uint32_t wrap = w12_mask(0u - (uint32_t)(j < 0));
         if (j < 0) j += 6;
         const Fq2S p = w12_fq2_mul(A[i], B[j]);
 #pragma unroll
@@ -416,7 +416,7 @@ LSA_HD Fq2S g6_coeff_square(int k, const Fq2S *A) {
         int t, u;
         bool wr;
         sqr_pair(k, j, t, u, wr);
-        const uint32_t wrap = 0u - (uint32_t)wr;
+        const uint32_t wrap = w12_mask(0u - (uint32_t)wr);
         const uint32_t sh = t == u ? 0u : 1u;                    // off-diagonal pairs count twice
         const Fq2S p = w12_fq2_mul(A[t], A[u]);
 #pragma unroll
@@ -432,7 +432,7 @@ LSA_HD Fq2S g6_coeff_sparse(int k, const Fq2S *A, const Fq2S *L) {
     F29x2 lo = F29x2::zero(), hi = F29x2::zero();
     for (int t = 0; t < 3; t++) {
         int i = k - (t == 0 ? 0 : t + 2);                       // b index 0, 3, 4
-        const uint32_t wrap = 0u - (uint32_t)(i < 0);
+        const uint32_t wrap = w12_mask(0u - (uint32_t)(i < 0));
         if (i < 0) i += 6;
         const Fq2S p = w12_fq2_mul(A[i], L[t]);
 #pragma unroll
@@ -590,7 +590,7 @@ static constexpr int G12_LDS_FQ2 = G12_GROUPS * G12_STRIDE;
 // component `part` of a*b: part 0: a0*b0 + a1*(KB p - b1), part 1: a0*b1 + a1*b0.  b's components < KB p.
 template <int KB>
 LSA_HD F29 g12_comp_mul(unsigned part, const Fq2S &a, const Fq2S &b) {
-    const uint32_t pm = 0u - part;
+    const uint32_t pm = w12_mask(0u - part);
     const F29 nb1 = sub_k<KB>(F29::zero(), b.c1.v);
     F29 y0, y1;
 #pragma unroll
