@@ -38,14 +38,7 @@ LSA_HD Fq2S w12_fq2_mul(const Fq2S &a, const Fq2S &b) {
     return {Fs{r.c0}, Fs{r.c1}};
 }
 
-// A lane mask (all ones / zero) the optimiser must not see through: it rewrites (a & m) | (b & ~m) with
-// m = -(condition) into v_cndmask_b32, which issues ~5x slower than the two bit operations on gfx950.
-LSA_HD uint32_t w12_mask(uint32_t m) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(m));
-#endif
-    return m;
-}
+LSA_HD uint32_t w12_mask(uint32_t m) { return lsa_mask(m); }      // (fp29.h)
 // component `part` (0: c0, 1: c1) of an Fq2 value in memory, by address: a select between the two
 // components costs 9 v_cndmask_b32 (each ~5x a plain VALU op on gfx950), an offset costs nothing
 LSA_HD const Fs &w12_comp(const Fq2S &v, unsigned part) { return (&v.c0)[part]; }
