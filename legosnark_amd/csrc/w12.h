@@ -39,6 +39,31 @@ LSA_HD Fq2S w12_fq2_mul(const Fq2S &a, const Fq2S &b) {
 }
 
 LSA_HD uint32_t w12_mask(uint32_t m) { return lsa_mask(m); }      // (fp29.h)
+// The engine's registers live in LDS but are reached through generic pointers (the executor
+// abstraction, host tests): every dereference then carries the null check of the generic -> LDS address
+// cast (v_cmp_ne_u64 + v_cndmask_b32, 46 pairs in one W12::mul).  On the device the hot accessors below
+// go through the LDS offset directly -- the low 32 bits of a generic address inside the LDS aperture.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) uint32_t w12_lds_u32;
+__device__ __forceinline__ w12_lds_u32 *w12_lds(const void *p) { return (w12_lds_u32 *)(uint32_t)(uintptr_t)p; }
+__device__ __forceinline__ Fs w12_load(const Fs *p) {
+    Fs r;
+    w12_lds_u32 *w = w12_lds(p);
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v.l[i] = w[i];
+    return r;
+}
+__device__ __forceinline__ Fq2S w12_load(const Fq2S *p) { return {w12_load(&p->c0), w12_load(&p->c1)}; }
+__device__ __forceinline__ void w12_store(Fs *p, const Fs &v) {
+    w12_lds_u32 *w = w12_lds(p);
+#pragma unroll
+    for (int i = 0; i < 9; i++) w[i] = v.v.l[i];
+}
+#else
+inline Fs w12_load(const Fs *p) { return *p; }
+inline Fq2S w12_load(const Fq2S *p) { return *p; }
+inline void w12_store(Fs *p, const Fs &v) { *p = v; }
+#endif
 // component `part` (0: c0, 1: c1) of an Fq2 value in memory, by address: a select between the two
 // components costs 9 v_cndmask_b32 (each ~5x a plain VALU op on gfx950), an offset costs nothing
 LSA_HD const Fs &w12_comp(const Fq2S &v, unsigned part) { return (&v.c0)[part]; }
@@ -143,7 +168,7 @@ struct W12 {
         x.par([=](unsigned lane) {
             for (unsigned t = lane; t < 72; t += nl) {
                 const unsigned i = t / 12, j = (t >> 1) % 6, part = t & 1;
-                const Fq2S ai = A[i];
+                const Fq2S ai = w12_load(&A[i]);
                 const F29x2 xa = w12_xi_times(F29x2{ai.c0.v, ai.c1.v});        // [< 20]
                 const uint32_t wrap = w12_mask(0u - (uint32_t)(i + j >= 6));
                 Fq2S asel;
@@ -152,17 +177,17 @@ struct W12 {
                     asel.c0.v.l[l] = (xa.c0.l[l] & wrap) | (ai.c0.v.l[l] & ~wrap);
                     asel.c1.v.l[l] = (xa.c1.l[l] & wrap) | (ai.c1.v.l[l] & ~wrap);
                 }
-                const Fs r = {w12_comp_mul<2>(part, asel, B[j])};
-                w12_comp(Pp[i * 6 + j], part) = r;
+                const Fs r = {w12_comp_mul<2>(part, asel, w12_load(&B[j]))};
+                w12_store(&w12_comp(Pp[i * 6 + j], part), r);
             }
         });
         x.par([=](unsigned lane) {
             if (lane < 12) {
                 const unsigned k = lane >> 1, part = lane & 1;
                 F29 sum = F29::zero();
-                for (int i = 0; i < 6; i++) sum = add_lazy(sum, w12_comp(Pp[i * 6 + ((int)k - i + 6) % 6], part).v);
+                for (int i = 0; i < 6; i++) sum = add_lazy(sum, w12_load(&w12_comp(Pp[i * 6 + ((int)k - i + 6) % 6], part)).v);
                 const Fs r = {f29_mul(w12_norm_u(sum), F29::one())};          // < 12p -> < 2p
-                w12_comp(D[k], part) = r;
+                w12_store(&w12_comp(D[k], part), r);
             }
         });
     }
