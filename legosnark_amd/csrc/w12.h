@@ -59,7 +59,9 @@ __device__ __forceinline__ void w12_store(Fs *p, const Fs &v) {
 #pragma unroll
     for (int i = 0; i < 9; i++) w[i] = v.v.l[i];
 }
+__device__ __forceinline__ void w12_store(Fq2S *p, const Fq2S &v) { w12_store(&p->c0, v.c0); w12_store(&p->c1, v.c1); }
 #else
+inline void w12_store(Fq2S *p, const Fq2S &v) { *p = v; }
 inline Fs w12_load(const Fs *p) { return *p; }
 inline Fq2S w12_load(const Fq2S *p) { return *p; }
 inline void w12_store(Fs *p, const Fs &v) { *p = v; }
