@@ -1629,10 +1629,17 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     // digits every bucket is long (26*n/512 entries), and the point of that path is latency:
     // anything above 4 entries is cut into chunks summed by a wavefront each.
     const uint32_t avg_pop = (uint32_t)(ne / nb + 1);
-    // (Wide digits: the top window covers only 255 - 20*12 = 15 bits, so 2^14 buckets carry n/2^14
-    // extra entries -- 88 against the average 26 at n = 2^20; the population order copes with
-    // that, so the threshold sits well above it.)
-    const uint32_t heavy_threshold = (wide && !big) ? 4u : (wide ? std::max<uint32_t>(64, 4 * avg_pop + 64) : std::max<uint32_t>(64, 2 * avg_pop + 32));
+    // wide digits: the fullest buckets are those of the lower half, which every window reaches -- n / B
+    // entries from each window of the widest width, twice that from each narrower one (36 at n = 2^20, 168
+    // at n = 2^24); twice that expectation (6 sigma and more) separates them from skewed inputs, whose
+    // long single-lane lists would otherwise bound the accumulate kernel (runs of equal scalars: 3.9 -> 3.2 ms)
+    uint32_t pop_lo = avg_pop;
+    if (wide && big) {
+        unsigned nfull = 0;
+        for (unsigned k = 0; k < nwin; k++) nfull += pl.width[k] == c;
+        pop_lo = (uint32_t)(((uint64_t)n * (nfull + 2 * (nwin - nfull))) / B + 1);
+    }
+    const uint32_t heavy_threshold = (wide && !big) ? 4u : (wide ? std::max<uint32_t>(64, 2 * pop_lo + 32) : std::max<uint32_t>(64, 2 * avg_pop + 32));
     uint32_t bin_shift = 0;                          // populations above 1024 share bins (the order only balances wavefronts)
     while (((heavy_threshold - 1) >> bin_shift) + 1 > SIZE_BINS - 1) bin_shift++;
     const uint32_t max_heavy = (uint32_t)std::min<size_t>(nb, ne / heavy_threshold + 1);
