@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "curves.h"
+#include "fs29.h"
 #include "glv.h"
 #include "msm.h"
 
@@ -107,6 +108,51 @@ template <class C>
 __global__ __launch_bounds__(256) void k_convert_bases(const Aff<typename C::Field> *__restrict__ in, typename C::Base *__restrict__ out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = C::from_affine(in[i]);
+}
+
+// G1: Jacobian (libff layout) -> packed affine bases in ONE kernel, on the 29-bit-limb field: a third
+// of the instructions per product of the 32-bit-limb Fq, no 64-byte staging array, and the same
+// canonical coordinates as k_normalize + k_convert_bases (affine coordinates are unique).  Per lane K
+// points share one Fermat inversion (Montgomery's trick).
+template <int K>
+__global__ __launch_bounds__(256) void k_prepare_g1(const Jac<Fq> *__restrict__ in, AffPacked *__restrict__ out, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, base = t * K;
+    if (base >= n) return;
+    const Fq one256 = Fq::one();
+    F29 prod[K];
+    F29 acc = F29::one();
+    bool need_inv = false;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        if (base + i < n) {
+            const Fq z = in[base + i].Z;
+            if (!z.is_zero() && z != one256) { acc = mul(acc, F29::from_mont256(z)); need_inv = true; }
+        }
+        prod[i] = acc;
+    }
+    F29 inv = need_inv ? Fs{acc}.inverse().v : F29::one();
+#pragma unroll
+    for (int i = K - 1; i >= 0; i--) {
+        if (base + i >= n) continue;
+        const Jac<Fq> p = in[base + i];
+        AffPacked r;
+        if (p.Z.is_zero()) {
+#pragma unroll
+            for (int w = 0; w < 8; w++) { r.x[w] = 0; r.y[w] = 0; }
+        } else {
+            F29 x = F29::from_mont256(p.X), y = F29::from_mont256(p.Y);
+            if (p.Z != one256) {
+                const F29 zi = mul(inv, i == 0 ? F29::one() : prod[i - 1]);      // 1 / Z_i
+                inv = mul(inv, F29::from_mont256(p.Z));
+                const F29 zi2 = sqr(zi);
+                x = mul(x, zi2);
+                y = mul(y, mul(zi2, zi));
+            }
+            x.canonical().pack256(r.x);
+            y.canonical().pack256(r.y);
+        }
+        out[base + i] = r;
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1421,6 +1467,13 @@ int prepare_bases(const Jac<F> *d_in, void *d_out, size_t n, hipStream_t st) {
     unsigned blocks = (unsigned)((threads + 255) / 256);
     if (std::is_same<typename C::Base, Aff<F>>::value) {
         hipLaunchKernelGGL((k_normalize<F, K>), dim3(blocks), dim3(256), 0, st, d_in, (Aff<F> *)d_out, n);
+        HIPCHK(hipGetLastError());
+        return LSA_OK;
+    }
+    if constexpr (std::is_same<F, Fq>::value) {
+        constexpr int KG = 16;                               // points per inversion (16 x 9 registers of prefix products)
+        const unsigned gblocks = (unsigned)(((n + KG - 1) / KG + 255) / 256);
+        hipLaunchKernelGGL((k_prepare_g1<KG>), dim3(gblocks), dim3(256), 0, st, d_in, (AffPacked *)d_out, n);
         HIPCHK(hipGetLastError());
         return LSA_OK;
     }
