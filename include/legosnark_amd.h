@@ -277,6 +277,46 @@ int lsa_final_exponentiation(const void *in_fq12, size_t n, void *out_fq12, int 
  * CPsc verifier shape (BASELINE.json configs[4]).  Host pointers. */
 int lsa_pairing_product(const void *g1_jac, const void *g2_jac, size_t n, void *out_gt);
 
+/* ---- G2 precomputation (libff G2_precomp) ------------------------------------------------- */
+/* libff's alt_bn128_ate_G2_precomp as bytes: QX, QY (the affine point), then the coefficient triple
+ * {ell_0, ell_VW, ell_VV} of each of the 102 steps of the ate loop (64 doublings, 36 additions, 2
+ * Frobenius steps), 308 Fq2 of 64 B in libff's layout. */
+#define LSA_ATE_NUM_COEFFS 102
+#define LSA_G2_PRECOMP_BYTES ((2 + 3 * LSA_ATE_NUM_COEFFS) * 64)
+size_t lsa_g2_precomp_bytes(void);   /* == LSA_G2_PRECOMP_BYTES */
+/* out_precomp[i] = precompute_G2(Q_i), i < n: replaces libff alt_bn128_pp::precompute_G2 where the
+ * reference keeps the result in a key and re-uses it in every verification (src/gadgets/subspace.cc:48,
+ * 66-70: C_precomp, a_precomp; src/gadgets/lipmaa.h:95-96: gammazg2_precomp; src/gadgets/poly.h:97-98).
+ * Q_i: libff G2 (192 B), out: n x LSA_G2_PRECOMP_BYTES.  Host pointers. */
+int lsa_g2_precompute(const void *g2_jac, size_t n, void *out_precomp);
+/* out[i] = miller_loop(precompute_G1(P_i), *q_precomp[i]), i < n, over precomputed G2 values
+ * (src/gadgets/subspace.cc:152-166 verifyLin3or4, src/gadgets/lipmaa.cc:194-200): only the Fq12 chain
+ * f <- f^2 * line(P) runs, 166 dependent rounds instead of 344.  q_precomp: n host pointers to
+ * LSA_G2_PRECOMP_BYTES each (equal pointers / equal contents share one device table).  Host pointers. */
+int lsa_miller_loop_precomp(const void *g1_jac, const void *const *q_precomp, size_t n, void *out_fq12);
+/* The general form every pairing entry point is a shape of:
+ *   out[j] = [final_exponentiation] ( prod_{i = seg_offsets[j]}^{seg_offsets[j+1]-1} m_i ),  j < nseg,
+ *   m_i = miller_loop(P_i, Q_i), or its conjugate (libff unitary_inverse) when flags[i] & 1.
+ * Q_i is *q_precomp[i] when q_precomp and q_precomp[i] are non-null, else the point g2_jac[i].
+ * flags may be null (no conjugates).  A verifier's whole check
+ *   final_exponentiation(lhs * rhs.unitary_inverse()) == GT::one()
+ * (src/utils/globl.h:94-105, src/gadgets/subspace.cc:166, src/gadgets/lipmaa.cc:203, src/gadgets/poly.h:110,122)
+ * is ONE product here: the pairs of a product share accumulators on the device, conjugated terms run as
+ * Miller loops on -P (the same Fq12 element).  Host pointers. */
+int lsa_pairing_terms(const void *g1_jac, const void *g2_jac, const void *const *q_precomp, const uint8_t *flags,
+                      const uint64_t *seg_offsets, size_t nseg, void *out_fq12, int final_exp);
+/* The device keeps one line table (22 KB) per distinct Q it has seen -- keyed by a 128-bit fingerprint of
+ * the bytes passed (the 192-byte point, or the precomp blob) -- so that a CRS element costs its G2
+ * arithmetic once.  max_tables: capacity (LRU; default 4096, env LSA_G2_TABLES); 0 turns the cache off
+ * (every call recomputes its tables).  Calls with more than 1024 terms or device-resident points bypass
+ * it.  stats: hits, misses, resident tables, evictions. */
+int lsa_g2_table_cache(size_t max_tables);
+/* Pairs of one product that share an accumulator f <- f^2 * prod_i line_i (1..4; 0 = chosen from the
+ * batch size: 1 up to 8192 terms, so that every pair has its own lanes while the chip is not full).
+ * The value of a product does not depend on it. */
+int lsa_pairing_set_chunk(unsigned pairs_per_accumulator);
+int lsa_g2_table_cache_stats(uint64_t out[4]);
+
 /* ---- multi-GPU: one process per GPU, one exchange step per MSM (RCCL over xGMI) --------------- */
 /* libff's multi_exp splits [0, n) into `chunks` contiguous ranges, runs multi_exp_inner on each
  * and sums the partials; multiExpMA forwards `chunks` (src/utils/globl.h:67-77).  Here a chunk is

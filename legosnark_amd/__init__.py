@@ -116,6 +116,13 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.lsa_comm_all_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.lsa_pairing_product_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.lsa_g2_precomp_bytes.restype = C.c_size_t
+        L.lsa_g2_precompute.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.lsa_miller_loop_precomp.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.lsa_pairing_terms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+        L.lsa_g2_table_cache.argtypes = [C.c_size_t]
+        L.lsa_pairing_set_chunk.argtypes = [C.c_uint]
+        L.lsa_g2_table_cache_stats.argtypes = [C.c_void_p]
         L.lsa_crs_cache_configure.argtypes = [C.c_int, C.c_size_t]
         L.lsa_crs_cache_clear.restype = None
         L.lsa_crs_cache_stats.argtypes = [C.POINTER(C.c_uint64)] * 4
@@ -629,6 +636,82 @@ def pairing_product_segments(g1, g2, offsets, final_exp=True):
     _check(lib().lsa_pairing_product_segments(_host_ptr(g1), _host_ptr(g2), _host_ptr(off), len(off) - 1, _host_ptr(out),
                                               1 if final_exp else 0))
     return out
+
+
+G2_PRECOMP_WORDS = (2 + 3 * 102) * 8          # LSA_G2_PRECOMP_BYTES / 8: QX, QY, 102 x {ell_0, ell_VW, ell_VV}
+
+
+def g2_precompute(g2):
+    """libff precompute_G2 for n points -> (n, G2_PRECOMP_WORDS) uint64: QX, QY, then the coefficient
+    triples of the 102 ate-loop steps (alt_bn128_ate_G2_precomp as bytes)."""
+    g2 = np.ascontiguousarray(g2, dtype=np.uint64).reshape(-1, 24)
+    out = np.zeros((len(g2), G2_PRECOMP_WORDS), dtype=np.uint64)
+    _check(lib().lsa_g2_precompute(_host_ptr(g2), len(g2), _host_ptr(out)))
+    return out
+
+
+def _precomp_ptrs(tables, index):
+    """tables: (m, G2_PRECOMP_WORDS) array; index: per-term row numbers (None: row i) -> ctypes array of row pointers."""
+    tables = np.ascontiguousarray(tables, dtype=np.uint64).reshape(-1, G2_PRECOMP_WORDS)
+    idx = range(len(tables)) if index is None else [int(i) for i in index]
+    base, stride = tables.ctypes.data, G2_PRECOMP_WORDS * 8
+    return tables, (C.c_void_p * len(idx))(*[None if i < 0 else base + i * stride for i in idx])
+
+
+def miller_loop_precomp(g1, tables, index=None):
+    """out[i] = miller_loop(precompute_G1(P_i), table of term i) over precomputed G2 values."""
+    g1 = np.ascontiguousarray(g1, dtype=np.uint64).reshape(-1, 12)
+    tables, ptrs = _precomp_ptrs(tables, index)
+    if len(ptrs) != len(g1):
+        raise ValueError("need one table per G1 point")
+    out = np.zeros((len(g1), 48), dtype=np.uint64)
+    _check(lib().lsa_miller_loop_precomp(_host_ptr(g1), ptrs, len(g1), _host_ptr(out)))
+    return out
+
+
+def pairing_terms(g1, offsets, g2=None, tables=None, index=None, flags=None, final_exp=True):
+    """out[j] = [final_exponentiation](prod over terms i of segment j of miller_loop(P_i, Q_i), conjugated where
+    flags[i] & 1).  Q_i: row index[i] of `tables` (index[i] < 0 or tables None: the point g2[i])."""
+    g1 = np.ascontiguousarray(g1, dtype=np.uint64).reshape(-1, 12)
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    if len(off) < 1 or int(off[-1]) != len(g1):
+        raise ValueError("offsets must end at the number of terms")
+    g2p = None
+    if g2 is not None:
+        g2 = np.ascontiguousarray(g2, dtype=np.uint64).reshape(-1, 24)
+        if len(g2) != len(g1):
+            raise ValueError("need as many G1 as G2 points")
+        g2p = _host_ptr(g2)
+    ptrs = None
+    if tables is not None:
+        tables, ptrs = _precomp_ptrs(tables, index)
+        if len(ptrs) != len(g1):
+            raise ValueError("need one table index per term")
+    fl = None
+    if flags is not None:
+        fl = np.ascontiguousarray(flags, dtype=np.uint8)
+        if len(fl) != len(g1):
+            raise ValueError("need one flag per term")
+    out = np.zeros((len(off) - 1, 48), dtype=np.uint64)
+    _check(lib().lsa_pairing_terms(_host_ptr(g1), g2p, ptrs, None if fl is None else _host_ptr(fl), _host_ptr(off), len(off) - 1,
+                                   _host_ptr(out), 1 if final_exp else 0))
+    return out
+
+
+def g2_table_cache(max_tables):
+    """Capacity of the device's G2 line-table cache (0: off; clears it)."""
+    _check(lib().lsa_g2_table_cache(int(max_tables)))
+
+
+def pairing_set_chunk(m):
+    """Pairs of a product that share one accumulator on the device (0: automatic)."""
+    _check(lib().lsa_pairing_set_chunk(int(m)))
+
+
+def g2_table_cache_stats():
+    out = (C.c_uint64 * 4)()
+    _check(lib().lsa_g2_table_cache_stats(out))
+    return {"hits": out[0], "misses": out[1], "resident": out[2], "evictions": out[3]}
 
 
 def fq12_product(f):

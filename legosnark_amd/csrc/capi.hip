@@ -246,29 +246,14 @@ int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars, siz
 }
 
 }  // extern "C"
-// grow-only device staging buffers of the host-buffer entry points (the libff shim calls
-// lsa_g1_msm thousands of times with tiny inputs: no hipMalloc/hipFree per call)
+// grow-only device staging buffers of the host-buffer entry points (StageBuf, capi_internal.h)
 namespace {
-struct StageBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return 0;
-        if (p) { (void)hipStreamSynchronize(g.stream); (void)hipFree(p); }
-        p = nullptr; cap = 0;
-        size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
-        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
-        cap = want;
-        return 0;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-};
-StageBuf g_stage_jac, g_stage_bases, g_stage_scalars, g_stage_gather;
-StageBuf g_pair_p, g_pair_q, g_pair_f, g_pair_s, g_pair_o;     // pairing host path: points, Miller values, product scratch, result
+StageBuf g_stage_jac, g_stage_bases, g_stage_scalars;
 }  // namespace
+namespace lsa { StageBuf g_stage_gather; }
 static void release_stage_buffers() {
     g_stage_jac.release(); g_stage_bases.release(); g_stage_scalars.release(); g_stage_gather.release();
-    g_pair_p.release(); g_pair_q.release(); g_pair_f.release(); g_pair_s.release(); g_pair_o.release();
+    pairing_release();
 }
 
 // ---------------------------------------------------------------- CRS cache behind lsa_g1_msm / lsa_g2_msm
@@ -1011,175 +996,6 @@ int lsa_fr_fold(const void *old, size_t half, const void *r, void *cur, int on_d
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));
     HIPCHK(hipMemcpy(cur, d_v.p, half * sizeof(Fr), hipMemcpyDeviceToHost));
-    return LSA_OK;
-}
-}  // extern "C"
-
-// ---------------------------------------------------------------- pairing
-namespace {
-
-// uploads n (P,Q) pairs and runs the Miller loops into the grow-only staging buffer g_pair_f (a
-// verifier calls this thousands of times: no hipMalloc / hipFree, which also keeps the device
-// from idling down between the upload and the kernel)
-int miller_upload_run(const void *g1, const void *g2, size_t n) {
-    if (g_pair_p.ensure(n * sizeof(Jac<Fq>)) || g_pair_q.ensure(n * sizeof(Jac<Fq2>)) || g_pair_f.ensure(n * fq12_bytes())) {
-        set_error("pairing: hipMalloc failed");
-        return LSA_ERR_NOMEM;
-    }
-    HIPCHK(hipMemcpyAsync(g_pair_p.p, g1, n * sizeof(Jac<Fq>), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(g_pair_q.p, g2, n * sizeof(Jac<Fq2>), hipMemcpyHostToDevice, g.stream));
-    return miller_device(g_pair_p.p, g_pair_q.p, n, g_pair_f.p, g.stream);
-}
-
-int miller_product_host(const void *g1, const void *g2, size_t n, void *out, bool final_exp, bool sharded = false) {
-    int rc = require_ready();
-    if (rc) return rc;
-    if (!out || (n && (!g1 || !g2))) { set_error("pairing: null argument"); return LSA_ERR_INVALID; }
-    void *res = nullptr;
-    if (sharded && lsa_comm_world() > 1) {
-        // per-rank Miller product (1 for an empty slice), all-gather of the Fq12 partials, product
-        // in rank order, one final exponentiation on every rank (SURVEY.md 8e "Pairings")
-        const size_t world = (size_t)lsa_comm_world();
-        if (g_pair_o.ensure(fq12_bytes()) || g_stage_gather.ensure(world * fq12_bytes()) || g_pair_s.ensure(((std::max(n, world) + 7) / 8) * fq12_bytes())) {
-            set_error("pairing: hipMalloc failed");
-            return LSA_ERR_NOMEM;
-        }
-        if (n == 0) {
-            Fq12 one = Fq12::one();
-            HIPCHK(hipMemcpyAsync(g_pair_o.p, &one, sizeof one, hipMemcpyHostToDevice, g.stream));
-            HIPCHK(hipStreamSynchronize(g.stream));
-        } else {
-            rc = miller_upload_run(g1, g2, n);
-            if (rc) return rc;
-            rc = fq12_product_device(g_pair_f.p, g_pair_s.p, n, &res, g.stream);
-            if (rc) return rc;
-            HIPCHK(hipMemcpyAsync(g_pair_o.p, res, fq12_bytes(), hipMemcpyDeviceToDevice, g.stream));
-        }
-        rc = lsa_comm_all_gather(g_pair_o.p, g_stage_gather.p, 12);
-        if (rc) return rc;
-        rc = fq12_product_device(g_stage_gather.p, g_pair_s.p, world, &res, g.stream);
-        if (rc) return rc;
-        if (final_exp) {
-            rc = final_exp_device(res, 1, g_pair_o.p, g.stream);
-            if (rc) return rc;
-            res = g_pair_o.p;
-        }
-        HIPCHK(hipMemcpyAsync(g.h_result, res, fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
-        HIPCHK(hipStreamSynchronize(g.stream));
-        memcpy(out, g.h_result, fq12_bytes());
-        return LSA_OK;
-    }
-    if (n == 0) {
-        // empty product = 1; final_exponentiation(1) = 1
-        Fq12 one = Fq12::one();
-        memcpy(out, &one, sizeof one);
-        return LSA_OK;
-    }
-    rc = miller_upload_run(g1, g2, n);
-    if (rc) return rc;
-    if (g_pair_s.ensure(((n + 7) / 8) * fq12_bytes()) || g_pair_o.ensure(fq12_bytes())) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
-    rc = fq12_product_device(g_pair_f.p, g_pair_s.p, n, &res, g.stream);
-    if (rc) return rc;
-    if (final_exp) {
-        rc = final_exp_device(res, 1, g_pair_o.p, g.stream);
-        if (rc) return rc;
-        res = g_pair_o.p;
-    }
-    HIPCHK(hipMemcpyAsync(g.h_result, res, fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    memcpy(out, g.h_result, fq12_bytes());
-    return LSA_OK;
-}
-}  // namespace
-
-extern "C" {
-int lsa_miller_loop(const void *g1, const void *g2, size_t n, void *out, int on_device) {
-    int rc = require_ready();
-    if (rc) return rc;
-    if (n == 0) return LSA_OK;
-    if (!g1 || !g2 || !out) { set_error("miller_loop: null argument"); return LSA_ERR_INVALID; }
-    if (on_device) return miller_device(g1, g2, n, out, g.stream);
-    rc = miller_upload_run(g1, g2, n);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(out, g_pair_f.p, n * fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    return LSA_OK;
-}
-int lsa_miller_loop_product(const void *g1, const void *g2, size_t n, void *out) {
-    return miller_product_host(g1, g2, n, out, false);
-}
-int lsa_pairing_product(const void *g1, const void *g2, size_t n, void *out) {
-    return miller_product_host(g1, g2, n, out, true);
-}
-// many independent products in one pass: one upload, one Miller launch over all pairs, one
-// product workgroup per segment, one batched final exponentiation, one download
-int lsa_pairing_product_segments(const void *g1, const void *g2, const uint64_t *seg_offsets, size_t nseg, void *out_gt, int final_exp) {
-    int rc = require_ready();
-    if (rc) return rc;
-    if (nseg == 0) return LSA_OK;
-    if (!seg_offsets || !out_gt) { set_error("pairing_product_segments: null argument"); return LSA_ERR_INVALID; }
-    if (seg_offsets[0] != 0) { set_error("pairing_product_segments: offsets must start at 0"); return LSA_ERR_INVALID; }
-    for (size_t j = 0; j < nseg; j++)
-        if (seg_offsets[j + 1] < seg_offsets[j]) { set_error("pairing_product_segments: offsets must not decrease"); return LSA_ERR_INVALID; }
-    const size_t n = seg_offsets[nseg];
-    if (n && (!g1 || !g2)) { set_error("pairing_product_segments: null argument"); return LSA_ERR_INVALID; }
-    if (g_pair_s.ensure(nseg * fq12_bytes()) || g_pair_o.ensure(nseg * fq12_bytes()) || g_stage_gather.ensure((nseg + 1) * sizeof(uint64_t)) ||
-        g_pair_f.ensure((n ? n : 1) * fq12_bytes())) {
-        set_error("pairing: hipMalloc failed");
-        return LSA_ERR_NOMEM;
-    }
-    if (n) {
-        rc = miller_upload_run(g1, g2, n);
-        if (rc) return rc;
-    }
-    HIPCHK(hipMemcpyAsync(g_stage_gather.p, seg_offsets, (nseg + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
-    rc = fq12_segment_products_device(g_pair_f.p, (const uint64_t *)g_stage_gather.p, nseg, g_pair_s.p, g.stream);
-    if (rc) return rc;
-    void *res = g_pair_s.p;
-    if (final_exp) {
-        rc = final_exp_device(g_pair_s.p, nseg, g_pair_o.p, g.stream);
-        if (rc) return rc;
-        res = g_pair_o.p;
-    }
-    HIPCHK(hipMemcpyAsync(out_gt, res, nseg * fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    return LSA_OK;
-}
-int lsa_pairing_product_sharded(const void *g1, const void *g2, size_t n_local, void *out) {
-    return miller_product_host(g1, g2, n_local, out, true, true);
-}
-int lsa_fq12_product(const void *in, size_t n, void *out) {
-    int rc = require_ready();
-    if (rc) return rc;
-    if (!out || (n && !in)) { set_error("fq12_product: null argument"); return LSA_ERR_INVALID; }
-    if (n == 0) {
-        Fq12 one = Fq12::one();
-        memcpy(out, &one, sizeof one);
-        return LSA_OK;
-    }
-    DevBuf d_f, d_s;
-    void *res = nullptr;
-    if (d_f.alloc(n * fq12_bytes()) || d_s.alloc(((n + 7) / 8) * fq12_bytes())) { set_error("fq12_product: hipMalloc failed"); return LSA_ERR_NOMEM; }
-    HIPCHK(hipMemcpyAsync(d_f.p, in, n * fq12_bytes(), hipMemcpyHostToDevice, g.stream));
-    rc = fq12_product_device(d_f.p, d_s.p, n, &res, g.stream);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(g.h_result, res, fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
-    memcpy(out, g.h_result, fq12_bytes());
-    return LSA_OK;
-}
-int lsa_final_exponentiation(const void *in, size_t n, void *out, int on_device) {
-    int rc = require_ready();
-    if (rc) return rc;
-    if (n == 0) return LSA_OK;
-    if (!in || !out) { set_error("final_exponentiation: null argument"); return LSA_ERR_INVALID; }
-    if (on_device) return final_exp_device(in, n, out, g.stream);
-    if (g_pair_f.ensure(n * fq12_bytes()) || g_pair_s.ensure(n * fq12_bytes())) { set_error("final_exponentiation: hipMalloc failed"); return LSA_ERR_NOMEM; }
-    HIPCHK(hipMemcpyAsync(g_pair_f.p, in, n * fq12_bytes(), hipMemcpyHostToDevice, g.stream));
-    rc = final_exp_device(g_pair_f.p, n, g_pair_s.p, g.stream);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(out, g_pair_s.p, n * fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
-    HIPCHK(hipStreamSynchronize(g.stream));
     return LSA_OK;
 }
 }  // extern "C"

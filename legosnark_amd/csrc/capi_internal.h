@@ -26,6 +26,25 @@ extern State g;
 
 int require_ready();
 void comm_release();               // comm.hip: called by lsa_shutdown
+void pairing_release();            // capi_pairing.hip: staging buffers and the G2 line-table cache
+
+// grow-only device staging buffer of the host-buffer entry points (the libff shim calls them
+// thousands of times with tiny inputs: no hipMalloc / hipFree per call)
+struct StageBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipStreamSynchronize(g.stream); (void)hipFree(p); }
+        p = nullptr; cap = 0;
+        size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return -1; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+extern StageBuf g_stage_gather;    // all-gather landing zone shared by the sharded MSM and pairing paths
 
 }  // namespace lsa
 

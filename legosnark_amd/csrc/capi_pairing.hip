@@ -1,0 +1,582 @@
+// legosnark_amd/csrc/capi_pairing.hip -- the pairing entry points of the C-ABI (include/legosnark_amd.h).
+//
+// Every entry point is one shape of the same job: n terms (P_i, Q_i), grouped into products, each
+// product optionally followed by a final exponentiation.  Q_i arrives either as a point (libff
+// precompute_G2 is then done here) or as libff's alt_bn128_ate_G2_precomp bytes (lsa_g2_precompute),
+// the form the reference's keys hold and re-use in every verification
+// (/root/reference/src/gadgets/subspace.cc:48,66-70,152-166; src/gadgets/lipmaa.h:95-96;
+// src/gadgets/poly.h:97-121).  The device works on line tables (tmiller.h): a table is built once per
+// distinct Q, kept resident in a cache keyed by a 128-bit fingerprint of the bytes the caller passed (the
+// point, or the precomp blob), and every Miller loop over it runs the Fq12 chain only.  Products share
+// accumulators (f <- f^2 * prod line_i) when there are more pairs than the chip has lanes for.
+// No CPU arithmetic: the host only fingerprints, deduplicates and lays out index arrays.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <unordered_map>
+#include <vector>
+
+#include "capi_internal.h"
+#include "tower.h"
+
+namespace lsa {
+// pairing.hip
+size_t g2_table_words();
+size_t g2_precomp_public_bytes();
+int g2_precomp_device(const void *d_g2, size_t n, uint32_t *const *d_tabs, hipStream_t st);
+int g2_table_export_device(const uint32_t *const *d_tabs, size_t n, void *d_public, hipStream_t st);
+int g2_table_import_device(const void *d_public, size_t n, uint32_t *const *d_tabs, hipStream_t st);
+int g2_table_identity_device(uint32_t *d_tab, hipStream_t st);
+unsigned miller_tab_max_pairs();
+int miller_tab_device(const void *d_g1, const uint32_t *const *d_tabs, const uint8_t *d_flags, const uint32_t *d_acc_off, size_t nacc, unsigned M,
+                      const uint32_t *d_ident, void *d_out, hipStream_t st);
+}  // namespace lsa
+
+using namespace lsa;
+
+namespace {
+
+StageBuf g_pair_p, g_pair_q, g_pair_f, g_pair_s, g_pair_o;     // points, Miller values, product scratch, results
+StageBuf g_pair_meta, g_pair_scratch_tabs, g_pair_pub;         // index arrays, uncached tables, public-form staging
+
+// pinned host staging for the small index arrays of a call (one H2D copy)
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipStreamSynchronize(g.stream); (void)hipHostFree(p); }
+        p = nullptr; cap = 0;
+        size_t want = bytes < 65536 ? 65536 : bytes + bytes / 4;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return -1; }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+PinnedBuf g_pin_meta, g_pin_q;
+// the pinned staging of a call must not be rewritten before its copies have run (an on_device call returns
+// without synchronising): recorded after the uploads, waited for at the start of the next call
+hipEvent_t g_uploaded = nullptr;
+bool g_upload_pending = false;
+int wait_uploads() {
+    if (g_upload_pending) { HIPCHK(hipEventSynchronize(g_uploaded)); g_upload_pending = false; }
+    return LSA_OK;
+}
+int mark_uploads() {
+    if (!g_uploaded) HIPCHK(hipEventCreateWithFlags(&g_uploaded, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(g_uploaded, g.stream));
+    g_upload_pending = true;
+    return LSA_OK;
+}
+
+// ---------------------------------------------------------------- G2 line-table cache
+struct Key128 {
+    uint64_t a, b;
+    bool operator==(const Key128 &o) const { return a == o.a && b == o.b; }
+};
+struct Key128Hash { size_t operator()(const Key128 &k) const { return (size_t)(k.a ^ (k.b * 0x9E3779B97F4A7C15ull)); } };
+
+// 128-bit fingerprint: two sets of four multiply-xor lanes with different multipliers and seeds ((h ^ w) * K is
+// a bijection in w: one changed word always changes both halves).  NOT cryptographic: it guards against stale
+// or coinciding inputs of an honest caller, not against chosen collisions.
+Key128 fingerprint(const void *bytes, size_t nbytes, uint64_t kind) {
+    const uint64_t *w = (const uint64_t *)bytes;
+    const size_t nw = nbytes / 8;
+    const uint64_t K1 = 0x9E3779B97F4A7C15ull, K2 = 0xC2B2AE3D27D4EB4Full;
+    uint64_t h[4] = {0x243F6A8885A308D3ull ^ kind, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull};
+    uint64_t q[4] = {0x452821E638D01377ull, 0xBE5466CF34E90C6Cull ^ kind, 0xC0AC29B7C97C50DDull, 0x3F84D5B5B5470917ull};
+    size_t i = 0;
+    for (; i + 4 <= nw; i += 4)
+        for (int l = 0; l < 4; l++) { h[l] = (h[l] ^ w[i + l]) * K1; q[l] = (q[l] ^ w[i + (l + 1) % 4]) * K2; q[l] ^= q[l] >> 29; }
+    for (; i < nw; i++) { h[0] = (h[0] ^ w[i]) * K1; q[0] = (q[0] ^ w[i]) * K2; q[0] ^= q[0] >> 29; }
+    auto rotl = [](uint64_t x, int k) { return (x << k) | (x >> (64 - k)); };
+    Key128 r;
+    r.a = h[0] ^ rotl(h[1], 17) ^ rotl(h[2], 31) ^ rotl(h[3], 47);
+    r.b = q[0] ^ rotl(q[1], 13) ^ rotl(q[2], 29) ^ rotl(q[3], 43);
+    r.a ^= r.a >> 32; r.a *= 0xD6E8FEB86659FD93ull; r.a ^= r.a >> 32;
+    r.b ^= r.b >> 31; r.b *= 0xFF51AFD7ED558CCDull; r.b ^= r.b >> 33;
+    return r;
+}
+
+struct TableCache {
+    static constexpr size_t BLOCK = 128;                  // tables per device allocation
+    size_t max_tables = 4096;                             // 90 MB; LSA_G2_TABLES / lsa_g2_table_cache
+    std::vector<void *> blocks;
+    struct Slot { Key128 key; uint64_t tick; bool used; };
+    std::vector<Slot> slots;
+    std::unordered_map<Key128, uint32_t, Key128Hash> map;
+    uint64_t tick = 0, hits = 0, misses = 0, evictions = 0;
+    uint32_t *ident = nullptr;                            // the table of a pair that is not there
+    bool env_read = false;
+
+    uint32_t *ptr(uint32_t slot) const { return (uint32_t *)((char *)blocks[slot / BLOCK] + (size_t)(slot % BLOCK) * g2_table_words() * 4); }
+    void read_env() {
+        if (env_read) return;
+        env_read = true;
+        if (const char *e = getenv("LSA_G2_TABLES")) max_tables = (size_t)strtoull(e, nullptr, 10);
+    }
+    int ensure_ident() {
+        if (ident) return 0;
+        if (hipMalloc((void **)&ident, g2_table_words() * 4) != hipSuccess) { ident = nullptr; return -1; }
+        return g2_table_identity_device(ident, g.stream);
+    }
+    // slot of `key`, -1 on a miss
+    long lookup(const Key128 &key) {
+        auto it = map.find(key);
+        if (it == map.end()) { misses++; return -1; }
+        hits++;
+        slots[it->second].tick = tick;
+        return (long)it->second;
+    }
+    // a free slot for `key` (the least recently used one that no term of the current call refers to), -1 if none
+    long insert(const Key128 &key) {
+        long s = -1;
+        if (slots.size() < max_tables) {
+            if (slots.size() == blocks.size() * BLOCK) {
+                void *b = nullptr;
+                if (hipMalloc(&b, BLOCK * g2_table_words() * 4) != hipSuccess) { (void)hipGetLastError(); return -1; }
+                blocks.push_back(b);
+            }
+            slots.push_back(Slot{key, tick, true});
+            s = (long)slots.size() - 1;
+        } else {
+            uint64_t best = tick;
+            for (size_t i = 0; i < slots.size(); i++)
+                if (slots[i].tick < best) { best = slots[i].tick; s = (long)i; }
+            if (s < 0) return -1;
+            map.erase(slots[(size_t)s].key);
+            evictions++;
+            slots[(size_t)s] = Slot{key, tick, true};
+        }
+        map[key] = (uint32_t)s;
+        return s;
+    }
+    void clear() {
+        for (void *b : blocks) (void)hipFree(b);
+        blocks.clear(); slots.clear(); map.clear();
+        if (ident) (void)hipFree(ident);
+        ident = nullptr;
+    }
+} g_tabs;
+
+// ---------------------------------------------------------------- one job description
+struct Terms {
+    const void *g1 = nullptr;              // n Jacobian G1 points
+    const void *g2 = nullptr;              // n Jacobian G2 points, or null
+    const void *const *qpre = nullptr;     // n pointers to LSA_G2_PRECOMP_BYTES blobs (a null entry: use g2[i]), or null
+    const uint8_t *flags = nullptr;        // bit 0: conjugate the term (libff unitary_inverse of its Miller value)
+    const uint64_t *seg = nullptr;         // nseg + 1 offsets; null: every term is its own product
+    size_t n = 0, nseg = 0;
+    bool on_device = false;                // g1 / g2 are device pointers (no cache: nothing to fingerprint on the host)
+};
+
+unsigned g_force_m = 0;                    // lsa_pairing_set_chunk: pairs per accumulator, 0 = by batch size
+inline int force_kernel() {
+    static const int f = getenv("LSA_MILLER_KERNEL") ? atoi(getenv("LSA_MILLER_KERNEL")) : 0;   // 1-4: the fused kernels of miller.h, 5: tables
+    return f;
+}
+
+// Miller products of the job on the device: *d_res points at nseg Fq12 values when this returns (stream-ordered)
+int run_miller(const Terms &t, void **d_res) {
+    const size_t n = t.n, nseg = t.nseg;
+    // ---- the fused kernels (miller.h): only when forced, and only for raw points without flags
+    const bool plain = !t.qpre && !t.flags;
+    if (plain && force_kernel() >= 1 && force_kernel() <= 4) {
+        const void *d_p = t.g1, *d_q = t.g2;
+        if (!t.on_device) {
+            if (g_pair_p.ensure(n * sizeof(Jac<Fq>)) || g_pair_q.ensure(n * sizeof(Jac<Fq2>))) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
+            HIPCHK(hipMemcpyAsync(g_pair_p.p, t.g1, n * sizeof(Jac<Fq>), hipMemcpyHostToDevice, g.stream));
+            HIPCHK(hipMemcpyAsync(g_pair_q.p, t.g2, n * sizeof(Jac<Fq2>), hipMemcpyHostToDevice, g.stream));
+            d_p = g_pair_p.p; d_q = g_pair_q.p;
+        }
+        if (g_pair_f.ensure((n ? n : 1) * fq12_bytes())) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
+        int rc = miller_device(d_p, d_q, n, g_pair_f.p, g.stream);
+        if (rc) return rc;
+        if (!t.seg) { *d_res = g_pair_f.p; return LSA_OK; }
+        if (nseg == 1) {
+            if (g_pair_s.ensure(((n + 7) / 8 + 1) * fq12_bytes())) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
+            if (n == 0) { Fq12 one = Fq12::one(); HIPCHK(hipMemcpyAsync(g_pair_s.p, &one, sizeof one, hipMemcpyHostToDevice, g.stream)); HIPCHK(hipStreamSynchronize(g.stream)); *d_res = g_pair_s.p; return LSA_OK; }
+            return fq12_product_device(g_pair_f.p, g_pair_s.p, n, d_res, g.stream);
+        }
+        if (g_pair_s.ensure(nseg * fq12_bytes()) || g_pair_meta.ensure((nseg + 1) * sizeof(uint64_t))) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
+        HIPCHK(hipMemcpyAsync(g_pair_meta.p, t.seg, (nseg + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));     // t.seg is pageable caller memory
+        rc = fq12_segment_products_device(g_pair_f.p, (const uint64_t *)g_pair_meta.p, nseg, g_pair_s.p, g.stream);
+        *d_res = g_pair_s.p;
+        return rc;
+    }
+
+    // ---- tables
+    { int rcw = wait_uploads(); if (rcw) return rcw; }
+    g_tabs.read_env();
+    if (g_tabs.ensure_ident()) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    g_tabs.tick++;
+    const size_t TW = g2_table_words(), PUB = g2_precomp_public_bytes();
+    // accumulators: a product of len pairs takes ceil(len / M) of them; M grows once the chip is full
+    // (four accumulators per wavefront, 1024 SIMDs)
+    unsigned M = 1;
+    while (M < miller_tab_max_pairs() && n > (size_t)M * 8192) M++;
+    if (g_force_m) M = g_force_m;
+    std::vector<uint64_t> own_seg;
+    const uint64_t *seg = t.seg;
+    size_t nprod = nseg;
+    if (!seg) {
+        own_seg.resize(n + 1);
+        for (size_t i = 0; i <= n; i++) own_seg[i] = i;
+        seg = own_seg.data();
+        nprod = n;
+    }
+    size_t nacc = 0;
+    for (size_t j = 0; j < nprod; j++) { const size_t len = (size_t)(seg[j + 1] - seg[j]); nacc += len ? (len + M - 1) / M : 1; }
+    // layout of the index arrays (one pinned staging buffer, one copy): table pointers, accumulator offsets,
+    // product offsets (in accumulators), flags
+    const size_t off_tab = 0, off_acc = off_tab + n * 8, off_prod = (off_acc + (nacc + 1) * 4 + 7) & ~(size_t)7, off_flag = off_prod + (nprod + 1) * 8,
+                 meta_bytes = off_flag + n + 8;
+    if (g_pin_meta.ensure(meta_bytes) || g_pair_meta.ensure(meta_bytes)) { set_error("pairing: staging allocation failed"); return LSA_ERR_NOMEM; }
+    char *hm = (char *)g_pin_meta.p;
+    uint64_t *h_tab = (uint64_t *)(hm + off_tab);
+    uint32_t *h_acc = (uint32_t *)(hm + off_acc);
+    uint64_t *h_prod = (uint64_t *)(hm + off_prod);
+    uint8_t *h_flag = (uint8_t *)(hm + off_flag);
+    {
+        size_t a = 0;
+        for (size_t j = 0; j < nprod; j++) {
+            h_prod[j] = a;
+            const size_t lo = (size_t)seg[j], hi = (size_t)seg[j + 1];
+            if (lo == hi) { h_acc[a++] = (uint32_t)lo; continue; }       // an empty product: one accumulator without pairs = 1
+            for (size_t s = lo; s < hi; s += M) h_acc[a++] = (uint32_t)s;
+        }
+        h_prod[nprod] = a;
+        h_acc[a] = (uint32_t)n;
+    }
+    // accumulator a covers [h_acc[a], min(h_acc[a+1], end of its product)): make that literally h_acc[a+1] by
+    // construction -- the next accumulator starts where this one ends, except after an empty product
+    // (same start) -- so nothing else is needed.
+    for (size_t i = 0; i < n; i++) h_flag[i] = t.flags ? (uint8_t)(t.flags[i] & 1) : (uint8_t)0;
+
+    // ---- resolve a device table for every term
+    const bool use_cache = !t.on_device && g_tabs.max_tables > 0 && n <= 1024;
+    std::vector<uint32_t> need_pre;        // terms whose table has to be computed from the point
+    std::vector<uint32_t> need_imp;        // terms whose table has to be imported from a precomp blob
+    size_t scratch_used = 0;
+    std::unordered_map<Key128, uint64_t, Key128Hash> seen;   // within this call
+    auto scratch_slot = [&](size_t k) { return (uint64_t)(uintptr_t)((uint32_t *)g_pair_scratch_tabs.p + k * TW); };
+    // uncached terms take scratch tables: count them first (the scratch buffer must not move afterwards)
+    size_t scratch_need = 0;
+    if (!use_cache) scratch_need = n;
+    else scratch_need = n;                 // worst case: the cache is full of this call's own tables
+    if (g_pair_scratch_tabs.ensure(std::max<size_t>(scratch_need, 1) * TW * 4)) { set_error("pairing: table scratch allocation failed"); return LSA_ERR_NOMEM; }
+    for (size_t i = 0; i < n; i++) {
+        const void *blob = t.qpre ? t.qpre[i] : nullptr;
+        if (!blob && !t.g2) { set_error("pairing: term %zu has neither a point nor a precomputed table", i); return LSA_ERR_INVALID; }
+        uint64_t dev = 0;
+        if (use_cache) {
+            const Key128 key = blob ? fingerprint(blob, PUB, 2) : fingerprint((const char *)t.g2 + i * sizeof(Jac<Fq2>), sizeof(Jac<Fq2>), 1);
+            auto it = seen.find(key);
+            if (it != seen.end()) dev = it->second;
+            else {
+                long s = g_tabs.lookup(key);
+                if (s >= 0) dev = (uint64_t)(uintptr_t)g_tabs.ptr((uint32_t)s);
+                else {
+                    s = g_tabs.insert(key);
+                    dev = s >= 0 ? (uint64_t)(uintptr_t)g_tabs.ptr((uint32_t)s) : scratch_slot(scratch_used++);
+                    (blob ? need_imp : need_pre).push_back((uint32_t)i);
+                }
+                seen.emplace(key, dev);
+            }
+        } else {
+            dev = scratch_slot(scratch_used++);
+            (blob ? need_imp : need_pre).push_back((uint32_t)i);
+        }
+        h_tab[i] = dev;
+    }
+
+    // ---- uploads
+    const void *d_g1 = t.g1;
+    if (!t.on_device) {
+        if (g_pair_p.ensure(std::max<size_t>(n, 1) * sizeof(Jac<Fq>))) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
+        if (n) HIPCHK(hipMemcpyAsync(g_pair_p.p, t.g1, n * sizeof(Jac<Fq>), hipMemcpyHostToDevice, g.stream));
+        d_g1 = g_pair_p.p;
+    }
+    HIPCHK(hipMemcpyAsync(g_pair_meta.p, hm, meta_bytes, hipMemcpyHostToDevice, g.stream));
+    const char *dm = (const char *)g_pair_meta.p;
+
+    // ---- missing tables
+    if (!need_pre.empty()) {
+        const size_t m = need_pre.size();
+        const void *d_q = nullptr;
+        const uint32_t *const *d_tp = nullptr;
+        // the points and the destination pointers of the misses, gathered into pinned staging
+        if (g_pin_q.ensure(m * (sizeof(Jac<Fq2>) + 8)) || g_pair_q.ensure(m * (sizeof(Jac<Fq2>) + 8))) { set_error("pairing: staging allocation failed"); return LSA_ERR_NOMEM; }
+        char *hq = (char *)g_pin_q.p;
+        uint64_t *hp = (uint64_t *)(hq + m * sizeof(Jac<Fq2>));
+        if (t.on_device && m == n) {
+            d_q = t.g2;                                             // all of them, in place
+            d_tp = (const uint32_t *const *)(dm + off_tab);
+        } else {
+            if (t.on_device) { set_error("pairing: internal (device points need tables for all terms)"); return LSA_ERR_INVALID; }
+            for (size_t k = 0; k < m; k++) {
+                memcpy(hq + k * sizeof(Jac<Fq2>), (const char *)t.g2 + (size_t)need_pre[k] * sizeof(Jac<Fq2>), sizeof(Jac<Fq2>));
+                hp[k] = h_tab[need_pre[k]];
+            }
+            HIPCHK(hipMemcpyAsync(g_pair_q.p, hq, m * (sizeof(Jac<Fq2>) + 8), hipMemcpyHostToDevice, g.stream));
+            d_q = g_pair_q.p;
+            d_tp = (const uint32_t *const *)((const char *)g_pair_q.p + m * sizeof(Jac<Fq2>));
+        }
+        int rc = g2_precomp_device(d_q, m, (uint32_t *const *)d_tp, g.stream);
+        if (rc) return rc;
+    }
+    if (!need_imp.empty()) {
+        const size_t m = need_imp.size();
+        if (g_pair_pub.ensure(m * (PUB + 8))) { set_error("pairing: staging allocation failed"); return LSA_ERR_NOMEM; }
+        std::vector<uint64_t> hp(m);
+        for (size_t k = 0; k < m; k++) {
+            HIPCHK(hipMemcpyAsync((char *)g_pair_pub.p + k * PUB, t.qpre[need_imp[k]], PUB, hipMemcpyHostToDevice, g.stream));
+            hp[k] = h_tab[need_imp[k]];
+        }
+        HIPCHK(hipMemcpyAsync((char *)g_pair_pub.p + m * PUB, hp.data(), m * 8, hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));     // hp is a local
+        int rc = g2_table_import_device(g_pair_pub.p, m, (uint32_t *const *)((char *)g_pair_pub.p + m * PUB), g.stream);
+        if (rc) return rc;
+    }
+
+    { int rcm = mark_uploads(); if (rcm) return rcm; }
+    // ---- Miller loops, one Fq12 per accumulator
+    if (g_pair_f.ensure(std::max<size_t>(nacc, 1) * fq12_bytes())) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    int rc = miller_tab_device(d_g1, (const uint32_t *const *)(dm + off_tab), (const uint8_t *)(dm + off_flag), (const uint32_t *)(dm + off_acc), nacc, M,
+                               g_tabs.ident, g_pair_f.p, g.stream);
+    if (rc) return rc;
+    // ---- products over the accumulators of each product
+    if (nacc == nprod) { *d_res = g_pair_f.p; return LSA_OK; }
+    if (nprod == 1) {
+        if (g_pair_s.ensure(((nacc + 7) / 8 + 1) * fq12_bytes())) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
+        return fq12_product_device(g_pair_f.p, g_pair_s.p, nacc, d_res, g.stream);
+    }
+    if (g_pair_s.ensure(nprod * fq12_bytes())) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    rc = fq12_segment_products_device(g_pair_f.p, (const uint64_t *)(dm + off_prod), nprod, g_pair_s.p, g.stream);
+    *d_res = g_pair_s.p;
+    return rc;
+}
+
+// the job with host results: out = nseg (or n) Fq12 values
+int run_terms_host(const Terms &t, void *out, bool final_exp) {
+    int rc = require_ready();
+    if (rc) return rc;
+    const size_t nres = t.seg ? t.nseg : t.n;
+    if (nres == 0) return LSA_OK;
+    if (!out || (t.n && !t.g1)) { set_error("pairing: null argument"); return LSA_ERR_INVALID; }
+    void *res = nullptr;
+    rc = run_miller(t, &res);
+    if (rc) return rc;
+    if (final_exp) {
+        if (g_pair_o.ensure(nres * fq12_bytes())) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
+        rc = final_exp_device(res, nres, g_pair_o.p, g.stream);
+        if (rc) return rc;
+        res = g_pair_o.p;
+    }
+    HIPCHK(hipMemcpyAsync(out, res, nres * fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return LSA_OK;
+}
+
+int check_segments(const uint64_t *seg, size_t nseg, const char *who) {
+    if (!seg) { set_error("%s: null argument", who); return LSA_ERR_INVALID; }
+    if (seg[0] != 0) { set_error("%s: offsets must start at 0", who); return LSA_ERR_INVALID; }
+    for (size_t j = 0; j < nseg; j++)
+        if (seg[j + 1] < seg[j]) { set_error("%s: offsets must not decrease", who); return LSA_ERR_INVALID; }
+    return LSA_OK;
+}
+
+}  // namespace
+
+namespace lsa {
+void pairing_release() {
+    g_pair_p.release(); g_pair_q.release(); g_pair_f.release(); g_pair_s.release(); g_pair_o.release();
+    g_pair_meta.release(); g_pair_scratch_tabs.release(); g_pair_pub.release();
+    g_pin_meta.release(); g_pin_q.release();
+    if (g_uploaded) { (void)hipEventDestroy(g_uploaded); g_uploaded = nullptr; }
+    g_upload_pending = false;
+    g_tabs.clear();
+}
+}  // namespace lsa
+
+extern "C" {
+
+size_t lsa_g2_precomp_bytes(void) { return g2_precomp_public_bytes(); }
+
+int lsa_g2_precompute(const void *g2_jac, size_t n, void *out_precomp) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (n == 0) return LSA_OK;
+    if (!g2_jac || !out_precomp) { set_error("g2_precompute: null argument"); return LSA_ERR_INVALID; }
+    const size_t TW = g2_table_words(), PUB = g2_precomp_public_bytes();
+    if (g_pair_q.ensure(n * sizeof(Jac<Fq2>)) || g_pair_scratch_tabs.ensure(n * TW * 4) || g_pair_pub.ensure(n * PUB) || g_pin_meta.ensure(n * 8) ||
+        g_pair_meta.ensure(n * 8)) {
+        set_error("g2_precompute: staging allocation failed");
+        return LSA_ERR_NOMEM;
+    }
+    rc = wait_uploads();
+    if (rc) return rc;
+    uint64_t *hp = (uint64_t *)g_pin_meta.p;
+    for (size_t i = 0; i < n; i++) hp[i] = (uint64_t)(uintptr_t)((uint32_t *)g_pair_scratch_tabs.p + i * TW);
+    HIPCHK(hipMemcpyAsync(g_pair_meta.p, hp, n * 8, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(g_pair_q.p, g2_jac, n * sizeof(Jac<Fq2>), hipMemcpyHostToDevice, g.stream));
+    rc = g2_precomp_device(g_pair_q.p, n, (uint32_t *const *)g_pair_meta.p, g.stream);
+    if (rc) return rc;
+    rc = g2_table_export_device((const uint32_t *const *)g_pair_meta.p, n, g_pair_pub.p, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out_precomp, g_pair_pub.p, n * PUB, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return LSA_OK;
+}
+
+int lsa_pairing_set_chunk(unsigned pairs_per_accumulator) {
+    if (pairs_per_accumulator > miller_tab_max_pairs()) { set_error("pairing_set_chunk: at most %u pairs share an accumulator", miller_tab_max_pairs()); return LSA_ERR_INVALID; }
+    g_force_m = pairs_per_accumulator;
+    return LSA_OK;
+}
+int lsa_g2_table_cache(size_t max_tables) {
+    int rc = require_ready();
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    g_tabs.env_read = true;
+    g_tabs.clear();
+    g_tabs.max_tables = max_tables;
+    return LSA_OK;
+}
+int lsa_g2_table_cache_stats(uint64_t out[4]) {
+    if (!out) return LSA_ERR_INVALID;
+    out[0] = g_tabs.hits; out[1] = g_tabs.misses; out[2] = g_tabs.slots.size(); out[3] = g_tabs.evictions;
+    return LSA_OK;
+}
+
+int lsa_miller_loop(const void *g1, const void *g2, size_t n, void *out, int on_device) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (n == 0) return LSA_OK;
+    if (!g1 || !g2 || !out) { set_error("miller_loop: null argument"); return LSA_ERR_INVALID; }
+    Terms t;
+    t.g1 = g1; t.g2 = g2; t.n = n; t.on_device = on_device != 0;
+    if (!on_device) return run_terms_host(t, out, false);
+    void *res = nullptr;
+    rc = run_miller(t, &res);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, res, n * fq12_bytes(), hipMemcpyDeviceToDevice, g.stream));
+    return LSA_OK;
+}
+int lsa_miller_loop_precomp(const void *g1, const void *const *q_precomp, size_t n, void *out) {
+    if (n && !q_precomp) { set_error("miller_loop_precomp: null argument"); return LSA_ERR_INVALID; }
+    for (size_t i = 0; i < n; i++)
+        if (!q_precomp[i]) { set_error("miller_loop_precomp: term %zu has no table", i); return LSA_ERR_INVALID; }
+    Terms t;
+    t.g1 = g1; t.qpre = q_precomp; t.n = n;
+    return run_terms_host(t, out, false);
+}
+int lsa_pairing_terms(const void *g1, const void *g2, const void *const *q_precomp, const uint8_t *flags, const uint64_t *seg_offsets, size_t nseg,
+                      void *out, int final_exp) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (nseg == 0) return LSA_OK;
+    rc = check_segments(seg_offsets, nseg, "pairing_terms");
+    if (rc) return rc;
+    Terms t;
+    t.g1 = g1; t.g2 = g2; t.qpre = q_precomp; t.flags = flags; t.seg = seg_offsets; t.nseg = nseg; t.n = (size_t)seg_offsets[nseg];
+    if (t.n && !g2 && !q_precomp) { set_error("pairing_terms: neither points nor tables"); return LSA_ERR_INVALID; }
+    return run_terms_host(t, out, final_exp != 0);
+}
+
+static int product_host(const void *g1, const void *g2, size_t n, void *out, bool final_exp, bool sharded) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (!out || (n && (!g1 || !g2))) { set_error("pairing: null argument"); return LSA_ERR_INVALID; }
+    const uint64_t seg[2] = {0, n};
+    Terms t;
+    t.g1 = g1; t.g2 = g2; t.seg = seg; t.nseg = 1; t.n = n;
+    if (!(sharded && lsa_comm_world() > 1)) return run_terms_host(t, out, final_exp);
+    // per-rank Miller product (1 for an empty slice), all-gather of the Fq12 partials, product in rank
+    // order, one final exponentiation on every rank (SURVEY.md 8e "Pairings").  A rank whose local part
+    // fails still takes part in the collective (with 1) and reports its error afterwards: the others
+    // must not block in ncclAllGather.
+    const size_t world = (size_t)lsa_comm_world();
+    void *res = nullptr;
+    int local = LSA_OK;
+    if (g_pair_o.ensure(fq12_bytes()) || g_stage_gather.ensure(world * fq12_bytes()) || g_pair_s.ensure((world + 8) * fq12_bytes())) local = LSA_ERR_NOMEM;
+    if (!local) local = run_miller(t, &res);
+    if (local == LSA_ERR_NOMEM && !g_pair_o.p) { set_error("pairing: hipMalloc failed"); return local; }   // nothing to contribute from
+    if (local) {
+        Fq12 one = Fq12::one();
+        (void)hipMemcpy(g_pair_o.p, &one, sizeof one, hipMemcpyHostToDevice);
+    } else {
+        HIPCHK(hipMemcpyAsync(g_pair_o.p, res, fq12_bytes(), hipMemcpyDeviceToDevice, g.stream));
+    }
+    rc = lsa_comm_all_gather(g_pair_o.p, g_stage_gather.p, 12);
+    if (local) return local;
+    if (rc) return rc;
+    rc = fq12_product_device(g_stage_gather.p, g_pair_s.p, world, &res, g.stream);
+    if (rc) return rc;
+    if (final_exp) {
+        rc = final_exp_device(res, 1, g_pair_o.p, g.stream);
+        if (rc) return rc;
+        res = g_pair_o.p;
+    }
+    HIPCHK(hipMemcpyAsync(g.h_result, res, fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    memcpy(out, g.h_result, fq12_bytes());
+    return LSA_OK;
+}
+int lsa_miller_loop_product(const void *g1, const void *g2, size_t n, void *out) { return product_host(g1, g2, n, out, false, false); }
+int lsa_pairing_product(const void *g1, const void *g2, size_t n, void *out) { return product_host(g1, g2, n, out, true, false); }
+int lsa_pairing_product_sharded(const void *g1, const void *g2, size_t n_local, void *out) { return product_host(g1, g2, n_local, out, true, true); }
+
+// many independent products in one pass: one upload, one Miller launch over all pairs, one product
+// workgroup per segment, one batched final exponentiation, one download
+int lsa_pairing_product_segments(const void *g1, const void *g2, const uint64_t *seg_offsets, size_t nseg, void *out_gt, int final_exp) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (nseg == 0) return LSA_OK;
+    rc = check_segments(seg_offsets, nseg, "pairing_product_segments");
+    if (rc) return rc;
+    if (!out_gt) { set_error("pairing_product_segments: null argument"); return LSA_ERR_INVALID; }
+    const size_t n = (size_t)seg_offsets[nseg];
+    if (n && (!g1 || !g2)) { set_error("pairing_product_segments: null argument"); return LSA_ERR_INVALID; }
+    Terms t;
+    t.g1 = g1; t.g2 = g2; t.seg = seg_offsets; t.nseg = nseg; t.n = n;
+    return run_terms_host(t, out_gt, final_exp != 0);
+}
+
+int lsa_fq12_product(const void *in, size_t n, void *out) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (!out || (n && !in)) { set_error("fq12_product: null argument"); return LSA_ERR_INVALID; }
+    if (n == 0) {
+        Fq12 one = Fq12::one();
+        memcpy(out, &one, sizeof one);
+        return LSA_OK;
+    }
+    void *res = nullptr;
+    if (g_pair_f.ensure(n * fq12_bytes()) || g_pair_s.ensure(((n + 7) / 8 + 1) * fq12_bytes())) { set_error("fq12_product: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    HIPCHK(hipMemcpyAsync(g_pair_f.p, in, n * fq12_bytes(), hipMemcpyHostToDevice, g.stream));
+    rc = fq12_product_device(g_pair_f.p, g_pair_s.p, n, &res, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(g.h_result, res, fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    memcpy(out, g.h_result, fq12_bytes());
+    return LSA_OK;
+}
+int lsa_final_exponentiation(const void *in, size_t n, void *out, int on_device) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (n == 0) return LSA_OK;
+    if (!in || !out) { set_error("final_exponentiation: null argument"); return LSA_ERR_INVALID; }
+    if (on_device) return final_exp_device(in, n, out, g.stream);
+    if (g_pair_f.ensure(n * fq12_bytes()) || g_pair_s.ensure(n * fq12_bytes())) { set_error("final_exponentiation: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    HIPCHK(hipMemcpyAsync(g_pair_f.p, in, n * fq12_bytes(), hipMemcpyHostToDevice, g.stream));
+    rc = final_exp_device(g_pair_f.p, n, g_pair_s.p, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(out, g_pair_s.p, n * fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return LSA_OK;
+}
+}  // extern "C"

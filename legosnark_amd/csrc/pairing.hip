@@ -24,6 +24,7 @@
 #include "msm.h"
 #include "tower.h"
 #include "miller.h"
+#include "tmiller.h"
 #include "w12.h"
 
 namespace lsa {
@@ -197,6 +198,91 @@ __global__ __launch_bounds__(64) void k_fq12_prod8(const Fq12 *__restrict__ in, 
     out[i] = store12(acc);
 }
 
+// ---- G2 line tables and Miller loops over them (tmiller.h) --------------------------------------------
+// libff alt_bn128_ate_precompute_G2 for five points per wavefront: tabs[i] (TM_TAB_WORDS words) <- table of g2[i]
+__global__ __launch_bounds__(64) void k_g2_precomp(const Jac<Fq2> *__restrict__ g2, size_t n, uint32_t *const *__restrict__ tabs) {
+    __shared__ Fq2S lds[G12_LDS_FQ2];
+    __shared__ uint32_t *out[G12_GROUPS];
+    const size_t lo = (size_t)blockIdx.x * G12_GROUPS;
+    if (lo >= n) return;
+    const unsigned count = (unsigned)(n - lo < (size_t)G12_GROUPS ? n - lo : (size_t)G12_GROUPS);
+    if (threadIdx.x < (unsigned)G12_GROUPS) out[threadIdx.x] = threadIdx.x < count ? tabs[lo + threadIdx.x] : nullptr;
+    __syncthreads();
+    WaveExec ex;
+    G12Pre<WaveExec> pre{ex, lds};
+    pre.run(g2 + lo, count, out);
+}
+
+// internal table (29-bit limbs, values < 2p) -> libff's alt_bn128_ate_G2_precomp as bytes: QX, QY, then
+// {ell_0, ell_VW, ell_VV} per step, canonical Montgomery Fq2 of 64 B.  One lane per Fq.
+__global__ __launch_bounds__(256) void k_g2_tab_export(const uint32_t *const *__restrict__ tabs, size_t n, Fq *__restrict__ pub) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, per = 2 * (size_t)G2_PRECOMP_FQ2;
+    if (i >= n * per) return;
+    const size_t t = i / per, f = i % per;                       // public Fq number f of table t
+    const size_t src = f < 4 ? 6 * (size_t)ATE_NUM_COEFFS + f : f - 4;   // the point sits behind the coefficients internally
+    Fs v;
+#pragma unroll
+    for (int l = 0; l < 9; l++) v.v.l[l] = tabs[t][src * 9 + l];
+    pub[i] = v.to_mont256();
+}
+__global__ __launch_bounds__(256) void k_g2_tab_import(const Fq *__restrict__ pub, size_t n, uint32_t *const *__restrict__ tabs) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, per = 2 * (size_t)G2_PRECOMP_FQ2;
+    if (i >= n * per) return;
+    const size_t t = i / per, f = i % per;
+    const size_t dst = f < 4 ? 6 * (size_t)ATE_NUM_COEFFS + f : f - 4;
+    const Fs v = Fs::from_mont256(pub[i]);
+#pragma unroll
+    for (int l = 0; l < 9; l++) tabs[t][dst * 9 + l] = v.v.l[l];
+}
+// every row = the line (1, 0, 0): the table of a pair that is not there
+__global__ void k_g2_tab_identity(uint32_t *tab) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (unsigned)TM_TAB_WORDS) return;
+    const unsigned wi = i % TM_LINE_WORDS;
+    uint32_t v = 0;
+    const F29 one = F29::one();
+#pragma unroll
+    for (int l = 0; l < 9; l++) if (wi == (unsigned)l) v = one.l[l];
+    tab[i] = i < (unsigned)(ATE_NUM_COEFFS * TM_LINE_WORDS) ? v : 0u;
+}
+
+// Four accumulators per wavefront: accumulator a multiplies the Miller loops of pairs [acc_off[a], acc_off[a+1])
+// (at most M <= TM_MAXM of them) over their tables.  flags bit 0: use -P (the conjugate value).
+__global__ __launch_bounds__(64) void k_miller_tab(const Jac<Fq> *__restrict__ g1, const uint32_t *const *__restrict__ tabs,
+                                                   const uint8_t *__restrict__ flags, const uint32_t *__restrict__ acc_off, size_t nacc,
+                                                   unsigned M, const uint32_t *__restrict__ ident, Fq12 *__restrict__ out) {
+    __shared__ Fq2S lds[TM_LDS_FQ2];
+    __shared__ const uint32_t *tp[TM_CHUNKS * TM_MAXM];
+    __shared__ const Jac<Fq> *pp[TM_CHUNKS * TM_MAXM];
+    __shared__ uint8_t ng[TM_CHUNKS * TM_MAXM];
+    __shared__ unsigned cnt[TM_CHUNKS];
+    const size_t a0 = (size_t)blockIdx.x * TM_CHUNKS;
+    if (a0 >= nacc) return;
+    const unsigned lane = threadIdx.x;
+    if (lane < (unsigned)(TM_CHUNKS * TM_MAXM)) {
+        const unsigned c = lane / TM_MAXM, i = lane % TM_MAXM;
+        unsigned lo = 0, len = 0;
+        if (a0 + c < nacc) { lo = acc_off[a0 + c]; len = acc_off[a0 + c + 1] - lo; }
+        const bool have = i < len;
+        tp[lane] = have ? tabs[lo + i] : ident;
+        pp[lane] = have ? g1 + lo + i : g1;
+        ng[lane] = have ? (uint8_t)(flags[lo + i] & 1) : (uint8_t)0;
+        if (i == 0) cnt[c] = len;
+    }
+    __syncthreads();
+    WaveExec ex;
+    TabMiller<WaveExec> tm{ex, lds, tp};
+    tm.run(pp, ng, cnt, M);
+    if (lane < 12u * TM_CHUNKS) {
+        const unsigned c = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
+        if (a0 + c < nacc) {
+            const unsigned t = (k & 1) * 3 + (k >> 1);                  // tower position of w^k
+            const Fq2S cf = lds[c * TM_STRIDE + TM_F + k];
+            reinterpret_cast<Fq *>(&out[a0 + c])[2 * t + part] = (part ? cf.c1 : cf.c0).to_mont256();
+        }
+    }
+}
+
 #define HIPCHK(x)                                                                      \
     do {                                                                               \
         hipError_t e_ = (x);                                                           \
@@ -262,6 +348,45 @@ int fq12_product_device(void *d_buf, void *d_scratch, size_t n, void **result, h
 int fq12_segment_products_device(const void *d_in, const uint64_t *d_off, size_t nseg, void *d_out, hipStream_t st) {
     if (nseg == 0) return LSA_OK;
     hipLaunchKernelGGL(k_fq12_prod_seg_wave, dim3((unsigned)nseg), dim3(128), 0, st, (const Fq12 *)d_in, d_off, (Fq12 *)d_out);
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
+
+// ---- tables
+size_t g2_table_words() { return (size_t)TM_TAB_WORDS; }
+size_t g2_precomp_public_bytes() { return (size_t)G2_PRECOMP_BYTES; }
+int g2_precomp_device(const void *d_g2, size_t n, uint32_t *const *d_tabs, hipStream_t st) {
+    if (n == 0) return LSA_OK;
+    hipLaunchKernelGGL(k_g2_precomp, dim3((unsigned)((n + G12_GROUPS - 1) / G12_GROUPS)), dim3(64), 0, st, (const Jac<Fq2> *)d_g2, n, d_tabs);
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
+int g2_table_export_device(const uint32_t *const *d_tabs, size_t n, void *d_public, hipStream_t st) {
+    if (n == 0) return LSA_OK;
+    const size_t total = n * 2 * (size_t)G2_PRECOMP_FQ2;
+    hipLaunchKernelGGL(k_g2_tab_export, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_tabs, n, (Fq *)d_public);
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
+int g2_table_import_device(const void *d_public, size_t n, uint32_t *const *d_tabs, hipStream_t st) {
+    if (n == 0) return LSA_OK;
+    const size_t total = n * 2 * (size_t)G2_PRECOMP_FQ2;
+    hipLaunchKernelGGL(k_g2_tab_import, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const Fq *)d_public, n, d_tabs);
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
+int g2_table_identity_device(uint32_t *d_tab, hipStream_t st) {
+    hipLaunchKernelGGL(k_g2_tab_identity, dim3((TM_TAB_WORDS + 255) / 256), dim3(256), 0, st, d_tab);
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
+unsigned miller_tab_max_pairs() { return (unsigned)TM_MAXM; }
+int miller_tab_device(const void *d_g1, const uint32_t *const *d_tabs, const uint8_t *d_flags, const uint32_t *d_acc_off, size_t nacc, unsigned M,
+                      const uint32_t *d_ident, void *d_out, hipStream_t st) {
+    if (nacc == 0) return LSA_OK;
+    if (M == 0 || M > (unsigned)TM_MAXM) { set_error("miller_tab: %u pairs per accumulator (1..%d)", M, TM_MAXM); return LSA_ERR_INVALID; }
+    hipLaunchKernelGGL(k_miller_tab, dim3((unsigned)((nacc + TM_CHUNKS - 1) / TM_CHUNKS)), dim3(64), 0, st, (const Jac<Fq> *)d_g1, d_tabs, d_flags,
+                       d_acc_off, nacc, M, d_ident, (Fq12 *)d_out);
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }

@@ -1,0 +1,124 @@
+// Host unit test of csrc/tmiller.h: the G2 line-table engine (G12Pre) against the one-lane step
+// formulas of miller.h, and the table-driven Miller loop with shared accumulators (TabMiller)
+// against products of one-lane Miller loops, executed phase by phase over emulated lane ids.
+#include <cstdio>
+#include <random>
+#include <vector>
+#include "tmiller.h"
+using namespace lsa;
+static std::mt19937_64 rng(11);
+static int fails = 0;
+#define CHECK(c, msg) do { if (!(c)) { if (fails < 20) printf("FAIL %s (line %d)\n", msg, __LINE__); fails++; } } while (0)
+static Fq rand_fq() {
+    for (;;) {
+        Fq r;
+        for (int i = 0; i < 4; i++) { uint64_t x = rng(); r.l[2 * i] = (uint32_t)x; r.l[2 * i + 1] = (uint32_t)(x >> 32); }
+        r.l[7] &= 0x3fffffffu;
+        bool lt = false;
+        for (int i = 7; i >= 0; --i) if (r.l[i] != FqParams::MOD[i]) { lt = r.l[i] < FqParams::MOD[i]; break; }
+        if (lt) return r;
+    }
+}
+struct LoopExec {
+    template <class F> void par(F f) { for (unsigned l = 0; l < 64; l++) f(l); }
+    unsigned nlanes() const { return 64; }
+};
+static Fq2S tab_fq2(const std::vector<uint32_t> &t, int idx) {
+    Fq2S r;
+    for (int i = 0; i < 9; i++) { r.c0.v.l[i] = t[idx * 18 + i]; r.c1.v.l[i] = t[idx * 18 + 9 + i]; }
+    return r;
+}
+// libff alt_bn128_ate_precompute_G2 with the one-lane step formulas of miller.h
+static std::vector<Line> expected_lines(const Jac<Fq2> &Q, P2 &qx, P2 &qy) {
+    Jac<Fq> dummy = {Fq::one(), Fq::one(), Fq::one()};
+    const AffinePair in = miller_affine_inputs(dummy, Q);
+    qx = in.qx; qy = in.qy;
+    Fq ti;
+    for (int i = 0; i < 8; i++) ti.l[i] = LSA_FQ_TWO_INV[i];
+    const PB two_inv = PB::from_mont256(ti);
+    const P2 twist_b = fq2_constT<PB>(LSA_TWIST_B);
+    G2Proj R = {qx, qy, P2::one()};
+    std::vector<Line> out;
+    for (int i = 63; i >= 0; --i) {
+        out.push_back(doubling_step(R, two_inv, twist_b));
+        if (ate_bit(i)) out.push_back(addition_step(qx, qy, R));
+    }
+    const P2 gx = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_X), gy = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_Y);
+    P2 q1x = gx * qx.conj(), q1y = gy * qy.conj();
+    P2 q2x = gx * q1x.conj(), q2y = (gy * q1y.conj()).neg();
+    out.push_back(addition_step(q1x, q1y, R));
+    out.push_back(addition_step(q2x, q2y, R));
+    return out;
+}
+int main() {
+    LoopExec ex;
+    // ---- line tables
+    const unsigned nq = 5;
+    Jac<Fq2> Qs[G12_GROUPS];
+    for (unsigned g = 0; g < nq; g++)
+        Qs[g] = {{rand_fq(), rand_fq()}, {rand_fq(), rand_fq()}, g % 2 ? Fq2::one() : Fq2{rand_fq(), rand_fq()}};
+    Qs[3].Z = Fq2::zero();
+    std::vector<std::vector<uint32_t>> tabs(nq + 1, std::vector<uint32_t>(TM_TAB_WORDS, 0xdeadbeefu));
+    {
+        std::vector<Fq2S> lds(G12_LDS_FQ2);
+        uint32_t *out[G12_GROUPS];
+        for (unsigned g = 0; g < (unsigned)G12_GROUPS; g++) out[g] = g < nq ? tabs[g].data() : nullptr;
+        G12Pre<LoopExec> pre{ex, lds.data()};
+        pre.run(Qs, nq, out);
+        for (unsigned g = 0; g < nq; g++) {
+            P2 qx, qy;
+            const std::vector<Line> want = expected_lines(Qs[g], qx, qy);
+            CHECK((int)want.size() == ATE_NUM_COEFFS, "102 coefficient triples");
+            bool ok = true;
+            for (int e = 0; e < ATE_NUM_COEFFS; e++)
+                ok = ok && tab_fq2(tabs[g], 3 * e) == want[e].e0 && tab_fq2(tabs[g], 3 * e + 1) == want[e].eVW && tab_fq2(tabs[g], 3 * e + 2) == want[e].eVV;
+            CHECK(ok, "line table");
+            CHECK(tab_fq2(tabs[g], 3 * ATE_NUM_COEFFS) == qx && tab_fq2(tabs[g], 3 * ATE_NUM_COEFFS + 1) == qy, "affine Q beside the table");
+            // bounds contract of the consumer: every stored value is tight and < 2p
+            bool tight = true;
+            for (int i = 0; i < TM_TAB_WORDS; i++) tight = tight && tabs[g][i] < (1u << 29);
+            CHECK(tight, "tight limbs");
+        }
+    }
+    // the identity table: every row is the line (1, 0, 0)
+    std::vector<uint32_t> &ident = tabs[nq];
+    for (int i = 0; i < TM_TAB_WORDS; i++) ident[i] = 0;
+    for (int e = 0; e < ATE_NUM_COEFFS; e++)
+        for (int i = 0; i < 9; i++) ident[e * TM_LINE_WORDS + i] = F29::one().l[i];
+    // ---- table-driven Miller loops, accumulators of 1..4 pairs, some terms conjugated
+    for (unsigned M = 1; M <= (unsigned)TM_MAXM; M++) {
+        std::vector<Fq2S> lds(TM_LDS_FQ2);
+        Jac<Fq> Ps[TM_CHUNKS * TM_MAXM];
+        const Jac<Fq> *Pp[TM_CHUNKS * TM_MAXM];
+        const uint32_t *tp[TM_CHUNKS * TM_MAXM];
+        uint8_t neg[TM_CHUNKS * TM_MAXM];
+        unsigned qi[TM_CHUNKS * TM_MAXM];
+        unsigned cnt[TM_CHUNKS];
+        for (int c = 0; c < TM_CHUNKS; c++) {
+            cnt[c] = c == 0 ? M : (unsigned)(rng() % (M + 1));          // an empty accumulator stays 1
+            for (unsigned i = 0; i < (unsigned)TM_MAXM; i++) {
+                const int s = c * TM_MAXM + (int)i;
+                Ps[s] = {rand_fq(), rand_fq(), (rng() & 1) ? Fq::one() : rand_fq()};
+                if (c == 1 && i == 0) Ps[s].Z = Fq::zero();
+                Pp[s] = &Ps[s];
+                neg[s] = (uint8_t)(rng() & 1);
+                qi[s] = (unsigned)(rng() % nq);
+                tp[s] = i < cnt[c] ? tabs[qi[s]].data() : ident.data();
+            }
+        }
+        TabMiller<LoopExec> tm{ex, lds.data(), tp};
+        tm.run(Pp, neg, cnt, M);
+        for (int c = 0; c < TM_CHUNKS; c++) {
+            Fq12S want = Fq12S::one();
+            for (unsigned i = 0; i < cnt[c]; i++) {
+                const int s = c * TM_MAXM + (int)i;
+                Fq12S f = miller_one(Ps[s], Qs[qi[s]]);
+                if (neg[s]) f = f.unitary_inverse();
+                want = fq12_mul(want, f);
+            }
+            CHECK(tm.result((unsigned)c) == want, "table-driven miller product");
+        }
+    }
+    printf(fails ? "FAILED (%d)\n" : "PASS\n", fails);
+    return fails ? 1 : 0;
+}

@@ -292,6 +292,35 @@ def reduced_pairing(p, q):
     return r
 
 
+G2_PRECOMP_WORDS = (2 + 3 * 102) * 8      # og2_precomp_t: QX, QY, 102 x {ell_0, ell_VW, ell_VV}
+
+
+def precompute_g2(q):
+    """libff alt_bn128_ate_precompute_G2 (oracle restatement) -> (G2_PRECOMP_WORDS,) uint64."""
+    q = np.ascontiguousarray(q, dtype=np.uint64)
+    r = np.zeros(G2_PRECOMP_WORDS, dtype=np.uint64)
+    lib().oracle_precompute_g2(_p(r), _p(q))
+    return r
+
+
+def miller_loop_precomp(p, qpre):
+    """libff miller_loop(precompute_G1(p), qpre)."""
+    p = np.ascontiguousarray(p, dtype=np.uint64)
+    qpre = np.ascontiguousarray(qpre, dtype=np.uint64)
+    pp = np.zeros(8, dtype=np.uint64)
+    lib().oracle_precompute_g1(_p(pp), _p(p))
+    r = np.zeros(48, dtype=np.uint64)
+    lib().oracle_miller_loop(_p(r), _p(pp), _p(qpre))
+    return r
+
+
+def fq12_unitary_inverse(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    r = np.zeros(48, dtype=np.uint64)
+    lib().ofq12_unitary_inverse(_p(r), _p(a))
+    return r
+
+
 def miller_loop_batch(ps, qs):
     ps = np.ascontiguousarray(ps, dtype=np.uint64).reshape(-1, 12)
     qs = np.ascontiguousarray(qs, dtype=np.uint64).reshape(-1, 24)
