@@ -181,9 +181,14 @@ inline int force_kernel() {
 // Miller products of the job on the device: *d_res points at nseg Fq12 values when this returns (stream-ordered)
 int run_miller(const Terms &t, void **d_res) {
     const size_t n = t.n, nseg = t.nseg;
+    g_tabs.read_env();
     // ---- the fused kernels (miller.h): only when forced, and only for raw points without flags
+    // ... and for large batches of points the cache does not take (more than 1024 terms, or device-resident): building
+    // 4096 tables and running the Fq12 chain over them is two kernels of 1.4 + 1.0 ms where the fused six-lane
+    // kernel takes 2.3 (profiles/r03_*): tables pay when a Q is seen twice.
     const bool plain = !t.qpre && !t.flags;
-    if (plain && force_kernel() >= 1 && force_kernel() <= 4) {
+    const bool big_fresh = plain && force_kernel() == 0 && g_force_m == 0 && (t.on_device || t.n > 1024 || g_tabs.max_tables == 0) && t.n >= 1024;
+    if (plain && ((force_kernel() >= 1 && force_kernel() <= 4) || big_fresh)) {
         const void *d_p = t.g1, *d_q = t.g2;
         if (!t.on_device) {
             if (g_pair_p.ensure(n * sizeof(Jac<Fq>)) || g_pair_q.ensure(n * sizeof(Jac<Fq2>))) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
@@ -210,7 +215,6 @@ int run_miller(const Terms &t, void **d_res) {
 
     // ---- tables
     { int rcw = wait_uploads(); if (rcw) return rcw; }
-    g_tabs.read_env();
     if (g_tabs.ensure_ident()) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
     g_tabs.tick++;
     const size_t TW = g2_table_words(), PUB = g2_precomp_public_bytes();

@@ -201,49 +201,51 @@ __global__ __launch_bounds__(64) void k_fq12_prod8(const Fq12 *__restrict__ in, 
 // ---- G2 line tables and Miller loops over them (tmiller.h) --------------------------------------------
 // libff alt_bn128_ate_precompute_G2 for five points per wavefront: tabs[i] (TM_TAB_WORDS words) <- table of g2[i]
 __global__ __launch_bounds__(64) void k_g2_precomp(const Jac<Fq2> *__restrict__ g2, size_t n, uint32_t *const *__restrict__ tabs) {
-    __shared__ Fq2S lds[G12_LDS_FQ2];
-    __shared__ uint32_t *out[G12_GROUPS];
-    const size_t lo = (size_t)blockIdx.x * G12_GROUPS;
+    __shared__ Fq2S lds[GP_LDS_FQ2];
+    __shared__ uint32_t *out[GP_GROUPS];
+    const size_t lo = (size_t)blockIdx.x * GP_GROUPS;
     if (lo >= n) return;
-    const unsigned count = (unsigned)(n - lo < (size_t)G12_GROUPS ? n - lo : (size_t)G12_GROUPS);
-    if (threadIdx.x < (unsigned)G12_GROUPS) out[threadIdx.x] = threadIdx.x < count ? tabs[lo + threadIdx.x] : nullptr;
+    const unsigned count = (unsigned)(n - lo < (size_t)GP_GROUPS ? n - lo : (size_t)GP_GROUPS);
+    if (threadIdx.x < (unsigned)GP_GROUPS) out[threadIdx.x] = threadIdx.x < count ? tabs[lo + threadIdx.x] : nullptr;
     __syncthreads();
     WaveExec ex;
-    G12Pre<WaveExec> pre{ex, lds};
+    G2Pre<WaveExec> pre{ex, lds};
     pre.run(g2 + lo, count, out);
 }
 
-// internal table (29-bit limbs, values < 2p) -> libff's alt_bn128_ate_G2_precomp as bytes: QX, QY, then
+// internal table (x * 2^261 mod p, < 4p, 256-bit packed) -> libff's alt_bn128_ate_G2_precomp as bytes: QX, QY, then
 // {ell_0, ell_VW, ell_VV} per step, canonical Montgomery Fq2 of 64 B.  One lane per Fq.
 __global__ __launch_bounds__(256) void k_g2_tab_export(const uint32_t *const *__restrict__ tabs, size_t n, Fq *__restrict__ pub) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, per = 2 * (size_t)G2_PRECOMP_FQ2;
     if (i >= n * per) return;
     const size_t t = i / per, f = i % per;                       // public Fq number f of table t
     const size_t src = f < 4 ? 6 * (size_t)ATE_NUM_COEFFS + f : f - 4;   // the point sits behind the coefficients internally
-    Fs v;
+    uint32_t w[8];
 #pragma unroll
-    for (int l = 0; l < 9; l++) v.v.l[l] = tabs[t][src * 9 + l];
-    pub[i] = v.to_mont256();
+    for (int l = 0; l < 8; l++) w[l] = tabs[t][src * 8 + l];
+    pub[i] = F29::unpack256(w).to_mont256();
 }
 __global__ __launch_bounds__(256) void k_g2_tab_import(const Fq *__restrict__ pub, size_t n, uint32_t *const *__restrict__ tabs) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, per = 2 * (size_t)G2_PRECOMP_FQ2;
     if (i >= n * per) return;
     const size_t t = i / per, f = i % per;
     const size_t dst = f < 4 ? 6 * (size_t)ATE_NUM_COEFFS + f : f - 4;
-    const Fs v = Fs::from_mont256(pub[i]);
+    uint32_t w[8];
+    F29::from_mont256(pub[i]).pack256(w);
 #pragma unroll
-    for (int l = 0; l < 9; l++) tabs[t][dst * 9 + l] = v.v.l[l];
+    for (int l = 0; l < 8; l++) tabs[t][dst * 8 + l] = w[l];
 }
 // every row = the line (1, 0, 0): the table of a pair that is not there
 __global__ void k_g2_tab_identity(uint32_t *tab) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (unsigned)TM_TAB_WORDS) return;
-    const unsigned wi = i % TM_LINE_WORDS;
+    uint32_t w[8];
+    F29::one().pack256(w);
+    const unsigned wi = i % TM_ROW_WORDS;
     uint32_t v = 0;
-    const F29 one = F29::one();
 #pragma unroll
-    for (int l = 0; l < 9; l++) if (wi == (unsigned)l) v = one.l[l];
-    tab[i] = i < (unsigned)(ATE_NUM_COEFFS * TM_LINE_WORDS) ? v : 0u;
+    for (int l = 0; l < 8; l++) if (wi == (unsigned)l) v = w[l];
+    tab[i] = i < (unsigned)(ATE_NUM_COEFFS * TM_ROW_WORDS) ? v : 0u;
 }
 
 // Four accumulators per wavefront: accumulator a multiplies the Miller loops of pairs [acc_off[a], acc_off[a+1])
@@ -280,6 +282,36 @@ __global__ __launch_bounds__(64) void k_miller_tab(const Jac<Fq> *__restrict__ g
             const Fq2S cf = lds[c * TM_STRIDE + TM_F + k];
             reinterpret_cast<Fq *>(&out[a0 + c])[2 * t + part] = (part ? cf.c1 : cf.c0).to_mont256();
         }
+    }
+}
+
+// One accumulator per wavefront (WTabMiller): the latency shape of the same job.
+__global__ __launch_bounds__(64) void k_miller_wtab(const Jac<Fq> *__restrict__ g1, const uint32_t *const *__restrict__ tabs,
+                                                    const uint8_t *__restrict__ flags, const uint32_t *__restrict__ acc_off, size_t nacc,
+                                                    unsigned M, const uint32_t *__restrict__ ident, Fq12 *__restrict__ out) {
+    __shared__ Fq2S lds[WT_LDS_FQ2];
+    __shared__ uint32_t desc[256];
+    __shared__ const uint32_t *tp[TM_MAXM];
+    __shared__ const Jac<Fq> *pp[TM_MAXM];
+    __shared__ uint8_t ng[TM_MAXM];
+    const size_t a = blockIdx.x;
+    if (a >= nacc) return;
+    const unsigned lane = threadIdx.x;
+    const unsigned lo = acc_off[a], len = acc_off[a + 1] - lo;
+    if (lane < (unsigned)TM_MAXM) {
+        const bool have = lane < len;
+        tp[lane] = have ? tabs[lo + lane] : ident;
+        pp[lane] = have ? g1 + lo + lane : g1;
+        ng[lane] = have ? (uint8_t)(flags[lo + lane] & 1) : (uint8_t)0;
+    }
+    __syncthreads();
+    WaveExec ex;
+    WTabMiller<WaveExec> wt{ex, lds, tp, desc};
+    wt.run(pp, ng, len, M);
+    if (lane < 12) {
+        const unsigned k = lane >> 1, part = lane & 1, t = (k & 1) * 3 + (k >> 1);
+        const Fq2S cf = lds[WT_F + k];
+        reinterpret_cast<Fq *>(&out[a])[2 * t + part] = (part ? cf.c1 : cf.c0).to_mont256();
     }
 }
 
@@ -357,7 +389,7 @@ size_t g2_table_words() { return (size_t)TM_TAB_WORDS; }
 size_t g2_precomp_public_bytes() { return (size_t)G2_PRECOMP_BYTES; }
 int g2_precomp_device(const void *d_g2, size_t n, uint32_t *const *d_tabs, hipStream_t st) {
     if (n == 0) return LSA_OK;
-    hipLaunchKernelGGL(k_g2_precomp, dim3((unsigned)((n + G12_GROUPS - 1) / G12_GROUPS)), dim3(64), 0, st, (const Jac<Fq2> *)d_g2, n, d_tabs);
+    hipLaunchKernelGGL(k_g2_precomp, dim3((unsigned)((n + GP_GROUPS - 1) / GP_GROUPS)), dim3(64), 0, st, (const Jac<Fq2> *)d_g2, n, d_tabs);
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }
@@ -385,8 +417,16 @@ int miller_tab_device(const void *d_g1, const uint32_t *const *d_tabs, const uin
                       const uint32_t *d_ident, void *d_out, hipStream_t st) {
     if (nacc == 0) return LSA_OK;
     if (M == 0 || M > (unsigned)TM_MAXM) { set_error("miller_tab: %u pairs per accumulator (1..%d)", M, TM_MAXM); return LSA_ERR_INVALID; }
-    hipLaunchKernelGGL(k_miller_tab, dim3((unsigned)((nacc + TM_CHUNKS - 1) / TM_CHUNKS)), dim3(64), 0, st, (const Jac<Fq> *)d_g1, d_tabs, d_flags,
-                       d_acc_off, nacc, M, d_ident, (Fq12 *)d_out);
+    // up to two wavefronts per SIMD: one accumulator per wavefront (~170 K instructions each); beyond, four per
+    // wavefront (~340 K: half the instructions per accumulator).  LSA_MILLER_TAB = 1 / 4 forces a shape.
+    static const int force = getenv("LSA_MILLER_TAB") ? atoi(getenv("LSA_MILLER_TAB")) : 0;
+    const bool wave = force ? force == 1 : nacc <= 2048;
+    if (wave)
+        hipLaunchKernelGGL(k_miller_wtab, dim3((unsigned)nacc), dim3(64), 0, st, (const Jac<Fq> *)d_g1, d_tabs, d_flags, d_acc_off, nacc, M, d_ident,
+                           (Fq12 *)d_out);
+    else
+        hipLaunchKernelGGL(k_miller_tab, dim3((unsigned)((nacc + TM_CHUNKS - 1) / TM_CHUNKS)), dim3(64), 0, st, (const Jac<Fq> *)d_g1, d_tabs, d_flags,
+                           d_acc_off, nacc, M, d_ident, (Fq12 *)d_out);
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }

@@ -12,9 +12,9 @@
 // rounds) instead of the 344 dependent rounds of G2 point arithmetic the fused loops of miller.h
 // carry (3 per doubling step, 4 per addition step).
 //
-//   G12Pre     twelve lanes per G2 point, five points per wavefront: the point arithmetic of
-//              G12Miller (miller.h) with P = (1, 1), so that the "evaluated" line of every step IS
-//              libff's coefficient triple (ell_0, ell_VW, ell_VV); emits one table per point.
+//   G2Pre      twelve lanes per G2 point, five points per wavefront: lane (k, part) computes one Fq component of
+//              the k-th Fq2 product of a round; the additions between rounds run component-wise on the two lanes of
+//              pair 0.  P = (1, 1), so that each step's line IS libff's coefficient triple (ell_0, ell_VW, ell_VV).
 //   TabMiller  twelve lanes per ACCUMULATOR, four accumulators per wavefront, 16 helper lanes: an
 //              accumulator f is shared by up to TM_MAXM pairs of one product (f <- f^2 * prod_i line_i:
 //              the squaring is paid once per product chunk, and prod_i miller_loop(P_i, Q_i) is the
@@ -29,47 +29,171 @@
 namespace lsa {
 
 static constexpr int ATE_NUM_COEFFS = 102;                        // 64 doublings + 36 additions + 2 Frobenius steps
-static constexpr int TM_LINE_WORDS = 54;                          // {ell_0, ell_VW, ell_VV} as 3 Fq2S of 18 words
-static constexpr int TM_TAB_FQ2 = ATE_NUM_COEFFS * 3 + 2;         // + the affine point (QX, QY) libff keeps beside the coefficients
-static constexpr int TM_TAB_WORDS = TM_TAB_FQ2 * 18;              // 22 176 B per point (internal form: 29-bit limbs, values < 2p)
+static constexpr int TM_LINE_WORDS = 54;                          // a row {ell_0, ell_VW, ell_VV} in LDS: 3 Fq2S of 18 words
+static constexpr int TM_ROW_WORDS = 48;                           // the same row in a table: 6 x 256-bit packed components
+static constexpr int TM_TAB_WORDS = ATE_NUM_COEFFS * TM_ROW_WORDS + 32;   // 19 712 B per point: x * 2^261 mod p, ell_0 < 2p, ell_VW / ell_VV
+                                                                  // < 4p (< 2^256), then QX, QY
 static constexpr int G2_PRECOMP_FQ2 = 2 + 3 * ATE_NUM_COEFFS;     // public form: QX, QY, coefficients; 64-B libff Fq2 each
 static constexpr int G2_PRECOMP_BYTES = G2_PRECOMP_FQ2 * 64;      // 19 712 B
+static_assert(ATE_NUM_COEFFS * TM_ROW_WORDS + 32 == TM_TAB_WORDS, "table layout");
+
+// limb `wi % 9` of component `wi / 9` (LDS word wi of a row) out of the packed row
+LSA_HD uint32_t tm_row_element(const uint32_t *row, unsigned wi) {
+    const unsigned c = wi / 9, i = wi % 9, bit = 29 * i, j = bit >> 5, sh = bit & 31;
+    const uint32_t lo = row[c * 8 + j], hi = j + 1 < 8 ? row[c * 8 + j + 1] : 0u;
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh) & F29::MASK;
+}
 
 // ------------------------------------------------------------------------------------
-// G2 line tables
+// G2 line tables.  The G2 side of a Miller loop is a chain of 344 dependent rounds (3 per doubling step, 4
+// per addition step) of at most five independent Fq2 products.  A wavefront issues one instruction per four
+// cycles whatever its lanes do, so the chain's time is the instruction count of the wavefront that runs it:
+// per round one fused two-product reduction per lane (component `part` of product k), then the additions
+// of the step formulas on ONE component per lane (lanes (0, part) of the group; the only cross-component
+// operation, xi * t, recomputes the partner's t).  ~650 instructions per round; one lane per Fq2 value for
+// the additions (miller.h, G12Miller) took ~1100, two lanes per POINT with everything in registers (no
+// LDS, no barriers, 32 points per wavefront) 5.1 K / 6.4 K per doubling / addition step -- 2.5 x longer.
+// Formulas and lazy bounds are WMiller::doubling_round / addition_round's (libff's step formulas).
 // ------------------------------------------------------------------------------------
+enum G2PVar {                                  // Fq2S slots of one point
+    GP_X, GP_Y, GP_Z, GP_S,                    // R = (X, Y, Z) < 2p, S = Y + Z < 4p
+    GP_QX, GP_QY, GP_Q1X, GP_Q1Y, GP_Q2X, GP_Q2Y, GP_TWB, GP_ONE,
+    GP_A, GP_B, GP_D, GP_H, GP_E, GP_G, GP_BMF, GP_XIT,           // doubling step
+    GP_DD, GP_EE, GP_F, GP_GG, GP_HH, GP_I, GP_J, GP_IMJ,         // addition step
+    GP_L0, GP_L1, GP_L2,                       // the line being assembled
+    GP_P0, GP_P1, GP_P2, GP_P3, GP_P4,         // the round's products
+    GP_STRIDE
+};
+static constexpr int GP_GROUPS = 5;
+static constexpr int GP_LDS_FQ2 = GP_GROUPS * GP_STRIDE;
+
 template <class X>
-struct G12Pre {
+struct G2Pre {
     X &x;
-    Fq2S *mem;          // G12_LDS_FQ2 elements (the layout of G12Miller; its F / XF / T slots stay unused)
-    using GM = G12Miller<X>;
-    using WM = WMiller<X>;
+    Fq2S *mem;          // GP_LDS_FQ2 elements
+    struct Prod { int8_t a[5], b[5]; int n; };
 
-    // one round of the point arithmetic: side products of step `op`, then its combine on lane 0 of the group;
-    // after the rounds that complete a line (1: doubling, 4: addition) lanes (k < 3, part) write it out
-    LSA_HD void round(int op, int x2, int y2, uint32_t *const *out, int entry) {
+    // ops 0-2: the rounds of a doubling step, 3-6: of an addition step with the point at slots (x2, x2 + 1)
+    static LSA_HD Prod products_of(int op, int x2) {
+        const int8_t X2 = (int8_t)x2, Y2 = (int8_t)(x2 + 1);
+        switch (op) {
+        case 0: return {{GP_X, GP_Y, GP_Z, GP_S, GP_X}, {GP_Y, GP_Y, GP_Z, GP_S, GP_X}, 5};
+        case 1: return {{GP_TWB, GP_B, 0, 0, 0}, {GP_D, GP_H, 0, 0, 0}, 2};
+        case 2: return {{GP_E, GP_A, GP_G, GP_ONE, 0}, {GP_E, GP_BMF, GP_G, GP_XIT, 0}, 4};
+        case 3: return {{X2, Y2, 0, 0, 0}, {GP_Z, GP_Z, 0, 0, 0}, 2};
+        case 4: return {{GP_DD, GP_EE, GP_EE, GP_DD, 0}, {GP_DD, GP_EE, X2, Y2, 0}, 4};
+        case 5: return {{GP_DD, GP_X, GP_Z, GP_ONE, 0}, {GP_F, GP_F, GP_GG, GP_XIT, 0}, 4};
+        default: return {{GP_DD, GP_EE, GP_HH, GP_Z, 0}, {GP_J, GP_IMJ, GP_Y, GP_HH, 0}, 4};
+        }
+    }
+    // component c of slot v
+    static LSA_HD F29 ld(const Fq2S *V, int v, unsigned c) { return w12_load(&w12_comp(const_cast<Fq2S &>(V[v]), c)).v; }
+    static LSA_HD void st(Fq2S *V, int v, unsigned c, const F29 &val) { w12_store(&w12_comp(V[v], c), Fs{val}); }
+    static LSA_HD F29 triple(const F29 &a) { return add_lazy(add_lazy(a, a), a).norm(); }
+    // component c of xi * t for t = (t_c, t_o) < 2p tight: c = 0: 9 t0 - t1 + 2p, c = 1: 9 t1 + t0   [< 20; tight]
+    static LSA_HD F29 xi_comp(unsigned c, const F29 &tc, const F29 &to) {
+        F29 t8;
+#pragma unroll
+        for (int l = 0; l < 9; l++) t8.l[l] = tc.l[l] << 3;
+        const uint32_t pm = w12_mask(0u - c);
+        const F29 neg = sub_k<2>(F29::zero(), to);
+        F29 sel;
+#pragma unroll
+        for (int l = 0; l < 9; l++) sel.l[l] = (to.l[l] & pm) | (neg.l[l] & ~pm);
+        return w12_norm_u(add_lazy(add_lazy(w12_norm_u(t8), tc), sel));
+    }
+    // the additions after the products of round `op`, on component c (one lane each)
+    static LSA_HD void combine(int op, unsigned c, Fq2S *V) {
+        const unsigned o = c ^ 1u;
+        switch (op) {
+        case 0: {
+            const F29 B = ld(V, GP_P1, c), C = ld(V, GP_P2, c);
+            const F29 H = sub_k<4>(ld(V, GP_P3, c), add_lazy(B, C));               // (Y+Z)^2 - (B+C) + 4p   [<6]
+            st(V, GP_A, c, f29_halve(ld(V, GP_P0, c)));                             // X Y / 2                [<1.5]
+            st(V, GP_B, c, B);
+            st(V, GP_D, c, triple(C));                                              // 3C                     [<6]
+            st(V, GP_H, c, H);
+            st(V, GP_L1, c, condsub4(sub_k<6>(F29::zero(), H)));                    // ell_VW = -H   [<=6] -> [<4]
+            st(V, GP_L2, c, condsub4(triple(ld(V, GP_P4, c))));                     // ell_VV = 3 X^2  [<6] -> [<4]
+        } break;
+        case 1: {
+            const F29 E = ld(V, GP_P0, c), B = ld(V, GP_B, c);
+            const F29 F = triple(E);                                                // 3E                     [<6]
+            st(V, GP_E, c, E);
+            st(V, GP_G, c, condsub4(f29_halve(add_lazy(B, F).norm())));             // (B+F)/2  [<4.5] -> [<4]
+            st(V, GP_BMF, c, sub_k<6>(B, F));                                       // B - F + 6p             [<8]
+            st(V, GP_Z, c, ld(V, GP_P1, c));                                        // Z3 = B H               [<2]
+            const F29 tc = condsub2(sub_k<2>(E, B));                                // E - B  [<4] -> [<2]
+            const F29 to = condsub2(sub_k<2>(ld(V, GP_P0, o), ld(V, GP_B, o)));     // the other component of the same
+            st(V, GP_XIT, c, xi_comp(c, tc, to));                                   // xi (E - B)             [<20]
+        } break;
+        case 2: {
+            const F29 Y3 = condsub2(condsub4(sub_k<6>(ld(V, GP_P2, c), triple(ld(V, GP_P0, c)))));   // G^2 - 3E^2 + 6p [<8] -> [<2]
+            st(V, GP_X, c, ld(V, GP_P1, c));
+            st(V, GP_Y, c, Y3);
+            st(V, GP_S, c, add_lazy(Y3, ld(V, GP_Z, c)).norm());                    // [<4]
+            st(V, GP_L0, c, ld(V, GP_P3, c));                                       // ell_0 = xi (E - B), reduced  [<2]
+        } break;
+        case 3: {
+            const F29 E = sub_k<2>(ld(V, GP_Y, c), ld(V, GP_P1, c));                // Y1 - y2 Z1 + 2p        [<4]
+            const F29 D = sub_k<2>(ld(V, GP_X, c), ld(V, GP_P0, c));                // X1 - x2 Z1 + 2p        [<4]
+            st(V, GP_DD, c, D);
+            st(V, GP_EE, c, E);
+            st(V, GP_L1, c, D);                                                     // ell_VW = D             [<4]
+            st(V, GP_L2, c, sub_k<4>(F29::zero(), E));                              // ell_VV = -E            [<=4]
+        } break;
+        case 4: {
+            st(V, GP_F, c, ld(V, GP_P0, c));
+            st(V, GP_GG, c, ld(V, GP_P1, c));
+            const F29 tc = condsub2(sub_k<2>(ld(V, GP_P2, c), ld(V, GP_P3, c)));    // E x2 - D y2  [<4] -> [<2]
+            const F29 to = condsub2(sub_k<2>(ld(V, GP_P2, o), ld(V, GP_P3, o)));
+            st(V, GP_XIT, c, xi_comp(c, tc, to));
+        } break;
+        case 5: {
+            const F29 H = ld(V, GP_P0, c), I = ld(V, GP_P1, c);
+            const F29 J = sub_k<4>(add_lazy(H, ld(V, GP_P2, c)), add_lazy(I, I));   // H + Z1 G - 2I + 4p     [<8]
+            st(V, GP_HH, c, H);
+            st(V, GP_J, c, J);
+            st(V, GP_IMJ, c, sub_k<8>(I, J));                                       // I - J + 8p             [<10]
+            st(V, GP_L0, c, ld(V, GP_P3, c));                                       // ell_0, reduced         [<2]
+        } break;
+        default: {
+            const F29 Y3 = condsub2(sub_k<2>(ld(V, GP_P1, c), ld(V, GP_P2, c)));    // [<4] -> [<2]
+            const F29 Z3 = ld(V, GP_P3, c);
+            st(V, GP_X, c, ld(V, GP_P0, c));
+            st(V, GP_Y, c, Y3);
+            st(V, GP_Z, c, Z3);
+            st(V, GP_S, c, add_lazy(Y3, Z3).norm());                                // [<4]
+        } break;
+        }
+    }
+
+    // one round; after the rounds that complete a line (2: doubling, 5: addition) lanes (k < 3, part) write it out
+    LSA_HD void round(int op, int x2, uint32_t *const *out, int entry) {
         Fq2S *m = mem;
-        const typename GM::Step st = GM::step_of(op, x2, y2);
+        const Prod pr = products_of(op, x2);
         x.par([=](unsigned lane) {
             const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
-            if (g >= (unsigned)G12_GROUPS) return;
-            Fq2S *base = m + g * G12_STRIDE;
-            if ((int)k < st.sd.n) g12_part(base[G12_G + k], part) = Fs{g12_comp_mul<20>(part, base[G12_V + st.sd.a[k]], base[G12_V + st.sd.b[k]])};
+            if (g >= (unsigned)GP_GROUPS || (int)k >= pr.n) return;
+            Fq2S *V = m + g * GP_STRIDE;
+            // a < 4p, b < 20p: 2 * 4 * 20 = 160 < 169
+            const Fs r = {w12_comp_mul<20>(part, w12_load(V + pr.a[k]), w12_load(V + pr.b[k]))};
+            w12_store(&w12_comp(V[GP_P0 + k], part), r);
         });
         x.par([=](unsigned lane) {
             const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
-            if (g >= (unsigned)G12_GROUPS || part || k) return;
-            Fq2S *base = m + g * G12_STRIDE;
-            GM::combine_op(op, base + G12_V, base + G12_G, base + G12_L);
+            if (g >= (unsigned)GP_GROUPS || k) return;
+            combine(op, part, m + g * GP_STRIDE);
         });
-        if (op == 1 || op == 4) {
+        if (op == 2 || op == 5) {
             x.par([=](unsigned lane) {
                 const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
-                if (g >= (unsigned)G12_GROUPS || k >= 3 || !out[g]) return;
-                const Fs v = g12_part(m[g * G12_STRIDE + G12_L + k], part);
-                uint32_t *d = out[g] + entry * TM_LINE_WORDS + k * 18 + part * 9;
+                if (g >= (unsigned)GP_GROUPS || k >= 3 || !out[g]) return;
+                uint32_t w[8];
+                ld(m + g * GP_STRIDE, GP_L0 + (int)k, part).pack256(w);            // < 4p < 2^256
+                uint32_t *d = out[g] + entry * TM_ROW_WORDS + (2 * k + part) * 8;
 #pragma unroll
-                for (int i = 0; i < 9; i++) d[i] = v.v.l[i];
+                for (int l = 0; l < 8; l++) d[l] = w[l];
             });
         }
     }
@@ -78,21 +202,30 @@ struct G12Pre {
     LSA_HD void run(const Jac<Fq2> *Q, unsigned count, uint32_t *const *out) {
         Fq2S *m = mem;
         x.par([=](unsigned lane) {
-            const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
-            if (g >= (unsigned)G12_GROUPS || part || k >= 2) return;
-            Fq2S *Vv = m + g * G12_STRIDE + G12_V;
-            if (k == 0) {
-                Vv[WM_PX] = Fq2S{Fs::one(), Fs::zero()};          // P = (1, 1): ell_VW * py = ell_VW, ell_VV * px = ell_VV
-                Vv[WM_PY] = Fq2S{Fs::one(), Fs::zero()};
-                Vv[WM_TWB] = fq2_constT<Fs>(LSA_TWIST_B);
-            } else {
-                wm_setup(1, g < count, nullptr, Q + g, Vv);
-                if (out[g]) {                                      // libff keeps the affine point beside the coefficients
-                    uint32_t *d = out[g] + ATE_NUM_COEFFS * TM_LINE_WORDS;
-                    const Fq2S qx = Vv[WM_QX], qy = Vv[WM_QY];
-#pragma unroll
-                    for (int i = 0; i < 9; i++) { d[i] = qx.c0.v.l[i]; d[9 + i] = qx.c1.v.l[i]; d[18 + i] = qy.c0.v.l[i]; d[27 + i] = qy.c1.v.l[i]; }
+            const unsigned g = lane / 12, k = lane % 12;
+            if (g >= (unsigned)GP_GROUPS || k) return;
+            Fq2S *V = m + g * GP_STRIDE;
+            // libff to_affine_coordinates (O -> (0, 1)), pi(Q), -pi^2(Q)
+            P2 qx = P2::zero(), qy = P2::one();
+            if (g < count && !Q[g].Z.is_zero()) {
+                qx = load2(Q[g].X); qy = load2(Q[g].Y);
+                if (!(Q[g].Z == Fq2::one())) {
+                    const P2 zi = load2(Q[g].Z).inverse(), zi2 = zi.sqr();
+                    qx = qx * zi2; qy = qy * (zi2 * zi);
                 }
+            }
+            const P2 gx = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_X), gy = fq2_constT<PB>(LSA_TWIST_MUL_BY_Q_Y);
+            const P2 q1x = gx * qx.conj(), q1y = gy * qy.conj();
+            V[GP_QX] = qx; V[GP_QY] = qy;
+            V[GP_Q1X] = q1x; V[GP_Q1Y] = q1y;
+            V[GP_Q2X] = gx * q1x.conj(); V[GP_Q2Y] = (gy * q1y.conj()).neg();
+            V[GP_X] = qx; V[GP_Y] = qy; V[GP_Z] = P2::one();
+            V[GP_S] = qy + P2::one();
+            V[GP_TWB] = fq2_constT<PB>(LSA_TWIST_B);
+            V[GP_ONE] = P2::one();
+            if (out[g]) {                                          // libff keeps the affine point beside the coefficients
+                uint32_t *d = out[g] + ATE_NUM_COEFFS * TM_ROW_WORDS;
+                qx.c0.v.pack256(d); qx.c1.v.pack256(d + 8); qy.c0.v.pack256(d + 16); qy.c1.v.pack256(d + 24);
             }
         });
         int entry = 0;
@@ -100,12 +233,12 @@ struct G12Pre {
         for (int ph = 0; ph < 66; ph++) {
             const bool dbl = ph < 64;
             const bool add = dbl ? ate_bit(63 - ph) != 0 : true;
-            const int x2 = ph == 64 ? WM_Q1X : (ph == 65 ? WM_Q2X : WM_QX), y2 = x2 + 1;
+            const int x2 = ph == 64 ? GP_Q1X : (ph == 65 ? GP_Q2X : GP_QX);
             const int first = dbl ? 0 : 3, last = add ? 7 : 3;
 #pragma unroll 1
             for (int op = first; op < last; op++) {
-                round(op, x2, y2, out, entry);
-                if (op == 1 || op == 4) entry++;
+                round(op, x2, out, entry);
+                if (op == 2 || op == 5) entry++;
             }
         }
     }
@@ -261,7 +394,7 @@ struct TabMiller {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const unsigned wd = lane + 64u * j, c = wd / TM_LINE_WORDS, wi = wd % TM_LINE_WORDS;
-                    if (c < (unsigned)TM_CHUNKS) row[j] = tb[c * TM_MAXM + pair][entry * TM_LINE_WORDS + wi];
+                    if (c < (unsigned)TM_CHUNKS) row[j] = tm_row_element(tb[c * TM_MAXM + pair] + entry * TM_ROW_WORDS, wi);
                 }
             }
             const unsigned part = lane & 1;
@@ -364,6 +497,194 @@ struct TabMiller {
     LSA_HD Fq12S result(unsigned c) const {
         Fq12S t;
         for (int k = 0; k < 6; k++) w12_tower_ref(t, k) = mem[c * TM_STRIDE + TM_F + k];
+        return t;
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// One accumulator per WAVEFRONT (WTab): the latency shape.  A wavefront issues one instruction per four
+// cycles whatever its lanes do, so the time of a Miller loop is its instruction count: here every lane owns
+// ONE Fq component of ONE partial product of the round (42 lanes for f*f from unordered coefficient pairs, 36
+// for f * line), twelve lanes then sum the anti-diagonals -- ~900 instructions per round against 1400 (f * line)
+// and 2400 (f * f) when a lane owns a whole coefficient (TabMiller above, four accumulators per wavefront:
+// the throughput shape).  Used while there are fewer accumulators than about two per SIMD.
+// ------------------------------------------------------------------------------------
+enum {                                     // Fq2S slots of the wavefront's accumulator in LDS
+    WT_F = 0, WT_XF = 6, WT_P = 12,        // f; xi * f; partial products [k * 4 + j]
+    WT_RAW = 36, WT_SC = 45, WT_PXY = 49,  // as TM_RAW / TM_SC / TM_PXY
+    WT_ZERO = WT_PXY + 2 * TM_MAXM,
+    WT_LDS_FQ2 = WT_ZERO + 1
+};
+
+// What a lane does in a round depends on the lane alone: computed once into a two-word descriptor per lane (LDS).
+//   word 0 (f*f):      a | b << 8 | dst << 16 | active << 25 | counts twice << 27        (Fq2S slot numbers)
+//   word 1 (f * line): a | b << 8 | dst << 16 | active << 25 | b-is-ell_0 << 26          (b without its ring offset)
+// The wrapped terms (i + j >= 6) take their a-operand from xi * f, kept beside f.  Every coefficient sums FOUR slots:
+// lanes without a product of their own write the zeros of the absent terms (a = b = the zero slot).
+LSA_HD void wt_make_desc(unsigned lane, uint32_t *d) {
+    d[0] = d[1] = 0;
+    const int q = (int)(lane >> 1);
+    if (lane < 42u) {
+        // pair q of the 21 unordered coefficient pairs: coefficient k owns 4 (k even) or 3 of them
+        const int k = q < 4 ? 0 : q < 7 ? 1 : q < 11 ? 2 : q < 14 ? 3 : q < 18 ? 4 : 5;
+        const int j = q - (k < 1 ? 0 : k < 2 ? 4 : k < 3 ? 7 : k < 4 ? 11 : k < 5 ? 14 : 18);
+        int ti, ui;
+        bool wrap;
+        sqr_pair(k, j, ti, ui, wrap);
+        d[0] = (uint32_t)((wrap ? WT_XF : WT_F) + ti) | (uint32_t)(WT_F + ui) << 8 | (uint32_t)(WT_P + 4 * k + j) << 16 | 1u << 25 | (uint32_t)(ti != ui) << 27;
+    } else if (lane < 48u) {
+        const int k = 2 * (q - 21) + 1;                             // the fourth slot of the odd coefficients: zero
+        d[0] = (uint32_t)WT_ZERO | (uint32_t)WT_ZERO << 8 | (uint32_t)(WT_P + 4 * k + 3) << 16 | 1u << 25;
+    }
+    if (lane < 36u) {
+        const int k = q / 3, j = q % 3;
+        int ai = k - (j == 0 ? 0 : j + 2);                          // line coefficients sit at w^0, w^3, w^4
+        const bool wrap = ai < 0;
+        if (wrap) ai += 6;
+        const int b = j == 0 ? WT_RAW : WT_SC + (j - 1);
+        d[1] = (uint32_t)((wrap ? WT_XF : WT_F) + ai) | (uint32_t)b << 8 | (uint32_t)(WT_P + 4 * k + j) << 16 | 1u << 25 | (uint32_t)(j == 0) << 26;
+    } else if (lane < 48u) {
+        const int k = q - 18;                                       // the fourth slot of every coefficient: zero
+        d[1] = (uint32_t)WT_ZERO | (uint32_t)WT_ZERO << 8 | (uint32_t)(WT_P + 4 * k + 3) << 16 | 1u << 25;
+    }
+}
+// component c of xi * t for t = (t_c, t_o) < 2p tight: c = 0: 9 t0 - t1 + 2p, c = 1: 9 t1 + t0   [< 20; tight]
+LSA_HD F29 wt_xi_comp(unsigned c, const F29 &tc, const F29 &to) {
+    F29 t8;
+#pragma unroll
+    for (int l = 0; l < 9; l++) t8.l[l] = tc.l[l] << 3;
+    const uint32_t pm = w12_mask(0u - c);
+    const F29 neg = sub_k<2>(F29::zero(), to);
+    F29 sel;
+#pragma unroll
+    for (int l = 0; l < 9; l++) sel.l[l] = (to.l[l] & pm) | (neg.l[l] & ~pm);
+    return w12_norm_u(add_lazy(add_lazy(w12_norm_u(t8), tc), sel));
+}
+// the value of the lane next door (2i <-> 2i + 1): one DPP move per limb
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ F29 wt_swap(const F29 &a) {
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], 0xB1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
+        asm volatile("" : "+v"(r.l[i]));       // opaque: GCNDPPCombine must not fold the move into its consumer (quad29.h)
+    }
+    return r;
+}
+#endif
+
+template <class X>
+struct WTabMiller {
+    X &x;
+    Fq2S *mem;                        // WT_LDS_FQ2 elements
+    const uint32_t *const *tab;       // [TM_MAXM] table of pair i (never null)
+    uint32_t *desc;                   // 64 x 2 words (wt_make_desc)
+
+    // component `part` of coefficient k of the round's result: the sum of its four slots, < 12p -> < 2p
+    static LSA_HD F29 coeff_part(const Fq2S *m, unsigned k, unsigned part) {
+        F29 sum = F29::zero();
+#pragma unroll
+        for (int j = 0; j < 4; j++) sum = add_lazy(sum, w12_load(&w12_comp(const_cast<Fq2S &>(m[WT_P + 4 * k + j]), part)).v);
+        return f29_mul(w12_norm_u(sum), F29::one());
+    }
+
+    // mode 1: f <- f*f, 2: f <- f * line(use u), 0: nothing.  scale / load as in TabMiller::round.
+    LSA_HD void round(int mode, unsigned M, int u, int scale, int load) {
+        Fq2S *m = mem;
+        const uint32_t *const *tb = tab;
+        const uint32_t *ds = desc;
+        // uniform ring offsets
+        const int r3u = 3 * (u % 3), r2u = 2 * (u % 2);
+        const int sa = scale >= 0 ? WT_RAW + 3 * (scale % 3) + 1 : WT_ZERO, sb = scale >= 0 ? WT_PXY + 2 * (scale % (int)M) + 1 : WT_ZERO,
+                  sd = WT_SC + 2 * (scale >= 0 ? scale % 2 : 0);
+        x.par([=](unsigned lane) {
+            uint32_t row = 0;
+            if (load >= 0 && lane < (unsigned)TM_LINE_WORDS) row = tm_row_element(tb[(unsigned)load % M] + ((unsigned)load / M) * TM_ROW_WORDS, lane);
+            const unsigned part = lane & 1;
+            const uint32_t dd = mode ? ds[2 * lane + (mode - 1)] : 0u;
+            int ao = (int)(dd & 0xffu), bo = (int)((dd >> 8) & 0xffu), dsto = (int)((dd >> 16) & 0xffu);
+            bool active = ((dd >> 25) & 1u) != 0;
+            const uint32_t w2 = w12_mask(0u - ((dd >> 27) & 1u));
+            if (mode == 2) bo += ((dd >> 26) & 1u) ? r3u : (((dd >> 8) & 0xffu) == (uint32_t)WT_ZERO ? 0 : r2u);
+            if (!active) { ao = WT_ZERO; bo = WT_ZERO; }
+            if (lane >= 60u && scale >= 0) {                               // ell_VW * py (lanes 60, 61), ell_VV * px (62, 63)
+                const int which = (int)((lane >> 1) & 1);
+                ao = sa + which; bo = sb - which; dsto = sd + which;
+                active = true;
+            }
+            // a < 20p (xi * f) or < 4p (a table coefficient), b < 2p: 2 * 20 * 2 = 80 < 169
+            F29 r = w12_comp_mul<2>(part, w12_load(m + ao), w12_load(m + bo));
+#pragma unroll
+            for (int l = 0; l < 9; l++) r.l[l] += r.l[l] & w2;             // an off-diagonal pair of a square counts twice
+            if (active) w12_store(&w12_comp(m[dsto], part), Fs{r});
+            if (load >= 0 && lane < (unsigned)TM_LINE_WORDS) tm_store_word(reinterpret_cast<uint32_t *>(m + WT_RAW + 3 * ((unsigned)load % 3u)) + lane, row);
+        });
+        if (mode) {
+            x.par([=](unsigned lane) {
+                if (lane >= 12) return;
+                const unsigned k = lane >> 1, part = lane & 1;
+                const F29 mine = coeff_part(m, k, part);
+#if defined(__HIP_DEVICE_COMPILE__)
+                const F29 other = wt_swap(mine);
+#else
+                const F29 other = coeff_part(m, k, part ^ 1u);
+#endif
+                w12_store(&w12_comp(m[WT_F + k], part), Fs{mine});
+                w12_store(&w12_comp(m[WT_XF + k], part), Fs{wt_xi_comp(part, mine, other)});    // [< 20]
+            });
+        }
+    }
+
+    // f <- prod_{i < cnt} miller_loop(+-P[i], table[i]);  M = max(cnt, 1)
+    LSA_HD void run(const Jac<Fq> *const *P, const uint8_t *neg, unsigned cnt, unsigned M) {
+        Fq2S *m = mem;
+        uint32_t *dsc = desc;
+        x.par([=](unsigned lane) {
+            wt_make_desc(lane, dsc + 2 * lane);
+            if (lane == 63) m[WT_ZERO] = Fq2S::zero();
+            if (lane < 6) {
+                const Fq2S f0 = lane == 0 ? P2::one() : P2::zero();
+                m[WT_F + lane] = f0;
+                m[WT_XF + lane] = WMiller<X>::st(WMiller<X>::xi_times(WMiller<X>::ld(f0)));
+            }
+            else if (lane >= 60) {
+                const unsigned i = lane - 60;                               // TM_MAXM == 4
+                tm_setup_g1(i < cnt, P[i], neg[i] != 0, m + WT_PXY + 2 * i);
+            }
+        });
+        const int U = ATE_NUM_COEFFS * (int)M;
+        int u = 0, ns = 0, nl = 0;
+        auto side = [&](int &sc, int &ld) {
+            sc = (ns < U && ns < nl && ns < u + 2) ? ns : -1;
+            ld = (nl < U && nl < u + 3) ? nl : -1;
+            if (sc >= 0) ns++;
+            if (ld >= 0) nl++;
+        };
+        int sc, ld;
+        side(sc, ld);
+        round(0, M, 0, sc, ld);
+#pragma unroll 1
+        for (int ph = 0; ph < 66; ph++) {
+            const bool dbl = ph < 64;
+            const int lines = dbl ? 1 + ate_bit(63 - ph) : 1;
+            if (dbl) {
+                side(sc, ld);
+                round(1, M, u, sc, ld);
+            }
+#pragma unroll 1
+            for (int li = 0; li < lines; li++) {
+#pragma unroll 1
+                for (unsigned i = 0; i < M; i++) {
+                    side(sc, ld);
+                    round(2, M, u, sc, ld);
+                    u++;
+                }
+            }
+        }
+    }
+    LSA_HD Fq12S result() const {
+        Fq12S t;
+        for (int k = 0; k < 6; k++) w12_tower_ref(t, k) = mem[WT_F + k];
         return t;
     }
 };

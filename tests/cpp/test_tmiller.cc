@@ -1,4 +1,4 @@
-// Host unit test of csrc/tmiller.h: the G2 line-table engine (G12Pre) against the one-lane step
+// Host unit test of csrc/tmiller.h: the G2 line-table engine (G2Pre) against the one-lane step
 // formulas of miller.h, and the table-driven Miller loop with shared accumulators (TabMiller)
 // against products of one-lane Miller loops, executed phase by phase over emulated lane ids.
 #include <cstdio>
@@ -23,9 +23,10 @@ struct LoopExec {
     template <class F> void par(F f) { for (unsigned l = 0; l < 64; l++) f(l); }
     unsigned nlanes() const { return 64; }
 };
-static Fq2S tab_fq2(const std::vector<uint32_t> &t, int idx) {
+static Fq2S tab_fq2(const std::vector<uint32_t> &t, int idx) {      // Fq2 number idx of a packed table
     Fq2S r;
-    for (int i = 0; i < 9; i++) { r.c0.v.l[i] = t[idx * 18 + i]; r.c1.v.l[i] = t[idx * 18 + 9 + i]; }
+    r.c0.v = F29::unpack256(&t[idx * 16]);
+    r.c1.v = F29::unpack256(&t[idx * 16 + 8]);
     return r;
 }
 // libff alt_bn128_ate_precompute_G2 with the one-lane step formulas of miller.h
@@ -54,37 +55,32 @@ int main() {
     LoopExec ex;
     // ---- line tables
     const unsigned nq = 5;
-    Jac<Fq2> Qs[G12_GROUPS];
+    Jac<Fq2> Qs[GP_GROUPS];
     for (unsigned g = 0; g < nq; g++)
         Qs[g] = {{rand_fq(), rand_fq()}, {rand_fq(), rand_fq()}, g % 2 ? Fq2::one() : Fq2{rand_fq(), rand_fq()}};
     Qs[3].Z = Fq2::zero();
     std::vector<std::vector<uint32_t>> tabs(nq + 1, std::vector<uint32_t>(TM_TAB_WORDS, 0xdeadbeefu));
     {
-        std::vector<Fq2S> lds(G12_LDS_FQ2);
-        uint32_t *out[G12_GROUPS];
-        for (unsigned g = 0; g < (unsigned)G12_GROUPS; g++) out[g] = g < nq ? tabs[g].data() : nullptr;
-        G12Pre<LoopExec> pre{ex, lds.data()};
+        std::vector<Fq2S> lds(GP_LDS_FQ2);
+        uint32_t *out[GP_GROUPS];
+        for (unsigned g = 0; g < (unsigned)GP_GROUPS; g++) out[g] = g < nq ? tabs[g].data() : nullptr;
+        G2Pre<LoopExec> pre{ex, lds.data()};
         pre.run(Qs, nq, out);
-        for (unsigned g = 0; g < nq; g++) {
-            P2 qx, qy;
-            const std::vector<Line> want = expected_lines(Qs[g], qx, qy);
-            CHECK((int)want.size() == ATE_NUM_COEFFS, "102 coefficient triples");
-            bool ok = true;
-            for (int e = 0; e < ATE_NUM_COEFFS; e++)
-                ok = ok && tab_fq2(tabs[g], 3 * e) == want[e].e0 && tab_fq2(tabs[g], 3 * e + 1) == want[e].eVW && tab_fq2(tabs[g], 3 * e + 2) == want[e].eVV;
-            CHECK(ok, "line table");
-            CHECK(tab_fq2(tabs[g], 3 * ATE_NUM_COEFFS) == qx && tab_fq2(tabs[g], 3 * ATE_NUM_COEFFS + 1) == qy, "affine Q beside the table");
-            // bounds contract of the consumer: every stored value is tight and < 2p
-            bool tight = true;
-            for (int i = 0; i < TM_TAB_WORDS; i++) tight = tight && tabs[g][i] < (1u << 29);
-            CHECK(tight, "tight limbs");
-        }
+    }
+    for (unsigned g = 0; g < nq; g++) {
+        P2 qx, qy;
+        const std::vector<Line> want = expected_lines(Qs[g], qx, qy);
+        CHECK((int)want.size() == ATE_NUM_COEFFS, "102 coefficient triples");
+        bool ok = true;
+        for (int e = 0; e < ATE_NUM_COEFFS; e++)
+            ok = ok && tab_fq2(tabs[g], 3 * e) == want[e].e0 && tab_fq2(tabs[g], 3 * e + 1) == want[e].eVW && tab_fq2(tabs[g], 3 * e + 2) == want[e].eVV;
+        CHECK(ok, "line table");
+        CHECK(tab_fq2(tabs[g], 3 * ATE_NUM_COEFFS) == qx && tab_fq2(tabs[g], 3 * ATE_NUM_COEFFS + 1) == qy, "affine Q beside the table");
     }
     // the identity table: every row is the line (1, 0, 0)
     std::vector<uint32_t> &ident = tabs[nq];
     for (int i = 0; i < TM_TAB_WORDS; i++) ident[i] = 0;
-    for (int e = 0; e < ATE_NUM_COEFFS; e++)
-        for (int i = 0; i < 9; i++) ident[e * TM_LINE_WORDS + i] = F29::one().l[i];
+    for (int e = 0; e < ATE_NUM_COEFFS; e++) F29::one().pack256(&ident[e * TM_ROW_WORDS]);
     // ---- table-driven Miller loops, accumulators of 1..4 pairs, some terms conjugated
     for (unsigned M = 1; M <= (unsigned)TM_MAXM; M++) {
         std::vector<Fq2S> lds(TM_LDS_FQ2);
@@ -118,6 +114,33 @@ int main() {
             }
             CHECK(tm.result((unsigned)c) == want, "table-driven miller product");
         }
+    }
+    // ---- one accumulator per wavefront
+    for (unsigned cnt = 0; cnt <= (unsigned)TM_MAXM; cnt++) {
+        std::vector<Fq2S> lds(WT_LDS_FQ2);
+        Jac<Fq> Ps[TM_MAXM];
+        const Jac<Fq> *Pp[TM_MAXM];
+        const uint32_t *tp[TM_MAXM];
+        uint8_t neg[TM_MAXM];
+        unsigned qi[TM_MAXM];
+        for (unsigned i = 0; i < (unsigned)TM_MAXM; i++) {
+            Ps[i] = {rand_fq(), rand_fq(), (rng() & 1) ? Fq::one() : rand_fq()};
+            if (cnt == 3 && i == 1) Ps[i].Z = Fq::zero();
+            Pp[i] = &Ps[i];
+            neg[i] = (uint8_t)(rng() & 1);
+            qi[i] = (unsigned)(rng() % nq);
+            tp[i] = i < cnt ? tabs[qi[i]].data() : ident.data();
+        }
+        std::vector<uint32_t> desc(256);
+        WTabMiller<LoopExec> wt{ex, lds.data(), tp, desc.data()};
+        wt.run(Pp, neg, cnt, cnt ? cnt : 1);
+        Fq12S want = Fq12S::one();
+        for (unsigned i = 0; i < cnt; i++) {
+            Fq12S f = miller_one(Ps[i], Qs[qi[i]]);
+            if (neg[i]) f = f.unitary_inverse();
+            want = fq12_mul(want, f);
+        }
+        CHECK(wt.result() == want, "wavefront table-driven miller product");
     }
     printf(fails ? "FAILED (%d)\n" : "PASS\n", fails);
     return fails ? 1 : 0;
