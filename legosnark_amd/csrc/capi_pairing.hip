@@ -436,6 +436,41 @@ int lsa_g2_precompute(const void *g2_jac, size_t n, void *out_precomp) {
     return LSA_OK;
 }
 
+// Builds the line tables of points the cache does not hold yet, asynchronously (no host synchronisation): a
+// verifier that derives its G2 points one after the other on the host (CPPoly::verify: pts[i] * g2,
+// /root/reference/src/gadgets/poly.h:116-118) overlaps the G2 arithmetic of point i with its own work on point i + 1.
+int lsa_g2_tables_prefetch(const void *g2_jac, size_t n) {
+    int rc = require_ready();
+    if (rc) return rc;
+    if (n == 0) return LSA_OK;
+    if (!g2_jac) { set_error("g2_tables_prefetch: null argument"); return LSA_ERR_INVALID; }
+    g_tabs.read_env();
+    if (g_tabs.max_tables == 0 || n > 1024) return LSA_OK;         // nothing to keep them in
+    rc = wait_uploads();
+    if (rc) return rc;
+    g_tabs.tick++;
+    if (g_pin_q.ensure(n * (sizeof(Jac<Fq2>) + 8)) || g_pair_q.ensure(n * (sizeof(Jac<Fq2>) + 8))) { set_error("g2_tables_prefetch: staging allocation failed"); return LSA_ERR_NOMEM; }
+    char *hq = (char *)g_pin_q.p;
+    size_t m = 0;
+    std::vector<uint64_t> dst;
+    for (size_t i = 0; i < n; i++) {
+        const char *q = (const char *)g2_jac + i * sizeof(Jac<Fq2>);
+        const Key128 key = fingerprint(q, sizeof(Jac<Fq2>), 1);
+        if (g_tabs.lookup(key) >= 0) continue;
+        const long s = g_tabs.insert(key);
+        if (s < 0) continue;                                        // full of tables of this very call: leave it to the Miller call
+        memcpy(hq + m * sizeof(Jac<Fq2>), q, sizeof(Jac<Fq2>));
+        dst.push_back((uint64_t)(uintptr_t)g_tabs.ptr((uint32_t)s));
+        m++;
+    }
+    if (m == 0) return LSA_OK;
+    memcpy(hq + m * sizeof(Jac<Fq2>), dst.data(), m * 8);
+    HIPCHK(hipMemcpyAsync(g_pair_q.p, hq, m * (sizeof(Jac<Fq2>) + 8), hipMemcpyHostToDevice, g.stream));
+    rc = mark_uploads();
+    if (rc) return rc;
+    return g2_precomp_device(g_pair_q.p, m, (uint32_t *const *)((const char *)g_pair_q.p + m * sizeof(Jac<Fq2>)), g.stream);
+}
+
 int lsa_pairing_set_chunk(unsigned pairs_per_accumulator) {
     if (pairs_per_accumulator > miller_tab_max_pairs()) { set_error("pairing_set_chunk: at most %u pairs share an accumulator", miller_tab_max_pairs()); return LSA_ERR_INVALID; }
     g_force_m = pairs_per_accumulator;

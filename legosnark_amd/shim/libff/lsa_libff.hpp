@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <random>
 #include <stdexcept>
 #include <cerrno>
@@ -350,20 +351,114 @@ public:
     }
 };
 
+// GT / Fqk values.  A value that comes out of miller_loop / double_miller_loop / reduced_pairing / final_exponentiation
+// is DEFERRED: it is the description "[final_exponentiation] (prod of Miller loops (P_i, Q_i)^(+-1) * constant)" and
+// becomes twelve field elements when somebody looks at it (==, <<, squared, a product with a plain value, val()).
+// The reference's verifiers only ever multiply such values, conjugate them, final-exponentiate and compare
+// (/root/reference/src/utils/globl.h:94-105, src/gadgets/subspace.cc:142-170, src/gadgets/poly.h:105-123,
+// src/gadgets/lipmaa.cc:187-207), so a whole check
+//     final_exponentiation(lhs * rhs.unitary_inverse()) == GT::one()
+// reaches the GPU as ONE lsa_pairing_terms call -- one upload, shared accumulators, one final exponentiation, one
+// download -- instead of four blocking calls.  The value is the same Fq12 element whichever way it is evaluated
+// (multiplication in Fq12 is exact).  LSA_SHIM_EAGER=1 evaluates every call at once (the round-2 behaviour).
+namespace lsa_shim {
+struct PairTerm {
+    lsa::Jac<lsa::Fq> P;
+    lsa::Jac<lsa::Fq2> Q;
+    uint8_t conj;
+};
+struct PairExpr {
+    std::vector<PairTerm> terms;
+    lsa::Fq12 cst = lsa::Fq12::one();      // product of the already evaluated factors
+    bool has_cst = false;
+    bool final_exp = false;
+    mutable bool done = false;             // every copy of a deferred value shares its node, hence its result
+    mutable lsa::Fq12 result;
+};
+inline bool eager() {
+    static const bool e = getenv("LSA_SHIM_EAGER") && getenv("LSA_SHIM_EAGER")[0] == '1';
+    return e;
+}
+inline const lsa::Fq12 &evaluate(const PairExpr &e) {
+    if (e.done) return e.result;
+    lsa::Fq12 out = e.cst;
+    const size_t n = e.terms.size();
+    if (n) {
+        std::vector<lsa::Jac<lsa::Fq>> ps(n);
+        std::vector<lsa::Jac<lsa::Fq2>> qs(n);
+        std::vector<uint8_t> fl(n);
+        for (size_t i = 0; i < n; i++) { ps[i] = e.terms[i].P; qs[i] = e.terms[i].Q; fl[i] = e.terms[i].conj; }
+        const uint64_t seg[2] = {0, n};
+        lsa_require(lsa_pairing_terms(ps.data(), qs.data(), nullptr, fl.data(), seg, 1, &out, e.final_exp && !e.has_cst), "pairing product");
+        if (e.has_cst) out = lsa::fq12_mul(out, e.cst);
+    }
+    if (e.final_exp && (e.has_cst || !n)) {
+        lsa::Fq12 in = out;
+        lsa_require(lsa_final_exponentiation(&in, 1, &out, 0), "final_exponentiation");
+    }
+    e.result = out;
+    e.done = true;
+    return e.result;
+}
+}  // namespace lsa_shim
+
 class alt_bn128_Fq12 {
+    mutable lsa::Fq12 v_;
+    mutable std::shared_ptr<const lsa_shim::PairExpr> e_;      // non-null: v_ is not there yet
 public:
-    lsa::Fq12 v;
-    alt_bn128_Fq12() : v(lsa::Fq12::one()) { v.c0.c0 = lsa::Fq2::zero(); }
-    alt_bn128_Fq12(const lsa::Fq12 &x) : v(x) {}
+    alt_bn128_Fq12() : v_(lsa::Fq12::one()) { v_.c0.c0 = lsa::Fq2::zero(); }
+    alt_bn128_Fq12(const lsa::Fq12 &x) : v_(x) {}
+    explicit alt_bn128_Fq12(std::shared_ptr<const lsa_shim::PairExpr> e) : v_(lsa::Fq12::one()), e_(std::move(e)) {
+        if (lsa_shim::eager()) val();
+    }
+    // the twelve field elements (libff layout); evaluates a deferred value
+    const lsa::Fq12 &val() const {
+        if (e_) { v_ = lsa_shim::evaluate(*e_); e_.reset(); }
+        return v_;
+    }
+    bool deferred() const { return e_ != nullptr; }
     static alt_bn128_Fq12 one() { return alt_bn128_Fq12(lsa::Fq12::one()); }
     static alt_bn128_Fq12 zero() { return alt_bn128_Fq12(); }
-    bool operator==(const alt_bn128_Fq12 &o) const { return v == o.v; }
-    bool operator!=(const alt_bn128_Fq12 &o) const { return !(v == o.v); }
-    alt_bn128_Fq12 operator*(const alt_bn128_Fq12 &o) const { return alt_bn128_Fq12(lsa::fq12_mul(v, o.v)); }
-    alt_bn128_Fq12 &operator*=(const alt_bn128_Fq12 &o) { v = lsa::fq12_mul(v, o.v); return *this; }
-    alt_bn128_Fq12 squared() const { return alt_bn128_Fq12(lsa::fq12_sqr(v)); }
-    alt_bn128_Fq12 inverse() const { return alt_bn128_Fq12(lsa::fq12_inverse(v)); }
-    alt_bn128_Fq12 unitary_inverse() const { return alt_bn128_Fq12(v.unitary_inverse()); }
+    bool operator==(const alt_bn128_Fq12 &o) const { return val() == o.val(); }
+    bool operator!=(const alt_bn128_Fq12 &o) const { return !(val() == o.val()); }
+    alt_bn128_Fq12 operator*(const alt_bn128_Fq12 &o) const {
+        if (!e_ && !o.e_) return alt_bn128_Fq12(lsa::fq12_mul(v_, o.v_));
+        // a deferred factor that is not final-exponentiated contributes its terms; anything else its value
+        auto r = std::make_shared<lsa_shim::PairExpr>();
+        for (const alt_bn128_Fq12 *f : {this, &o}) {
+            if (f->e_ && !f->e_->final_exp && !f->e_->done) {
+                r->terms.insert(r->terms.end(), f->e_->terms.begin(), f->e_->terms.end());
+                if (f->e_->has_cst) { r->cst = r->has_cst ? lsa::fq12_mul(r->cst, f->e_->cst) : f->e_->cst; r->has_cst = true; }
+            } else {
+                const lsa::Fq12 &x = f->val();
+                r->cst = r->has_cst ? lsa::fq12_mul(r->cst, x) : x;
+                r->has_cst = true;
+            }
+        }
+        if (r->has_cst && r->cst == lsa::Fq12::one()) r->has_cst = false;     // acc = Fqk::one(); acc = acc * miller_loop(...)
+        return alt_bn128_Fq12(std::shared_ptr<const lsa_shim::PairExpr>(std::move(r)));
+    }
+    alt_bn128_Fq12 &operator*=(const alt_bn128_Fq12 &o) { *this = *this * o; return *this; }
+    alt_bn128_Fq12 squared() const { return alt_bn128_Fq12(lsa::fq12_sqr(val())); }
+    alt_bn128_Fq12 inverse() const { return alt_bn128_Fq12(lsa::fq12_inverse(val())); }
+    // conjugation over Fq6 (the inverse of a unitary element).  It is a field automorphism, and the conjugate of a
+    // Miller loop on (P, Q) is the Miller loop on (-P, Q): a deferred product conjugates term by term
+    alt_bn128_Fq12 unitary_inverse() const {
+        if (!e_ || e_->final_exp || e_->done) return alt_bn128_Fq12(val().unitary_inverse());
+        auto r = std::make_shared<lsa_shim::PairExpr>(*e_);
+        for (auto &t : r->terms) t.conj ^= 1;
+        if (r->has_cst) r->cst = r->cst.unitary_inverse();
+        return alt_bn128_Fq12(std::shared_ptr<const lsa_shim::PairExpr>(std::move(r)));
+    }
+    // libff final_exponentiation (alt_bn128_pp::final_exponentiation forwards here)
+    alt_bn128_Fq12 final_exponentiated() const {
+        auto r = std::make_shared<lsa_shim::PairExpr>();
+        if (e_ && !e_->final_exp && !e_->done) *r = *e_;
+        else { r->cst = val(); r->has_cst = true; }
+        r->final_exp = true;
+        r->done = false;
+        return alt_bn128_Fq12(std::shared_ptr<const lsa_shim::PairExpr>(std::move(r)));
+    }
     alt_bn128_Fq12 operator^(const bigint<4> &e) const {
         alt_bn128_Fq12 acc = one();
         for (long i = 255; i >= 0; --i) { acc = acc.squared(); if (e.test_bit(i)) acc *= *this; }
@@ -373,17 +468,18 @@ public:
     // libff Fp12_2over3over2 / Fp6_3over2 operator<< / >>: c0 SEP c1 (SEP c2) recursively, i.e.
     // the twelve Fq coefficients in tower order separated by OUTPUT_SEPARATOR
     friend std::ostream &operator<<(std::ostream &os, const alt_bn128_Fq12 &a) {
-        const lsa::Fq2 *c = reinterpret_cast<const lsa::Fq2 *>(&a.v);      // c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2
+        const lsa::Fq2 *c = reinterpret_cast<const lsa::Fq2 *>(&a.val());  // c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2
         for (int i = 0; i < 6; i++) os << alt_bn128_Fq2(c[i]) << (i < 5 ? LSA_OUTPUT_SEPARATOR : "");
         return os;
     }
     friend std::istream &operator>>(std::istream &is, alt_bn128_Fq12 &a) {
-        lsa::Fq2 *c = reinterpret_cast<lsa::Fq2 *>(&a.v);
+        lsa::Fq12 x;
+        lsa::Fq2 *c = reinterpret_cast<lsa::Fq2 *>(&x);
         for (int i = 0; i < 6; i++) { alt_bn128_Fq2 t; is >> t; c[i] = t.v; }
+        a = alt_bn128_Fq12(x);
         return is;
     }
 };
-static_assert(sizeof(alt_bn128_Fq12) == 384, "GT layout");
 using alt_bn128_GT = alt_bn128_Fq12;
 
 // ---------------------------------------------------------------- groups
@@ -503,8 +599,73 @@ static_assert(sizeof(alt_bn128_G1) == 96 && sizeof(alt_bn128_G2) == 192, "libff 
 static_assert(sizeof(alt_bn128_Fr) == 32, "libff field layout");
 
 // ---------------------------------------------------------------- pairing-friendly curve "pp"
-struct alt_bn128_G1_precomp { alt_bn128_G1 P; };   // libff keeps (PX,PY); the GPU normalises itself
-struct alt_bn128_G2_precomp { alt_bn128_G2 Q; };   // libff keeps ~100 line coefficients; fused on the GPU
+// libff alt_bn128_ate_G1_precomp: the affine coordinates (to_affine_coordinates: O -> (0, 1, 0)).  Normalised here, on
+// the host, once -- the Miller kernels then never invert.
+struct alt_bn128_G1_precomp {
+    alt_bn128_G1 P;                                       // Z == 1 or the point at infinity
+    alt_bn128_Fq PX() const { return alt_bn128_Fq(P.is_zero() ? lsa::Fq::zero() : P.X); }
+    alt_bn128_Fq PY() const { return alt_bn128_Fq(P.is_zero() ? lsa::Fq::one() : P.Y); }
+    bool operator==(const alt_bn128_G1_precomp &o) const { return PX() == o.PX() && PY() == o.PY(); }
+};
+// libff alt_bn128_ate_ell_coeffs / alt_bn128_ate_G2_precomp: QX, QY and the coefficient triple of each of the 102
+// steps of the ate loop.  The device keeps its own copy of the table per distinct Q (include/legosnark_amd.h, "G2
+// precomputation"), so the host copy is only fetched when somebody asks for it (coeffs(), ==, <<).
+struct alt_bn128_ate_ell_coeffs {
+    alt_bn128_Fq2 ell_0, ell_VW, ell_VV;
+    bool operator==(const alt_bn128_ate_ell_coeffs &o) const { return ell_0 == o.ell_0 && ell_VW == o.ell_VW && ell_VV == o.ell_VV; }
+    friend std::ostream &operator<<(std::ostream &os, const alt_bn128_ate_ell_coeffs &c) {
+        return os << c.ell_0 << LSA_OUTPUT_SEPARATOR << c.ell_VW << LSA_OUTPUT_SEPARATOR << c.ell_VV;
+    }
+    friend std::istream &operator>>(std::istream &is, alt_bn128_ate_ell_coeffs &c) { return is >> c.ell_0 >> c.ell_VW >> c.ell_VV; }
+};
+static_assert(sizeof(alt_bn128_ate_ell_coeffs) == 192, "libff coefficient triple");
+struct alt_bn128_G2_precomp {
+    alt_bn128_G2 Q;                                       // Z == 1 or the point at infinity
+    mutable std::shared_ptr<std::vector<uint8_t>> blob;   // LSA_G2_PRECOMP_BYTES: QX, QY, coefficients (lazy)
+    const std::vector<uint8_t> &bytes() const {
+        if (!blob) {
+            blob = std::make_shared<std::vector<uint8_t>>(LSA_G2_PRECOMP_BYTES);
+            lsa_require(lsa_g2_precompute(&Q, 1, blob->data()), "precompute_G2");
+        }
+        return *blob;
+    }
+    alt_bn128_Fq2 QX() const { return alt_bn128_Fq2(Q.is_zero() ? lsa::Fq2::zero() : Q.X); }
+    alt_bn128_Fq2 QY() const { return alt_bn128_Fq2(Q.is_zero() ? lsa::Fq2::one() : Q.Y); }
+    std::vector<alt_bn128_ate_ell_coeffs> coeffs() const {
+        std::vector<alt_bn128_ate_ell_coeffs> c(LSA_ATE_NUM_COEFFS);
+        memcpy((void *)c.data(), bytes().data() + 128, LSA_ATE_NUM_COEFFS * sizeof(alt_bn128_ate_ell_coeffs));
+        return c;
+    }
+    bool operator==(const alt_bn128_G2_precomp &o) const { return bytes() == o.bytes(); }
+    // libff operator<<: QX SEP QY NL, the number of coefficients NL, one triple per line
+    friend std::ostream &operator<<(std::ostream &os, const alt_bn128_G2_precomp &p) {
+        os << p.QX() << LSA_OUTPUT_SEPARATOR << p.QY() << "\n";
+        const auto c = p.coeffs();
+        os << c.size() << "\n";
+        for (const auto &x : c) os << x << LSA_OUTPUT_NEWLINE;
+        return os;
+    }
+    friend std::istream &operator>>(std::istream &is, alt_bn128_G2_precomp &p) {
+        alt_bn128_Fq2 qx, qy;
+        is >> qx;
+        is >> qy;
+        size_t n = 0;
+        is >> n;
+        if (n != (size_t)LSA_ATE_NUM_COEFFS) { is.setstate(std::ios::failbit); return is; }
+        auto b = std::make_shared<std::vector<uint8_t>>(LSA_G2_PRECOMP_BYTES);
+        memcpy(b->data(), &qx.v, 64);
+        memcpy(b->data() + 64, &qy.v, 64);
+        for (size_t i = 0; i < n; i++) {
+            alt_bn128_ate_ell_coeffs c;
+            is >> c;
+            memcpy(b->data() + 128 + i * 192, (const void *)&c, 192);
+        }
+        const bool inf = qx == alt_bn128_Fq2::zero() && qy == alt_bn128_Fq2::one();      // libff's affine form of O is (0, 1)
+        p.Q = inf ? alt_bn128_G2::zero() : alt_bn128_G2(qx.v, qy.v, lsa::Fq2::one());
+        p.blob = b;
+        return is;
+    }
+};
 
 class alt_bn128_pp {
 public:
@@ -525,30 +686,32 @@ public:
         const char *d = getenv("LSA_DEVICE");
         lsa_require(lsa_init(d ? atoi(d) : 0), "init_public_params");
     }
-    static alt_bn128_G1_precomp precompute_G1(const alt_bn128_G1 &P) { return {P}; }
-    static alt_bn128_G2_precomp precompute_G2(const alt_bn128_G2 &Q) { return {Q}; }
-    static alt_bn128_Fq12 miller_loop(const alt_bn128_G1_precomp &p, const alt_bn128_G2_precomp &q) {
-        alt_bn128_Fq12 out;
-        lsa_require(lsa_miller_loop(&p.P, &q.Q, 1, &out, 0), "miller_loop");
-        return out;
+    static alt_bn128_G1_precomp precompute_G1(const alt_bn128_G1 &P) {
+        alt_bn128_G1 a = P;
+        a.to_affine_coordinates();
+        return {a};
     }
+    // The device starts on the line table of a point it has not seen (asynchronously) and keeps it; the value only
+    // carries Q, and its coefficients on demand.
+    static alt_bn128_G2_precomp precompute_G2(const alt_bn128_G2 &Q) {
+        alt_bn128_G2 a = Q;
+        a.to_affine_coordinates();
+        lsa_require(lsa_g2_tables_prefetch(&a, 1), "precompute_G2");
+        return {a, nullptr};
+    }
+    static alt_bn128_Fq12 miller_term(const alt_bn128_G1_precomp &p, const alt_bn128_G2_precomp &q) {
+        auto e = std::make_shared<lsa_shim::PairExpr>();
+        e->terms.push_back(lsa_shim::PairTerm{p.P.jac(), q.Q.jac(), 0});
+        return alt_bn128_Fq12(std::shared_ptr<const lsa_shim::PairExpr>(std::move(e)));
+    }
+    static alt_bn128_Fq12 miller_loop(const alt_bn128_G1_precomp &p, const alt_bn128_G2_precomp &q) { return miller_term(p, q); }
     static alt_bn128_Fq12 double_miller_loop(const alt_bn128_G1_precomp &p1, const alt_bn128_G2_precomp &q1,
                                              const alt_bn128_G1_precomp &p2, const alt_bn128_G2_precomp &q2) {
-        alt_bn128_G1 ps[2] = {p1.P, p2.P};
-        alt_bn128_G2 qs[2] = {q1.Q, q2.Q};
-        alt_bn128_Fq12 out;
-        lsa_require(lsa_miller_loop_product(ps, qs, 2, &out), "double_miller_loop");
-        return out;
+        return miller_term(p1, q1) * miller_term(p2, q2);
     }
-    static alt_bn128_GT final_exponentiation(const alt_bn128_Fq12 &elt) {
-        alt_bn128_GT out;
-        lsa_require(lsa_final_exponentiation(&elt, 1, &out, 0), "final_exponentiation");
-        return out;
-    }
+    static alt_bn128_GT final_exponentiation(const alt_bn128_Fq12 &elt) { return elt.final_exponentiated(); }
     static alt_bn128_GT reduced_pairing(const alt_bn128_G1 &P, const alt_bn128_G2 &Q) {
-        alt_bn128_GT out;
-        lsa_require(lsa_pairing_product(&P, &Q, 1, &out), "reduced_pairing");
-        return out;
+        return final_exponentiation(miller_loop(precompute_G1(P), precompute_G2(Q)));
     }
     static alt_bn128_Fq12 pairing(const alt_bn128_G1 &P, const alt_bn128_G2 &Q) { return miller_loop(precompute_G1(P), precompute_G2(Q)); }
 };

@@ -82,11 +82,12 @@ int main() {
     CHECK(load<Fr_>(dump(frs)) == frs);
 #endif
     // GT
-    alt_bn128_Fq12 f = alt_bn128_Fq12::one();
+    lsa::Fq12 fv = lsa::Fq12::one();
     {
-        lsa::Fq2 *c = reinterpret_cast<lsa::Fq2 *>(&f.v);
+        lsa::Fq2 *c = reinterpret_cast<lsa::Fq2 *>(&fv);
         for (int i = 0; i < 6; i++) c[i] = lsa::Fq2{lsa::Fq::from_u32(10 + i), lsa::Fq::from_u32(100 + i)};
     }
+    const alt_bn128_Fq12 f(fv);
 #if !defined(BINARY_OUTPUT)
     std::cout << "LINE GT x | " << f << "\n";
 #endif

@@ -51,6 +51,25 @@ def test_keygen_matrix_batched_call_equals_reference_column_loop():
     assert '"mismatches": 0' in r.stdout
 
 
+def test_verifier_side_through_the_shim_deferred_equals_call_by_call():
+    """legosnark_amd/shim/checks/pairing_check.cc: libff G2_precomp semantics (coefficients, stream format), deferred
+    GT values against explicit C-ABI calls bit for bit, the reference's own simple_pairing_check on true and false
+    statements, and its unchanged CPPoly::verify returning the same boolean whether the shim defers or not."""
+    import json
+    outs = []
+    for eager in ("0", "1"):
+        exe = os.path.join(BIN, "pairing_check")
+        if not os.path.exists(exe):
+            pytest.skip("%s missing: run __graft_entry__.build() where /root/reference exists" % exe)
+        env = dict(os.environ, LSA_SEED="11", LSA_SHIM_EAGER=eager)
+        r = subprocess.run([exe, "6"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
+        assert r.returncode == 0, r.stdout[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0]["failures"] == 0 and outs[1]["failures"] == 0
+    assert outs[0]["eager"] is False and outs[1]["eager"] is True
+    assert outs[0]["cppoly_verify"] == outs[1]["cppoly_verify"]
+
+
 def test_cplink_built_by_the_references_own_cmake_verifies():
     """The reference's unchanged CMakeLists.txt with depends/libsnark and depends/fmt replaced by
     legosnark_amd/shim/cmake (targets snark, ff, fmt::fmt-header-only)."""
