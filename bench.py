@@ -23,8 +23,15 @@ of the timed loop's last step is checked by the known-discrete-log identity.
 
 Prints ONE JSON line (rank 0) with the throughput, a `roofline` object for the dominant kernel
 (bucket accumulation; 96 algorithmic bytes per pair against the HBM peak, plus the field-
-multiplication rate against the measured integer ceiling, which is what really bounds it) and a
-`cpu_baseline` object (the oracle = libff-algorithm restatement, timed on this host).
+multiplication rate against the measured integer ceiling, which is what really bounds it), a
+`cpu_baseline` object (the oracle = libff-algorithm restatement, timed on this host) and a `configs`
+block: the other BASELINE.json configs (G2 MSM 2^20, CPpoly d=20, the 2^12-pairing product, the CPhad
+verifier shape, the CPlink prover MSM), each result-checked, each with its time, algorithmic bytes and
+field-multiplication rate (legosnark_amd/benchcfg.py).
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks (one child
+`python -m torch.distributed.run --nproc-per-node N bench.py ...`, started before this process
+touches torch or the GPU) and relays rank 0's line; the line's n_gpus must equal N or the run fails.
 """
 import argparse
 import json
@@ -100,6 +107,45 @@ def pmc_traffic(kernel_substr="k_accumulate", exclude="heavy", timeout_s=150):
                       "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 half-count correction, calibrated on streaming reads)"}
 
 
+def being_profiled():
+    """True under rocprofv3 / rocprof (their preloaded tool library): no nested profiler runs then."""
+    env = os.environ
+    return any(k.startswith("ROCPROF") or k.startswith("ROCP_") for k in env) or "rocprof" in env.get("LD_PRELOAD", "") or \
+        "rocprofiler" in env.get("LD_PRELOAD", "") or "rocprofiler" in env.get("HSA_TOOLS_LIB", "")
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 without a launcher: start N ranks as ONE child process tree (torch.distributed.run), relay
+    rank 0's JSON line, fail unless it reports n_gpus == N.  Runs before this process imports torch or touches the
+    GPU; the parent never initialises a device (no exec from a GPU-initialised process either)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if r.returncode != 0 or line is None:
+        sys.stderr.write("bench.py: the %d-rank run failed (exit %d)\n%s\n" % (args.gpus, r.returncode, r.stdout[-2000:]))
+        return r.returncode or 1
+    got = json.loads(line).get("n_gpus")
+    if got != args.gpus:
+        sys.stderr.write("bench.py: asked for %d GPUs, the ranks report n_gpus = %r\n" % (args.gpus, got))
+        return 1
+    print(line, flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,12 +159,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
+    ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE.json configs)")
+    ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1: print the launch command and exit")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, [a for a in sys.argv[1:] if a != "--dry-launch"]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("WORLD_SIZE (%s) != --gpus (%d): this run would not measure what it was asked to" % (os.environ.get("WORLD_SIZE", "unset"), args.gpus))
 
     # roofline.traffic: two short profiled child runs of this script, before this process
     # initialises the GPU (or even imports torch)
     traffic = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_pmc and not args.total_log2n and args.log2n == 20:
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_pmc and not args.total_log2n and args.log2n == 20 and not being_profiled():
         traffic = pmc_traffic()
 
     import numpy as np
@@ -129,8 +184,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # debug hooks to exercise the multi-process path on a one-GPU box: every rank on cuda:0 and
@@ -403,7 +456,7 @@ def main():
                                     + ("lsa_msm_run_sharded_async (C-ABI, csrc/comm.hip)" if comm_kind == "capi" else "torch.distributed + lsa_g1_sum_on"))
                        if world > 1 else "single GPU"},
             "result_checked_by_identity": checked,
-            "roofline": {"kernel": "k_accumulate<CurveG1>", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": "k_accumulate<CurveG1>", "bound": "hbm", "limited_by": "integer VALU (see valu)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
                          "algorithmic_bytes_per_launch": n_local * ALG_BYTES_PER_PAIR,
@@ -422,6 +475,13 @@ def main():
                           "step i+1; stage_ms are measured under that overlap; LSA_NO_OVERLAP=1 serialises",
         }
         out.update(extra)
+        if not args.no_configs and world == 1 and not strong and args.log2n == 20:
+            # the other BASELINE.json configs, each result-checked (a failed check carries "error" and no time)
+            from legosnark_amd import benchcfg
+            out["configs"] = benchcfg.measure(lsa, torch, np, dev, log2n=20, d=20, log2pairs=12, reps=5,
+                                              only={"g2_msm", "cppoly", "pairing", "cphad_verify"})
+            if any("error" in c for c in out["configs"]):
+                raise SystemExit("bench.py: a config's result check failed: %s" % [c for c in out["configs"] if "error" in c])
         if not args.no_cpu_baseline and world == 1 and not strong:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as o   # the checker, timed as the reported CPU baseline

@@ -15,7 +15,9 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "liblegosnark_amd.so")
+# LSA_LIB_VARIANT=loopback: the TEST build whose comm.hip carries the one-GPU stand-in for a multi-rank collective
+# (csrc/Makefile); the product library is the default and does not contain it
+LIB_PATH = os.path.join(_PKG, "liblegosnark_amd_loopback.so" if os.environ.get("LSA_LIB_VARIANT") == "loopback" else "liblegosnark_amd.so")
 _lib = None
 
 MSM_STAGES = 8

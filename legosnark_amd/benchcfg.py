@@ -1,0 +1,257 @@
+"""Measurements of the BASELINE.json configs that are not the headline bench line, shared by bench.py (its
+`configs` block) and tools/bench_configs.py.  EVERY time returned belongs to a result that was checked in the same
+run -- by the known-discrete-log identity (k*G recomputed by the fixed-base batch_exp kernel, a different code path
+from the MSM) or, for pairings, by planted products that must equal one.  A config whose check fails returns
+{"config": ..., "error": ...} and no time.
+
+  cplink_prover   SubspaceSnark::prove shape (subspace.cc:78-85): MSM over N+2 pairs, w[0] = 0
+  g2_msm          alt_bn128 G2 MSM
+  cppoly          CPpoly d-variable commit + prove ladder (poly.h:30-32,76-88)
+  pairing         ONE product of 2^k Miller loops over pairs never seen + one final exponentiation (BASELINE configs[4])
+  cphad_verify    the CPhad verifier's pairing shape: 187 Miller loops in 62 products, 62 final exponentiations; with
+                  every Q resident (a verifier's keys) and with every Q fresh
+Inputs follow legosnark_amd/synth.py.  Field-multiplication counts are libff-shape operation counts
+(Fq2 product = 3 Fq products, Fq2 square = 2), stated per line; the ceiling is the microbenchmarked chip-wide rate of
+the 9 x 29-bit Montgomery product (profiles/r01_ubench_field_mul.txt)."""
+import time
+
+FMUL_PEAK_G = 175.0
+HBM_PEAK_GBS = 8000.0
+FQ_PER_FQ2_MUL, FQ_PER_FQ2_SQR = 3, 2
+# one Miller loop as libff runs it: 64 doubling steps, 36 + 2 addition steps.  G2 side of a doubling step: 4 Fq2
+# products + 6 squares; of an addition step: 11 + 2; f side: Fq12 square (12 Fq2 products) + mul_by_024 (13), resp.
+# mul_by_024; 4 Fq products scale each line by (px, py)
+MILLER_G2_DBL = 4 * FQ_PER_FQ2_MUL + 6 * FQ_PER_FQ2_SQR
+MILLER_G2_ADD = 11 * FQ_PER_FQ2_MUL + 2 * FQ_PER_FQ2_SQR
+MILLER_F_DBL = (12 + 13) * FQ_PER_FQ2_MUL + 4
+MILLER_F_ADD = 13 * FQ_PER_FQ2_MUL + 4
+MILLER_FQ_MULS = 64 * (MILLER_G2_DBL + MILLER_F_DBL) + 38 * (MILLER_G2_ADD + MILLER_F_ADD)      # 9 632: the G2 arithmetic included
+MILLER_FQ_MULS_RESIDENT = 64 * MILLER_F_DBL + 38 * MILLER_F_ADD                               # 6 690: over a resident line table
+# final exponentiation: 3 exp-by-z of 62 cyclotomic squarings (9 Fq2 squares) + ~19 products (18 Fq2 products), ~20 more
+# products, one inversion (~100 Fq products), 5 Frobenius maps
+FINAL_EXP_FQ_MULS = 3 * (62 * 9 * FQ_PER_FQ2_SQR + 19 * 18 * FQ_PER_FQ2_MUL) + 20 * 18 * FQ_PER_FQ2_MUL + 100 + 5 * 15
+G2_MSM_FQ_MULS_PER_ADD = 10 * FQ_PER_FQ2_MUL      # XYZZ mixed addition over Fq2: 8 products + 2 squares, counted as 10 products
+
+
+def measure(lsa, torch, np, dev, log2n=20, d=20, log2pairs=12, reps=5, only=None):
+    """Runs the selected configs on `dev` and returns a list of dicts (one per line)."""
+    from legosnark_amd import curve, synth
+    G1, G2 = curve.generator("g1"), curve.generator("g2")
+    rng = synth.Xoshiro256ss(seed=synth.SEED ^ 0xBC)
+    rinv = pow(curve.MONT, -1, curve.R)
+    out = []
+
+    def to_dev(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+
+    def host(t):
+        return t.cpu().numpy().view(np.uint64)
+
+    def affine(group, pts):
+        w = 12 if group == "g1" else 24
+        return lsa.normalize(group, np.ascontiguousarray(pts, dtype=np.uint64).reshape(-1, w))
+
+    def k_times_gen(group, ks):
+        sc = np.stack([curve.fr_mont(k) for k in ks])
+        return affine(group, lsa.batch_exp(group, G1 if group == "g1" else G2, sc))
+
+    def timed(fn, n):
+        fn(); lsa.synchronize(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        lsa.synchronize(); torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def best_of(fn, n, before=None):
+        fn()
+        ts = []
+        for _ in range(n):
+            if before:
+                before()
+            t0 = time.perf_counter()
+            r = fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return r, min(ts)
+
+    def emit(cfg, ok, fields):
+        if not ok:
+            out.append({"config": cfg, "error": "result check failed -- no time reported"})
+            return
+        dct = {"config": cfg, "result_checked": True}
+        dct.update(fields)
+        out.append(dct)
+
+    def valu(fq_mults, ms):
+        g = fq_mults / (ms * 1e-3) / 1e9
+        return {"achieved_Gfmul_s": round(g, 3), "peak_Gfmul_s": FMUL_PEAK_G, "frac": round(g / FMUL_PEAK_G, 4), "fq_mults": int(fq_mults)}
+
+    def on(name):
+        return only is None or name in only
+
+    half = max(1, reps // 2)
+    if on("cplink_prover"):
+        N = 1 << log2n
+        a, b = rng.fr_int(), rng.fr_int()
+        x = synth.arith_fr_mont(a, b, N + 2)
+        w = rng.uniform_fr(N + 2)
+        w[0] = 0
+        P = lsa.Bases("g1", lsa.batch_exp("g1", G1, to_dev(x)), on_device=True)
+        d_w = to_dev(w)
+        res = torch.zeros(12, dtype=torch.int64, device=dev)
+        ms = timed(lambda: P.msm_async(d_w, res), reps)
+        ok = np.array_equal(affine("g1", host(res))[0], k_times_gen("g1", [synth.fr_dot_mont(w, x)])[0])
+        fm = P.field_mults_per_pair(N + 2)
+        emit("CPlink prover (SubspaceSnark::prove MSM), N=2^%d, resident CRS and witness" % log2n, ok,
+             {"pairs": N + 2, "ms": ms, "algorithmic_bytes": 96 * (N + 2), "valu": valu((N + 2) * fm, ms)})
+        P.close()
+
+    if on("g2_msm"):
+        n = 1 << log2n
+        a, b = rng.fr_int(), rng.fr_int()
+        x = synth.arith_fr_mont(a, b, n)
+        s = rng.uniform_fr(n)
+        Q = lsa.Bases("g2", lsa.batch_exp("g2", G2, to_dev(x)), on_device=True)
+        d_s = to_dev(s)
+        res = torch.zeros(24, dtype=torch.int64, device=dev)
+        ms = timed(lambda: Q.msm_async(d_s, res), half)
+        ok = np.array_equal(affine("g2", host(res))[0], k_times_gen("g2", [synth.fr_dot_mont(s, x)])[0])
+        adds = Q.field_mults_per_pair(n) // 10 if Q.has_table() else 16
+        emit("G2 MSM n=2^%d, resident bases" % log2n, ok,
+             {"ms": ms, "pairs_per_s": n / ms * 1e3, "algorithmic_bytes": 160 * n, "hbm_frac_algorithmic": round(160 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+              "valu": valu(n * adds * G2_MSM_FQ_MULS_PER_ADD, ms), "bucket_additions_per_pair": adds})
+        Q.close()
+
+    if on("cppoly"):
+        n = 1 << d
+        g1 = torch.from_numpy(G1.view(np.int64)).to(dev).repeat(n, 1).contiguous()
+        g2 = torch.from_numpy(G2.view(np.int64)).to(dev).repeat(n, 1).contiguous()
+        B1 = lsa.Bases("g1", g1, on_device=True)
+        B2 = lsa.Bases("g2", g2, on_device=True)
+        del g1, g2
+        v = rng.uniform_fr(n)
+        s = to_dev(v)
+        o1 = torch.zeros(12, dtype=torch.int64, device=dev)
+        o2 = torch.zeros(24, dtype=torch.int64, device=dev)
+
+        def commit():                                # commit.h:154-155: one shared scalar sort
+            lsa.commit_async(B1, B2, s, o1, o2)
+
+        def commit_two_calls():
+            B1.msm_async(s, o1)
+            B2.msm_async(s, o2)
+
+        r = to_dev(rng.uniform_fr(d))
+        w = torch.empty_like(s)
+        outs = torch.zeros((2 * d, 12), dtype=torch.int64, device=dev)
+
+        def fold():
+            lsa.cppoly_witness(s, r, out=w)          # poly.h:55-67 on the device
+
+        def ladder():                                # poly.h:76-88, scalars = slices of w
+            start = 0
+            for i in range(d):
+                m = 1 << (d - 1 - i)
+                B1.msm_async(w[start:start + m], outs[2 * i], n=m)
+                if i:
+                    B1.msm_async(w[start:start + m], outs[2 * i + 1], n=m)
+                start += m
+
+        # the ladder as an integrator issues it: rungs of up to 2^15 pairs in ONE segmented call (consecutive slices
+        # of w; witnessa[i] is the same sum as witness[i] and is not recomputed), the longer rungs one call each
+        starts = np.concatenate([[0], np.cumsum([1 << (d - 1 - i) for i in range(d)])]).astype(np.uint64)
+        first_small = next(i for i in range(d) if (1 << (d - 1 - i)) <= (1 << 15))
+        seg_outs = torch.zeros((d, 12), dtype=torch.int64, device=dev)
+
+        def ladder_segmented():
+            for i in range(first_small):
+                B1.msm_async(w[int(starts[i]):int(starts[i + 1])], seg_outs[i], n=1 << (d - 1 - i))
+            B1.msm_segments_async(w, starts[first_small:], seg_outs[first_small:])
+
+        def prove():
+            fold()
+            ladder_segmented() if B1.has_table() else ladder()
+
+        ms_c2 = timed(commit_two_calls, half)
+        ms_c = timed(commit, half)
+        ms_f = timed(fold, half)
+        ms_l = timed(ladder, half)
+        ms_ls = timed(ladder_segmented, half) if B1.has_table() else None
+        ms_p = timed(prove, half)
+        vs = synth.fr_sum_mont(v)
+        ok = np.array_equal(affine("g1", host(o1))[0], k_times_gen("g1", [vs])[0])
+        ok = ok and np.array_equal(affine("g2", host(o2))[0], k_times_gen("g2", [vs])[0])
+        wh = host(w)
+        ks, slots, start = [], [], 0
+        for i in range(d):
+            m = 1 << (d - 1 - i)
+            k = synth.fr_sum_mont(wh[start:start + m])
+            ks.append(k); slots.append(2 * i)
+            if i:
+                ks.append(k); slots.append(2 * i + 1)
+            start += m
+        want_pts = k_times_gen("g1", ks)
+        ok = ok and np.array_equal(affine("g1", host(outs)[slots]), want_pts)
+        if B1.has_table():
+            seg_slots = [sl // 2 for sl in slots]
+            ok = ok and np.array_equal(affine("g1", host(seg_outs)[seg_slots]), want_pts)
+        fm1 = B1.field_mults_per_pair(n)
+        adds2 = B2.field_mults_per_pair(n) // 10 if B2.has_table() else 16
+        emit("CPpoly d=%d: commit (G1 + G2 MSM of 2^%d, one shared sort) and prove (witness recursion + MSM ladder)" % (d, d), ok,
+             {"commit_ms": ms_c, "commit_as_two_msm_calls_ms": ms_c2, "prove_fold_ms": ms_f, "prove_msm_ladder_39_calls_ms": ms_l,
+              "prove_msm_ladder_segmented_ms": ms_ls, "prove_total_ms": ms_p, "prove_pairs": (n - 1) + (n // 2 - 1), "msms_checked": len(ks) + 2,
+              "commit_algorithmic_bytes": (96 + 160) * n, "commit_valu": valu(n * (fm1 + adds2 * G2_MSM_FQ_MULS_PER_ADD), ms_c)})
+        B1.close(); B2.close()
+
+    fq12_one = np.zeros(48, dtype=np.uint64)
+    fq12_one[0:4] = curve.fq_mont(1)
+
+    def fr_int(limbs):
+        return synth.limbs_to_int(limbs) * rinv % curve.R
+
+    def planted(n):
+        """n pairs (alpha_i G1, beta_i G2), normalised, with sum alpha_i beta_i = 0: the product of their pairings is one."""
+        al, be = rng.uniform_fr(n), rng.uniform_fr(n)
+        be[-1] = curve.fr_mont((-synth.fr_dot_mont(al[:-1], be[:-1])) * pow(fr_int(al[-1]), -1, curve.R) % curve.R)
+        return lsa.normalize("g1", lsa.batch_exp("g1", G1, al)), lsa.normalize("g2", lsa.batch_exp("g2", G2, be))
+
+    if on("pairing"):
+        n = 1 << log2pairs
+        ps, qs = planted(n)
+        res, ms = best_of(lambda: lsa.pairing_product(ps, qs), max(2, reps))
+        emit("pairing product: 2^%d Miller loops on pairs never seen + 1 final exponentiation (host buffers, planted == 1)" % log2pairs,
+             np.array_equal(res, fq12_one),
+             {"ms": ms, "pairings_per_s": n / ms * 1e3, "algorithmic_bytes": 192 * n + 384,
+              "valu": valu(n * MILLER_FQ_MULS + FINAL_EXP_FQ_MULS, ms),
+              "note": "whole call (upload + Miller loops + product tree + final exponentiation); more than 1024 pairs bypass the "
+                      "line-table cache, so every call redoes the G2 arithmetic"})
+
+    if on("cphad_verify"):
+        # CPhad verify at d = 20: 187 Miller loops in 62 products, each followed by a final exponentiation
+        sizes = [3] * 61 + [4]
+        groups = [planted(m) for m in sizes]
+        ps = np.concatenate([g[0] for g in groups]); qs = np.concatenate([g[1] for g in groups])
+        edges = np.cumsum([0] + sizes).astype(np.uint64)
+        nl, nf = len(ps), len(sizes)
+        lsa.g2_table_cache(4096)
+        res, ms = best_of(lambda: lsa.pairing_product_segments(ps, qs, edges), max(2, reps))
+        emit("CPhad verifier shape: %d Miller loops in %d products + %d final exponentiations, every Q resident (keys)" % (nl, nf, nf),
+             all(np.array_equal(r_, fq12_one) for r_ in res),
+             {"ms": ms, "algorithmic_bytes": 192 * nl + 384 * nf, "valu": valu(nl * MILLER_FQ_MULS_RESIDENT + nf * FINAL_EXP_FQ_MULS, ms)})
+        lsa.g2_table_cache(0)
+        res, ms = best_of(lambda: lsa.pairing_product_segments(ps, qs, edges), max(2, reps))
+        emit("CPhad verifier shape: %d Miller loops in %d products + %d final exponentiations, every Q fresh (table cache off)" % (nl, nf, nf),
+             all(np.array_equal(r_, fq12_one) for r_ in res),
+             {"ms": ms, "algorithmic_bytes": 192 * nl + 384 * nf, "valu": valu(nl * MILLER_FQ_MULS + nf * FINAL_EXP_FQ_MULS, ms)})
+        lsa.g2_table_cache(4096)
+        # one Miller loop and one whole check, as the reference's verifiers issue them (globl.h:94-105)
+        P1, Q1 = ps[:1], qs[:1]
+        ref = lsa.miller_loop(P1, Q1)
+        res, ms = best_of(lambda: lsa.miller_loop(P1, Q1), max(3, reps))
+        emit("one miller_loop on a resident Q (host buffers, blocking)", np.array_equal(res, ref), {"ms": ms, "valu": valu(MILLER_FQ_MULS_RESIDENT, ms)})
+        p2, q2 = planted(2)
+        off2 = np.array([0, 2], dtype=np.uint64)
+        res, ms = best_of(lambda: lsa.pairing_terms(p2, off2, g2=q2), max(3, reps))
+        emit("one pairing check of two terms (simple_pairing_check as one product), both Q resident", np.array_equal(res[0], fq12_one),
+             {"ms": ms, "valu": valu(2 * MILLER_FQ_MULS_RESIDENT + FINAL_EXP_FQ_MULS, ms)})
+    return out

@@ -224,8 +224,9 @@ int lsa_commit_run_async(const lsa_bases *g1_bases, const lsa_bases *g2_bases, c
     if (!g1_bases || !g2_bases || !d_out_g1 || !d_out_g2 || (n && !d_scalars)) { set_error("commit_run: null argument"); return LSA_ERR_INVALID; }
     if (g1_bases->group != 1 || g2_bases->group != 2) { set_error("commit_run: needs a G1 and a G2 handle, in that order"); return LSA_ERR_INVALID; }
     if (n > g1_bases->n || n > g2_bases->n) { set_error("commit_run: %zu pairs exceed the bases (%zu, %zu)", n, g1_bases->n, g2_bases->n); return LSA_ERR_INVALID; }
-    // one shared sort when both handles carry copies over the same number of points; else two calls
-    if (n && g1_bases->table_stride && g1_bases->table_stride == g2_bases->table_stride)
+    // one shared sort when both handles carry copies over the same number of points AND an MSM of n pairs runs
+    // over them (an explicit table threshold above n sends both to the plain pipeline); else two calls
+    if (n && g1_bases->table_stride && g1_bases->table_stride == g2_bases->table_stride && msm_uses_table(n))
         return msm_commit_pair_device(g1_bases->d_aff, g2_bases->d_aff, (const Fr *)d_scalars, n, (Jac<Fq> *)d_out_g1, (Jac<Fq2> *)d_out_g2, g.stream,
                                       g1_bases->table_stride);
     rc = msm_device<Fq>(g1_bases->d_aff, 0, (const Fr *)d_scalars, n, (Jac<Fq> *)d_out_g1, g.stream, g1_bases->table_stride);
@@ -346,7 +347,12 @@ class HashPool {
         cv_.notify_all();
         for (auto &t : th_) if (t.joinable()) t.join();
         th_.clear();
+        // back to the initial state: workers started later begin with seen = 0 and must find gen_ = 0, or each
+        // would take a phantom first generation and decrement active_ once too often (lsa_shutdown -> lsa_init)
+        std::lock_guard<std::mutex> lk(m_);
         stop_ = false;
+        gen_ = 0;
+        active_ = 0;
     }
     // starts hashing `bytes` bytes (a multiple of 8) in units of unit_bytes (the last one may be
     // short); out: one u64 per unit; a task = units_per_task consecutive units
@@ -356,15 +362,17 @@ class HashPool {
         ntasks_ = (nunits_ + units_per_task - 1) / units_per_task;
         next_.store(0);
         if (ntasks_ < 8) return;                     // small: the caller does it alone in finish()
-        if (th_.empty()) {
-            unsigned hw = std::thread::hardware_concurrency();
-            const char *e = getenv("LSA_HASH_THREADS");
-            unsigned want = e ? (unsigned)atoi(e) : (hw > 16 ? 15 : (hw > 1 ? hw - 1 : 0));
-            for (unsigned i = 0; i < want; i++) th_.emplace_back([this] { loop(); });
-        }
-        if (th_.empty()) return;
         {
+            // workers are spawned inside the block that publishes the generation: none can observe a
+            // half-initialised pool
             std::lock_guard<std::mutex> lk(m_);
+            if (th_.empty()) {
+                unsigned hw = std::thread::hardware_concurrency();
+                const char *e = getenv("LSA_HASH_THREADS");
+                unsigned want = e ? (unsigned)atoi(e) : (hw > 16 ? 15 : (hw > 1 ? hw - 1 : 0));
+                for (unsigned i = 0; i < want; i++) th_.emplace_back([this] { loop(); });
+            }
+            if (th_.empty()) return;
             active_ = th_.size();
             gen_++;
         }
@@ -566,15 +574,11 @@ static inline double ms_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// this process's MSM into g.d_result (stream-ordered, tails joined); the host-side wall-clock split in `st`
 template <class F>
-static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *out_jac, int group, bool sharded = false) {
-    int rc = require_ready();
-    if (rc) return rc;
-    if (sharded && lsa_comm_world() <= 1) sharded = false;
-    if (!out_jac || (n && (!bases_jac || !scalars))) { set_error("msm: null argument"); return LSA_ERR_INVALID; }
-    const auto t_all = std::chrono::steady_clock::now();
-    lsa_host_stats st = {};
-    st.n = n;
+static int msm_host_local(const void *bases_jac, const void *scalars, size_t n, int group, lsa_host_stats &st,
+                          std::chrono::steady_clock::time_point &t_msm) {
+    int rc = LSA_OK;
     crs_configure_from_env();
     const bool cached = g_crs.mode != 0 && n >= CRS_MIN_POINTS;
     if (g_stage_scalars.ensure(n * sizeof(Fr))) { set_error("msm: staging allocation failed"); return LSA_ERR_NOMEM; }
@@ -620,20 +624,37 @@ static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *
         }
         d_bases = g_stage_bases.p;
     }
-    auto t0 = std::chrono::steady_clock::now();
+    t_msm = std::chrono::steady_clock::now();
     rc = msm_device<F>(d_bases, 0, (const Fr *)g_stage_scalars.p, n, (Jac<F> *)g.d_result, g.stream, table_stride);
     if (rc) return rc;
-    rc = msm_join(g.stream);
+    return msm_join(g.stream);
+}
+
+template <class F>
+static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *out_jac, int group, bool sharded = false) {
+    int rc = require_ready();
     if (rc) return rc;
+    if (sharded && lsa_comm_world() <= 1) sharded = false;
+    if (!out_jac || (n && (!bases_jac || !scalars))) { set_error("msm: null argument"); return LSA_ERR_INVALID; }
+    const auto t_all = std::chrono::steady_clock::now();
+    lsa_host_stats st = {};
+    st.n = n;
+    auto t0 = std::chrono::steady_clock::now();
+    rc = msm_host_local<F>(bases_jac, scalars, n, group, st, t0);
     if (sharded) {
-        // this rank's slice is one libff chunk: all-gather the partials, sum them in rank order
+        // this rank's slice is one libff chunk: all-gather the partials, sum them in rank order.  A rank whose
+        // local part failed still takes part (with the point at infinity: all-zero bytes) and reports its error
+        // afterwards -- the other ranks must not be left blocking in ncclAllGather.
+        const int local = rc;
         const size_t world = (size_t)lsa_comm_world();
+        if (local) (void)hipMemsetAsync(g.d_result, 0, sizeof(Jac<F>), g.stream);
         if (g_stage_gather.ensure(world * sizeof(Jac<F>))) { set_error("msm: staging allocation failed"); return LSA_ERR_NOMEM; }
         rc = lsa_comm_all_gather(g.d_result, g_stage_gather.p, group);
+        if (local) return local;
         if (rc) return rc;
         rc = sum_points_device<F>((const Jac<F> *)g_stage_gather.p, world, (Jac<F> *)g.d_result, g.stream);
-        if (rc) return rc;
     }
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(g.h_result, g.d_result, sizeof(Jac<F>), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     memcpy(out_jac, g.h_result, sizeof(Jac<F>));

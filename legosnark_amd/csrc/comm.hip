@@ -16,6 +16,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
+#include <time.h>
 #include <unistd.h>
 #include <chrono>
 #include <thread>
@@ -39,15 +41,19 @@ struct Comm {
     hipEvent_t done[DEPTH] = {};
     bool used[DEPTH] = {};
     unsigned calls = 0;
-    // test hook (env LSA_COMM_LOOPBACK=W with a one-rank communicator): behave as rank 0 of W ranks
-    // whose peers all contribute THIS rank's partial -- the collective becomes W device copies, so the
-    // whole multi-rank step (side stream, rotating buffers, events, fold) runs on one GPU, where RCCL
-    // itself refuses more than one rank; the result is W times the local one
+#if defined(LSA_COMM_TEST_LOOPBACK)
+    // TEST BUILD ONLY (liblegosnark_amd_loopback.so, csrc/Makefile; the product library does not contain it): env
+    // LSA_COMM_LOOPBACK=W with a one-rank communicator behaves as rank 0 of W ranks whose peers all contribute THIS
+    // rank's partial -- the collective becomes W device copies, so the whole multi-rank step (side stream, rotating
+    // buffers, events, fold) runs on one GPU, where RCCL itself refuses more than one rank; the result is W times
+    // the local one
     int loopback = 0;
+#endif
 } c;
 
 // all-gather of `bytes` per rank on `stream` (ncclAllGather of u64 words, or the loopback copies)
 int gather_all(const void *send, void *recv, size_t bytes, hipStream_t stream) {
+#if defined(LSA_COMM_TEST_LOOPBACK)
     if (c.loopback) {
         for (int r = 0; r < c.world; r++)
             if (hipMemcpyAsync((char *)recv + (size_t)r * bytes, send, bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
@@ -56,6 +62,7 @@ int gather_all(const void *send, void *recv, size_t bytes, hipStream_t stream) {
             }
         return LSA_OK;
     }
+#endif
     ncclResult_t r_ = ncclAllGather(send, recv, bytes / 8, ncclUint64, c.comm, stream);
     if (r_ != ncclSuccess) { set_error("ncclAllGather failed: %s", ncclGetErrorString(r_)); return LSA_ERR_HIP; }
     return LSA_OK;
@@ -147,8 +154,10 @@ int lsa_comm_init(int rank, int world, const void *id128) {
     NCCLCHK(ncclCommInitRank(&c.comm, world, id, rank));
     c.rank = rank;
     c.world = world;
+#if defined(LSA_COMM_TEST_LOOPBACK)
     const char *lb = getenv("LSA_COMM_LOOPBACK");
     if (world == 1 && lb && atoi(lb) > 1 && atoi(lb) <= 64) { c.loopback = atoi(lb); c.world = c.loopback; }
+#endif
     HIPCHK(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&c.front, hipEventDisableTiming));
     for (int j = 0; j < DEPTH; j++) {
@@ -158,6 +167,32 @@ int lsa_comm_init(int rank, int world, const void *id128) {
     }
     c.active = true;
     return LSA_OK;
+}
+
+// when this process started (seconds since the epoch): /proc/self/stat field 22 is in clock ticks since boot; the
+// library's own first use is a good enough stand-in when /proc is not there
+static time_t process_start_time() {
+    static const time_t first_use = time(nullptr);
+    FILE *f = fopen("/proc/self/stat", "r");
+    if (!f) return first_use;
+    char buf[2048];
+    size_t got = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[got] = 0;
+    const char *p = strrchr(buf, ')');           // the command name may contain spaces
+    if (!p) return first_use;
+    unsigned long long ticks = 0;
+    int field = 2;
+    for (p++; *p && field < 22; p++) if (*p == ' ') field++;
+    if (field != 22 || sscanf(p, "%llu", &ticks) != 1) return first_use;
+    double up = 0;
+    FILE *u = fopen("/proc/uptime", "r");
+    if (!u) return first_use;
+    const int ok = fscanf(u, "%lf", &up);
+    fclose(u);
+    if (ok != 1) return first_use;
+    const long hz = sysconf(_SC_CLK_TCK);
+    return (time_t)((double)time(nullptr) - up + (double)ticks / (double)(hz > 0 ? hz : 100));
 }
 
 // single-node bootstrap for C++ callers without their own transport: rank 0 writes the id to
@@ -177,9 +212,13 @@ int lsa_comm_init_file(int rank, int world, const char *path, int timeout_s) {
         fclose(f);
         if (rename(tmp, path) != 0) { set_error("comm_init_file: cannot rename %s -> %s", tmp, path); return LSA_ERR_INVALID; }
     } else {
+        // a file left behind by an earlier (crashed) run must not be taken for this run's id: only a file written
+        // after this process started counts (one node, one clock; the ranks of a job start together)
         const auto t0 = std::chrono::steady_clock::now();
+        const time_t not_before = process_start_time() - 2;
         for (;;) {
-            FILE *f = fopen(path, "rb");
+            struct stat sb;
+            FILE *f = (stat(path, &sb) == 0 && sb.st_mtime >= not_before) ? fopen(path, "rb") : nullptr;
             if (f) {
                 size_t got = fread(id, 1, sizeof id, f);
                 fclose(f);

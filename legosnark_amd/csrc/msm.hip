@@ -1579,6 +1579,8 @@ size_t msm_merge_min() {
     return g_merge_min;
 }
 static size_t table_use_min() { return g_merge_min_explicit ? msm_merge_min() : 1; }
+// whether an MSM of n pairs on a handle that carries the copies runs over them (the wide-window pipeline)
+bool msm_uses_table(size_t n) { return n >= table_use_min(); }
 
 template <class C>
 __global__ __launch_bounds__(256) void k_shift_window(const typename C::Base *__restrict__ prev, Jac<typename C::Field> *__restrict__ out,

@@ -5,7 +5,7 @@
 // Every rank builds the same CRS P (N + 2 points, as SubspaceSnark::prove sees it,
 // src/gadgets/subspace.cc:78-85) and witness w, takes the contiguous range libff's multi_exp
 // would give chunk `rank` (lsa_shard_range), and calls the UNCHANGED multiExpMA on that chunk:
-// with a communicator set, the shim's multi_exp forwards to lsa_g1_msm_sharded (local MSM +
+// inside a libff::lsa_sharded_scope (and with a communicator set) the shim's multi_exp forwards to lsa_g1_msm_sharded (local MSM +
 // one RCCL all-gather of the 96-byte partials + sum), so every rank receives the proof element.
 // Rank 0 compares it with the single-GPU multiExpMA over the whole vectors.
 //
@@ -46,10 +46,16 @@ int main(int argc, char **argv) {
     lsa_shard_range(n, world, rank, &lo, &hi);
     vector<LG1> P_chunk(P.begin() + lo, P.begin() + hi);
     vector<LFr> w_chunk(w.begin() + lo, w.begin() + hi);
-    LG1 sharded = multiExpMA<LG1>(P_chunk, w_chunk);          // unchanged reference call; sum over all ranks
-    LG1 again = multiExpMA<LG1>(P_chunk, w_chunk);            // second call: CRS cache hit on the chunk
+    LG1 sharded, again;
+    {
+        libff::lsa_sharded_scope spmd;                         // inside: this rank's chunk in, the sum over all ranks out
+        sharded = multiExpMA<LG1>(P_chunk, w_chunk);          // unchanged reference call
+        again = multiExpMA<LG1>(P_chunk, w_chunk);            // second call: CRS cache hit on the chunk
+    }
+    // outside the scope a multi_exp over replicated inputs stays a whole sum on this GPU, communicator or not
+    LG1 replicated = multiExpMA<LG1>(P, w);
 
-    const bool ok = sharded == whole && again == whole;
+    const bool ok = sharded == whole && again == whole && replicated == whole;
     printf("{\"rank\": %d, \"world\": %d, \"n\": %zu, \"chunk\": [%zu, %zu], \"matches_single_gpu\": %s}\n", rank, world, n, lo, hi,
            ok ? "true" : "false");
     lsa_comm_destroy();

@@ -744,6 +744,17 @@ template <class T> struct group_id;
 template <> struct group_id<alt_bn128_G1> { static const int value = 1; };
 template <> struct group_id<alt_bn128_G2> { static const int value = 2; };
 
+}  // namespace detail
+// RAII: multi_exp / multiExpMA calls inside the scope are the SPMD form -- this rank's chunk in, the sum over all
+// ranks out.  Every rank must issue the same sequence of such calls (each is a collective).
+struct lsa_sharded_scope {
+    lsa_sharded_scope() { depth()++; }
+    ~lsa_sharded_scope() { depth()--; }
+    lsa_sharded_scope(const lsa_sharded_scope &) = delete;
+    lsa_sharded_scope &operator=(const lsa_sharded_scope &) = delete;
+    static int &depth() { static thread_local int d = 0; return d; }
+};
+namespace detail {
 template <class T, class FieldT>
 T msm_forward(typename std::vector<T>::const_iterator vec_start, typename std::vector<T>::const_iterator vec_end,
               typename std::vector<FieldT>::const_iterator scalar_start, typename std::vector<FieldT>::const_iterator scalar_end,
@@ -755,11 +766,12 @@ T msm_forward(typename std::vector<T>::const_iterator vec_start, typename std::v
     T out;
     const void *b = n ? (const void *)&*vec_start : nullptr;
     const void *s = n ? (const void *)&*scalar_start : nullptr;
-    // SPMD provers (one process per GPU, lsa_comm_init done): every rank passes ITS chunk of the
-    // vectors -- the contiguous range lsa_shard_range() gives it, i.e. libff's own `chunks` split
-    // with chunks = world -- and receives the sum over all ranks (one RCCL all-gather of the
-    // Jacobian partials).  Without a communicator this is the single-GPU call.
-    if (lsa_comm_world() > 1) {
+    // SPMD provers (one process per GPU, lsa_comm_init done) inside an lsa_sharded_scope: every rank passes ITS
+    // chunk of the vectors -- the contiguous range lsa_shard_range() gives it, i.e. libff's own `chunks` split with
+    // chunks = world -- and receives the sum over all ranks (one RCCL all-gather of the Jacobian partials).
+    // Outside such a scope a multi_exp is a whole sum on this GPU even when a communicator exists: the call site
+    // cannot say whether its vectors are a chunk or everything (keygen, commitments over replicated inputs).
+    if (lsa_sharded_scope::depth() > 0 && lsa_comm_world() > 1) {
         if (group_id<T>::value == 1) lsa_require(lsa_g1_msm_sharded(b, s, n, &out), "multi_exp<G1> (sharded)");
         else lsa_require(lsa_g2_msm_sharded(b, s, n, &out), "multi_exp<G2> (sharded)");
         return out;

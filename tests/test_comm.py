@@ -82,41 +82,59 @@ def test_one_rank_communicator_matches_single_gpu_entry_points(lsa, tmp_path):
     lsa.comm_destroy()
 
 
+_LOOPBACK_BODY = r"""
+import numpy as np, torch, sys
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+import legosnark_amd as lsa
+import oracle_lib as o
+assert lsa.LIB_PATH.endswith("liblegosnark_amd_loopback.so")
+lsa.init(0)
+W = 3
+lsa.comm_init(0, 1, lsa.comm_unique_id())
+assert lsa.comm_world() == W
+n = 5000
+bases = o.arith_bases("g1", 12, 5, n)
+sc, _ = o.random_scalars(n, seed=21)
+one = o.multi_exp("g1", bases, sc, mode="mixed")
+want = o.g1_canonical_affine(o.g1_mul(one, o.fr_mont(W)))
+B = lsa.Bases("g1", bases)
+d_s = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
+outs = torch.zeros((9, 12), dtype=torch.int64, device="cuda:0")
+for i in range(9):                                    # more than twice the rotating buffer sets
+    B.msm_sharded_async(d_s, outs[i])
+lsa.comm_join()
+lsa.synchronize()
+for i in range(9):
+    assert o.g1_canonical_affine(outs[i].cpu().numpy().view(np.uint64)) == want, i
+assert o.g1_canonical_affine(B.msm_sharded(d_s)) == want
+assert o.g1_canonical_affine(lsa.msm_sharded("g1", bases, sc)) == want
+q = o.arith_bases("g2", 3, 11, 4)
+p = o.arith_bases("g1", 9, 2, 4)
+e1 = lsa.pairing_product(p, q)
+e3 = o.fq12_mul(o.fq12_mul(e1, e1), e1)
+assert np.array_equal(lsa.pairing_product_sharded(p, q), e3)
+B.close()
+lsa.comm_destroy()
+print("LOOPBACK OK")
+"""
+
+
 @pytest.mark.gpu
-def test_multi_rank_step_on_one_gpu_with_loopback_peers(lsa, monkeypatch):
-    """LSA_COMM_LOOPBACK=W: a one-rank communicator that behaves as rank 0 of W ranks whose peers
-    contribute this rank's own partial (W device copies instead of ncclAllGather).  Runs the whole
-    world > 1 code path of csrc/comm.hip -- side stream, rotating buffer sets, events, k_sum_points,
-    the host-vector entry point, the sharded pairing product -- on one GPU; results are W times /
-    the W-th power of the local ones."""
-    import torch
-    import oracle_lib as o
-    W = 3
-    monkeypatch.setenv("LSA_COMM_LOOPBACK", str(W))
-    lsa.comm_init(0, 1, lsa.comm_unique_id())
-    try:
-        assert lsa.comm_world() == W
-        n = 5000
-        bases = o.arith_bases("g1", 12, 5, n)
-        sc, _ = o.random_scalars(n, seed=21)
-        one = o.multi_exp("g1", bases, sc, mode="mixed")
-        want = o.g1_canonical_affine(o.g1_mul(one, o.fr_mont(W)))
-        B = lsa.Bases("g1", bases)
-        d_s = torch.from_numpy(sc.view(np.int64)).to("cuda:0")
-        outs = torch.zeros((9, 12), dtype=torch.int64, device="cuda:0")
-        for i in range(9):                                    # more than twice the rotating buffer sets
-            B.msm_sharded_async(d_s, outs[i])
-        lsa.comm_join()
-        lsa.synchronize()
-        for i in range(9):
-            assert o.g1_canonical_affine(outs[i].cpu().numpy().view(np.uint64)) == want, i
-        assert o.g1_canonical_affine(B.msm_sharded(d_s)) == want
-        assert o.g1_canonical_affine(lsa.msm_sharded("g1", bases, sc)) == want
-        q = o.arith_bases("g2", 3, 11, 4)
-        p = o.arith_bases("g1", 9, 2, 4)
-        e1 = lsa.pairing_product(p, q)
-        e3 = o.fq12_mul(o.fq12_mul(e1, e1), e1)
-        assert np.array_equal(lsa.pairing_product_sharded(p, q), e3)
-        B.close()
-    finally:
-        lsa.comm_destroy()
+def test_multi_rank_step_on_one_gpu_with_loopback_peers():
+    """The TEST build of the library (liblegosnark_amd_loopback.so: comm.hip compiled with LSA_COMM_TEST_LOOPBACK;
+    the product library has no such hook) with LSA_COMM_LOOPBACK=W: a one-rank communicator that behaves as rank 0
+    of W ranks whose peers contribute this rank's own partial (W device copies instead of ncclAllGather).  Runs the
+    whole world > 1 code path of csrc/comm.hip -- side stream, rotating buffer sets, events, k_sum_points, the
+    host-vector entry point, the sharded pairing product -- on one GPU; results are W times / the W-th power of
+    the local ones.  In its own process: the variant is chosen when the library is loaded."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LSA_LIB_VARIANT="loopback", LSA_COMM_LOOPBACK="3")
+    body = _LOOPBACK_BODY % {"tests": os.path.join(root, "tests"), "root": root}
+    r = subprocess.run([sys.executable, "-c", body], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "LOOPBACK OK" in r.stdout, r.stdout[-3000:]
+
+
+def test_product_library_has_no_loopback_hook():
+    blob = open(os.path.join(os.path.dirname(legosnark_amd.LIB_PATH), "liblegosnark_amd.so"), "rb").read()
+    assert b"LSA_COMM_LOOPBACK" not in blob
