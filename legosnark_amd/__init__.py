@@ -32,7 +32,7 @@ class HostStats(C.Structure):
     """lsa_host_stats: host-side wall-clock split of the latest lsa_g1_msm / lsa_g2_msm call."""
     _fields_ = [("n", C.c_size_t), ("cache_hit", C.c_int), ("table", C.c_int), ("h2d_scalars_ms", C.c_double),
                 ("fingerprint_wait_ms", C.c_double), ("bases_prepare_ms", C.c_double), ("msm_ms", C.c_double),
-                ("total_ms", C.c_double)]
+                ("total_ms", C.c_double), ("table_building", C.c_int)]
 
 
 def build(verbose=False):
@@ -127,6 +127,7 @@ def lib():
         L.lsa_g2_table_cache_stats.argtypes = [C.c_void_p]
         L.lsa_crs_cache_configure.argtypes = [C.c_int, C.c_size_t]
         L.lsa_crs_cache_clear.restype = None
+        L.lsa_crs_cache_table_after.argtypes = [C.c_uint]
         L.lsa_crs_cache_stats.argtypes = [C.POINTER(C.c_uint64)] * 4
         L.lsa_msm_host_stats.argtypes = [C.POINTER(HostStats)]
         _lib = L
@@ -310,6 +311,16 @@ def crs_cache_stats():
     v = [C.c_uint64() for _ in range(4)]
     lib().lsa_crs_cache_stats(*[C.byref(x) for x in v])
     return dict(zip(("hits", "misses", "resident_bytes", "entries"), [int(x.value) for x in v]))
+
+
+def crs_cache_table_after(hits):
+    """Hits before a cached CRS vector's pre-shifted copies are built in the background (0: never)."""
+    _check(lib().lsa_crs_cache_table_after(int(hits)))
+
+
+def crs_cache_wait_tables():
+    """Blocks until every background table build has finished and its entry has switched."""
+    _check(lib().lsa_crs_cache_wait_tables())
 
 
 def msm_host_stats():

@@ -10,6 +10,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -385,6 +387,89 @@ class HashPool {
     }
 };
 
+// One background build: allocates the table, fills copy 0 from the entry's prepared bases and derives the other copies
+// one at a time on a low-priority stream, each time waiting (at most 2 ms) for lsa_stream() to be idle first -- an MSM
+// issued meanwhile overlaps with at most one copy step (~1 ms of the GPU at 2^20 points).
+struct TableBuild {
+    std::atomic<int> state{0};                      // 0: queued / running, 1: table complete, 2: failed or cancelled (buffers freed)
+    std::atomic<bool> cancel{false};
+    const void *bases = nullptr;                    // the entry's prepared bases (read-only)
+    void *big = nullptr, *tmp = nullptr;
+    size_t n = 0;
+    int group = 1;
+};
+class TableBuilder {
+    std::thread th_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::shared_ptr<TableBuild>> q_;
+    bool stop_ = false;
+    std::atomic<bool> abandon_{false};              // process exit: no more HIP calls from this thread (the runtime may be gone)
+    hipStream_t stream_ = nullptr;
+
+    void run(TableBuild &j) {
+        const size_t tw = msm_table_windows(j.group, j.n), per = msm_base_bytes(j.group);
+        const size_t jac = j.group == 1 ? sizeof(Jac<Fq>) : sizeof(Jac<Fq2>);
+        bool ok = hipMalloc(&j.big, tw * j.n * per) == hipSuccess && hipMalloc(&j.tmp, j.n * jac) == hipSuccess;
+        ok = ok && hipMemcpyAsync(j.big, j.bases, j.n * per, hipMemcpyDeviceToDevice, stream_) == hipSuccess;
+        for (unsigned k = 1; ok && k < tw && !j.cancel.load() && !abandon_.load(); k++) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (hipStreamQuery(g.stream) == hipErrorNotReady && !j.cancel.load() &&
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < 2.0)
+                std::this_thread::sleep_for(std::chrono::microseconds(30));
+            const int rc = j.group == 1 ? precompute_window_step<Fq>(j.big, j.n, j.tmp, k, stream_) : precompute_window_step<Fq2>(j.big, j.n, j.tmp, k, stream_);
+            ok = rc == LSA_OK && hipStreamSynchronize(stream_) == hipSuccess;
+        }
+        if (abandon_.load()) { j.state.store(2); return; }
+        if (ok && !j.cancel.load() && hipStreamSynchronize(stream_) == hipSuccess) { j.state.store(1); return; }
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(stream_);
+        if (j.big) (void)hipFree(j.big);
+        if (j.tmp) (void)hipFree(j.tmp);
+        j.big = j.tmp = nullptr;
+        j.state.store(2);
+    }
+    void loop(int device) {
+        (void)hipSetDevice(device);
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&stream_, hipStreamNonBlocking, least) != hipSuccess) stream_ = nullptr;
+        for (;;) {
+            std::shared_ptr<TableBuild> j;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                if (stop_ && q_.empty()) break;
+                j = q_.front();
+                q_.pop_front();
+            }
+            if (!stream_ || j->cancel.load()) { j->state.store(2); continue; }
+            run(*j);
+        }
+        if (stream_ && !abandon_.load()) (void)hipStreamDestroy(stream_);
+        stream_ = nullptr;
+    }
+
+  public:
+    ~TableBuilder() { abandon_.store(true); shutdown(); }
+    void submit(std::shared_ptr<TableBuild> j) {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!th_.joinable()) { stop_ = false; th_ = std::thread([this, d = g.device] { loop(d); }); }
+        q_.push_back(std::move(j));
+        cv_.notify_all();
+    }
+    // after this every submitted build has state != 0
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            for (auto &j : q_) j->cancel.store(true);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+};
+
 struct CrsEntry {
     const void *ptr = nullptr;
     size_t n = 0;
@@ -396,6 +481,11 @@ struct CrsEntry {
     size_t bytes = 0;
     uint64_t tick = 0;
     unsigned hits = 0;
+    // the pre-shifted window copies are built by a background thread (TableBuilder): the entry keeps serving the
+    // plain layout until the build has finished, then switches; nobody ever waits for the 26 copies
+    std::shared_ptr<TableBuild> build;
+    void *small = nullptr;                          // the plain bases after the switch (an MSM queued earlier may still read them)
+    bool building() const { return build && build->state.load() == 0; }
 };
 
 struct CrsCache {
@@ -405,6 +495,9 @@ struct CrsCache {
     std::vector<CrsEntry> entries;
     HashPool pool;
     std::vector<uint64_t> scratch_fp;
+    TableBuilder builder;
+    unsigned table_after = 1;                       // hits before an entry's copies are built (0: never); LSA_CRS_TABLE_AFTER
+    std::vector<void *> garbage;                    // device buffers to free once the device is idle
 } g_crs;
 
 lsa_host_stats g_host_stats = {};
@@ -417,6 +510,7 @@ void crs_configure_from_env() {
         if (e[0] == '0' || !strcmp(e, "off")) g_crs.mode = 0;
         else if (!strcmp(e, "sampled") || e[0] == '1') g_crs.mode = 1;
     }
+    if (const char *ta = getenv("LSA_CRS_TABLE_AFTER")) g_crs.table_after = (unsigned)atoi(ta);
     const char *mb = getenv("LSA_CRS_CACHE_MB");
     if (mb && atoll(mb) > 0) g_crs.budget = (size_t)atoll(mb) << 20;
     if (g_crs.budget == 0) {
@@ -431,6 +525,29 @@ size_t bases_device_bytes(const lsa_bases *b) {
     return b->n * per * (b->table_stride ? msm_table_windows(b->group, b->n) : 1);
 }
 
+// frees what an entry owns beyond its handle; a build in flight is cancelled and waited for (it reads the entry's bases)
+void crs_release_entry(CrsEntry &e) {
+    if (e.build) {
+        e.build->cancel.store(true);
+        while (e.build->state.load() == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (e.build->state.load() == 1) {              // complete but never adopted
+            if (e.build->big) (void)hipFree(e.build->big);
+            if (e.build->tmp) (void)hipFree(e.build->tmp);
+        }
+        e.build.reset();
+    }
+    if (e.small) (void)hipFree(e.small);
+    e.small = nullptr;
+}
+bool crs_entry_building(const lsa_bases *b) {
+    for (auto &x : g_crs.entries) if (x.b == b) return x.building();
+    return false;
+}
+void crs_collect_garbage() {
+    for (void *p : g_crs.garbage) (void)hipFree(p);
+    g_crs.garbage.clear();
+}
+
 void crs_evict_to(size_t budget) {
     while (g_crs.bytes > budget && !g_crs.entries.empty()) {
         size_t victim = 0;
@@ -438,6 +555,7 @@ void crs_evict_to(size_t budget) {
         (void)msm_join(g.stream);
         (void)hipStreamSynchronize(g.stream);       // no MSM may still read the victim
         g_crs.bytes -= g_crs.entries[victim].bytes;
+        crs_release_entry(g_crs.entries[victim]);
         lsa_bases_destroy(g_crs.entries[victim].b);
         g_crs.entries.erase(g_crs.entries.begin() + victim);
     }
@@ -455,6 +573,7 @@ void crs_trim(uint64_t keep) {
         (void)msm_join(g.stream);
         (void)hipStreamSynchronize(g.stream);       // no MSM may still read the victim
         g_crs.bytes -= g_crs.entries[victim].bytes;
+        crs_release_entry(g_crs.entries[victim]);
         lsa_bases_destroy(g_crs.entries[victim].b);
         g_crs.entries.erase(g_crs.entries.begin() + victim);
     }
@@ -476,27 +595,44 @@ std::vector<size_t> sample_positions(size_t n) {
 
 static void crs_cache_clear() {
     crs_evict_to(0);
+    crs_collect_garbage();
+    g_crs.builder.shutdown();
     g_crs.pool.stop();
     g_crs.bytes = 0;
 }
 
-// adds the pre-shifted window copies to a handle that was created without them
+// Background build of an entry's pre-shifted copies.  After `table_after` hits the entry's build is handed to the
+// builder thread (allocation, copy 0, the 25 shift + normalise steps -- all off this thread): this MSM and the
+// following ones keep using the plain layout.  Once the build has finished, the handle switches to the table (the
+// plain buffer is kept until the entry goes: an MSM queued earlier may still read it).
 template <class F>
-static int bases_add_table(lsa_bases *b) {
+static int crs_table_progress(CrsEntry &e) {
+    lsa_bases *b = e.b;
     const char *pe = getenv("LSA_PRECOMPUTE");
-    if (b->table_stride || b->n < msm_merge_min() || (pe && pe[0] == '0')) return LSA_OK;
-    const size_t tw = msm_table_windows(b->group, b->n), per = msm_base_bytes(b->group);
+    if (b->table_stride || b->n < msm_merge_min() || (pe && pe[0] == '0') || g_crs.table_after == 0) return LSA_OK;
+    if (e.build) {
+        const int st = e.build->state.load();
+        if (st == 0) return LSA_OK;                                    // not yet
+        if (st == 1) {
+            const size_t before = bases_device_bytes(b);
+            e.small = b->d_aff;
+            b->d_aff = e.build->big;
+            b->table_stride = b->n;
+            g_crs.garbage.push_back(e.build->tmp);
+            e.bytes += bases_device_bytes(b);                          // the plain copy stays resident too
+            g_crs.bytes += bases_device_bytes(b);
+            (void)before;
+        }
+        e.build.reset();                                               // a failed build (no memory) leaves a plain entry
+        return LSA_OK;
+    }
+    if (e.hits < g_crs.table_after || e.hits > g_crs.table_after + 8) return LSA_OK;     // (no endless retries after a failure)
+    const size_t tw = msm_table_windows(b->group, b->n);
     if ((uint64_t)b->n * tw >= (1u << 30)) return LSA_OK;
-    void *big = nullptr;
-    if (hipMalloc(&big, tw * b->n * per) != hipSuccess) { (void)hipGetLastError(); return LSA_OK; }   // stays a plain handle
-    int rc = msm_join(g.stream);
-    if (rc) { (void)hipFree(big); return rc; }
-    HIPCHK(hipMemcpyAsync(big, b->d_aff, b->n * per, hipMemcpyDeviceToDevice, g.stream));
-    rc = precompute_windows<F>(big, b->n, g.stream);   // synchronises the stream
-    if (rc) { (void)hipFree(big); return rc; }
-    (void)hipFree(b->d_aff);
-    b->d_aff = big;
-    b->table_stride = b->n;
+    auto j = std::make_shared<TableBuild>();
+    j->bases = b->d_aff; j->n = b->n; j->group = b->group;
+    e.build = j;
+    g_crs.builder.submit(j);
     return LSA_OK;
 }
 
@@ -523,13 +659,9 @@ static int crs_lookup_or_insert(const void *bases_jac, size_t n, int group, cons
         e.tick = ++g_crs.tick;
         e.hits++;
         g_crs.hits++;
-        if (!e.b->table_stride) {                     // second use: worth the pre-shifted copies
-            size_t before = bases_device_bytes(e.b);
-            int rc = bases_add_table<F>(e.b);
+        if (!e.b->table_stride) {                     // re-used: worth the pre-shifted copies -- built in the background
+            int rc = crs_table_progress<F>(e);
             if (rc) return rc;
-            size_t after = bases_device_bytes(e.b);
-            e.bytes += after - before;
-            g_crs.bytes += after - before;
         }
         lsa_bases *found = e.b;
         const uint64_t keep = e.tick;
@@ -544,6 +676,7 @@ static int crs_lookup_or_insert(const void *bases_jac, size_t n, int group, cons
             (void)msm_join(g.stream);
             (void)hipStreamSynchronize(g.stream);
             g_crs.bytes -= g_crs.entries[i].bytes;
+            crs_release_entry(g_crs.entries[i]);
             lsa_bases_destroy(g_crs.entries[i].b);
             g_crs.entries.erase(g_crs.entries.begin() + i);
         } else i++;
@@ -605,6 +738,7 @@ static int msm_host_local(const void *bases_jac, const void *scalars, size_t n, 
         st.bases_prepare_ms = ms_since(t0);
         st.cache_hit = hit ? 1 : 0;
         st.table = b->table_stride ? 1 : 0;
+        st.table_building = crs_entry_building(b) ? 1 : 0;
         d_bases = b->d_aff;
         table_stride = b->table_stride;
     } else {
@@ -658,6 +792,7 @@ static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *
     HIPCHK(hipMemcpyAsync(g.h_result, g.d_result, sizeof(Jac<F>), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     memcpy(out_jac, g.h_result, sizeof(Jac<F>));
+    if (!g_crs.garbage.empty()) crs_collect_garbage();     // lsa_stream() has just drained
     st.msm_ms = ms_since(t0);
     st.total_ms = ms_since(t_all);
     g_host_stats = st;
@@ -696,6 +831,23 @@ int lsa_crs_cache_stats(uint64_t *hits, uint64_t *misses, uint64_t *resident_byt
     if (misses) *misses = g_crs.misses;
     if (resident_bytes) *resident_bytes = g_crs.bytes;
     if (entries) *entries = g_crs.entries.size();
+    return LSA_OK;
+}
+int lsa_crs_cache_table_after(unsigned hits) {
+    crs_configure_from_env();
+    g_crs.table_after = hits;
+    return LSA_OK;
+}
+// blocks until every background table build has finished and its entry has switched (tests, benchmarks)
+int lsa_crs_cache_wait_tables(void) {
+    int rc = require_ready();
+    if (rc) return rc;
+    for (auto &e : g_crs.entries) {
+        if (!e.build) continue;
+        while (e.build->state.load() == 0) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        rc = e.group == 1 ? crs_table_progress<Fq>(e) : crs_table_progress<Fq2>(e);
+        if (rc) return rc;
+    }
     return LSA_OK;
 }
 int lsa_msm_host_stats(lsa_host_stats *out) {

@@ -48,6 +48,9 @@ void msm_set_merge_min(size_t n);
 // fills windows 1.. of a table whose window 0 holds the n prepared bases
 template <class F>
 int precompute_windows(void *d_table, size_t n, hipStream_t st);
+// copy k (1 <= k < msm_table_windows) from copy k - 1: no allocation, no synchronisation; d_tmp: n Jacobian points of scratch
+template <class F>
+int precompute_window_step(void *d_table, size_t n, void *d_tmp, unsigned k, hipStream_t st);
 
 // out[i] = scalars[i] * base (fixed base); d_scalars/d_out device-resident.
 template <class F>

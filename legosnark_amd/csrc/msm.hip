@@ -1612,6 +1612,19 @@ int precompute_windows(void *d_table, size_t n, hipStream_t st) {
     if (e != hipSuccess) { set_error("precompute_windows: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
     return LSA_OK;
 }
+// One copy of the same: copy k (1 <= k < msm_table_windows) from copy k - 1, no allocation, no synchronisation; d_tmp
+// holds n Jacobian points.  The background builder of the CRS cache issues the copies one at a time.
+template <class F>
+int precompute_window_step(void *d_table, size_t n, void *d_tmp, unsigned k, hipStream_t st) {
+    using C = typename CurveOf<F>::type;
+    const TableGrid grid = table_grid(n);
+    if (n == 0 || k == 0 || k >= grid.ncopies) return LSA_OK;
+    typename C::Base *tbl = (typename C::Base *)d_table;
+    hipLaunchKernelGGL((k_shift_window<C>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tbl + (size_t)(k - 1) * n, (Jac<F> *)d_tmp, n, grid.pos[k] - grid.pos[k - 1]);
+    return prepare_bases<F>((const Jac<F> *)d_tmp, tbl + (size_t)k * n, n, st);
+}
+template int precompute_window_step<Fq>(void *, size_t, void *, unsigned, hipStream_t);
+template int precompute_window_step<Fq2>(void *, size_t, void *, unsigned, hipStream_t);
 template int precompute_windows<Fq>(void *, size_t, hipStream_t);
 template int precompute_windows<Fq2>(void *, size_t, hipStream_t);
 

@@ -321,6 +321,20 @@ def fq12_unitary_inverse(a):
     return r
 
 
+def fq12_inverse(a):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    r = np.zeros(48, dtype=np.uint64)
+    lib().ofq12_inverse(_p(r), _p(a))
+    return r
+
+
+def fq12_frobenius(a, power):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    r = np.zeros(48, dtype=np.uint64)
+    lib().ofq12_frobenius(_p(r), _p(a), C.c_uint(power))
+    return r
+
+
 def miller_loop_batch(ps, qs):
     ps = np.ascontiguousarray(ps, dtype=np.uint64).reshape(-1, 12)
     qs = np.ascontiguousarray(qs, dtype=np.uint64).reshape(-1, 24)

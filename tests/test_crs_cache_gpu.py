@@ -109,14 +109,38 @@ def test_table_built_on_first_reuse_and_lru_eviction(fresh_cache):
     assert lsa.msm_host_stats()["table"] == 0             # cold: plain layout
     assert canon("g1", lsa.msm("g1", vecs[0], sc)) == wants[0]
     st = lsa.msm_host_stats()
-    assert st["cache_hit"] == 1 and st["table"] == 1      # first re-use: pre-shifted copies built
+    # first re-use: the pre-shifted copies are STARTED in the background; this call ran on the plain layout
+    assert st["cache_hit"] == 1 and st["table"] == 0 and st["table_building"] == 1
+    lsa.crs_cache_wait_tables()
+    assert canon("g1", lsa.msm("g1", vecs[0], sc)) == wants[0]          # the same point over the copies
+    st = lsa.msm_host_stats()
+    assert st["cache_hit"] == 1 and st["table"] == 1 and st["table_building"] == 0
     one = lsa.crs_cache_stats()["resident_bytes"]
-    assert one % (n * 64) == 0 and one // (n * 64) >= 12      # one 64-byte copy of every point per window
+    assert one % (n * 64) == 0 and one // (n * 64) >= 12      # one 64-byte copy of every point per window (+ the plain one)
+    # without waiting: calls issued while the build runs switch over on their own, every result the same point
+    lsa.crs_cache_clear()
+    seen_table = False
+    for i in range(40):
+        assert canon("g1", lsa.msm("g1", vecs[0], sc)) == wants[0], i
+        seen_table = seen_table or lsa.msm_host_stats()["table"] == 1
+    assert seen_table
+    # a policy of three hits: the build starts at the third re-use
+    lsa.crs_cache_clear()
+    lsa.crs_cache_table_after(3)
+    try:
+        for i in range(4):
+            assert canon("g1", lsa.msm("g1", vecs[0], sc)) == wants[0]
+            assert lsa.msm_host_stats()["table_building"] == (1 if i == 3 else 0), i
+    finally:
+        lsa.crs_cache_table_after(1)
+    lsa.crs_cache_wait_tables()
     # budget for two such entries: the least recently used one goes
     lsa.crs_cache_configure(lsa.CRS_CACHE_FULL, 2 * one + 1024)
     for k in (1, 2):
         for _ in range(2):
             assert canon("g1", lsa.msm("g1", vecs[k], sc)) == wants[k]
+        lsa.crs_cache_wait_tables()
+        assert canon("g1", lsa.msm("g1", vecs[k], sc)) == wants[k]
     st = lsa.crs_cache_stats()
     assert st["entries"] == 2 and st["resident_bytes"] <= 2 * one + 1024
     s0 = lsa.crs_cache_stats()

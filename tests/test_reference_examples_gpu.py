@@ -16,12 +16,26 @@ BIN = os.path.join(ROOT, "build", "reference")
 CMAKE_BIN = os.path.join(ROOT, "build", "reference_cmake", "src", "examples")
 
 
+def require_binary(exe):
+    """The binaries are built from the reference's sources, which exist only in the dev container; build/ travels
+    with the snapshot.  tests/golden/reference_build_manifest.json (tracked, written by __graft_entry__.build())
+    lists what was built: a listed binary that is missing is a FAILURE -- lost evidence must not look like a skip.
+    Without a manifest (a checkout that never ran build() next to the reference) there is nothing to run."""
+    if os.path.exists(exe):
+        return
+    import json
+    manifest = os.path.join(ROOT, "tests", "golden", "reference_build_manifest.json")
+    listed = []
+    if os.path.exists(manifest):
+        listed = json.load(open(manifest)).get("binaries", [])
+    rel = os.path.relpath(exe, ROOT)
+    assert rel not in listed, "%s was built by __graft_entry__.build() (manifest) but is missing from this snapshot" % rel
+    pytest.skip("%s missing and not in the build manifest: run __graft_entry__.build() where /root/reference exists" % exe)
+
+
 def run(name, *args, seed="7", bindir=BIN):
     exe = os.path.join(bindir, name)
-    if not os.path.exists(exe):
-        # the binaries are built from the reference's sources, which exist only in the dev
-        # container (build/ travels with the snapshot); nothing to run if they were not shipped
-        pytest.skip("%s missing: run __graft_entry__.build() where /root/reference exists" % exe)
+    require_binary(exe)
     env = dict(os.environ, LSA_SEED=seed)
     return subprocess.run([exe, *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
 
@@ -59,8 +73,7 @@ def test_verifier_side_through_the_shim_deferred_equals_call_by_call():
     outs = []
     for eager in ("0", "1"):
         exe = os.path.join(BIN, "pairing_check")
-        if not os.path.exists(exe):
-            pytest.skip("%s missing: run __graft_entry__.build() where /root/reference exists" % exe)
+        require_binary(exe)
         env = dict(os.environ, LSA_SEED="11", LSA_SHIM_EAGER=eager)
         r = subprocess.run([exe, "6"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
         assert r.returncode == 0, r.stdout[-2000:]
@@ -86,8 +99,7 @@ def test_multiexpma_on_a_chunk_per_process_from_cpp(tmp_path):
     C++ route to more than one GPU.  One rank here (RCCL wants one device per rank); the same
     binary runs with WORLD_SIZE = N, RANK = r, LSA_DEVICE = r on an N-GPU node."""
     exe = os.path.join(BIN, "spmd_prover_check")
-    if not os.path.exists(exe):
-        pytest.skip("%s missing" % exe)
+    require_binary(exe)
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LSA_COMM_FILE=str(tmp_path / "comm.id"))
     r = subprocess.run([exe, "12"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
