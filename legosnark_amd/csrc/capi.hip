@@ -410,6 +410,14 @@ class TableBuilder {
     void run(TableBuild &j) {
         const size_t tw = msm_table_windows(j.group, j.n), per = msm_base_bytes(j.group);
         const size_t jac = j.group == 1 ? sizeof(Jac<Fq>) : sizeof(Jac<Fq2>);
+        // the call that asked for the build is still running its own MSM: let it finish first (it is the "second call")
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            std::this_thread::sleep_for(std::chrono::microseconds(200));
+            while (hipStreamQuery(g.stream) == hipErrorNotReady && !j.cancel.load() &&
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < 6.0)
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
         bool ok = hipMalloc(&j.big, tw * j.n * per) == hipSuccess && hipMalloc(&j.tmp, j.n * jac) == hipSuccess;
         ok = ok && hipMemcpyAsync(j.big, j.bases, j.n * per, hipMemcpyDeviceToDevice, stream_) == hipSuccess;
         for (unsigned k = 1; ok && k < tw && !j.cancel.load() && !abandon_.load(); k++) {

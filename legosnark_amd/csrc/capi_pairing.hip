@@ -31,6 +31,7 @@ int g2_table_identity_device(uint32_t *d_tab, hipStream_t st);
 unsigned miller_tab_max_pairs();
 int miller_tab_device(const void *d_g1, const uint32_t *const *d_tabs, const uint8_t *d_flags, const uint32_t *d_acc_off, size_t nacc, unsigned M,
                       const uint32_t *d_ident, void *d_out, hipStream_t st);
+int miller_fused_device(const void *d_g1, const void *d_g2, const uint8_t *d_flags, uint32_t *const *d_tabs, size_t n, void *d_out, hipStream_t st);
 }  // namespace lsa
 
 using namespace lsa;
@@ -178,17 +179,57 @@ inline int force_kernel() {
     return f;
 }
 
+// The job through the fused kernel (pairing.hip, k_miller_fused: G2 arithmetic and Fq12 chain side by side in one
+// workgroup, one Miller value per term), then the products.  emit: per term, the device table to fill on the way
+// (0: none) -- the tables of points seen for the first time go into the cache while their first loop runs.
+int run_fused(const Terms &t, const std::vector<uint64_t> &emit, void **d_res) {
+    const size_t n = t.n, nprod = t.seg ? t.nseg : n;
+    int rc = wait_uploads();
+    if (rc) return rc;
+    const size_t off_seg = 0, off_emit = off_seg + (nprod + 1) * 8, off_flag = off_emit + n * 8, meta_bytes = off_flag + n + 8;
+    if (g_pin_meta.ensure(meta_bytes) || g_pair_meta.ensure(meta_bytes) || g_pair_f.ensure(std::max<size_t>(n, 1) * fq12_bytes()) ||
+        g_pair_s.ensure(((n + 7) / 8 + nprod + 1) * fq12_bytes())) {
+        set_error("pairing: staging allocation failed");
+        return LSA_ERR_NOMEM;
+    }
+    char *hm = (char *)g_pin_meta.p;
+    uint64_t *h_seg = (uint64_t *)(hm + off_seg), *h_emit = (uint64_t *)(hm + off_emit);
+    uint8_t *h_flag = (uint8_t *)(hm + off_flag);
+    for (size_t j = 0; j <= nprod; j++) h_seg[j] = t.seg ? t.seg[j] : j;
+    for (size_t i = 0; i < n; i++) { h_emit[i] = emit.empty() ? 0 : emit[i]; h_flag[i] = t.flags ? (uint8_t)(t.flags[i] & 1) : (uint8_t)0; }
+    const void *d_p = t.g1, *d_q = t.g2;
+    if (!t.on_device) {
+        if (g_pair_p.ensure(std::max<size_t>(n, 1) * sizeof(Jac<Fq>)) || g_pair_q.ensure(std::max<size_t>(n, 1) * sizeof(Jac<Fq2>))) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
+        if (n) {
+            HIPCHK(hipMemcpyAsync(g_pair_p.p, t.g1, n * sizeof(Jac<Fq>), hipMemcpyHostToDevice, g.stream));
+            HIPCHK(hipMemcpyAsync(g_pair_q.p, t.g2, n * sizeof(Jac<Fq2>), hipMemcpyHostToDevice, g.stream));
+        }
+        d_p = g_pair_p.p; d_q = g_pair_q.p;
+    }
+    HIPCHK(hipMemcpyAsync(g_pair_meta.p, hm, meta_bytes, hipMemcpyHostToDevice, g.stream));
+    rc = mark_uploads();
+    if (rc) return rc;
+    const char *dm = (const char *)g_pair_meta.p;
+    rc = miller_fused_device(d_p, d_q, (const uint8_t *)(dm + off_flag), emit.empty() ? nullptr : (uint32_t *const *)(dm + off_emit), n, g_pair_f.p, g.stream);
+    if (rc) return rc;
+    if (!t.seg) { *d_res = g_pair_f.p; return LSA_OK; }
+    if (nprod == 1 && n > 0) return fq12_product_device(g_pair_f.p, g_pair_s.p, n, d_res, g.stream);
+    rc = fq12_segment_products_device(g_pair_f.p, (const uint64_t *)(dm + off_seg), nprod, g_pair_s.p, g.stream);
+    *d_res = g_pair_s.p;
+    return rc;
+}
+
 // Miller products of the job on the device: *d_res points at nseg Fq12 values when this returns (stream-ordered)
 int run_miller(const Terms &t, void **d_res) {
     const size_t n = t.n, nseg = t.nseg;
     g_tabs.read_env();
-    // ---- the fused kernels (miller.h): only when forced, and only for raw points without flags
-    // ... and for large batches of points the cache does not take (more than 1024 terms, or device-resident): building
-    // 4096 tables and running the Fq12 chain over them is two kernels of 1.4 + 1.0 ms where the fused six-lane
-    // kernel takes 2.3 (profiles/r03_*): tables pay when a Q is seen twice.
+    // ---- points the cache does not take (more than 1024 terms, device-resident, cache off): the fused kernel -- G2
+    // arithmetic and Fq12 chain side by side, no table through memory.  (LSA_MILLER_KERNEL = 6 forces it, 5 the tables.)
+    const bool no_cache = t.on_device || t.n > 1024 || g_tabs.max_tables == 0;
+    if (!t.qpre && t.n && g_force_m == 0 && ((force_kernel() == 0 && no_cache) || force_kernel() == 6)) return run_fused(t, {}, d_res);
+    // ---- the round-1/2 kernels of miller.h (one to twelve lanes per pairing, everything fused per lane group): only when forced
     const bool plain = !t.qpre && !t.flags;
-    const bool big_fresh = plain && force_kernel() == 0 && g_force_m == 0 && (t.on_device || t.n > 1024 || g_tabs.max_tables == 0) && t.n >= 1024;
-    if (plain && ((force_kernel() >= 1 && force_kernel() <= 4) || big_fresh)) {
+    if (plain && force_kernel() >= 1 && force_kernel() <= 4) {
         const void *d_p = t.g1, *d_q = t.g2;
         if (!t.on_device) {
             if (g_pair_p.ensure(n * sizeof(Jac<Fq>)) || g_pair_q.ensure(n * sizeof(Jac<Fq2>))) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
@@ -295,6 +336,15 @@ int run_miller(const Terms &t, void **d_res) {
             (blob ? need_imp : need_pre).push_back((uint32_t)i);
         }
         h_tab[i] = dev;
+    }
+
+    // ---- points seen for the first time and no precomputed tables among the terms: the fused kernel computes every
+    // term (while the chip is not full a resident Q gains nothing from its table: the call waits for the new ones
+    // anyway) and fills the new tables on the way
+    if (use_cache && !t.qpre && !need_pre.empty() && g_force_m == 0 && force_kernel() != 5) {
+        std::vector<uint64_t> emit(n, 0);
+        for (uint32_t i : need_pre) emit[i] = h_tab[i];
+        return run_fused(t, emit, d_res);
     }
 
     // ---- uploads

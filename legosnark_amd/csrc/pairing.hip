@@ -203,14 +203,97 @@ __global__ __launch_bounds__(64) void k_fq12_prod8(const Fq12 *__restrict__ in, 
 __global__ __launch_bounds__(64) void k_g2_precomp(const Jac<Fq2> *__restrict__ g2, size_t n, uint32_t *const *__restrict__ tabs) {
     __shared__ Fq2S lds[GP_LDS_FQ2];
     __shared__ uint32_t *out[GP_GROUPS];
+    __shared__ const Jac<Fq2> *qp[GP_GROUPS];
     const size_t lo = (size_t)blockIdx.x * GP_GROUPS;
     if (lo >= n) return;
     const unsigned count = (unsigned)(n - lo < (size_t)GP_GROUPS ? n - lo : (size_t)GP_GROUPS);
-    if (threadIdx.x < (unsigned)GP_GROUPS) out[threadIdx.x] = threadIdx.x < count ? tabs[lo + threadIdx.x] : nullptr;
+    if (threadIdx.x < (unsigned)GP_GROUPS) {
+        out[threadIdx.x] = threadIdx.x < count ? tabs[lo + threadIdx.x] : nullptr;
+        qp[threadIdx.x] = g2 + lo + (threadIdx.x < count ? threadIdx.x : 0);
+    }
     __syncthreads();
     WaveExec ex;
     G2Pre<WaveExec> pre{ex, lds};
-    pre.run(g2 + lo, count, out);
+    pre.run(qp, count, out);
+}
+
+// Pairs the device has no table for, FUSED: a workgroup of two wavefronts owns four pairs -- wavefront 0 runs the G2
+// point arithmetic (G2Pre, four groups) one table entry ahead and puts each line straight into the row ring of
+// wavefront 1, which runs the Fq12 chain (TabMiller, four accumulators); one workgroup barrier per entry.  The G2 side
+// (2.5 K / 3.4 K instructions per doubling / addition entry) and the f side (3.8 K / 1.9 K) overlap instead of adding
+// up, no table ever goes through memory, and 4096 pairs fill the chip with 2048 wavefronts.
+struct WaveLocalExec {
+    // one wavefront of a larger workgroup: its phases are ordered by the wavefront's own in-order LDS queue; only the
+    // compiler has to be kept from moving memory accesses across the phase boundary
+    template <class F>
+    __device__ __forceinline__ void par(F f) {
+        f(threadIdx.x & 63u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ unsigned nlanes() const { return 64; }
+};
+static constexpr int FU_PAIRS = TM_CHUNKS;                              // pairs per workgroup
+// tabs (optional): tabs[i] non-null -> the table of g2[i] is also written there (a point seen for the first time: its
+// table goes into the cache while its first Miller loop runs).
+__global__ __launch_bounds__(128) void k_miller_fused(const Jac<Fq> *__restrict__ g1, const Jac<Fq2> *__restrict__ g2, const uint8_t *__restrict__ flags,
+                                                      uint32_t *const *__restrict__ tabs, size_t n, Fq12 *__restrict__ out) {
+    __shared__ Fq2S g2mem[FU_PAIRS * GP_STRIDE];
+    __shared__ Fq2S tmmem[TM_LDS_FQ2];
+    __shared__ const Jac<Fq2> *qp[FU_PAIRS];
+    __shared__ const Jac<Fq> *pp[TM_CHUNKS * TM_MAXM];
+    __shared__ uint8_t ng[TM_CHUNKS * TM_MAXM];
+    __shared__ unsigned cnt[TM_CHUNKS];
+    __shared__ Fq2S *rows[3][FU_PAIRS];
+    __shared__ uint32_t *tout[FU_PAIRS];
+    __shared__ uint8_t kinds[ATE_NUM_COEFFS];
+    const size_t lo = (size_t)blockIdx.x * FU_PAIRS;
+    if (lo >= n) return;
+    const unsigned count = (unsigned)(n - lo < (size_t)FU_PAIRS ? n - lo : (size_t)FU_PAIRS);
+    const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    if (tid < (unsigned)ATE_NUM_COEFFS) kinds[tid] = (uint8_t)tm_entry_kind((int)tid);
+    if (tid < (unsigned)FU_PAIRS) {
+        const bool have = tid < count;
+        qp[tid] = g2 + lo + (have ? tid : 0);
+        cnt[tid] = have ? 1u : 0u;
+        tout[tid] = have && tabs ? tabs[lo + tid] : nullptr;
+        for (int s = 0; s < 3; s++) rows[s][tid] = tmmem + tid * TM_STRIDE + TM_RAW + 3 * s;
+    }
+    if (tid < (unsigned)(TM_CHUNKS * TM_MAXM)) {
+        const unsigned c = tid / TM_MAXM, i = tid % TM_MAXM;
+        const bool have = i == 0 && c < count;
+        pp[tid] = g1 + lo + (have ? c : 0);
+        ng[tid] = have && flags ? (uint8_t)(flags[lo + c] & 1) : (uint8_t)0;
+    }
+    __syncthreads();
+    WaveLocalExec ex;
+    G2Pre<WaveLocalExec, FU_PAIRS> pre{ex, g2mem};
+    TabMiller<WaveLocalExec> tm{ex, tmmem, nullptr};
+    if (wave == 0) {
+        pre.setup(qp, count, tout);
+        pre.entry_rounds(kinds[0], 0, tout, rows[0]);
+    } else {
+        tm.setup(pp, ng, cnt);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int e = 0; e < ATE_NUM_COEFFS; e++) {
+        if (wave == 0) {
+            if (e + 1 < ATE_NUM_COEFFS) pre.entry_rounds(kinds[e + 1], e + 1, tout, rows[(e + 1) % 3]);
+        } else {
+            tm.entry_from_lds(kinds[e], e);
+        }
+        __syncthreads();
+    }
+    if (wave == 1 && lane < 12u * TM_CHUNKS) {
+        const unsigned c = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
+        if (c < count) {
+            const unsigned t = (k & 1) * 3 + (k >> 1);                  // tower position of w^k
+            const Fq2S cf = tmmem[c * TM_STRIDE + TM_F + k];
+            reinterpret_cast<Fq *>(&out[lo + c])[2 * t + part] = (part ? cf.c1 : cf.c0).to_mont256();
+        }
+    }
 }
 
 // internal table (x * 2^261 mod p, < 4p, 256-bit packed) -> libff's alt_bn128_ate_G2_precomp as bytes: QX, QY, then
@@ -409,6 +492,13 @@ int g2_table_import_device(const void *d_public, size_t n, uint32_t *const *d_ta
 }
 int g2_table_identity_device(uint32_t *d_tab, hipStream_t st) {
     hipLaunchKernelGGL(k_g2_tab_identity, dim3((TM_TAB_WORDS + 255) / 256), dim3(256), 0, st, d_tab);
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
+int miller_fused_device(const void *d_g1, const void *d_g2, const uint8_t *d_flags, uint32_t *const *d_tabs, size_t n, void *d_out, hipStream_t st) {
+    if (n == 0) return LSA_OK;
+    hipLaunchKernelGGL(k_miller_fused, dim3((unsigned)((n + FU_PAIRS - 1) / FU_PAIRS)), dim3(128), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, d_flags,
+                       d_tabs, n, (Fq12 *)d_out);
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }

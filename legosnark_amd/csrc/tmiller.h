@@ -67,10 +67,24 @@ enum G2PVar {                                  // Fq2S slots of one point
 static constexpr int GP_GROUPS = 5;
 static constexpr int GP_LDS_FQ2 = GP_GROUPS * GP_STRIDE;
 
-template <class X>
+// which step of the ate loop table entry e belongs to: 0: a doubling step, 1: the addition of Q, 2: of pi(Q), 3: of -pi^2(Q)
+LSA_HD int tm_entry_kind(int e) {
+    int idx = 0;
+    for (int i = 63; i >= 0; --i) {
+        if (idx == e) return 0;
+        idx++;
+        if (ate_bit(i)) {
+            if (idx == e) return 1;
+            idx++;
+        }
+    }
+    return e == idx ? 2 : 3;
+}
+
+template <class X, int NG = GP_GROUPS>
 struct G2Pre {
     X &x;
-    Fq2S *mem;          // GP_LDS_FQ2 elements
+    Fq2S *mem;          // NG * GP_STRIDE elements
     struct Prod { int8_t a[5], b[5]; int n; };
 
     // ops 0-2: the rounds of a doubling step, 3-6: of an addition step with the point at slots (x2, x2 + 1)
@@ -168,13 +182,14 @@ struct G2Pre {
         }
     }
 
-    // one round; after the rounds that complete a line (2: doubling, 5: addition) lanes (k < 3, part) write it out
-    LSA_HD void round(int op, int x2, uint32_t *const *out, int entry) {
+    // one round; after the rounds that complete a line (2: doubling, 5: addition) lanes (k < 3, part) write it out: into the
+    // table out[g] (packed, global memory) and / or as three Fq2S at rows[g] (LDS: the consumer's row ring)
+    LSA_HD void round(int op, int x2, uint32_t *const *out, int entry, Fq2S *const *rows = nullptr) {
         Fq2S *m = mem;
         const Prod pr = products_of(op, x2);
         x.par([=](unsigned lane) {
             const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
-            if (g >= (unsigned)GP_GROUPS || (int)k >= pr.n) return;
+            if (g >= (unsigned)NG || (int)k >= pr.n) return;
             Fq2S *V = m + g * GP_STRIDE;
             // a < 4p, b < 20p: 2 * 4 * 20 = 160 < 169
             const Fs r = {w12_comp_mul<20>(part, w12_load(V + pr.a[k]), w12_load(V + pr.b[k]))};
@@ -182,35 +197,46 @@ struct G2Pre {
         });
         x.par([=](unsigned lane) {
             const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
-            if (g >= (unsigned)GP_GROUPS || k) return;
+            if (g >= (unsigned)NG || k) return;
             combine(op, part, m + g * GP_STRIDE);
         });
         if (op == 2 || op == 5) {
             x.par([=](unsigned lane) {
                 const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
-                if (g >= (unsigned)GP_GROUPS || k >= 3 || !out[g]) return;
+                if (g >= (unsigned)NG || k >= 3) return;
+                const F29 v = ld(m + g * GP_STRIDE, GP_L0 + (int)k, part);
+                if (rows && rows[g]) w12_store(&w12_comp(rows[g][k], part), Fs{v});
+                if (!out || !out[g]) return;
                 uint32_t w[8];
-                ld(m + g * GP_STRIDE, GP_L0 + (int)k, part).pack256(w);            // < 4p < 2^256
+                v.pack256(w);                                                      // < 4p < 2^256
                 uint32_t *d = out[g] + entry * TM_ROW_WORDS + (2 * k + part) * 8;
 #pragma unroll
                 for (int l = 0; l < 8; l++) d[l] = w[l];
             });
         }
     }
+    // the rounds of table entry `entry` (its kind: tm_entry_kind)
+    LSA_HD void entry_rounds(int kind, int entry, uint32_t *const *out, Fq2S *const *rows) {
+        const int x2 = kind == 2 ? GP_Q1X : (kind == 3 ? GP_Q2X : GP_QX);
+        const int first = kind == 0 ? 0 : 3, last = kind == 0 ? 3 : 7;
+#pragma unroll 1
+        for (int op = first; op < last; op++) round(op, x2, out, entry, rows);
+    }
 
-    // tables out[g] (TM_TAB_WORDS words each, null: idle group) <- precompute_G2(Q[g])
-    LSA_HD void run(const Jac<Fq2> *Q, unsigned count, uint32_t *const *out) {
+    // libff to_affine_coordinates (O -> (0, 1)), pi(Q), -pi^2(Q), R = Q for the points Q[g], g < count
+    LSA_HD void setup(const Jac<Fq2> *const *Qp, unsigned count, uint32_t *const *out) {
         Fq2S *m = mem;
         x.par([=](unsigned lane) {
             const unsigned g = lane / 12, k = lane % 12;
-            if (g >= (unsigned)GP_GROUPS || k) return;
+            if (g >= (unsigned)NG || k) return;
+            const Jac<Fq2> *Q = g < count ? Qp[g] : nullptr;
             Fq2S *V = m + g * GP_STRIDE;
             // libff to_affine_coordinates (O -> (0, 1)), pi(Q), -pi^2(Q)
             P2 qx = P2::zero(), qy = P2::one();
-            if (g < count && !Q[g].Z.is_zero()) {
-                qx = load2(Q[g].X); qy = load2(Q[g].Y);
-                if (!(Q[g].Z == Fq2::one())) {
-                    const P2 zi = load2(Q[g].Z).inverse(), zi2 = zi.sqr();
+            if (Q && !Q->Z.is_zero()) {
+                qx = load2(Q->X); qy = load2(Q->Y);
+                if (!(Q->Z == Fq2::one())) {
+                    const P2 zi = load2(Q->Z).inverse(), zi2 = zi.sqr();
                     qx = qx * zi2; qy = qy * (zi2 * zi);
                 }
             }
@@ -223,24 +249,17 @@ struct G2Pre {
             V[GP_S] = qy + P2::one();
             V[GP_TWB] = fq2_constT<PB>(LSA_TWIST_B);
             V[GP_ONE] = P2::one();
-            if (out[g]) {                                          // libff keeps the affine point beside the coefficients
+            if (out && out[g]) {                                   // libff keeps the affine point beside the coefficients
                 uint32_t *d = out[g] + ATE_NUM_COEFFS * TM_ROW_WORDS;
                 qx.c0.v.pack256(d); qx.c1.v.pack256(d + 8); qy.c0.v.pack256(d + 16); qy.c1.v.pack256(d + 24);
             }
         });
-        int entry = 0;
+    }
+    // tables out[g] (TM_TAB_WORDS words each, null: idle group) <- precompute_G2(Q[g])
+    LSA_HD void run(const Jac<Fq2> *const *Qp, unsigned count, uint32_t *const *out) {
+        setup(Qp, count, out);
 #pragma unroll 1
-        for (int ph = 0; ph < 66; ph++) {
-            const bool dbl = ph < 64;
-            const bool add = dbl ? ate_bit(63 - ph) != 0 : true;
-            const int x2 = ph == 64 ? GP_Q1X : (ph == 65 ? GP_Q2X : GP_QX);
-            const int first = dbl ? 0 : 3, last = add ? 7 : 3;
-#pragma unroll 1
-            for (int op = first; op < last; op++) {
-                round(op, x2, out, entry);
-                if (op == 2 || op == 5) entry++;
-            }
-        }
+        for (int e = 0; e < ATE_NUM_COEFFS; e++) entry_rounds(tm_entry_kind(e), e, out, nullptr);
     }
 };
 
@@ -445,8 +464,8 @@ struct TabMiller {
         }
     }
 
-    // accumulator c < nacc: F <- prod_{i < cnt[c]} miller_loop(+-P[c][i], table[c][i]);  M = max cnt
-    LSA_HD void run(const Jac<Fq> *const *P, const uint8_t *neg, const unsigned *cnt, unsigned M) {
+    // f = 1, the affine G1 points
+    LSA_HD void setup(const Jac<Fq> *const *P, const uint8_t *neg, const unsigned *cnt) {
         Fq2S *m = mem;
         x.par([=](unsigned lane) {
             if (lane == 63) m[TM_ZERO] = Fq2S::zero();
@@ -462,6 +481,17 @@ struct TabMiller {
                 tm_setup_g1(i < cnt[c], P[c * TM_MAXM + i], neg[c * TM_MAXM + i] != 0, m + c * TM_STRIDE + TM_PXY + 2 * i);
             }
         });
+    }
+    // One table entry with ONE pair per accumulator whose row {ell_0, ell_VW, ell_VV} somebody else has put into slot
+    // entry % 3 of the RAW ring (the fused kernel: the G2 wavefront of the workgroup): scale it beside f*f (doubling
+    // steps) or in a round of its own, then f <- f * line.
+    LSA_HD void entry_from_lds(int kind, int entry) {
+        round(kind == 0 ? 1 : 0, 1, entry, entry, -1);
+        round(2, 1, entry, -1, -1);
+    }
+    // accumulator c < nacc: F <- prod_{i < cnt[c]} miller_loop(+-P[c][i], table[c][i]);  M = max cnt
+    LSA_HD void run(const Jac<Fq> *const *P, const uint8_t *neg, const unsigned *cnt, unsigned M) {
+        setup(P, neg, cnt);
         const int U = ATE_NUM_COEFFS * (int)M;
         int u = 0, ns = 0, nl = 0;
         // what the helper lanes and the prefetch do beside the main work of a round that is about to consume use u

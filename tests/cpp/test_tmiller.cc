@@ -64,8 +64,10 @@ int main() {
         std::vector<Fq2S> lds(GP_LDS_FQ2);
         uint32_t *out[GP_GROUPS];
         for (unsigned g = 0; g < (unsigned)GP_GROUPS; g++) out[g] = g < nq ? tabs[g].data() : nullptr;
+        const Jac<Fq2> *Qp[GP_GROUPS];
+        for (unsigned g = 0; g < (unsigned)GP_GROUPS; g++) Qp[g] = &Qs[g < nq ? g : 0];
         G2Pre<LoopExec> pre{ex, lds.data()};
-        pre.run(Qs, nq, out);
+        pre.run(Qp, nq, out);
     }
     for (unsigned g = 0; g < nq; g++) {
         P2 qx, qy;
@@ -113,6 +115,39 @@ int main() {
                 want = fq12_mul(want, f);
             }
             CHECK(tm.result((unsigned)c) == want, "table-driven miller product");
+        }
+    }
+    // ---- the fused shape: the G2 engine one entry ahead of the Fq12 chain, lines handed over in the row ring, no table
+    {
+        const unsigned np = 3;                                          // one idle pair
+        std::vector<Fq2S> g2mem(TM_CHUNKS * GP_STRIDE), tmmem(TM_LDS_FQ2);
+        Jac<Fq> Ps[TM_CHUNKS * TM_MAXM];
+        const Jac<Fq> *Pp[TM_CHUNKS * TM_MAXM];
+        const Jac<Fq2> *Qp[TM_CHUNKS];
+        uint8_t neg[TM_CHUNKS * TM_MAXM] = {0};
+        unsigned cnt[TM_CHUNKS];
+        Fq2S *rows[3][TM_CHUNKS];
+        for (int c = 0; c < TM_CHUNKS; c++) {
+            Ps[c * TM_MAXM] = {rand_fq(), rand_fq(), c == 1 ? Fq::one() : rand_fq()};
+            for (int i = 0; i < TM_MAXM; i++) Pp[c * TM_MAXM + i] = &Ps[c * TM_MAXM];
+            neg[c * TM_MAXM] = (uint8_t)(c & 1);
+            Qp[c] = &Qs[c];
+            cnt[c] = (unsigned)c < np ? 1u : 0u;
+            for (int s = 0; s < 3; s++) rows[s][c] = tmmem.data() + c * TM_STRIDE + TM_RAW + 3 * s;
+        }
+        G2Pre<LoopExec, TM_CHUNKS> pre{ex, g2mem.data()};
+        TabMiller<LoopExec> tm{ex, tmmem.data(), nullptr};
+        pre.setup(Qp, np, nullptr);
+        tm.setup(Pp, neg, cnt);
+        pre.entry_rounds(tm_entry_kind(0), 0, nullptr, rows[0]);
+        for (int e = 0; e < ATE_NUM_COEFFS; e++) {
+            if (e + 1 < ATE_NUM_COEFFS) pre.entry_rounds(tm_entry_kind(e + 1), e + 1, nullptr, rows[(e + 1) % 3]);
+            tm.entry_from_lds(tm_entry_kind(e), e);
+        }
+        for (unsigned c = 0; c < np; c++) {
+            Fq12S f = miller_one(Ps[c * TM_MAXM], Qs[c]);
+            if (neg[c * TM_MAXM]) f = f.unitary_inverse();
+            CHECK(tm.result(c) == f, "fused G2 + Fq12 chain");
         }
     }
     // ---- one accumulator per wavefront
