@@ -131,7 +131,28 @@ def lib():
         L.lsa_crs_cache_stats.argtypes = [C.POINTER(C.c_uint64)] * 4
         L.lsa_msm_host_stats.argtypes = [C.POINTER(HostStats)]
         _lib = L
+        mapped = rccl_paths()
+        if len(mapped) > 1:
+            raise LsaError("two RCCL builds are mapped into this process (%s): load torch before anything that links "
+                           "/opt/rocm/lib/librccl.so.1, or set LD_LIBRARY_PATH so that both resolve to the same file" % ", ".join(mapped))
     return _lib
+
+
+def rccl_paths():
+    """The librccl files mapped into this process (one per distinct path).  torch's wheel bundles its own librccl.so and
+    the library links librccl.so.1: both have the SONAME librccl.so.1, so whichever is loaded first serves both -- lib()
+    loads torch first, hence torch's copy.  Exactly ONE must be mapped: two RCCL builds in one process would each own a
+    separate set of communicators and IPC handles."""
+    lib()
+    paths = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "librccl" in line:
+                    paths.add(line.split()[-1])
+    except OSError:
+        pass
+    return sorted(paths)
 
 
 def _check(rc):

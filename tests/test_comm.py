@@ -36,6 +36,14 @@ def test_library_links_rccl_and_rccl_has_the_collectives():
         assert hasattr(rccl, sym), sym
 
 
+def test_exactly_one_rccl_is_mapped():
+    """torch's bundled librccl.so and the library's librccl.so.1 dependency share a SONAME; whichever is loaded first
+    must serve both (legosnark_amd.lib() loads torch first and refuses to continue with two)."""
+    import torch  # noqa: F401
+    paths = legosnark_amd.rccl_paths()
+    assert len(paths) == 1, paths
+
+
 def test_comm_entry_points_fail_loudly_without_device_or_communicator():
     if legosnark_amd.device_count() > 0:
         pytest.skip("GPU present")
