@@ -258,8 +258,14 @@ struct G2Pre {
     // tables out[g] (TM_TAB_WORDS words each, null: idle group) <- precompute_G2(Q[g])
     LSA_HD void run(const Jac<Fq2> *const *Qp, unsigned count, uint32_t *const *out) {
         setup(Qp, count, out);
+        int e = 0;
 #pragma unroll 1
-        for (int e = 0; e < ATE_NUM_COEFFS; e++) entry_rounds(tm_entry_kind(e), e, out, nullptr);
+        for (int i = 63; i >= 0; --i) {                      // (the schedule tm_entry_kind() describes, walked incrementally)
+            entry_rounds(0, e++, out, nullptr);
+            if (ate_bit(i)) entry_rounds(1, e++, out, nullptr);
+        }
+        entry_rounds(2, e++, out, nullptr);
+        entry_rounds(3, e++, out, nullptr);
     }
 };
 
