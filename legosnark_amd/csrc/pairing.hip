@@ -270,18 +270,15 @@ __global__ __launch_bounds__(128) void k_miller_fused(const Jac<Fq> *__restrict_
     WaveLocalExec ex;
     G2Pre<WaveLocalExec, FU_PAIRS> pre{ex, g2mem};
     TabMiller<WaveLocalExec> tm{ex, tmmem, nullptr};
-    if (wave == 0) {
-        pre.setup(qp, count, tout);
-        pre.entry_rounds(kinds[0], 0, tout, rows[0]);
-    } else {
-        tm.setup(pp, ng, cnt);
-    }
+    if (wave == 0) pre.setup(qp, count, tout);
+    else tm.setup(pp, ng, cnt);
     __syncthreads();
+    // step e: the G2 wavefront computes entry e + 1 while the Fq12 wavefront consumes entry e (one call site each)
 #pragma unroll 1
-    for (int e = 0; e < ATE_NUM_COEFFS; e++) {
+    for (int e = -1; e < ATE_NUM_COEFFS; e++) {
         if (wave == 0) {
             if (e + 1 < ATE_NUM_COEFFS) pre.entry_rounds(kinds[e + 1], e + 1, tout, rows[(e + 1) % 3]);
-        } else {
+        } else if (e >= 0) {
             tm.entry_from_lds(kinds[e], e);
         }
         __syncthreads();

@@ -81,23 +81,41 @@ LSA_HD int tm_entry_kind(int e) {
     return e == idx ? 2 : 3;
 }
 
+// the same schedule walked incrementally: next() returns the kind of entry 0, 1, 2, ...
+struct TmSchedule {
+    int bit = 63, tail = 0;
+    bool add_pending = false;
+    LSA_HD int next() {
+        if (bit < 0) return 2 + tail++;
+        if (add_pending) { add_pending = false; bit--; return 1; }
+        if (ate_bit(bit)) add_pending = true;
+        else bit--;
+        return 0;
+    }
+};
+
 template <class X, int NG = GP_GROUPS>
 struct G2Pre {
     X &x;
     Fq2S *mem;          // NG * GP_STRIDE elements
-    struct Prod { int8_t a[5], b[5]; int n; };
+    // the <= 5 products of a round as packed slot lists (byte k = operand of product k): a lane picks its operand with
+    // a shift -- an int8 array indexed by the lane lives in scratch, two dependent scratch loads per round
+    struct Prod { uint64_t a, b; int n; };
+    static constexpr uint64_t pack5(int v0, int v1 = 0, int v2 = 0, int v3 = 0, int v4 = 0) {
+        return (uint64_t)v0 | (uint64_t)v1 << 8 | (uint64_t)v2 << 16 | (uint64_t)v3 << 24 | (uint64_t)v4 << 32;
+    }
 
     // ops 0-2: the rounds of a doubling step, 3-6: of an addition step with the point at slots (x2, x2 + 1)
     static LSA_HD Prod products_of(int op, int x2) {
-        const int8_t X2 = (int8_t)x2, Y2 = (int8_t)(x2 + 1);
+        const int X2 = x2, Y2 = x2 + 1;
         switch (op) {
-        case 0: return {{GP_X, GP_Y, GP_Z, GP_S, GP_X}, {GP_Y, GP_Y, GP_Z, GP_S, GP_X}, 5};
-        case 1: return {{GP_TWB, GP_B, 0, 0, 0}, {GP_D, GP_H, 0, 0, 0}, 2};
-        case 2: return {{GP_E, GP_A, GP_G, GP_ONE, 0}, {GP_E, GP_BMF, GP_G, GP_XIT, 0}, 4};
-        case 3: return {{X2, Y2, 0, 0, 0}, {GP_Z, GP_Z, 0, 0, 0}, 2};
-        case 4: return {{GP_DD, GP_EE, GP_EE, GP_DD, 0}, {GP_DD, GP_EE, X2, Y2, 0}, 4};
-        case 5: return {{GP_DD, GP_X, GP_Z, GP_ONE, 0}, {GP_F, GP_F, GP_GG, GP_XIT, 0}, 4};
-        default: return {{GP_DD, GP_EE, GP_HH, GP_Z, 0}, {GP_J, GP_IMJ, GP_Y, GP_HH, 0}, 4};
+        case 0: return {pack5(GP_X, GP_Y, GP_Z, GP_S, GP_X), pack5(GP_Y, GP_Y, GP_Z, GP_S, GP_X), 5};
+        case 1: return {pack5(GP_TWB, GP_B), pack5(GP_D, GP_H), 2};
+        case 2: return {pack5(GP_E, GP_A, GP_G, GP_ONE), pack5(GP_E, GP_BMF, GP_G, GP_XIT), 4};
+        case 3: return {pack5(X2, Y2), pack5(GP_Z, GP_Z), 2};
+        case 4: return {pack5(GP_DD, GP_EE, GP_EE, GP_DD), pack5(GP_DD, GP_EE, X2, Y2), 4};
+        case 5: return {pack5(GP_DD, GP_X, GP_Z, GP_ONE), pack5(GP_F, GP_F, GP_GG, GP_XIT), 4};
+        default: return {pack5(GP_DD, GP_EE, GP_HH, GP_Z), pack5(GP_J, GP_IMJ, GP_Y, GP_HH), 4};
         }
     }
     // component c of slot v
@@ -192,7 +210,7 @@ struct G2Pre {
             if (g >= (unsigned)NG || (int)k >= pr.n) return;
             Fq2S *V = m + g * GP_STRIDE;
             // a < 4p, b < 20p: 2 * 4 * 20 = 160 < 169
-            const Fs r = {w12_comp_mul<20>(part, w12_load(V + pr.a[k]), w12_load(V + pr.b[k]))};
+            const Fs r = {w12_comp_mul<20>(part, w12_load(V + (unsigned)((pr.a >> (8 * k)) & 0xffu)), w12_load(V + (unsigned)((pr.b >> (8 * k)) & 0xffu)))};
             w12_store(&w12_comp(V[GP_P0 + k], part), r);
         });
         x.par([=](unsigned lane) {
@@ -258,14 +276,9 @@ struct G2Pre {
     // tables out[g] (TM_TAB_WORDS words each, null: idle group) <- precompute_G2(Q[g])
     LSA_HD void run(const Jac<Fq2> *const *Qp, unsigned count, uint32_t *const *out) {
         setup(Qp, count, out);
-        int e = 0;
+        TmSchedule sch;
 #pragma unroll 1
-        for (int i = 63; i >= 0; --i) {                      // (the schedule tm_entry_kind() describes, walked incrementally)
-            entry_rounds(0, e++, out, nullptr);
-            if (ate_bit(i)) entry_rounds(1, e++, out, nullptr);
-        }
-        entry_rounds(2, e++, out, nullptr);
-        entry_rounds(3, e++, out, nullptr);
+        for (int e = 0; e < ATE_NUM_COEFFS; e++) entry_rounds(sch.next(), e, out, nullptr);     // ONE call site: the rounds' code once
     }
 };
 
@@ -492,8 +505,8 @@ struct TabMiller {
     // entry % 3 of the RAW ring (the fused kernel: the G2 wavefront of the workgroup): scale it beside f*f (doubling
     // steps) or in a round of its own, then f <- f * line.
     LSA_HD void entry_from_lds(int kind, int entry) {
-        round(kind == 0 ? 1 : 0, 1, entry, entry, -1);
-        round(2, 1, entry, -1, -1);
+#pragma unroll 1
+        for (int r = 0; r < 2; r++) round(r ? 2 : (kind == 0 ? 1 : 0), 1, entry, r ? -1 : entry, -1);     // (one call site)
     }
     // accumulator c < nacc: F <- prod_{i < cnt[c]} miller_loop(+-P[c][i], table[c][i]);  M = max cnt
     LSA_HD void run(const Jac<Fq> *const *P, const uint8_t *neg, const unsigned *cnt, unsigned M) {
