@@ -678,6 +678,32 @@ static int crs_lookup_or_insert(const void *bases_jac, size_t n, int group, cons
         *hit = true;
         return LSA_OK;
     }
+    // Not under this pointer -- but maybe under another one: the reference hands multiExpMA COPIES of its key vectors
+    // (CommScheme::getBases1() returns g1s by value, /root/reference/src/prototools/commit.h:145-147, and CPPoly::prove
+    // calls it once per proof, src/gadgets/poly.h:73), so the same bytes arrive at a new address with every proof.
+    // With full fingerprints the cache is content-addressed: an entry of the same group whose unit fingerprints equal
+    // the request's is the same vector (or, prefix rule as above, starts with it); it is re-keyed to the new pointer.
+    if (g_crs.mode == 2) {
+        for (auto &e : g_crs.entries) {
+            if (e.group != group || e.n < n || e.ptr == bases_jac) continue;
+            if (e.n != n && n % CRS_UNIT_POINTS != 0) continue;
+            if (memcmp(fp.data(), e.unit_fp.data(), nun * sizeof(uint64_t)) != 0) continue;
+            if (e.n == n) e.ptr = bases_jac;          // a whole-vector match follows the copy; a prefix match leaves the entry where it is
+            e.tick = ++g_crs.tick;
+            e.hits++;
+            g_crs.hits++;
+            if (!e.b->table_stride) {
+                int rc = crs_table_progress<F>(e);
+                if (rc) return rc;
+            }
+            lsa_bases *found = e.b;
+            const uint64_t keep = e.tick;
+            crs_trim(keep);
+            *out = found;
+            *hit = true;
+            return LSA_OK;
+        }
+    }
     // miss: drop stale entries for this pointer, upload + normalise (no table yet), insert
     for (size_t i = 0; i < g_crs.entries.size();) {
         if (g_crs.entries[i].ptr == bases_jac && g_crs.entries[i].group == group && g_crs.entries[i].n <= n) {

@@ -58,11 +58,11 @@ def test_hit_on_same_vector_miss_on_any_mutation(fresh_cache, group, n):
     bases[i + 1, 0] ^= np.uint64(1)
     assert canon(group, lsa.msm(group, bases, sc)) == want2
     assert delta(lsa, s1) == (0, 2)
-    # equal content at another address: its own entry
+    # equal content at another address: the cache is content-addressed (full fingerprints), the copy hits the entry
     other = bases.copy()
     s1 = lsa.crs_cache_stats()
     assert canon(group, lsa.msm(group, other, sc)) == canon(group, o.multi_exp(group, bases, sc, mode="mixed"))
-    assert delta(lsa, s1) == (0, 1)
+    assert delta(lsa, s1) == (1, 0)
 
 
 def test_prefix_requests_cppoly_ladder_shape(fresh_cache):
@@ -146,6 +146,30 @@ def test_table_built_on_first_reuse_and_lru_eviction(fresh_cache):
     s0 = lsa.crs_cache_stats()
     assert canon("g1", lsa.msm("g1", vecs[0], sc)) == wants[0]          # evicted: miss, right answer
     assert delta(lsa, s0) == (0, 1)
+
+
+def test_a_copy_of_a_cached_vector_at_another_address_is_a_hit(fresh_cache):
+    """The reference passes multiExpMA copies of its key vectors (CommScheme::getBases1() returns g1s by value,
+    src/prototools/commit.h:145-147): with full fingerprints the cache is content-addressed, so the same bytes at a
+    new address hit (whole vector and 64-aligned prefix); one changed point is a miss."""
+    lsa = fresh_cache
+    n = 4096
+    bases = np.ascontiguousarray(o.arith_bases("g1", 5, 9, n))
+    sc, _ = o.random_scalars(n, seed=4)
+    want = canon("g1", o.multi_exp("g1", bases, sc, mode="mixed"))
+    s0 = lsa.crs_cache_stats()
+    assert canon("g1", lsa.msm("g1", bases, sc)) == want
+    copy1 = bases.copy()
+    assert copy1.ctypes.data != bases.ctypes.data
+    assert canon("g1", lsa.msm("g1", copy1, sc)) == want
+    assert delta(lsa, s0) == (1, 1) and lsa.crs_cache_stats()["entries"] == 1
+    copy2 = bases[:1024].copy()                                    # a prefix of 16 units at yet another address
+    assert canon("g1", lsa.msm("g1", copy2, sc[:1024])) == canon("g1", o.multi_exp("g1", copy2, sc[:1024], mode="mixed"))
+    assert delta(lsa, s0) == (2, 1)
+    copy3 = bases.copy()
+    copy3[7] = copy3[8]
+    assert canon("g1", lsa.msm("g1", copy3, sc)) == canon("g1", o.multi_exp("g1", copy3, sc, mode="mixed"))
+    assert delta(lsa, s0) == (2, 2)
 
 
 def test_sampled_mode_and_off(fresh_cache):
