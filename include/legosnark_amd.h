@@ -83,14 +83,15 @@ int lsa_g2_msm(const void *bases_jac, const void *scalars_mont, size_t n, size_t
  * mode 0 (LSA_CRS_CACHE=0): every call uploads and normalises its bases.  Entries are evicted
  * least-recently-used beyond max_bytes of device memory (0 keeps the current budget; default
  * min(1/4 of the device, 64 GiB), env LSA_CRS_CACHE_MB).  The first re-use of an entry of at
- * least the table threshold also STARTS building its pre-shifted window copies (lsa_crs_cache_table_after). */
+ * least the table threshold that has been hit often enough also STARTS building its pre-shifted window copies
+ * (lsa_crs_cache_table_after). */
 int lsa_crs_cache_configure(int mode, size_t max_bytes);
 /* The pre-shifted copies of an entry are built in the BACKGROUND (a low-priority stream, 26 copies ~ 27 ms of GPU time
- * at 2^20 points) once the entry has been hit `hits` times (default 1: the first re-use; 0: never; env
- * LSA_CRS_TABLE_AFTER): the call that starts the build and the calls during it run at plain-pipeline speed, the
- * entry switches to the copies when they are complete -- results are the same point either way.  The copies save
- * ~1.2 ms per 2^20-pair MSM and hold 26 x 64 B per G1 point (128 B per G2 point); raise `hits` for keys that prove
- * only a few times. */
+ * at 2^20 G1 points, 64 ms for G2) once the entry has been hit `hits` times (default 23, the break-even of 27 ms
+ * against the ~1.2 ms a 2^20-pair MSM saves with them; 0: never; env LSA_CRS_TABLE_AFTER): the call that starts the
+ * build and the calls during it run at plain-pipeline speed, the entry switches to the copies when they are complete
+ * -- results are the same point either way.  They hold 26 x 64 B per G1 point (128 B per G2 point).  A prover that
+ * knows it will re-use a key many times sets 1. */
 int lsa_crs_cache_table_after(unsigned hits);
 /* Blocks until every background build has finished and its entry has switched (tests, benchmarks). */
 int lsa_crs_cache_wait_tables(void);

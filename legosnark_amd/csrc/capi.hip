@@ -280,6 +280,7 @@ namespace {
 
 constexpr size_t CRS_UNIT_POINTS = 64;          // fingerprint granularity (a prefix of k units can be verified against a longer entry)
 constexpr size_t CRS_TASK_UNITS = 64;           // units per hashing task (4096 points)
+constexpr unsigned CRS_TABLE_AFTER_DEFAULT = 23;
 constexpr size_t CRS_MIN_POINTS = 1024;         // smaller vectors are cheaper to re-upload than to look up
 
 inline uint64_t hash_words(const uint64_t *w, size_t nwords) {
@@ -504,7 +505,10 @@ struct CrsCache {
     HashPool pool;
     std::vector<uint64_t> scratch_fp;
     TableBuilder builder;
-    unsigned table_after = 1;                       // hits before an entry's copies are built (0: never); LSA_CRS_TABLE_AFTER
+    // hits before an entry's copies are built (0: never; LSA_CRS_TABLE_AFTER).  The copies of 2^20 G1 points cost ~27 ms of
+    // GPU time and save ~1.2 ms per MSM: building them at the 23rd hit is the break-even rule (never more than twice the
+    // cost of the better choice in hindsight); a key that proves a handful of times never pays for them
+    unsigned table_after = CRS_TABLE_AFTER_DEFAULT;
     std::vector<void *> garbage;                    // device buffers to free once the device is idle
 } g_crs;
 
@@ -634,7 +638,7 @@ static int crs_table_progress(CrsEntry &e) {
         e.build.reset();                                               // a failed build (no memory) leaves a plain entry
         return LSA_OK;
     }
-    if (e.hits < g_crs.table_after || e.hits > g_crs.table_after + 8) return LSA_OK;     // (no endless retries after a failure)
+    if (e.hits < g_crs.table_after || e.hits > g_crs.table_after + 8) return LSA_OK;     // (no endless retries after a failed build)
     const size_t tw = msm_table_windows(b->group, b->n);
     if ((uint64_t)b->n * tw >= (1u << 30)) return LSA_OK;
     auto j = std::make_shared<TableBuild>();

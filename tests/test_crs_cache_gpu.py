@@ -16,9 +16,11 @@ def canon(group, pt):
 def fresh_cache(lsa):
     lsa.crs_cache_configure(lsa.CRS_CACHE_FULL, 8 << 30)
     lsa.crs_cache_clear()
+    lsa.crs_cache_table_after(1)          # these tests want the copies at the first re-use (the default waits for the 23rd hit)
     yield lsa
     lsa.crs_cache_configure(lsa.CRS_CACHE_FULL, 8 << 30)
     lsa.crs_cache_clear()
+    lsa.crs_cache_table_after(23)
     lsa.set_table_threshold(0)
 
 
