@@ -221,7 +221,9 @@ __global__ __launch_bounds__(64) void k_g2_precomp(const Jac<Fq2> *__restrict__ 
 // point arithmetic (G2Pre, four groups) one table entry ahead and puts each line straight into the row ring of
 // wavefront 1, which runs the Fq12 chain (TabMiller, four accumulators); one workgroup barrier per entry.  The G2 side
 // (2.5 K / 3.4 K instructions per doubling / addition entry) and the f side (3.8 K / 1.9 K) overlap instead of adding
-// up, no table ever goes through memory, and 4096 pairs fill the chip with 2048 wavefronts.
+// up, no table ever goes through memory.  The G2 wavefront also scales each line by the pair's (px, py) -- on lanes that
+// are free in the round after the one that fixes ell_VW and ell_VV -- so the Fq12 wavefront needs no helper lanes and no
+// scaling rounds and serves FIVE accumulators (TabMillerP): 1640 wavefronts for 4096 pairs.
 struct WaveLocalExec {
     // one wavefront of a larger workgroup: its phases are ordered by the wavefront's own in-order LDS queue; only the
     // compiler has to be kept from moving memory accesses across the phase boundary
@@ -234,17 +236,17 @@ struct WaveLocalExec {
     }
     __device__ __forceinline__ unsigned nlanes() const { return 64; }
 };
-static constexpr int FU_PAIRS = TM_CHUNKS;                              // pairs per workgroup
+static constexpr int FU_PAIRS = 5;                                     // pairs per workgroup: 60 lanes of each wavefront
 // tabs (optional): tabs[i] non-null -> the table of g2[i] is also written there (a point seen for the first time: its
 // table goes into the cache while its first Miller loop runs).
 __global__ __launch_bounds__(128) void k_miller_fused(const Jac<Fq> *__restrict__ g1, const Jac<Fq2> *__restrict__ g2, const uint8_t *__restrict__ flags,
                                                       uint32_t *const *__restrict__ tabs, size_t n, Fq12 *__restrict__ out) {
+    using TP = TabMillerP<WaveLocalExec, FU_PAIRS>;
     __shared__ Fq2S g2mem[FU_PAIRS * GP_STRIDE];
-    __shared__ Fq2S tmmem[TM_LDS_FQ2];
+    __shared__ Fq2S tpmem[TP::LDS_FQ2];
     __shared__ const Jac<Fq2> *qp[FU_PAIRS];
-    __shared__ const Jac<Fq> *pp[TM_CHUNKS * TM_MAXM];
-    __shared__ uint8_t ng[TM_CHUNKS * TM_MAXM];
-    __shared__ unsigned cnt[TM_CHUNKS];
+    __shared__ const Jac<Fq> *pp[FU_PAIRS];
+    __shared__ uint8_t ng[FU_PAIRS];
     __shared__ Fq2S *rows[3][FU_PAIRS];
     __shared__ uint32_t *tout[FU_PAIRS];
     __shared__ uint8_t kinds[ATE_NUM_COEFFS];
@@ -256,42 +258,43 @@ __global__ __launch_bounds__(128) void k_miller_fused(const Jac<Fq> *__restrict_
     if (tid < (unsigned)FU_PAIRS) {
         const bool have = tid < count;
         qp[tid] = g2 + lo + (have ? tid : 0);
-        cnt[tid] = have ? 1u : 0u;
+        pp[tid] = g1 + lo + (have ? tid : 0);
+        ng[tid] = have && flags ? (uint8_t)(flags[lo + tid] & 1) : (uint8_t)0;
         tout[tid] = have && tabs ? tabs[lo + tid] : nullptr;
-        for (int s = 0; s < 3; s++) rows[s][tid] = tmmem + tid * TM_STRIDE + TM_RAW + 3 * s;
-    }
-    if (tid < (unsigned)(TM_CHUNKS * TM_MAXM)) {
-        const unsigned c = tid / TM_MAXM, i = tid % TM_MAXM;
-        const bool have = i == 0 && c < count;
-        pp[tid] = g1 + lo + (have ? c : 0);
-        ng[tid] = have && flags ? (uint8_t)(flags[lo + c] & 1) : (uint8_t)0;
+        for (int s = 0; s < 3; s++) rows[s][tid] = tpmem + tid * TP_STRIDE + TP_RAW + 3 * s;
     }
     __syncthreads();
     WaveLocalExec ex;
     G2Pre<WaveLocalExec, FU_PAIRS> pre{ex, g2mem};
-    TabMiller<WaveLocalExec> tm{ex, tmmem, nullptr};
-    if (wave == 0) pre.setup(qp, count, tout);
-    else tm.setup(pp, ng, cnt);
+    TP tp{ex, tpmem};
+    if (wave == 0) {
+        pre.setup(qp, count, tout);
+        pre.setup_g1(pp, ng, count);
+    } else {
+        tp.setup();
+    }
     __syncthreads();
-    // step e: the G2 wavefront computes entry e + 1 while the Fq12 wavefront consumes entry e (one call site each)
+    // step e: the G2 wavefront computes entry e + 1 (scaled by the pair's (px, py)) while the Fq12 wavefront consumes
+    // entry e (one call site each)
 #pragma unroll 1
     for (int e = -1; e < ATE_NUM_COEFFS; e++) {
         if (wave == 0) {
-            if (e + 1 < ATE_NUM_COEFFS) pre.entry_rounds(kinds[e + 1], e + 1, tout, rows[(e + 1) % 3]);
+            if (e + 1 < ATE_NUM_COEFFS) pre.entry_rounds(kinds[e + 1], e + 1, tout, rows[(e + 1) % 3], true);
         } else if (e >= 0) {
-            tm.entry_from_lds(kinds[e], e);
+            tp.entry(kinds[e], e);
         }
         __syncthreads();
     }
-    if (wave == 1 && lane < 12u * TM_CHUNKS) {
+    if (wave == 1 && lane < 12u * FU_PAIRS) {
         const unsigned c = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
         if (c < count) {
             const unsigned t = (k & 1) * 3 + (k >> 1);                  // tower position of w^k
-            const Fq2S cf = tmmem[c * TM_STRIDE + TM_F + k];
+            const Fq2S cf = tpmem[c * TP_STRIDE + TP_F + k];
             reinterpret_cast<Fq *>(&out[lo + c])[2 * t + part] = (part ? cf.c1 : cf.c0).to_mont256();
         }
     }
 }
+
 
 // internal table (x * 2^261 mod p, < 4p, 256-bit packed) -> libff's alt_bn128_ate_G2_precomp as bytes: QX, QY, then
 // {ell_0, ell_VW, ell_VV} per step, canonical Montgomery Fq2 of 64 B.  One lane per Fq.

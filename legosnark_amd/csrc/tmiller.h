@@ -55,13 +55,31 @@ LSA_HD uint32_t tm_row_element(const uint32_t *row, unsigned wi) {
 // LDS, no barriers, 32 points per wavefront) 5.1 K / 6.4 K per doubling / addition step -- 2.5 x longer.
 // Formulas and lazy bounds are WMiller::doubling_round / addition_round's (libff's step formulas).
 // ------------------------------------------------------------------------------------
+// precompute_G1 for one pair (libff to_affine_coordinates: O -> (0, 1)); neg: use -P (the Miller value of
+// (-P, Q) is the conjugate -- libff unitary_inverse -- of that of (P, Q): conjugation negates the odd
+// powers of w and only ell_VW * py sits on one)
+LSA_HD void tm_setup_g1(bool valid, const Jac<Fq> *P, bool neg, Fq2S *pxy) {
+    PB px = PB::zero(), py = PB::one();
+    if (valid && !P->Z.is_zero()) {
+        px = PB::from_mont256(P->X); py = PB::from_mont256(P->Y);
+        if (!(P->Z == Fq::one())) {
+            const PB zi = PB::from_mont256(P->Z).inverse(), zi2 = zi.sqr();
+            px = px * zi2; py = py * (zi2 * zi);
+        }
+    }
+    if (neg) py = py.neg();
+    pxy[0] = Fq2S{px, PB::zero()};
+    pxy[1] = Fq2S{py, PB::zero()};
+}
+
 enum G2PVar {                                  // Fq2S slots of one point
     GP_X, GP_Y, GP_Z, GP_S,                    // R = (X, Y, Z) < 2p, S = Y + Z < 4p
     GP_QX, GP_QY, GP_Q1X, GP_Q1Y, GP_Q2X, GP_Q2Y, GP_TWB, GP_ONE,
     GP_A, GP_B, GP_D, GP_H, GP_E, GP_G, GP_BMF, GP_XIT,           // doubling step
     GP_DD, GP_EE, GP_F, GP_GG, GP_HH, GP_I, GP_J, GP_IMJ,         // addition step
     GP_L0, GP_L1, GP_L2,                       // the line being assembled
-    GP_P0, GP_P1, GP_P2, GP_P3, GP_P4,         // the round's products
+    GP_PX, GP_PY, GP_S1, GP_S2,                // fused kernel: (px, 0), (py, 0) of the pair's G1 point; ell_VW * py, ell_VV * px
+    GP_P0, GP_P1, GP_P2, GP_P3, GP_P4, GP_P5,  // the round's products
     GP_STRIDE
 };
 static constexpr int GP_GROUPS = 5;
@@ -101,19 +119,21 @@ struct G2Pre {
     // the <= 5 products of a round as packed slot lists (byte k = operand of product k): a lane picks its operand with
     // a shift -- an int8 array indexed by the lane lives in scratch, two dependent scratch loads per round
     struct Prod { uint64_t a, b; int n; };
-    static constexpr uint64_t pack5(int v0, int v1 = 0, int v2 = 0, int v3 = 0, int v4 = 0) {
-        return (uint64_t)v0 | (uint64_t)v1 << 8 | (uint64_t)v2 << 16 | (uint64_t)v3 << 24 | (uint64_t)v4 << 32;
+    static constexpr uint64_t pack5(int v0, int v1 = 0, int v2 = 0, int v3 = 0, int v4 = 0, int v5 = 0) {
+        return (uint64_t)v0 | (uint64_t)v1 << 8 | (uint64_t)v2 << 16 | (uint64_t)v3 << 24 | (uint64_t)v4 << 32 | (uint64_t)v5 << 40;
     }
 
-    // ops 0-2: the rounds of a doubling step, 3-6: of an addition step with the point at slots (x2, x2 + 1)
-    static LSA_HD Prod products_of(int op, int x2) {
+    // ops 0-2: the rounds of a doubling step, 3-6: of an addition step with the point at slots (x2, x2 + 1).
+    // scaled (the fused kernel): the round after the one that fixes ell_VW and ell_VV also multiplies them by (py, px) on
+    // lanes that are free there, so that the consumer gets its line ready to use
+    static LSA_HD Prod products_of(int op, int x2, bool scaled) {
         const int X2 = x2, Y2 = x2 + 1;
         switch (op) {
         case 0: return {pack5(GP_X, GP_Y, GP_Z, GP_S, GP_X), pack5(GP_Y, GP_Y, GP_Z, GP_S, GP_X), 5};
-        case 1: return {pack5(GP_TWB, GP_B), pack5(GP_D, GP_H), 2};
+        case 1: return {pack5(GP_TWB, GP_B, GP_L1, GP_L2), pack5(GP_D, GP_H, GP_PY, GP_PX), scaled ? 4 : 2};
         case 2: return {pack5(GP_E, GP_A, GP_G, GP_ONE), pack5(GP_E, GP_BMF, GP_G, GP_XIT), 4};
         case 3: return {pack5(X2, Y2), pack5(GP_Z, GP_Z), 2};
-        case 4: return {pack5(GP_DD, GP_EE, GP_EE, GP_DD), pack5(GP_DD, GP_EE, X2, Y2), 4};
+        case 4: return {pack5(GP_DD, GP_EE, GP_EE, GP_DD, GP_L1, GP_L2), pack5(GP_DD, GP_EE, X2, Y2, GP_PY, GP_PX), scaled ? 6 : 4};
         case 5: return {pack5(GP_DD, GP_X, GP_Z, GP_ONE), pack5(GP_F, GP_F, GP_GG, GP_XIT), 4};
         default: return {pack5(GP_DD, GP_EE, GP_HH, GP_Z), pack5(GP_J, GP_IMJ, GP_Y, GP_HH), 4};
         }
@@ -158,6 +178,8 @@ struct G2Pre {
             const F29 tc = condsub2(sub_k<2>(E, B));                                // E - B  [<4] -> [<2]
             const F29 to = condsub2(sub_k<2>(ld(V, GP_P0, o), ld(V, GP_B, o)));     // the other component of the same
             st(V, GP_XIT, c, xi_comp(c, tc, to));                                   // xi (E - B)             [<20]
+            st(V, GP_S1, c, ld(V, GP_P2, c));                                       // (scaled mode: ell_VW * py, ell_VV * px; else unused)
+            st(V, GP_S2, c, ld(V, GP_P3, c));
         } break;
         case 2: {
             const F29 Y3 = condsub2(condsub4(sub_k<6>(ld(V, GP_P2, c), triple(ld(V, GP_P0, c)))));   // G^2 - 3E^2 + 6p [<8] -> [<2]
@@ -180,6 +202,8 @@ struct G2Pre {
             const F29 tc = condsub2(sub_k<2>(ld(V, GP_P2, c), ld(V, GP_P3, c)));    // E x2 - D y2  [<4] -> [<2]
             const F29 to = condsub2(sub_k<2>(ld(V, GP_P2, o), ld(V, GP_P3, o)));
             st(V, GP_XIT, c, xi_comp(c, tc, to));
+            st(V, GP_S1, c, ld(V, GP_P4, c));
+            st(V, GP_S2, c, ld(V, GP_P5, c));
         } break;
         case 5: {
             const F29 H = ld(V, GP_P0, c), I = ld(V, GP_P1, c);
@@ -202,9 +226,9 @@ struct G2Pre {
 
     // one round; after the rounds that complete a line (2: doubling, 5: addition) lanes (k < 3, part) write it out: into the
     // table out[g] (packed, global memory) and / or as three Fq2S at rows[g] (LDS: the consumer's row ring)
-    LSA_HD void round(int op, int x2, uint32_t *const *out, int entry, Fq2S *const *rows = nullptr) {
+    LSA_HD void round(int op, int x2, uint32_t *const *out, int entry, Fq2S *const *rows = nullptr, bool scaled = false) {
         Fq2S *m = mem;
-        const Prod pr = products_of(op, x2);
+        const Prod pr = products_of(op, x2, scaled);
         x.par([=](unsigned lane) {
             const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
             if (g >= (unsigned)NG || (int)k >= pr.n) return;
@@ -223,7 +247,8 @@ struct G2Pre {
                 const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
                 if (g >= (unsigned)NG || k >= 3) return;
                 const F29 v = ld(m + g * GP_STRIDE, GP_L0 + (int)k, part);
-                if (rows && rows[g]) w12_store(&w12_comp(rows[g][k], part), Fs{v});
+                // the consumer's row: {ell_0, ell_VW, ell_VV}, or in scaled mode {ell_0, ell_VW * py, ell_VV * px}
+                if (rows && rows[g]) w12_store(&w12_comp(rows[g][k], part), Fs{scaled && k ? ld(m + g * GP_STRIDE, GP_S1 + (int)k - 1, part) : v});
                 if (!out || !out[g]) return;
                 uint32_t w[8];
                 v.pack256(w);                                                      // < 4p < 2^256
@@ -234,11 +259,20 @@ struct G2Pre {
         }
     }
     // the rounds of table entry `entry` (its kind: tm_entry_kind)
-    LSA_HD void entry_rounds(int kind, int entry, uint32_t *const *out, Fq2S *const *rows) {
+    LSA_HD void entry_rounds(int kind, int entry, uint32_t *const *out, Fq2S *const *rows, bool scaled = false) {
         const int x2 = kind == 2 ? GP_Q1X : (kind == 3 ? GP_Q2X : GP_QX);
         const int first = kind == 0 ? 0 : 3, last = kind == 0 ? 3 : 7;
 #pragma unroll 1
-        for (int op = first; op < last; op++) round(op, x2, out, entry, rows);
+        for (int op = first; op < last; op++) round(op, x2, out, entry, rows, scaled);
+    }
+    // scaled mode: the affine G1 point of each pair (libff precompute_G1; neg: -P, the conjugate Miller value)
+    LSA_HD void setup_g1(const Jac<Fq> *const *Pp, const uint8_t *neg, unsigned count) {
+        Fq2S *m = mem;
+        x.par([=](unsigned lane) {
+            const unsigned g = lane / 12, k = lane % 12;
+            if (g >= (unsigned)NG || k != 2) return;
+            tm_setup_g1(g < count, Pp[g], g < count && neg[g] != 0, m + g * GP_STRIDE + GP_PX);
+        });
     }
 
     // libff to_affine_coordinates (O -> (0, 1)), pi(Q), -pi^2(Q), R = Q for the points Q[g], g < count
@@ -355,23 +389,6 @@ __device__ __forceinline__ void tm_store_word(uint32_t *p, uint32_t v) { *w12_ld
 #else
 inline void tm_store_word(uint32_t *p, uint32_t v) { *p = v; }
 #endif
-
-// precompute_G1 for one pair (libff to_affine_coordinates: O -> (0, 1)); neg: use -P (the Miller value of
-// (-P, Q) is the conjugate -- libff unitary_inverse -- of that of (P, Q): conjugation negates the odd
-// powers of w and only ell_VW * py sits on one)
-LSA_HD void tm_setup_g1(bool valid, const Jac<Fq> *P, bool neg, Fq2S *pxy) {
-    PB px = PB::zero(), py = PB::one();
-    if (valid && !P->Z.is_zero()) {
-        px = PB::from_mont256(P->X); py = PB::from_mont256(P->Y);
-        if (!(P->Z == Fq::one())) {
-            const PB zi = PB::from_mont256(P->Z).inverse(), zi2 = zi.sqr();
-            px = px * zi2; py = py * (zi2 * zi);
-        }
-    }
-    if (neg) py = py.neg();
-    pxy[0] = Fq2S{px, PB::zero()};
-    pxy[1] = Fq2S{py, PB::zero()};
-}
 
 template <class X>
 struct TabMiller {
@@ -501,13 +518,6 @@ struct TabMiller {
             }
         });
     }
-    // One table entry with ONE pair per accumulator whose row {ell_0, ell_VW, ell_VV} somebody else has put into slot
-    // entry % 3 of the RAW ring (the fused kernel: the G2 wavefront of the workgroup): scale it beside f*f (doubling
-    // steps) or in a round of its own, then f <- f * line.
-    LSA_HD void entry_from_lds(int kind, int entry) {
-#pragma unroll 1
-        for (int r = 0; r < 2; r++) round(r ? 2 : (kind == 0 ? 1 : 0), 1, entry, r ? -1 : entry, -1);     // (one call site)
-    }
     // accumulator c < nacc: F <- prod_{i < cnt[c]} miller_loop(+-P[c][i], table[c][i]);  M = max cnt
     LSA_HD void run(const Jac<Fq> *const *P, const uint8_t *neg, const unsigned *cnt, unsigned M) {
         setup(P, neg, cnt);
@@ -546,6 +556,98 @@ struct TabMiller {
     LSA_HD Fq12S result(unsigned c) const {
         Fq12S t;
         for (int k = 0; k < 6; k++) w12_tower_ref(t, k) = mem[c * TM_STRIDE + TM_F + k];
+        return t;
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// The Fq12 chain of the fused kernel: NC accumulators per wavefront, ONE pair each, every line delivered READY TO USE
+// ({ell_0, ell_VW * py, ell_VV * px}, by the G2 wavefront of the workgroup) into slot entry % 3 of the accumulator's row
+// ring.  No helper lanes, no scaling rounds, no global loads: five accumulators fill sixty lanes.
+// ------------------------------------------------------------------------------------
+enum { TP_F = 0, TP_XF = 6, TP_T = 12, TP_RAW = 18, TP_STRIDE = 27 };
+template <class X, int NC>
+struct TabMillerP {
+    static_assert(12 * NC <= 64, "one wavefront");
+    static constexpr int ZERO = NC * TP_STRIDE;
+    static constexpr int LDS_FQ2 = ZERO + 1;
+    X &x;
+    Fq2S *mem;                        // LDS_FQ2 elements
+    using WM = WMiller<X>;
+
+    LSA_HD void setup() {
+        Fq2S *m = mem;
+        x.par([=](unsigned lane) {
+            if (lane == 63) m[ZERO] = Fq2S::zero();
+            if (lane >= 12u * NC || (lane & 1)) return;
+            const unsigned c = lane / 12, k = (lane % 12) >> 1;
+            const Fq2S f0 = k == 0 ? P2::one() : P2::zero();
+            m[c * TP_STRIDE + TP_F + k] = f0;
+            m[c * TP_STRIDE + TP_XF + k] = WM::st(WM::xi_times(WM::ld(f0)));
+        });
+    }
+    // mode 1: f <- f*f, 2: f <- f * line(entry)
+    LSA_HD void round(int mode, int entry) {
+        Fq2S *m = mem;
+        x.par([=](unsigned lane) {
+            if (lane >= 12u * NC) return;
+            const unsigned part = lane & 1;
+            const int base = (int)(lane / 12) * TP_STRIDE, k = (int)((lane % 12) >> 1);
+            Fs *dst = &g12_part(m[base + TP_T + k], part);
+            if (mode == 2) {
+                // three products, ONE reduction: a < 20p (xi * f) in at most two terms, b < 2p: 4 * 40 + 2 * 4 = 168 < 169 p^2
+                F29 xa[6], yb[6];
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    int ai = k - (j == 0 ? 0 : j + 2);                      // line coefficients sit at w^0, w^3, w^4
+                    const bool wrap = ai < 0;
+                    if (wrap) ai += 6;
+                    tm_comp_operands<2>(part, w12_load(m + base + (wrap ? TP_XF : TP_F) + ai), w12_load(m + base + TP_RAW + 3 * (entry % 3) + j),
+                                        xa[2 * j], yb[2 * j], xa[2 * j + 1], yb[2 * j + 1]);
+                }
+                w12_store(dst, Fs{dotn<6>(xa, yb)});
+            } else {
+                // the 4 (k even) or 3 unordered pairs of a square, reduced one by one, summed with their weights (6 in
+                // all) and brought back under 2p by a Montgomery product with 1
+                F29 sum = F29::zero();
+#pragma unroll 1
+                for (int j = 0; j < 4; j++) {
+                    int ao = ZERO, bo = ZERO;
+                    uint32_t w2 = 0;
+                    if (j < sqr_pair_count(k)) {
+                        int ti, ui;
+                        bool wrap;
+                        sqr_pair(k, j, ti, ui, wrap);
+                        ao = base + (wrap ? TP_XF : TP_F) + ti;
+                        bo = base + TP_F + ui;
+                        w2 = ti == ui ? 0u : ~0u;
+                    }
+                    const F29 x1 = g12_comp_mul<2>(part, w12_load(m + ao), w12_load(m + bo));
+                    w2 = w12_mask(w2);
+#pragma unroll
+                    for (int l = 0; l < 9; l++) sum.l[l] += x1.l[l] + (x1.l[l] & w2);
+                }
+                w12_store(dst, Fs{mul(w12_norm_u(sum), F29::one())});
+            }
+        });
+        x.par([=](unsigned lane) {
+            if (lane >= 12u * NC || (lane & 1)) return;
+            const unsigned c = lane / 12, k = (lane % 12) >> 1;
+            Fq2S *base = m + c * TP_STRIDE;
+            const Fq2S tv = base[TP_T + k];
+            base[TP_F + k] = tv;
+            base[TP_XF + k] = WM::st(WM::xi_times(WM::ld(tv)));                              // [< 20]
+        });
+    }
+    // one table entry (kind 0: a doubling step)
+    LSA_HD void entry(int kind, int e) {
+#pragma unroll 1
+        for (int r = kind == 0 ? 0 : 1; r < 2; r++) round(r ? 2 : 1, e);                     // (one call site)
+    }
+    LSA_HD Fq2S *row(unsigned c, int slot) const { return mem + c * TP_STRIDE + TP_RAW + 3 * slot; }
+    LSA_HD Fq12S result(unsigned c) const {
+        Fq12S t;
+        for (int k = 0; k < 6; k++) w12_tower_ref(t, k) = mem[c * TP_STRIDE + TP_F + k];
         return t;
     }
 };

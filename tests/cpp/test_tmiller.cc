@@ -117,37 +117,46 @@ int main() {
             CHECK(tm.result((unsigned)c) == want, "table-driven miller product");
         }
     }
-    // ---- the fused shape: the G2 engine one entry ahead of the Fq12 chain, lines handed over in the row ring, no table
+    // ---- the fused shape: the G2 engine one entry ahead of the Fq12 chain, lines (already scaled by the pair's G1 point)
+    // handed over in the row ring, no table
     {
-        const unsigned np = 3;                                          // one idle pair
-        std::vector<Fq2S> g2mem(TM_CHUNKS * GP_STRIDE), tmmem(TM_LDS_FQ2);
-        Jac<Fq> Ps[TM_CHUNKS * TM_MAXM];
-        const Jac<Fq> *Pp[TM_CHUNKS * TM_MAXM];
-        const Jac<Fq2> *Qp[TM_CHUNKS];
-        uint8_t neg[TM_CHUNKS * TM_MAXM] = {0};
-        unsigned cnt[TM_CHUNKS];
-        Fq2S *rows[3][TM_CHUNKS];
-        for (int c = 0; c < TM_CHUNKS; c++) {
-            Ps[c * TM_MAXM] = {rand_fq(), rand_fq(), c == 1 ? Fq::one() : rand_fq()};
-            for (int i = 0; i < TM_MAXM; i++) Pp[c * TM_MAXM + i] = &Ps[c * TM_MAXM];
-            neg[c * TM_MAXM] = (uint8_t)(c & 1);
-            Qp[c] = &Qs[c];
-            cnt[c] = (unsigned)c < np ? 1u : 0u;
-            for (int s = 0; s < 3; s++) rows[s][c] = tmmem.data() + c * TM_STRIDE + TM_RAW + 3 * s;
+        constexpr int NP = 5;
+        using TP = TabMillerP<LoopExec, NP>;
+        const unsigned np = 4;                                          // one idle pair
+        std::vector<Fq2S> g2mem(NP * GP_STRIDE), tpmem(TP::LDS_FQ2);
+        Jac<Fq> Ps[NP];
+        const Jac<Fq> *Pp[NP];
+        const Jac<Fq2> *Qp[NP];
+        uint8_t neg[NP];
+        Fq2S *rows[3][NP];
+        for (int c = 0; c < NP; c++) {
+            Ps[c] = {rand_fq(), rand_fq(), c == 1 ? Fq::one() : rand_fq()};
+            if (c == 2) Ps[c].Z = Fq::zero();
+            Pp[c] = &Ps[c];
+            neg[c] = (uint8_t)(c & 1);
+            Qp[c] = &Qs[c % (int)nq];
+            for (int s = 0; s < 3; s++) rows[s][c] = tpmem.data() + c * TP_STRIDE + TP_RAW + 3 * s;
         }
-        G2Pre<LoopExec, TM_CHUNKS> pre{ex, g2mem.data()};
-        TabMiller<LoopExec> tm{ex, tmmem.data(), nullptr};
-        pre.setup(Qp, np, nullptr);
-        tm.setup(Pp, neg, cnt);
-        pre.entry_rounds(tm_entry_kind(0), 0, nullptr, rows[0]);
-        for (int e = 0; e < ATE_NUM_COEFFS; e++) {
-            if (e + 1 < ATE_NUM_COEFFS) pre.entry_rounds(tm_entry_kind(e + 1), e + 1, nullptr, rows[(e + 1) % 3]);
-            tm.entry_from_lds(tm_entry_kind(e), e);
+        std::vector<std::vector<uint32_t>> tabs2(np, std::vector<uint32_t>(TM_TAB_WORDS, 0xdeadbeefu));
+        uint32_t *tout[NP];
+        for (int c = 0; c < NP; c++) tout[c] = (unsigned)c < np ? tabs2[c].data() : nullptr;
+        G2Pre<LoopExec, NP> pre{ex, g2mem.data()};
+        TP tp{ex, tpmem.data()};
+        pre.setup(Qp, np, tout);
+        pre.setup_g1(Pp, neg, np);
+        tp.setup();
+        for (int e = -1; e < ATE_NUM_COEFFS; e++) {
+            if (e + 1 < ATE_NUM_COEFFS) pre.entry_rounds(tm_entry_kind(e + 1), e + 1, tout, rows[(e + 1) % 3], true);
+            if (e >= 0) tp.entry(tm_entry_kind(e), e);
         }
         for (unsigned c = 0; c < np; c++) {
-            Fq12S f = miller_one(Ps[c * TM_MAXM], Qs[c]);
-            if (neg[c * TM_MAXM]) f = f.unitary_inverse();
-            CHECK(tm.result(c) == f, "fused G2 + Fq12 chain");
+            Fq12S f = miller_one(Ps[c], Qs[c % nq]);
+            if (neg[c]) f = f.unitary_inverse();
+            CHECK(tp.result(c) == f, "fused G2 + Fq12 chain");
+            // the table written on the way is the UNSCALED one
+            bool same = true;
+            for (int i = 0; i < TM_TAB_WORDS; i++) same = same && tabs2[c][i] == tabs[c % nq][i];
+            CHECK(same, "table emitted by the fused engine");
         }
     }
     // ---- one accumulator per wavefront
