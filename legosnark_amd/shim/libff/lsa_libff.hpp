@@ -24,6 +24,7 @@
 #include <random>
 #include <stdexcept>
 #include <cerrno>
+#include <pthread.h>
 #include <sys/random.h>
 #include <sys/types.h>
 #include <string>
@@ -32,8 +33,62 @@
 #include "../../../include/legosnark_amd.h"
 #include "../../csrc/ec.h"
 #include "../../csrc/tower.h"
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
 
 namespace libff {
+
+// LSA_SHIM_STATS=1: at exit, one JSON line on stderr saying how many calls of each kind the program made through this
+// header and how long it spent inside them -- the rest of a reference binary's run time is the reference's own host
+// code (witness recursions, sumcheck tables, vector copies).  One relaxed atomic add per call when off.
+namespace lsa_shim {
+enum StatKind { ST_MSM_G1, ST_MSM_G2, ST_PAIRING, ST_G2_PRECOMP, ST_BATCH_EXP, ST_NORMALIZE, ST_SCALAR_MUL_HOST, ST_SPARSE_MSM, ST_KINDS };
+struct Stats {
+    std::atomic<uint64_t> calls[ST_KINDS], ns[ST_KINDS], items[ST_KINDS];
+    std::chrono::steady_clock::time_point born = std::chrono::steady_clock::now();
+    static const char *name(int k) {
+        static const char *const n[ST_KINDS] = {"msm_g1", "msm_g2", "pairing", "g2_precompute", "batch_exp", "normalize", "scalar_mul_host", "sparse_msm"};
+        return n[k];
+    }
+    static void report() {
+        Stats &s = get();
+        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s.born).count();
+        double inside = 0;
+        fprintf(stderr, "{\"lsa_shim_stats\": {");
+        for (int k = 0; k < ST_KINDS; k++) {
+            const double ms = (double)s.ns[k].load() * 1e-6;
+            inside += ms;
+            fprintf(stderr, "\"%s\": {\"calls\": %llu, \"items\": %llu, \"ms\": %.3f}, ", name(k), (unsigned long long)s.calls[k].load(),
+                    (unsigned long long)s.items[k].load(), ms);
+        }
+        fprintf(stderr, "\"inside_ms\": %.3f, \"process_ms\": %.3f}}\n", inside, wall);
+    }
+    static Stats &get() {
+        static Stats *s = [] {
+            Stats *t = new Stats();
+            for (int k = 0; k < ST_KINDS; k++) { t->calls[k] = 0; t->ns[k] = 0; t->items[k] = 0; }
+            const char *e = getenv("LSA_SHIM_STATS");
+            if (e && e[0] == '1') atexit(report);
+            return t;
+        }();
+        return *s;
+    }
+};
+struct StatScope {
+    const int kind;
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    StatScope(int k, size_t items) : kind(k) {
+        Stats &s = Stats::get();
+        s.calls[k].fetch_add(1, std::memory_order_relaxed);
+        s.items[k].fetch_add(items, std::memory_order_relaxed);
+    }
+    ~StatScope() {
+        Stats::get().ns[kind].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
+                                        std::memory_order_relaxed);
+    }
+};
+}  // namespace lsa_shim
 
 // ---------------------------------------------------------------- errors
 inline void lsa_require(int rc, const char *what) {
@@ -92,18 +147,38 @@ inline void lsa_random_bytes(void *buf, size_t len) {
     unsigned char *p = (unsigned char *)buf;
     for (size_t i = 0; i < len; i += 8) { uint64_t r = g(); memcpy(p + i, &r, len - i < 8 ? len - i : 8); }
 #else
+    // One system call per 4 KiB, not per field element (a vector of 2^20 random scalars is a million draws): a
+    // per-thread pool of CSPRNG output, every byte handed out once and wiped, emptied in the child of a fork.
+    struct Pool {
+        unsigned char bytes[4096];
+        size_t left = 0;
+        static void os_fill(unsigned char *p, size_t len) {
+            size_t got = 0;
+            while (got < len) {
+                ssize_t r = getrandom(p + got, len - got, 0);
+                if (r > 0) { got += (size_t)r; continue; }
+                if (r < 0 && errno == EINTR) continue;
+                break;                             // ENOSYS etc.: fall back below
+            }
+            if (got < len) {
+                std::random_device rd;
+                for (; got < len; got++) p[got] = (unsigned char)rd();
+            }
+        }
+        static Pool &mine() {
+            static thread_local Pool pool;
+            static const int registered = pthread_atfork(nullptr, nullptr, [] { Pool &q = mine(); memset(q.bytes, 0, sizeof q.bytes); q.left = 0; });
+            (void)registered;
+            return pool;
+        }
+    };
     unsigned char *p = (unsigned char *)buf;
-    size_t got = 0;
-    while (got < len) {
-        ssize_t r = getrandom(p + got, len - got, 0);
-        if (r > 0) { got += (size_t)r; continue; }
-        if (r < 0 && errno == EINTR) continue;
-        break;                                     // ENOSYS etc.: fall back below
-    }
-    if (got < len) {
-        std::random_device rd;
-        for (; got < len; got++) p[got] = (unsigned char)rd();
-    }
+    if (len > sizeof(Pool::bytes) / 4) { Pool::os_fill(p, len); return; }
+    Pool &pool = Pool::mine();
+    if (pool.left < len) { Pool::os_fill(pool.bytes, sizeof pool.bytes); pool.left = sizeof pool.bytes; }
+    pool.left -= len;
+    memcpy(p, pool.bytes + pool.left, len);
+    memset(pool.bytes + pool.left, 0, len);
 #endif
 }
 
@@ -381,6 +456,7 @@ inline bool eager() {
 }
 inline const lsa::Fq12 &evaluate(const PairExpr &e) {
     if (e.done) return e.result;
+    StatScope scope(ST_PAIRING, e.terms.size());
     lsa::Fq12 out = e.cst;
     const size_t n = e.terms.size();
     if (n) {
@@ -524,6 +600,7 @@ public:
     void print() const { std::cout << *this << "\n"; }
     // libff "scalar * point": MSB-first double-and-add on the canonical scalar (cold path)
     friend G_shim operator*(const alt_bn128_Fr &k, const G_shim &p) {
+        lsa_shim::StatScope scope(lsa_shim::ST_SCALAR_MUL_HOST, 1);
         bigint<4> e = k.as_bigint();
         Jac res = Jac::inf(), base = p.jac();
         bool found = false;
@@ -694,6 +771,7 @@ public:
     // The device starts on the line table of a point it has not seen (asynchronously) and keeps it; the value only
     // carries Q, and its coefficients on demand.
     static alt_bn128_G2_precomp precompute_G2(const alt_bn128_G2 &Q) {
+        lsa_shim::StatScope scope(lsa_shim::ST_G2_PRECOMP, 1);
         alt_bn128_G2 a = Q;
         a.to_affine_coordinates();
         lsa_require(lsa_g2_tables_prefetch(&a, 1), "precompute_G2");
@@ -764,6 +842,7 @@ T msm_forward(typename std::vector<T>::const_iterator vec_start, typename std::v
     assert((size_t)(scalar_end - scalar_start) == n);
     (void)scalar_end;
     T out;
+    lsa_shim::StatScope scope(group_id<T>::value == 1 ? lsa_shim::ST_MSM_G1 : lsa_shim::ST_MSM_G2, n);
     const void *b = n ? (const void *)&*vec_start : nullptr;
     const void *s = n ? (const void *)&*scalar_start : nullptr;
     // SPMD provers (one process per GPU, lsa_comm_init done) inside an lsa_sharded_scope: every rank passes ITS
@@ -822,6 +901,7 @@ void lsa_mtxmultiexp(std::vector<alt_bn128_G1> &out, const std::vector<FieldT> &
         col_ptr[j + 1] = vals.size();
     }
     out.assign(m.size(), alt_bn128_G1::zero());
+    lsa_shim::StatScope scope(lsa_shim::ST_SPARSE_MSM, nnz);
     lsa_require(lsa_g1_sparse_matrix_msm(vals.data(), rows.data(), col_ptr.data(), m.size(), exps.data(), exps.size(), out.data()),
                 "mtxmultiexp");
 }
@@ -851,6 +931,7 @@ std::vector<T> batch_exp(const size_t scalar_size, const size_t window, const wi
     (void)scalar_size; (void)window;
     std::vector<T> out(v.size());
     if (v.empty()) return out;
+    lsa_shim::StatScope scope(lsa_shim::ST_BATCH_EXP, v.size());
     if (detail::group_id<T>::value == 1) lsa_require(lsa_g1_batch_exp(&table.base, v.data(), v.size(), out.data(), 0), "batch_exp<G1>");
     else lsa_require(lsa_g2_batch_exp(&table.base, v.data(), v.size(), out.data(), 0), "batch_exp<G2>");
     return out;
@@ -862,6 +943,7 @@ T windowed_exp(const size_t scalar_size, const size_t window, const window_table
 template <typename T>
 void batch_to_special(std::vector<T> &vec) {
     if (vec.empty()) return;
+    lsa_shim::StatScope scope(lsa_shim::ST_NORMALIZE, vec.size());
     if (detail::group_id<T>::value == 1) lsa_require(lsa_g1_normalize(vec.data(), vec.size(), vec.data()), "batch_to_special");
     else lsa_require(lsa_g2_normalize(vec.data(), vec.size(), vec.data()), "batch_to_special");
 }

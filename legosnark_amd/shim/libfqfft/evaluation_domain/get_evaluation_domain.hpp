@@ -41,7 +41,21 @@ public:
         const FieldT Z = (t ^ (unsigned long)m) - FieldT::one();
         FieldT l = Z * FieldT((unsigned long)m).inverse();
         FieldT r = FieldT::one();
-        for (size_t i = 0; i < m; ++i) { u[i] = l * (t - r).inverse(); l *= omega; r *= omega; }
+        // u[i] = l_i / (t - r_i), l_i = l omega^i, r_i = omega^i -- libfqfft inverts every denominator on its own; here
+        // all m share ONE inversion (prefix products forward, peel backward): the same field elements, three products
+        // per entry instead of an inversion (m = 2^20: seconds -> a tenth of one).  No denominator is zero (t is not
+        // in the domain: handled above).
+        std::vector<FieldT> pre(m);
+        FieldT acc = FieldT::one();
+        for (size_t i = 0; i < m; ++i) { u[i] = t - r; pre[i] = acc; acc *= u[i]; r *= omega; }
+        FieldT inv = acc.inverse();
+        std::vector<FieldT> ls(m);
+        for (size_t i = 0; i < m; ++i) { ls[i] = l; l *= omega; }
+        for (size_t i = m; i-- > 0;) {
+            const FieldT d = u[i];
+            u[i] = ls[i] * (inv * pre[i]);
+            inv *= d;
+        }
         return u;
     }
     virtual FieldT get_domain_element(const size_t idx) { return omega ^ (unsigned long)idx; }

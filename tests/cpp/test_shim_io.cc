@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "libff/lsa_libff.hpp"
+#include "libfqfft/evaluation_domain/get_evaluation_domain.hpp"
 
 using namespace libff;
 typedef alt_bn128_Fr Fr_;
@@ -103,6 +104,33 @@ int main() {
     Fr_ a = Fr_::random_element(), b = Fr_::random_element();
     CHECK(a != b);
     CHECK(Fr_(a.as_bigint()) == a);
+    // a pool of random bytes serves many draws: no draw repeats, every one reduced
+    {
+        std::vector<Fr_> rs(1000);
+        for (auto &x : rs) x = Fr_::random_element();
+        bool distinct = true;
+        for (size_t i = 0; i + 1 < rs.size(); i++) distinct = distinct && rs[i] != rs[i + 1] && Fr_(rs[i].as_bigint()) == rs[i];
+        CHECK(distinct);
+    }
+    // evaluate_all_lagrange_polynomials (one shared inversion) against libfqfft's entry-by-entry formula
+    // u[i] = Z(t) / m * omega^i / (t - omega^i), on a point outside the domain and on a domain element
+    {
+        const size_t m = 64;
+        auto dom = libfqfft::get_evaluation_domain<Fr_>(m);
+        const Fr_ t = Fr_::random_element();
+        const std::vector<Fr_> u = dom->evaluate_all_lagrange_polynomials(t);
+        const Fr_ omega = dom->get_domain_element(1);
+        const Fr_ Z = (t ^ (unsigned long)m) - Fr_::one();
+        Fr_ l = Z * Fr_((unsigned long)m).inverse(), r = Fr_::one(), sum = Fr_::zero();
+        bool same = u.size() == m;
+        for (size_t i = 0; i < m && same; i++) { same = u[i] == l * (t - r).inverse(); sum += u[i]; l *= omega; r *= omega; }
+        CHECK(same);
+        CHECK(sum == Fr_::one());
+        const std::vector<Fr_> e = dom->evaluate_all_lagrange_polynomials(dom->get_domain_element(5));
+        bool ind = true;
+        for (size_t i = 0; i < m; i++) ind = ind && e[i] == (i == 5 ? Fr_::one() : Fr_::zero());
+        CHECK(ind);
+    }
     printf(fails ? "FAILED %d\n" : "PASS\n", fails);
     return fails ? 1 : 0;
 }

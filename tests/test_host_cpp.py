@@ -31,3 +31,18 @@ def test_host_cpp_with_the_32_bit_limb_product(name, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-DLSA_FP_HOST32", "-I", os.path.join(ROOT, "legosnark_amd", "csrc"), src, "-o", exe])
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-2000:]
+
+
+def test_host_64_bit_limbs_agree_with_the_device_limbs(tmp_path):
+    """fp.h on the host: four 64-bit limbs, carry intrinsics, binary-Euclid inverse (what the reference's own host
+    loops run on through the shim).  The device variant (-DLSA_FP_HOST32: eight 32-bit limbs, Fermat inverse) must
+    print the same digests over the same operand sequence, edge values included."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_fp_host.cc")
+    outs = []
+    for tag, flags in (("64", []), ("32", ["-DLSA_FP_HOST32"])):
+        exe = str(tmp_path / ("test_fp_host_" + tag))
+        subprocess.check_call(["g++", "-std=c++17", "-O2", *flags, "-I", os.path.join(ROOT, "legosnark_amd", "csrc"), src, "-o", exe])
+        r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-2000:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and outs[0].count("inv ") == 2
