@@ -90,6 +90,7 @@ void lsa_shutdown(void) {
     crs_cache_clear();
     msm_release_workspace();
     release_stage_buffers();
+    upload_release();
     (void)hipFree(g.d_result);
     (void)hipHostFree(g.h_result);
     (void)hipStreamDestroy(g.stream);
@@ -118,6 +119,172 @@ unsigned lsa_msm_window_bits(size_t n) { return msm_window_bits(2 * n); }   // G
 int lsa_profile_enable(int on) { msm_profile_enable(on != 0); return LSA_OK; }
 int lsa_profile_last_msm(float ms[LSA_MSM_STAGES]) { return msm_profile_last(ms); }
 
+}  // extern "C"
+
+// ---------------------------------------------------------------- staged host <-> device copies (capi_internal.h)
+namespace lsa {
+namespace {
+class HostCopier {
+    static constexpr size_t SLOT = (size_t)2 << 20;
+    static constexpr unsigned MAX_WORKERS = 8, SLOTS_PER_WORKER = 2;
+    struct Slot { void *p = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
+    struct Worker { Slot slot[SLOTS_PER_WORKER]; unsigned turn = 0; };
+    Worker w_[MAX_WORKERS];
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, cv_done_;
+    uint64_t gen_ = 0;
+    unsigned active_ = 0;
+    bool stop_ = false, broken_ = false;
+    // the job
+    char *dev_ = nullptr, *host_ = nullptr;
+    bool down_ = false;
+    size_t bytes_ = 0, nchunks_ = 0;
+    std::atomic<size_t> next_{0};
+    std::atomic<int> err_{0};
+
+    bool slot_ready(Slot &s) {
+        if (!s.p) {
+            if (hipHostMalloc(&s.p, SLOT, hipHostMallocDefault) != hipSuccess) { s.p = nullptr; return false; }
+            if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { s.ev = nullptr; return false; }
+        }
+        if (!s.ev) return false;
+        if (s.pending) { if (hipEventSynchronize(s.ev) != hipSuccess) return false; s.pending = false; }
+        return true;
+    }
+    void work(unsigned id) {
+        if (id) (void)hipSetDevice(g.device);
+        Worker &w = w_[id];
+        for (;;) {
+            const size_t c = next_.fetch_add(1);
+            if (c >= nchunks_) break;
+            const size_t lo = c * SLOT, len = bytes_ - lo < SLOT ? bytes_ - lo : SLOT;
+            Slot &s = w.slot[w.turn++ % SLOTS_PER_WORKER];
+            if (!slot_ready(s)) { err_ = 1; continue; }
+            if (down_) {
+                if (hipMemcpyAsync(s.p, dev_ + lo, len, hipMemcpyDeviceToHost, g.stream) != hipSuccess || hipEventRecord(s.ev, g.stream) != hipSuccess ||
+                    hipEventSynchronize(s.ev) != hipSuccess) { err_ = 1; continue; }
+                memcpy(host_ + lo, s.p, len);
+            } else {
+                memcpy(s.p, host_ + lo, len);
+                if (hipMemcpyAsync(dev_ + lo, s.p, len, hipMemcpyHostToDevice, g.stream) != hipSuccess || hipEventRecord(s.ev, g.stream) != hipSuccess) { err_ = 1; continue; }
+                s.pending = true;
+            }
+        }
+    }
+    void loop(unsigned id) {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            work(id);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (--active_ == 0) cv_done_.notify_all();
+            }
+        }
+    }
+
+  public:
+    ~HostCopier() { stop_threads(); }
+    // 0: done (up: every copy is on the stream; down: the bytes are in host memory), 1: not taken, < 0: LSA error
+    int run(void *dev, void *host, size_t bytes, bool down) {
+        if (broken_) return 1;
+        dev_ = (char *)dev; host_ = (char *)host; bytes_ = bytes; down_ = down;
+        nchunks_ = (bytes + SLOT - 1) / SLOT;
+        next_.store(0);
+        err_.store(0);
+        const bool alone = nchunks_ < 2;                  // one piece: not worth waking anybody
+        if (!alone) {
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                if (th_.empty()) {
+                    const unsigned hw = std::thread::hardware_concurrency();
+                    const char *e = getenv("LSA_H2D_THREADS");
+                    unsigned want = e ? (unsigned)atoi(e) : (hw > 8 ? 6 : (hw > 2 ? hw / 2 : 1));
+                    if (want < 1) want = 1;
+                    if (want > MAX_WORKERS) want = MAX_WORKERS;
+                    for (unsigned i = 1; i < want; i++) th_.emplace_back([this, i] { loop(i); });
+                }
+                active_ = (unsigned)th_.size();
+                gen_++;
+            }
+            cv_.notify_all();
+        }
+        work(0);
+        if (!alone) {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_done_.wait(lk, [&] { return active_ == 0; });
+        }
+        if (err_.load()) {
+            broken_ = true;
+            set_error("a staged host <-> device copy failed (%s)", hipGetErrorString(hipGetLastError()));
+            return LSA_ERR_HIP;
+        }
+        return 0;
+    }
+    void stop_threads() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : th_) if (t.joinable()) t.join();
+        th_.clear();
+        std::lock_guard<std::mutex> lk(m_);
+        stop_ = false;
+        gen_ = 0;
+        active_ = 0;
+    }
+    void release() {
+        stop_threads();
+        for (auto &w : w_)
+            for (auto &s : w.slot) {
+                if (s.ev) { if (s.pending) (void)hipEventSynchronize(s.ev); (void)hipEventDestroy(s.ev); }
+                if (s.p) (void)hipHostFree(s.p);
+                s = Slot();
+            }
+        broken_ = false;
+    }
+};
+HostCopier g_copier;
+// 0 auto, 1 direct, 2 staged at every size
+int copy_mode() {
+    static const int mode = [] {
+        const char *e = getenv("LSA_H2D");
+        return !e ? 0 : (strcmp(e, "direct") == 0 ? 1 : (strcmp(e, "staged") == 0 ? 2 : 0));
+    }();
+    return mode;
+}
+constexpr size_t STAGE_FROM = (size_t)32 << 10;       // below: the runtime copies through its own staging buffer
+}  // namespace
+
+int upload_host(void *d_dst, const void *h_src, size_t bytes) {
+    if (bytes == 0) return LSA_OK;
+    if (copy_mode() != 1 && (bytes >= STAGE_FROM || copy_mode() == 2)) {
+        const int rc = g_copier.run(d_dst, const_cast<void *>(h_src), bytes, false);
+        if (rc <= 0) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, g.stream));
+    return LSA_OK;
+}
+int download_host(void *h_dst, const void *d_src, size_t bytes) {
+    if (bytes == 0) return LSA_OK;
+    if (copy_mode() != 1 && (bytes >= STAGE_FROM || copy_mode() == 2)) {
+        const int rc = g_copier.run(const_cast<void *>(d_src), h_dst, bytes, true);
+        if (rc <= 0) return rc;
+    }
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return LSA_OK;
+}
+void upload_release() { g_copier.release(); }
+}  // namespace lsa
+extern "C" {
 // ---------------------------------------------------------------- bases
 }  // extern "C"
 template <class F>
@@ -152,8 +319,8 @@ static int bases_create(const void *bases_jac, size_t n, int src_on_device, int 
                 set_error("bases_create: hipMalloc of %zu bytes failed", n * sizeof(Jac<F>));
                 return LSA_ERR_NOMEM;
             }
-            hipError_t e = hipMemcpyAsync(tmp, bases_jac, n * sizeof(Jac<F>), hipMemcpyHostToDevice, g.stream);
-            if (e != hipSuccess) { (void)hipFree(tmp); (void)hipFree(b->d_aff); delete b; set_error("bases_create: H2D failed: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
+            const int urc = upload_host(tmp, bases_jac, n * sizeof(Jac<F>));
+            if (urc) { (void)hipStreamSynchronize(g.stream); (void)hipFree(tmp); (void)hipFree(b->d_aff); delete b; return urc; }
             d_in = (const Jac<F> *)tmp;
         }
         rc = prepare_bases<F>(d_in, b->d_aff, n, g.stream);
@@ -762,11 +929,11 @@ static int msm_host_local(const void *bases_jac, const void *scalars, size_t n, 
             g_crs.pool.begin(bases_jac, n * sizeof(Jac<F>), CRS_UNIT_POINTS * sizeof(Jac<F>), CRS_TASK_UNITS, g_crs.scratch_fp.data());
         }
         auto t0 = std::chrono::steady_clock::now();
-        const hipError_t ce = hipMemcpyAsync(g_stage_scalars.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream);
+        const int ce = upload_host(g_stage_scalars.p, scalars, n * sizeof(Fr));
         st.h2d_scalars_ms = ms_since(t0);
         t0 = std::chrono::steady_clock::now();
         if (g_crs.mode == 2) g_crs.pool.finish();       // also on the error path: the workers read the caller's buffer
-        HIPCHK(ce);
+        if (ce) return ce;
         st.fingerprint_wait_ms = ms_since(t0);
         t0 = std::chrono::steady_clock::now();
         lsa_bases *b = nullptr;
@@ -786,10 +953,12 @@ static int msm_host_local(const void *bases_jac, const void *scalars, size_t n, 
         }
         if (n) {
             auto t0 = std::chrono::steady_clock::now();
-            HIPCHK(hipMemcpyAsync(g_stage_jac.p, bases_jac, n * sizeof(Jac<F>), hipMemcpyHostToDevice, g.stream));
+            rc = upload_host(g_stage_jac.p, bases_jac, n * sizeof(Jac<F>));
+            if (rc) return rc;
             st.bases_prepare_ms = ms_since(t0);
             t0 = std::chrono::steady_clock::now();
-            HIPCHK(hipMemcpyAsync(g_stage_scalars.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+            rc = upload_host(g_stage_scalars.p, scalars, n * sizeof(Fr));
+            if (rc) return rc;
             st.h2d_scalars_ms = ms_since(t0);
             rc = prepare_bases<F>((const Jac<F> *)g_stage_jac.p, g_stage_bases.p, n, g.stream);
             if (rc) return rc;
@@ -908,11 +1077,11 @@ static int normalize_host(const void *in_jac, size_t n, void *out_jac) {
         set_error("normalize: hipMalloc failed");
         return LSA_ERR_NOMEM;
     }
-    hipError_t e = hipMemcpyAsync(d_in, in_jac, n * sizeof(Jac<F>), hipMemcpyHostToDevice, g.stream);
-    if (e == hipSuccess) rc = normalize_to_affine<F>((const Jac<F> *)d_in, (Aff<F> *)d_aff, n, g.stream);
+    rc = upload_host(d_in, in_jac, n * sizeof(Jac<F>));
+    if (!rc) rc = normalize_to_affine<F>((const Jac<F> *)d_in, (Aff<F> *)d_aff, n, g.stream);
     std::vector<Aff<F>> host(n);
-    if (e == hipSuccess && !rc) e = hipMemcpyAsync(host.data(), d_aff, n * sizeof(Aff<F>), hipMemcpyDeviceToHost, g.stream);
-    if (e == hipSuccess && !rc) e = hipStreamSynchronize(g.stream);
+    if (!rc) rc = download_host(host.data(), d_aff, n * sizeof(Aff<F>));
+    const hipError_t e = hipStreamSynchronize(g.stream);
     (void)hipFree(d_in);
     (void)hipFree(d_aff);
     if (rc) return rc;
@@ -946,9 +1115,10 @@ static int batch_exp_any(const void *base_jac, const void *scalars, size_t n, vo
         set_error("batch_exp: hipMalloc failed");
         return LSA_ERR_NOMEM;
     }
-    hipError_t e = hipMemcpyAsync(d_sc, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream);
-    if (e == hipSuccess) rc = batch_exp_device<F>(base, (const Fr *)d_sc, n, (Jac<F> *)d_out, g.stream);
-    if (e == hipSuccess && !rc) e = hipMemcpy(out_jac, d_out, n * sizeof(Jac<F>), hipMemcpyDeviceToHost);
+    rc = upload_host(d_sc, scalars, n * sizeof(Fr));
+    if (!rc) rc = batch_exp_device<F>(base, (const Fr *)d_sc, n, (Jac<F> *)d_out, g.stream);
+    if (!rc) rc = download_host(out_jac, d_out, n * sizeof(Jac<F>));
+    const hipError_t e = hipStreamSynchronize(g.stream);
     (void)hipFree(d_sc);
     (void)hipFree(d_out);
     if (rc) return rc;
@@ -1022,11 +1192,11 @@ int lsa_g1_scalar_mul_batch(const void *pts_jac, const void *scalars, size_t n, 
         set_error("scalar_mul_batch: hipMalloc failed");
         return LSA_ERR_NOMEM;
     }
-    HIPCHK(hipMemcpyAsync(d_p.p, pts_jac, n * sizeof(Jac<Fq>), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(d_s.p, scalars, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    LSA_UPLOAD(d_p.p, pts_jac, n * sizeof(Jac<Fq>));
+    LSA_UPLOAD(d_s.p, scalars, n * sizeof(Fr));
     rc = g1_scalar_mul_device((const Jac<Fq> *)d_p.p, (const Fr *)d_s.p, nullptr, n, (Jac<Fq> *)d_o.p, g.stream);
     if (rc) return rc;
-    HIPCHK(hipMemcpy(out_jac, d_o.p, n * sizeof(Jac<Fq>), hipMemcpyDeviceToHost));
+    LSA_DOWNLOAD(out_jac, d_o.p, n * sizeof(Jac<Fq>));
     return LSA_OK;
 }
 
@@ -1052,17 +1222,17 @@ int lsa_g1_sparse_matrix_msm(const void *vals_jac, const uint32_t *rows, const u
         return LSA_ERR_NOMEM;
     }
     if (nnz) {
-        HIPCHK(hipMemcpyAsync(d_v.p, vals_jac, nnz * sizeof(Jac<Fq>), hipMemcpyHostToDevice, g.stream));
-        HIPCHK(hipMemcpyAsync(d_r.p, rows, nnz * sizeof(uint32_t), hipMemcpyHostToDevice, g.stream));
-        HIPCHK(hipMemcpyAsync(d_e.p, exps, nrows * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+        LSA_UPLOAD(d_v.p, vals_jac, nnz * sizeof(Jac<Fq>));
+        LSA_UPLOAD(d_r.p, rows, nnz * sizeof(uint32_t));
+        LSA_UPLOAD(d_e.p, exps, nrows * sizeof(Fr));
     }
-    HIPCHK(hipMemcpyAsync(d_c.p, col_ptr, (ncols + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+    LSA_UPLOAD(d_c.p, col_ptr, (ncols + 1) * sizeof(uint64_t));
     rc = g1_scalar_mul_device((const Jac<Fq> *)d_v.p, (const Fr *)d_e.p, (const uint32_t *)d_r.p, nnz, (Jac<Fq> *)d_items.p, g.stream);
     if (rc) return rc;
     rc = g1_column_sums_device((const Jac<Fq> *)d_items.p, (const uint64_t *)d_c.p, ncols, (Jac<Fq> *)d_o.p, g.stream);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));
-    HIPCHK(hipMemcpy(out_jac, d_o.p, ncols * sizeof(Jac<Fq>), hipMemcpyDeviceToHost));
+    LSA_DOWNLOAD(out_jac, d_o.p, ncols * sizeof(Jac<Fq>));
     return LSA_OK;
 }
 }  // extern "C"
@@ -1084,12 +1254,12 @@ int lsa_fr_cppoly_witness(const void *v, size_t d, const void *r, void *w, int o
         return LSA_OK;
     }
     if (d_v.alloc(N * sizeof(Fr)) || d_r.alloc((d + 1) * sizeof(Fr)) || d_w.alloc(N * sizeof(Fr))) { set_error("cppoly_witness: hipMalloc failed"); return LSA_ERR_NOMEM; }
-    HIPCHK(hipMemcpyAsync(d_v.p, v, N * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-    if (d) HIPCHK(hipMemcpyAsync(d_r.p, r, d * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    LSA_UPLOAD(d_v.p, v, N * sizeof(Fr));
+    if (d) LSA_UPLOAD(d_r.p, r, d * sizeof(Fr));
     rc = fr_cppoly_fold_device((const Fr *)d_v.p, d, (const Fr *)d_r.p, (Fr *)d_w.p, (Fr *)d_tmp.p, g.stream);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));
-    HIPCHK(hipMemcpy(w, d_w.p, N * sizeof(Fr), hipMemcpyDeviceToHost));
+    LSA_DOWNLOAD(w, d_w.p, N * sizeof(Fr));
     return LSA_OK;
 }
 
@@ -1108,12 +1278,12 @@ int lsa_fr_eval_mle(const void *v, size_t d, const void *r, void *out, int on_de
         return LSA_OK;
     }
     if (d_v.alloc(N * sizeof(Fr)) || d_r.alloc((d + 1) * sizeof(Fr)) || d_o.alloc(sizeof(Fr))) { set_error("eval_mle: hipMalloc failed"); return LSA_ERR_NOMEM; }
-    HIPCHK(hipMemcpyAsync(d_v.p, v, N * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-    if (d) HIPCHK(hipMemcpyAsync(d_r.p, r, d * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    LSA_UPLOAD(d_v.p, v, N * sizeof(Fr));
+    if (d) LSA_UPLOAD(d_r.p, r, d * sizeof(Fr));
     rc = fr_eval_mle_device((const Fr *)d_v.p, d, (const Fr *)d_r.p, (Fr *)d_tmp.p, (Fr *)d_o.p, g.stream);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));
-    HIPCHK(hipMemcpy(out, d_o.p, sizeof(Fr), hipMemcpyDeviceToHost));
+    LSA_DOWNLOAD(out, d_o.p, sizeof(Fr));
     return LSA_OK;
 }
 
@@ -1134,19 +1304,19 @@ int lsa_fr_sumcheck_round(const void *suff, const void *const *tables, size_t m,
     } else {
         for (size_t t = 0; t < m; t++) {
             if (d_tab[t].alloc(2 * half * sizeof(Fr))) { set_error("sumcheck_round: hipMalloc failed"); return LSA_ERR_NOMEM; }
-            HIPCHK(hipMemcpyAsync(d_tab[t].p, tables[t], 2 * half * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+            LSA_UPLOAD(d_tab[t].p, tables[t], 2 * half * sizeof(Fr));
             tabs[t] = (const Fr *)d_tab[t].p;
         }
         if (suff) {
             if (d_suff.alloc(half * sizeof(Fr))) { set_error("sumcheck_round: hipMalloc failed"); return LSA_ERR_NOMEM; }
-            HIPCHK(hipMemcpyAsync(d_suff.p, suff, half * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+            LSA_UPLOAD(d_suff.p, suff, half * sizeof(Fr));
             sf = (const Fr *)d_suff.p;
         }
     }
     rc = fr_sumcheck_round_device(sf, tabs, m, half, (const Fr *)pre, (const Fr *)rho_j, (Fr *)d_partial.p, (Fr *)d_out.p, g.stream);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));
-    HIPCHK(hipMemcpy(out_coeffs, d_out.p, ncoef * sizeof(Fr), hipMemcpyDeviceToHost));
+    LSA_DOWNLOAD(out_coeffs, d_out.p, ncoef * sizeof(Fr));
     return LSA_OK;
 }
 
@@ -1160,11 +1330,11 @@ int lsa_fr_scale_upper(const void *old, size_t half, const void *k, void *cur, i
     if (on_device) return fr_scale_upper_device((const Fr *)old, half, kk, (Fr *)cur, g.stream);
     DevBuf d_v;
     if (d_v.alloc(2 * half * sizeof(Fr))) { set_error("fr_scale_upper: hipMalloc failed"); return LSA_ERR_NOMEM; }
-    HIPCHK(hipMemcpyAsync(d_v.p, old, 2 * half * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    LSA_UPLOAD(d_v.p, old, 2 * half * sizeof(Fr));
     rc = fr_scale_upper_device((const Fr *)d_v.p, half, kk, (Fr *)d_v.p, g.stream);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));
-    HIPCHK(hipMemcpy(cur, d_v.p, half * sizeof(Fr), hipMemcpyDeviceToHost));
+    LSA_DOWNLOAD(cur, d_v.p, half * sizeof(Fr));
     return LSA_OK;
 }
 
@@ -1183,13 +1353,13 @@ int lsa_fr_ntt(void *a, size_t log_n, const void *omega, int inverse, const void
     Fr *da = (Fr *)a;
     if (!on_device) {
         if (d_a.alloc(n * sizeof(Fr))) { set_error("fr_ntt: hipMalloc failed"); return LSA_ERR_NOMEM; }
-        HIPCHK(hipMemcpyAsync(d_a.p, a, n * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+        LSA_UPLOAD(d_a.p, a, n * sizeof(Fr));
         da = (Fr *)d_a.p;
     }
     rc = fr_ntt_device(da, (unsigned)log_n, w, inverse != 0, coset_g ? &gco : nullptr, (Fr *)d_tw.p, g.stream);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));      // the twiddle table is freed on return
-    if (!on_device) HIPCHK(hipMemcpy(a, d_a.p, n * sizeof(Fr), hipMemcpyDeviceToHost));
+    if (!on_device) LSA_DOWNLOAD(a, d_a.p, n * sizeof(Fr));
     return LSA_OK;
 }
 
@@ -1201,12 +1371,12 @@ int lsa_fr_fold(const void *old, size_t half, const void *r, void *cur, int on_d
     if (on_device) return fr_fold_halves_device((const Fr *)old, half, (const Fr *)r, (Fr *)cur, g.stream);
     DevBuf d_v, d_r;
     if (d_v.alloc(2 * half * sizeof(Fr)) || d_r.alloc(sizeof(Fr))) { set_error("fr_fold: hipMalloc failed"); return LSA_ERR_NOMEM; }
-    HIPCHK(hipMemcpyAsync(d_v.p, old, 2 * half * sizeof(Fr), hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(d_r.p, r, sizeof(Fr), hipMemcpyHostToDevice, g.stream));
+    LSA_UPLOAD(d_v.p, old, 2 * half * sizeof(Fr));
+    LSA_UPLOAD(d_r.p, r, sizeof(Fr));
     rc = fr_fold_halves_device((const Fr *)d_v.p, half, (const Fr *)d_r.p, (Fr *)d_v.p, g.stream);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));
-    HIPCHK(hipMemcpy(cur, d_v.p, half * sizeof(Fr), hipMemcpyDeviceToHost));
+    LSA_DOWNLOAD(cur, d_v.p, half * sizeof(Fr));
     return LSA_OK;
 }
 }  // extern "C"

@@ -44,7 +44,21 @@ struct StageBuf {
     }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
-extern StageBuf g_stage_gather;    // all-gather landing zone shared by the sharded MSM and pairing paths
+extern StageBuf g_stage_gather;
+
+// Pageable host memory <-> device on lsa_stream(), WITHOUT ever handing a caller's buffer to the runtime.  For
+// large pageable copies hipMemcpy pins the caller's pages in place and keeps the registration; when the caller later
+// frees that vector (munmap -- every std::vector<Fr> of 2^20 scalars is its own mapping) the driver evicts the
+// process's queues and the next submission waits 12-25 ms (measured: tools/native/h2d_vectors.cc, a CPPoly::prove-shaped
+// ladder of MSMs 29 -> 15 ms).  From 32 KiB up the copies go through pinned 2-MiB slots owned by the library; from two
+// slots up a few threads share the memcpy work.  upload_host: every copy is ON THE STREAM when it returns (then
+// asynchronous, like hipMemcpyAsync); download_host: blocking, the bytes are in h_dst when it returns.
+// LSA_H2D=direct|staged overrides the choice (direct = plain hipMemcpyAsync).
+int upload_host(void *d_dst, const void *h_src, size_t bytes);
+int download_host(void *h_dst, const void *d_src, size_t bytes);
+void upload_release();             // threads, pinned slots (lsa_shutdown)
+#define LSA_UPLOAD(dst, src, bytes) do { int u_ = upload_host((dst), (src), (bytes)); if (u_) return u_; } while (0)
+#define LSA_DOWNLOAD(dst, src, bytes) do { int u_ = download_host((dst), (src), (bytes)); if (u_) return u_; } while (0)    // all-gather landing zone shared by the sharded MSM and pairing paths
 
 }  // namespace lsa
 

@@ -201,8 +201,8 @@ int run_fused(const Terms &t, const std::vector<uint64_t> &emit, void **d_res) {
     if (!t.on_device) {
         if (g_pair_p.ensure(std::max<size_t>(n, 1) * sizeof(Jac<Fq>)) || g_pair_q.ensure(std::max<size_t>(n, 1) * sizeof(Jac<Fq2>))) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
         if (n) {
-            HIPCHK(hipMemcpyAsync(g_pair_p.p, t.g1, n * sizeof(Jac<Fq>), hipMemcpyHostToDevice, g.stream));
-            HIPCHK(hipMemcpyAsync(g_pair_q.p, t.g2, n * sizeof(Jac<Fq2>), hipMemcpyHostToDevice, g.stream));
+            LSA_UPLOAD(g_pair_p.p, t.g1, n * sizeof(Jac<Fq>));
+            LSA_UPLOAD(g_pair_q.p, t.g2, n * sizeof(Jac<Fq2>));
         }
         d_p = g_pair_p.p; d_q = g_pair_q.p;
     }
@@ -233,8 +233,8 @@ int run_miller(const Terms &t, void **d_res) {
         const void *d_p = t.g1, *d_q = t.g2;
         if (!t.on_device) {
             if (g_pair_p.ensure(n * sizeof(Jac<Fq>)) || g_pair_q.ensure(n * sizeof(Jac<Fq2>))) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
-            HIPCHK(hipMemcpyAsync(g_pair_p.p, t.g1, n * sizeof(Jac<Fq>), hipMemcpyHostToDevice, g.stream));
-            HIPCHK(hipMemcpyAsync(g_pair_q.p, t.g2, n * sizeof(Jac<Fq2>), hipMemcpyHostToDevice, g.stream));
+            LSA_UPLOAD(g_pair_p.p, t.g1, n * sizeof(Jac<Fq>));
+            LSA_UPLOAD(g_pair_q.p, t.g2, n * sizeof(Jac<Fq2>));
             d_p = g_pair_p.p; d_q = g_pair_q.p;
         }
         if (g_pair_f.ensure((n ? n : 1) * fq12_bytes())) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
@@ -247,7 +247,7 @@ int run_miller(const Terms &t, void **d_res) {
             return fq12_product_device(g_pair_f.p, g_pair_s.p, n, d_res, g.stream);
         }
         if (g_pair_s.ensure(nseg * fq12_bytes()) || g_pair_meta.ensure((nseg + 1) * sizeof(uint64_t))) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
-        HIPCHK(hipMemcpyAsync(g_pair_meta.p, t.seg, (nseg + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, g.stream));
+        LSA_UPLOAD(g_pair_meta.p, t.seg, (nseg + 1) * sizeof(uint64_t));
         HIPCHK(hipStreamSynchronize(g.stream));     // t.seg is pageable caller memory
         rc = fq12_segment_products_device(g_pair_f.p, (const uint64_t *)g_pair_meta.p, nseg, g_pair_s.p, g.stream);
         *d_res = g_pair_s.p;
@@ -351,7 +351,7 @@ int run_miller(const Terms &t, void **d_res) {
     const void *d_g1 = t.g1;
     if (!t.on_device) {
         if (g_pair_p.ensure(std::max<size_t>(n, 1) * sizeof(Jac<Fq>))) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
-        if (n) HIPCHK(hipMemcpyAsync(g_pair_p.p, t.g1, n * sizeof(Jac<Fq>), hipMemcpyHostToDevice, g.stream));
+        if (n) LSA_UPLOAD(g_pair_p.p, t.g1, n * sizeof(Jac<Fq>));
         d_g1 = g_pair_p.p;
     }
     HIPCHK(hipMemcpyAsync(g_pair_meta.p, hm, meta_bytes, hipMemcpyHostToDevice, g.stream));
@@ -387,7 +387,7 @@ int run_miller(const Terms &t, void **d_res) {
         if (g_pair_pub.ensure(m * (PUB + 8))) { set_error("pairing: staging allocation failed"); return LSA_ERR_NOMEM; }
         std::vector<uint64_t> hp(m);
         for (size_t k = 0; k < m; k++) {
-            HIPCHK(hipMemcpyAsync((char *)g_pair_pub.p + k * PUB, t.qpre[need_imp[k]], PUB, hipMemcpyHostToDevice, g.stream));
+            LSA_UPLOAD((char *)g_pair_pub.p + k * PUB, t.qpre[need_imp[k]], PUB);
             hp[k] = h_tab[need_imp[k]];
         }
         HIPCHK(hipMemcpyAsync((char *)g_pair_pub.p + m * PUB, hp.data(), m * 8, hipMemcpyHostToDevice, g.stream));
@@ -430,7 +430,7 @@ int run_terms_host(const Terms &t, void *out, bool final_exp) {
         if (rc) return rc;
         res = g_pair_o.p;
     }
-    HIPCHK(hipMemcpyAsync(out, res, nres * fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
+    LSA_DOWNLOAD(out, res, nres * fq12_bytes());
     HIPCHK(hipStreamSynchronize(g.stream));
     return LSA_OK;
 }
@@ -476,12 +476,12 @@ int lsa_g2_precompute(const void *g2_jac, size_t n, void *out_precomp) {
     uint64_t *hp = (uint64_t *)g_pin_meta.p;
     for (size_t i = 0; i < n; i++) hp[i] = (uint64_t)(uintptr_t)((uint32_t *)g_pair_scratch_tabs.p + i * TW);
     HIPCHK(hipMemcpyAsync(g_pair_meta.p, hp, n * 8, hipMemcpyHostToDevice, g.stream));
-    HIPCHK(hipMemcpyAsync(g_pair_q.p, g2_jac, n * sizeof(Jac<Fq2>), hipMemcpyHostToDevice, g.stream));
+    LSA_UPLOAD(g_pair_q.p, g2_jac, n * sizeof(Jac<Fq2>));
     rc = g2_precomp_device(g_pair_q.p, n, (uint32_t *const *)g_pair_meta.p, g.stream);
     if (rc) return rc;
     rc = g2_table_export_device((const uint32_t *const *)g_pair_meta.p, n, g_pair_pub.p, g.stream);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(out_precomp, g_pair_pub.p, n * PUB, hipMemcpyDeviceToHost, g.stream));
+    LSA_DOWNLOAD(out_precomp, g_pair_pub.p, n * PUB);
     HIPCHK(hipStreamSynchronize(g.stream));
     return LSA_OK;
 }
@@ -646,7 +646,7 @@ int lsa_fq12_product(const void *in, size_t n, void *out) {
     }
     void *res = nullptr;
     if (g_pair_f.ensure(n * fq12_bytes()) || g_pair_s.ensure(((n + 7) / 8 + 1) * fq12_bytes())) { set_error("fq12_product: hipMalloc failed"); return LSA_ERR_NOMEM; }
-    HIPCHK(hipMemcpyAsync(g_pair_f.p, in, n * fq12_bytes(), hipMemcpyHostToDevice, g.stream));
+    LSA_UPLOAD(g_pair_f.p, in, n * fq12_bytes());
     rc = fq12_product_device(g_pair_f.p, g_pair_s.p, n, &res, g.stream);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(g.h_result, res, fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
@@ -661,10 +661,10 @@ int lsa_final_exponentiation(const void *in, size_t n, void *out, int on_device)
     if (!in || !out) { set_error("final_exponentiation: null argument"); return LSA_ERR_INVALID; }
     if (on_device) return final_exp_device(in, n, out, g.stream);
     if (g_pair_f.ensure(n * fq12_bytes()) || g_pair_s.ensure(n * fq12_bytes())) { set_error("final_exponentiation: hipMalloc failed"); return LSA_ERR_NOMEM; }
-    HIPCHK(hipMemcpyAsync(g_pair_f.p, in, n * fq12_bytes(), hipMemcpyHostToDevice, g.stream));
+    LSA_UPLOAD(g_pair_f.p, in, n * fq12_bytes());
     rc = final_exp_device(g_pair_f.p, n, g_pair_s.p, g.stream);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(out, g_pair_s.p, n * fq12_bytes(), hipMemcpyDeviceToHost, g.stream));
+    LSA_DOWNLOAD(out, g_pair_s.p, n * fq12_bytes());
     HIPCHK(hipStreamSynchronize(g.stream));
     return LSA_OK;
 }

@@ -46,6 +46,8 @@ namespace lsa_shim {
 enum StatKind { ST_MSM_G1, ST_MSM_G2, ST_PAIRING, ST_G2_PRECOMP, ST_BATCH_EXP, ST_NORMALIZE, ST_SCALAR_MUL_HOST, ST_SPARSE_MSM, ST_KINDS };
 struct Stats {
     std::atomic<uint64_t> calls[ST_KINDS], ns[ST_KINDS], items[ST_KINDS];
+    std::atomic<uint64_t> msm_us[4], msm_hits, msm_tables;     // lsa_msm_host_stats summed: h2d, fingerprint wait, bases, kernels
+    bool on = false;
     std::chrono::steady_clock::time_point born = std::chrono::steady_clock::now();
     static const char *name(int k) {
         static const char *const n[ST_KINDS] = {"msm_g1", "msm_g2", "pairing", "g2_precompute", "batch_exp", "normalize", "scalar_mul_host", "sparse_msm"};
@@ -62,14 +64,21 @@ struct Stats {
             fprintf(stderr, "\"%s\": {\"calls\": %llu, \"items\": %llu, \"ms\": %.3f}, ", name(k), (unsigned long long)s.calls[k].load(),
                     (unsigned long long)s.items[k].load(), ms);
         }
+        fprintf(stderr, "\"msm_host_path\": {\"h2d_scalars_ms\": %.3f, \"fingerprint_wait_ms\": %.3f, \"bases_prepare_ms\": %.3f, \"kernels_ms\": %.3f, "
+                        "\"cache_hits\": %llu, \"on_pre_shifted_copies\": %llu}, ",
+                (double)s.msm_us[0].load() * 1e-3, (double)s.msm_us[1].load() * 1e-3, (double)s.msm_us[2].load() * 1e-3, (double)s.msm_us[3].load() * 1e-3,
+                (unsigned long long)s.msm_hits.load(), (unsigned long long)s.msm_tables.load());
         fprintf(stderr, "\"inside_ms\": %.3f, \"process_ms\": %.3f}}\n", inside, wall);
     }
     static Stats &get() {
         static Stats *s = [] {
             Stats *t = new Stats();
             for (int k = 0; k < ST_KINDS; k++) { t->calls[k] = 0; t->ns[k] = 0; t->items[k] = 0; }
+            for (int k = 0; k < 4; k++) t->msm_us[k] = 0;
+            t->msm_hits = 0;
+            t->msm_tables = 0;
             const char *e = getenv("LSA_SHIM_STATS");
-            if (e && e[0] == '1') atexit(report);
+            if (e && e[0] == '1') { t->on = true; atexit(report); }
             return t;
         }();
         return *s;
@@ -857,6 +866,18 @@ T msm_forward(typename std::vector<T>::const_iterator vec_start, typename std::v
     }
     if (group_id<T>::value == 1) lsa_require(lsa_g1_msm(b, s, n, chunks, &out), "multi_exp<G1>");
     else lsa_require(lsa_g2_msm(b, s, n, chunks, &out), "multi_exp<G2>");
+    if (lsa_shim::Stats::get().on) {
+        lsa_host_stats hs;
+        if (lsa_msm_host_stats(&hs) == LSA_OK) {
+            lsa_shim::Stats &st = lsa_shim::Stats::get();
+            st.msm_us[0] += (uint64_t)(hs.h2d_scalars_ms * 1e3);
+            st.msm_us[1] += (uint64_t)(hs.fingerprint_wait_ms * 1e3);
+            st.msm_us[2] += (uint64_t)(hs.bases_prepare_ms * 1e3);
+            st.msm_us[3] += (uint64_t)(hs.msm_ms * 1e3);
+            st.msm_hits += (uint64_t)(hs.cache_hit != 0);
+            st.msm_tables += (uint64_t)(hs.table != 0);
+        }
+    }
     return out;
 }
 }  // namespace detail
