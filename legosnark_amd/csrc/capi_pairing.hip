@@ -162,6 +162,30 @@ struct TableCache {
     }
 } g_tabs;
 
+// Tables lsa_g2_tables_prefetch has promised (their slots are taken, their keys resolve) but not yet built: built
+// five at a time (one wavefront of k_g2_precomp holds five points and takes as long for five as for one) or when a
+// Miller call arrives, whichever is first -- always before anything on lsa_stream() can read them.  A verifier that
+// derives twenty G2 points one after the other (CPPoly::verify, src/gadgets/poly.h:115-118) pays four launches, not
+// twenty dependent ones.
+struct PendingTables {
+    std::vector<Jac<Fq2>> pts;
+    std::vector<uint64_t> dst;
+    StageBuf dev;
+    static constexpr size_t BATCH = 5;
+    int flush() {
+        const size_t m = pts.size();
+        if (m == 0) return LSA_OK;
+        std::vector<char> h(m * (sizeof(Jac<Fq2>) + 8));
+        memcpy(h.data(), pts.data(), m * sizeof(Jac<Fq2>));
+        memcpy(h.data() + m * sizeof(Jac<Fq2>), dst.data(), m * 8);
+        pts.clear();
+        dst.clear();
+        if (dev.ensure(h.size())) { set_error("g2_tables_prefetch: staging allocation failed"); return LSA_ERR_NOMEM; }
+        LSA_UPLOAD(dev.p, h.data(), h.size());
+        return g2_precomp_device(dev.p, m, (uint32_t *const *)((const char *)dev.p + m * sizeof(Jac<Fq2>)), g.stream);
+    }
+} g_pending;
+
 // ---------------------------------------------------------------- one job description
 struct Terms {
     const void *g1 = nullptr;              // n Jacobian G1 points
@@ -256,6 +280,7 @@ int run_miller(const Terms &t, void **d_res) {
 
     // ---- tables
     { int rcw = wait_uploads(); if (rcw) return rcw; }
+    { int rcp = g_pending.flush(); if (rcp) return rcp; }       // promised tables: on the stream before anything reads them
     if (g_tabs.ensure_ident()) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }
     g_tabs.tick++;
     const size_t TW = g2_table_words(), PUB = g2_precomp_public_bytes();
@@ -452,6 +477,7 @@ void pairing_release() {
     g_pin_meta.release(); g_pin_q.release();
     if (g_uploaded) { (void)hipEventDestroy(g_uploaded); g_uploaded = nullptr; }
     g_upload_pending = false;
+    g_pending.pts.clear(); g_pending.dst.clear(); g_pending.dev.release();
     g_tabs.clear();
 }
 }  // namespace lsa
@@ -496,29 +522,21 @@ int lsa_g2_tables_prefetch(const void *g2_jac, size_t n) {
     if (!g2_jac) { set_error("g2_tables_prefetch: null argument"); return LSA_ERR_INVALID; }
     g_tabs.read_env();
     if (g_tabs.max_tables == 0 || n > 1024) return LSA_OK;         // nothing to keep them in
-    rc = wait_uploads();
-    if (rc) return rc;
     g_tabs.tick++;
-    if (g_pin_q.ensure(n * (sizeof(Jac<Fq2>) + 8)) || g_pair_q.ensure(n * (sizeof(Jac<Fq2>) + 8))) { set_error("g2_tables_prefetch: staging allocation failed"); return LSA_ERR_NOMEM; }
-    char *hq = (char *)g_pin_q.p;
-    size_t m = 0;
-    std::vector<uint64_t> dst;
     for (size_t i = 0; i < n; i++) {
         const char *q = (const char *)g2_jac + i * sizeof(Jac<Fq2>);
         const Key128 key = fingerprint(q, sizeof(Jac<Fq2>), 1);
         if (g_tabs.lookup(key) >= 0) continue;
         const long s = g_tabs.insert(key);
         if (s < 0) continue;                                        // full of tables of this very call: leave it to the Miller call
-        memcpy(hq + m * sizeof(Jac<Fq2>), q, sizeof(Jac<Fq2>));
-        dst.push_back((uint64_t)(uintptr_t)g_tabs.ptr((uint32_t)s));
-        m++;
+        Jac<Fq2> pt;
+        memcpy(&pt, q, sizeof pt);
+        g_pending.pts.push_back(pt);
+        g_pending.dst.push_back((uint64_t)(uintptr_t)g_tabs.ptr((uint32_t)s));
     }
-    if (m == 0) return LSA_OK;
-    memcpy(hq + m * sizeof(Jac<Fq2>), dst.data(), m * 8);
-    HIPCHK(hipMemcpyAsync(g_pair_q.p, hq, m * (sizeof(Jac<Fq2>) + 8), hipMemcpyHostToDevice, g.stream));
-    rc = mark_uploads();
-    if (rc) return rc;
-    return g2_precomp_device(g_pair_q.p, m, (uint32_t *const *)((const char *)g_pair_q.p + m * sizeof(Jac<Fq2>)), g.stream);
+    // (a cache smaller than a batch could hand a promised slot to somebody else before it is built)
+    if (g_pending.pts.size() >= PendingTables::BATCH || g_tabs.max_tables < 4 * PendingTables::BATCH) return g_pending.flush();
+    return LSA_OK;
 }
 
 int lsa_pairing_set_chunk(unsigned pairs_per_accumulator) {
@@ -529,6 +547,8 @@ int lsa_pairing_set_chunk(unsigned pairs_per_accumulator) {
 int lsa_g2_table_cache(size_t max_tables) {
     int rc = require_ready();
     if (rc) return rc;
+    g_pending.pts.clear();                                      // their slots go with the cache
+    g_pending.dst.clear();
     HIPCHK(hipStreamSynchronize(g.stream));
     g_tabs.env_read = true;
     g_tabs.clear();
