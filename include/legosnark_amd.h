@@ -87,15 +87,11 @@ int lsa_g2_msm(const void *bases_jac, const void *scalars_mont, size_t n, size_t
  * (lsa_crs_cache_table_after). */
 int lsa_crs_cache_configure(int mode, size_t max_bytes);
 /* The pre-shifted copies of an entry are built in the BACKGROUND (a low-priority stream, 26 copies ~ 27 ms of GPU time
- * at 2^20 G1 points, 64 ms for G2) once the entry has been hit often enough: the call that starts the build and the
- * calls during it run at plain-pipeline speed, the entry switches to the copies when they are complete -- results are
- * the same point either way.  They hold 26 x 64 B per G1 point (128 B per G2 point).
- *   LSA_CRS_TABLE_AFTER_AUTO (the default): the break-even count for the vector's size -- 23 hits at 2^20 points and
- *     above (27 ms against the ~1.2 ms a 2^20-pair MSM saves), proportionally fewer below, never under two (a vector
- *     of a few thousand points: under a millisecond to build, ~0.6 ms saved per MSM); vectors from 1024 points on.
- *   any other value (or env LSA_CRS_TABLE_AFTER): exactly that many hits, for vectors of at least the table threshold
- *     (lsa_msm_set_table_threshold, default 2^19 points); 0: never; 1: a prover that knows it will re-use its key. */
-#define LSA_CRS_TABLE_AFTER_AUTO 0xffffffffu
+ * at 2^20 G1 points, 64 ms for G2) once the entry has been hit `hits` times (default 23, the break-even of 27 ms
+ * against the ~1.2 ms a 2^20-pair MSM saves with them; 0: never; env LSA_CRS_TABLE_AFTER): the call that starts the
+ * build and the calls during it run at plain-pipeline speed, the entry switches to the copies when they are complete
+ * -- results are the same point either way.  They hold 26 x 64 B per G1 point (128 B per G2 point).  A prover that
+ * knows it will re-use a key many times sets 1. */
 int lsa_crs_cache_table_after(unsigned hits);
 /* Blocks until every background build has finished and its entry has switched (tests, benchmarks). */
 int lsa_crs_cache_wait_tables(void);

@@ -334,10 +334,9 @@ def crs_cache_stats():
     return dict(zip(("hits", "misses", "resident_bytes", "entries"), [int(x.value) for x in v]))
 
 
-def crs_cache_table_after(hits=None):
-    """Hits before a cached CRS vector's pre-shifted copies are built in the background (0: never; None: the default,
-    the break-even count for the vector's size -- include/legosnark_amd.h, LSA_CRS_TABLE_AFTER_AUTO)."""
-    _check(lib().lsa_crs_cache_table_after(0xFFFFFFFF if hits is None else int(hits)))
+def crs_cache_table_after(hits):
+    """Hits before a cached CRS vector's pre-shifted copies are built in the background (0: never)."""
+    _check(lib().lsa_crs_cache_table_after(int(hits)))
 
 
 def crs_cache_wait_tables():

@@ -676,7 +676,6 @@ struct CrsCache {
     // GPU time and save ~1.2 ms per MSM: building them at the 23rd hit is the break-even rule (never more than twice the
     // cost of the better choice in hindsight); a key that proves a handful of times never pays for them
     unsigned table_after = CRS_TABLE_AFTER_DEFAULT;
-    bool table_after_auto = true;                   // the default: scaled with the vector's size (crs_table_progress)
     std::vector<void *> garbage;                    // device buffers to free once the device is idle
 } g_crs;
 
@@ -690,7 +689,7 @@ void crs_configure_from_env() {
         if (e[0] == '0' || !strcmp(e, "off")) g_crs.mode = 0;
         else if (!strcmp(e, "sampled") || e[0] == '1') g_crs.mode = 1;
     }
-    if (const char *ta = getenv("LSA_CRS_TABLE_AFTER")) { g_crs.table_after = (unsigned)atoi(ta); g_crs.table_after_auto = false; }
+    if (const char *ta = getenv("LSA_CRS_TABLE_AFTER")) g_crs.table_after = (unsigned)atoi(ta);
     const char *mb = getenv("LSA_CRS_CACHE_MB");
     if (mb && atoll(mb) > 0) g_crs.budget = (size_t)atoll(mb) << 20;
     if (g_crs.budget == 0) {
@@ -789,16 +788,7 @@ template <class F>
 static int crs_table_progress(CrsEntry &e) {
     lsa_bases *b = e.b;
     const char *pe = getenv("LSA_PRECOMPUTE");
-    // the copies pay for themselves after build time / gain per call re-uses: ~23 at 2^20 points (27 ms / 1.17 ms), two
-    // for a few thousand points (under a millisecond to build; the plain layout's fold over 127 doublings alone is 0.35
-    // ms per call) -- the configured count scales down with the vector, never below two re-uses (one when set to one)
-    const size_t table_min = msm_merge_min_is_explicit() ? msm_merge_min() : (g_crs.table_after_auto ? CRS_MIN_POINTS : msm_merge_min());
-    if (b->table_stride || b->n < table_min || (pe && pe[0] == '0') || g_crs.table_after == 0) return LSA_OK;
-    uint64_t after = g_crs.table_after;                                                   // a configured count is taken as it is
-    if (g_crs.table_after_auto) {
-        const uint64_t scaled = ((uint64_t)CRS_TABLE_AFTER_DEFAULT * b->n + (((uint64_t)1 << 20) - 1)) >> 20;
-        after = scaled < 2 ? 2 : (scaled > CRS_TABLE_AFTER_DEFAULT ? CRS_TABLE_AFTER_DEFAULT : scaled);
-    }
+    if (b->table_stride || b->n < msm_merge_min() || (pe && pe[0] == '0') || g_crs.table_after == 0) return LSA_OK;
     if (e.build) {
         const int st = e.build->state.load();
         if (st == 0) return LSA_OK;                                    // not yet
@@ -815,7 +805,7 @@ static int crs_table_progress(CrsEntry &e) {
         e.build.reset();                                               // a failed build (no memory) leaves a plain entry
         return LSA_OK;
     }
-    if (e.hits < after || e.hits > after + 8) return LSA_OK;                             // (no endless retries after a failed build)
+    if (e.hits < g_crs.table_after || e.hits > g_crs.table_after + 8) return LSA_OK;     // (no endless retries after a failed build)
     const size_t tw = msm_table_windows(b->group, b->n);
     if ((uint64_t)b->n * tw >= (1u << 30)) return LSA_OK;
     auto j = std::make_shared<TableBuild>();
@@ -1052,8 +1042,7 @@ int lsa_crs_cache_stats(uint64_t *hits, uint64_t *misses, uint64_t *resident_byt
 }
 int lsa_crs_cache_table_after(unsigned hits) {
     crs_configure_from_env();
-    g_crs.table_after_auto = hits == LSA_CRS_TABLE_AFTER_AUTO;
-    g_crs.table_after = g_crs.table_after_auto ? CRS_TABLE_AFTER_DEFAULT : hits;
+    g_crs.table_after = hits;
     return LSA_OK;
 }
 // blocks until every background table build has finished and its entry has switched (tests, benchmarks)

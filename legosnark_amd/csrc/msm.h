@@ -43,7 +43,6 @@ int msm_commit_pair_device(const void *d_g1_bases, const void *d_g2_bases, const
 unsigned msm_table_windows(int group, size_t n);
 unsigned msm_field_mults_per_pair(size_t n, size_t table_n);
 size_t msm_merge_min();
-bool msm_merge_min_is_explicit();   // set by msm_set_merge_min(n != 0)
 bool msm_uses_table(size_t n);    // an MSM of n pairs on a table-carrying handle takes the wide-window pipeline
 void msm_set_merge_min(size_t n);
 // fills windows 1.. of a table whose window 0 holds the n prepared bases

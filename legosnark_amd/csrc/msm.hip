@@ -1578,7 +1578,6 @@ size_t msm_merge_min() {
     }
     return g_merge_min;
 }
-bool msm_merge_min_is_explicit() { return g_merge_min_explicit; }
 static size_t table_use_min() { return g_merge_min_explicit ? msm_merge_min() : 1; }
 // whether an MSM of n pairs on a handle that carries the copies runs over them (the wide-window pipeline)
 bool msm_uses_table(size_t n) { return n >= table_use_min(); }

@@ -20,7 +20,7 @@ def fresh_cache(lsa):
     yield lsa
     lsa.crs_cache_configure(lsa.CRS_CACHE_FULL, 8 << 30)
     lsa.crs_cache_clear()
-    lsa.crs_cache_table_after(None)
+    lsa.crs_cache_table_after(23)
     lsa.set_table_threshold(0)
 
 
@@ -193,35 +193,3 @@ def test_sampled_mode_and_off(fresh_cache):
     for _ in range(2):
         assert canon("g1", lsa.msm("g1", bases, sc)) == canon("g1", o.multi_exp("g1", bases, sc, mode="mixed"))
     assert delta(lsa, s0) == (0, 0) and lsa.crs_cache_stats()["entries"] == 0
-
-
-@pytest.mark.parametrize("group,n", [("g1", 1024), ("g1", 1500), ("g1", 5000), ("g1", 40000), ("g2", 3000)])
-def test_small_vectors_get_the_copies_after_two_reuses(lsa, group, n):
-    """The default policy scales the number of re-uses with the vector (23 at 2^20 points, two for a few thousand: the
-    copies of a small vector take under a millisecond to build and save the plain layout's fold).  Same point before,
-    while and after the switch; prefixes of the entry use the copies too."""
-    lsa.crs_cache_configure(lsa.CRS_CACHE_FULL, 8 << 30)
-    lsa.crs_cache_clear()
-    lsa.crs_cache_table_after(None)
-    lsa.set_table_threshold(0)
-    try:
-        bases = np.ascontiguousarray(o.arith_bases(group, 99 + n, 5, n))
-        sc, _ = o.random_scalars(n, seed=n)
-        want = canon(group, o.multi_exp(group, bases, sc, mode="mixed"))
-        seen = []
-        for i in range(4):
-            assert canon(group, lsa.msm(group, bases, sc)) == want, i
-            st = lsa.msm_host_stats()
-            seen.append((st["cache_hit"], st["table"], st["table_building"]))
-        assert seen[0] == (0, 0, 0) and seen[1] == (1, 0, 0)          # cold, first re-use: plain layout
-        assert seen[2][0] == 1 and (seen[2][2] == 1 or seen[2][1] == 1)  # second re-use: the build starts (or is already done)
-        lsa.crs_cache_wait_tables()
-        assert canon(group, lsa.msm(group, bases, sc)) == want
-        assert lsa.msm_host_stats()["table"] == 1
-        m = (n // 2) // 64 * 64
-        if m >= 1024:
-            assert canon(group, lsa.msm(group, bases, sc[:m])) == canon(group, o.multi_exp(group, bases[:m], sc[:m], mode="mixed"))
-            st = lsa.msm_host_stats()
-            assert st["cache_hit"] == 1 and st["table"] == 1
-    finally:
-        lsa.crs_cache_clear()

@@ -3,7 +3,6 @@
 //   g++ -std=c++17 -O2 -I include tools/native/h2d_vectors.cc -o build/h2d_vectors -Llegosnark_amd -llegosnark_amd -Wl,-rpath,$PWD/legosnark_amd -Wl,-rpath,/opt/rocm/lib
 #include <chrono>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "legosnark_amd.h"
@@ -14,7 +13,7 @@ int main(int argc, char **argv) {
     const bool keep = argc > 1 && strcmp(argv[1], "keep") == 0;     // keep every vector alive: no munmap between calls
     std::vector<std::vector<Fr32>> held;
     if (lsa_init(0)) { fprintf(stderr, "%s\n", lsa_last_error()); return 1; }
-    const size_t N = argc > 2 ? (size_t)atol(argv[2]) : (size_t)1 << 20;
+    const size_t N = 1 << 20;
     // bases: copies of the generator (Montgomery (1, 2, 1))
     std::vector<G1J> bases(N);
     {
@@ -31,7 +30,7 @@ int main(int argc, char **argv) {
     for (int rep = 0; rep < 3; rep++) {
         double h2d = 0, fp = 0, bp = 0, ms = 0, tot = 0;
         size_t bytes = 0;
-        for (size_t n = N; n >= (N >= 4096 ? 4096 : 1); n >>= 1) {
+        for (size_t n = N; n >= 4096; n >>= 1) {
             std::vector<Fr32> tmp(n);
             for (size_t i = 0; i < n; i++) tmp[i] = v[i];
             if (lsa_g1_msm(bases.data(), tmp.data(), n, 1, &out)) { fprintf(stderr, "%s\n", lsa_last_error()); return 1; }
