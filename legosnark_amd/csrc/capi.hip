@@ -55,6 +55,15 @@ int lsa_device_count(void) {
 }
 
 const char *lsa_last_error(void) { return g_err; }
+}  // extern "C"
+namespace lsa {
+bool trace_on() {
+    static const bool on = getenv("LSA_TRACE") && getenv("LSA_TRACE")[0] == '1';
+    return on;
+}
+double CallTrace::now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace lsa
+extern "C" {
 
 int lsa_init(int device) {
     if (g.ready && g.device == device) return LSA_OK;
@@ -80,6 +89,7 @@ int lsa_init(int device) {
     HIPCHK(hipHostMalloc(&g.h_result, 512, hipHostMallocDefault));
     g.device = device;
     g.ready = true;
+    upload_prepare();
     return LSA_OK;
 }
 
@@ -143,13 +153,32 @@ class HostCopier {
     std::atomic<size_t> next_{0};
     std::atomic<int> err_{0};
 
+    void *arena_ = nullptr;                           // every slot, one pinned allocation
+    unsigned nworkers_ = 0;
     bool slot_ready(Slot &s) {
-        if (!s.p) {
-            if (hipHostMalloc(&s.p, SLOT, hipHostMallocDefault) != hipSuccess) { s.p = nullptr; return false; }
-            if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { s.ev = nullptr; return false; }
-        }
-        if (!s.ev) return false;
+        if (!s.p || !s.ev) return false;
         if (s.pending) { if (hipEventSynchronize(s.ev) != hipSuccess) return false; s.pending = false; }
+        return true;
+    }
+    // threads, the pinned slots and their events, all at once (lsa_init: not inside somebody's first timed call --
+    // sixteen separate pinned allocations took 8 ms of the unchanged hadamard's Lipmaa prover)
+    bool prepare_locked() {
+        if (arena_) return true;
+        const unsigned hw = std::thread::hardware_concurrency();
+        const char *e = getenv("LSA_H2D_THREADS");
+        unsigned want = e ? (unsigned)atoi(e) : (hw > 8 ? 6 : (hw > 2 ? hw / 2 : 1));
+        if (want < 1) want = 1;
+        if (want > MAX_WORKERS) want = MAX_WORKERS;
+        if (hipHostMalloc(&arena_, (size_t)want * SLOTS_PER_WORKER * SLOT, hipHostMallocDefault) != hipSuccess) { arena_ = nullptr; return false; }
+        for (unsigned i = 0; i < want; i++)
+            for (unsigned k = 0; k < SLOTS_PER_WORKER; k++) {
+                Slot &s = w_[i].slot[k];
+                s.p = (char *)arena_ + ((size_t)i * SLOTS_PER_WORKER + k) * SLOT;
+                s.pending = false;
+                if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { s.ev = nullptr; return false; }
+            }
+        nworkers_ = want;
+        for (unsigned i = 1; i < want; i++) th_.emplace_back([this, i] { loop(i); });
         return true;
     }
     void work(unsigned id) {
@@ -198,23 +227,17 @@ class HostCopier {
         nchunks_ = (bytes + SLOT - 1) / SLOT;
         next_.store(0);
         err_.store(0);
-        const bool alone = nchunks_ < 2;                  // one piece: not worth waking anybody
-        if (!alone) {
-            {
-                std::lock_guard<std::mutex> lk(m_);
-                if (th_.empty()) {
-                    const unsigned hw = std::thread::hardware_concurrency();
-                    const char *e = getenv("LSA_H2D_THREADS");
-                    unsigned want = e ? (unsigned)atoi(e) : (hw > 8 ? 6 : (hw > 2 ? hw / 2 : 1));
-                    if (want < 1) want = 1;
-                    if (want > MAX_WORKERS) want = MAX_WORKERS;
-                    for (unsigned i = 1; i < want; i++) th_.emplace_back([this, i] { loop(i); });
-                }
+        bool alone = nchunks_ < 2;                        // one piece: not worth waking anybody
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            if (!prepare_locked()) { broken_ = true; return 1; }
+            if (th_.empty()) alone = true;
+            if (!alone) {
                 active_ = (unsigned)th_.size();
                 gen_++;
             }
-            cv_.notify_all();
         }
+        if (!alone) cv_.notify_all();
         work(0);
         if (!alone) {
             std::unique_lock<std::mutex> lk(m_);
@@ -240,14 +263,20 @@ class HostCopier {
         gen_ = 0;
         active_ = 0;
     }
+    void prepare() {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!prepare_locked()) broken_ = true;
+    }
     void release() {
         stop_threads();
         for (auto &w : w_)
             for (auto &s : w.slot) {
                 if (s.ev) { if (s.pending) (void)hipEventSynchronize(s.ev); (void)hipEventDestroy(s.ev); }
-                if (s.p) (void)hipHostFree(s.p);
                 s = Slot();
             }
+        if (arena_) (void)hipHostFree(arena_);
+        arena_ = nullptr;
+        nworkers_ = 0;
         broken_ = false;
     }
 };
@@ -283,6 +312,23 @@ int download_host(void *h_dst, const void *d_src, size_t bytes) {
     return LSA_OK;
 }
 void upload_release() { g_copier.release(); }
+void upload_prepare() {
+    if (copy_mode() == 1) return;
+    g_copier.prepare();
+    // the runtime sets up a copy engine's queue at the first pinned transfer of a direction and size class (measured:
+    // 8.4 ms inside the first 128-KiB download of a process that had only done larger ones; none with
+    // HSA_ENABLE_SDMA=0): pay that here for every size a slot can carry, not inside a caller's first NTT
+    void *d = nullptr;
+    if (hipMalloc(&d, (size_t)4 << 20) != hipSuccess) { (void)hipGetLastError(); return; }
+    std::vector<char> h((size_t)4 << 20, 0);
+    for (size_t bytes = STAGE_FROM; bytes <= ((size_t)4 << 20); bytes <<= 1) {
+        if (upload_host(d, h.data(), bytes) != LSA_OK) break;
+        (void)hipStreamSynchronize(g.stream);                       // (a download on an idle stream takes another path)
+        if (download_host(h.data(), d, bytes) != LSA_OK) break;
+    }
+    (void)hipStreamSynchronize(g.stream);
+    (void)hipFree(d);
+}
 }  // namespace lsa
 extern "C" {
 // ---------------------------------------------------------------- bases
@@ -973,6 +1019,7 @@ static int msm_host_local(const void *bases_jac, const void *scalars, size_t n, 
 
 template <class F>
 static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *out_jac, int group, bool sharded = false) {
+    LSA_TRACE_CALL("msm", n);
     int rc = require_ready();
     if (rc) return rc;
     if (sharded && lsa_comm_world() <= 1) sharded = false;
@@ -1067,6 +1114,7 @@ int lsa_msm_host_stats(lsa_host_stats *out) {
 }  // extern "C"
 template <class F>
 static int normalize_host(const void *in_jac, size_t n, void *out_jac) {
+    LSA_TRACE_CALL("normalize", n);
     int rc = require_ready();
     if (rc) return rc;
     if (n == 0) return LSA_OK;
@@ -1102,6 +1150,7 @@ int lsa_g2_normalize(const void *in_jac, size_t n, void *out_jac) { return norma
 // ---------------------------------------------------------------- batch_exp / sum
 template <class F>
 static int batch_exp_any(const void *base_jac, const void *scalars, size_t n, void *out_jac, int on_device) {
+    LSA_TRACE_CALL("batch_exp", n);
     int rc = require_ready();
     if (rc) return rc;
     if (n == 0) return LSA_OK;
@@ -1180,6 +1229,7 @@ struct DevBuf {
 // ---------------------------------------------------------------- variable-base scalar mul / sparse matrix
 extern "C" {
 int lsa_g1_scalar_mul_batch(const void *pts_jac, const void *scalars, size_t n, void *out_jac, int on_device) {
+    LSA_TRACE_CALL("g1_scalar_mul_batch", n);
     int rc = require_ready();
     if (rc) return rc;
     if (n == 0) return LSA_OK;
@@ -1240,6 +1290,7 @@ int lsa_g1_sparse_matrix_msm(const void *vals_jac, const uint32_t *rows, const u
 // ---------------------------------------------------------------- Fr vectors
 extern "C" {
 int lsa_fr_cppoly_witness(const void *v, size_t d, const void *r, void *w, int on_device) {
+    LSA_TRACE_CALL("fr_cppoly_witness", (size_t)1 << d);
     int rc = require_ready();
     if (rc) return rc;
     if (d > 40) { set_error("cppoly_witness: d = %zu too large", d); return LSA_ERR_INVALID; }
@@ -1264,6 +1315,7 @@ int lsa_fr_cppoly_witness(const void *v, size_t d, const void *r, void *w, int o
 }
 
 int lsa_fr_eval_mle(const void *v, size_t d, const void *r, void *out, int on_device) {
+    LSA_TRACE_CALL("fr_eval_mle", (size_t)1 << d);
     int rc = require_ready();
     if (rc) return rc;
     if (d > 40) { set_error("eval_mle: d = %zu too large", d); return LSA_ERR_INVALID; }
@@ -1321,6 +1373,7 @@ int lsa_fr_sumcheck_round(const void *suff, const void *const *tables, size_t m,
 }
 
 int lsa_fr_scale_upper(const void *old, size_t half, const void *k, void *cur, int on_device) {
+    LSA_TRACE_CALL("fr_scale_upper", half);
     int rc = require_ready();
     if (rc) return rc;
     if (half == 0) return LSA_OK;
@@ -1339,6 +1392,7 @@ int lsa_fr_scale_upper(const void *old, size_t half, const void *k, void *cur, i
 }
 
 int lsa_fr_ntt(void *a, size_t log_n, const void *omega, int inverse, const void *coset_g, int on_device) {
+    LSA_TRACE_CALL("fr_ntt", (size_t)1 << log_n);
     int rc = require_ready();
     if (rc) return rc;
     if (log_n > 28) { set_error("fr_ntt: log_n = %zu exceeds the 2-adicity of Fr (28)", log_n); return LSA_ERR_INVALID; }
@@ -1358,12 +1412,16 @@ int lsa_fr_ntt(void *a, size_t log_n, const void *omega, int inverse, const void
     }
     rc = fr_ntt_device(da, (unsigned)log_n, w, inverse != 0, coset_g ? &gco : nullptr, (Fr *)d_tw.p, g.stream);
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(g.stream));      // the twiddle table is freed on return
+    // the twiddle table is freed on return: the download (blocking, behind the kernels on the same stream) or an
+    // explicit wait drains the stream first.  (The download is enqueued BEHIND the kernels, not after a wait for them:
+    // the first device -> host copy a process issues on an idle stream costs it 8 ms of copy-engine set-up on this stack.)
     if (!on_device) LSA_DOWNLOAD(a, d_a.p, n * sizeof(Fr));
+    else HIPCHK(hipStreamSynchronize(g.stream));
     return LSA_OK;
 }
 
 int lsa_fr_fold(const void *old, size_t half, const void *r, void *cur, int on_device) {
+    LSA_TRACE_CALL("fr_fold", half);
     int rc = require_ready();
     if (rc) return rc;
     if (half == 0) return LSA_OK;

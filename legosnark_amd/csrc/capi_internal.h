@@ -2,6 +2,7 @@
 // C-ABI (capi.hip: single-GPU entry points; comm.hip: the multi-GPU exchange step).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include "msm.h"
 
 namespace lsa {
@@ -25,6 +26,19 @@ extern State g;
     } while (0)
 
 int require_ready();
+
+// LSA_TRACE=1: one line on stderr per host-facing call -- name, size, wall time (what a caller's profile of the
+// library looks like from outside; off: one predictable branch).
+bool trace_on();
+struct CallTrace {
+    const char *name;
+    size_t n;
+    double t0;
+    static double now_ms();
+    CallTrace(const char *nm, size_t items) : name(nm), n(items), t0(trace_on() ? now_ms() : 0) {}
+    ~CallTrace() { if (trace_on()) fprintf(stderr, "[lsa] %-28s n=%-9zu %9.3f ms\n", name, n, now_ms() - t0); }
+};
+#define LSA_TRACE_CALL(name, items) CallTrace trace_scope_((name), (size_t)(items))
 void comm_release();               // comm.hip: called by lsa_shutdown
 void pairing_release();            // capi_pairing.hip: staging buffers and the G2 line-table cache
 
@@ -57,6 +71,7 @@ extern StageBuf g_stage_gather;
 int upload_host(void *d_dst, const void *h_src, size_t bytes);
 int download_host(void *h_dst, const void *d_src, size_t bytes);
 void upload_release();             // threads, pinned slots (lsa_shutdown)
+void upload_prepare();             // the same, created (lsa_init)
 #define LSA_UPLOAD(dst, src, bytes) do { int u_ = upload_host((dst), (src), (bytes)); if (u_) return u_; } while (0)
 #define LSA_DOWNLOAD(dst, src, bytes) do { int u_ = download_host((dst), (src), (bytes)); if (u_) return u_; } while (0)    // all-gather landing zone shared by the sharded MSM and pairing paths
 

@@ -441,6 +441,7 @@ int run_miller(const Terms &t, void **d_res) {
 
 // the job with host results: out = nseg (or n) Fq12 values
 int run_terms_host(const Terms &t, void *out, bool final_exp) {
+    LSA_TRACE_CALL("pairing_terms", t.n);
     int rc = require_ready();
     if (rc) return rc;
     const size_t nres = t.seg ? t.nseg : t.n;
@@ -487,6 +488,7 @@ extern "C" {
 size_t lsa_g2_precomp_bytes(void) { return g2_precomp_public_bytes(); }
 
 int lsa_g2_precompute(const void *g2_jac, size_t n, void *out_precomp) {
+    LSA_TRACE_CALL("g2_precompute", n);
     int rc = require_ready();
     if (rc) return rc;
     if (n == 0) return LSA_OK;
@@ -516,6 +518,7 @@ int lsa_g2_precompute(const void *g2_jac, size_t n, void *out_precomp) {
 // verifier that derives its G2 points one after the other on the host (CPPoly::verify: pts[i] * g2,
 // /root/reference/src/gadgets/poly.h:116-118) overlaps the G2 arithmetic of point i with its own work on point i + 1.
 int lsa_g2_tables_prefetch(const void *g2_jac, size_t n) {
+    LSA_TRACE_CALL("g2_tables_prefetch", n);
     int rc = require_ready();
     if (rc) return rc;
     if (n == 0) return LSA_OK;
@@ -597,6 +600,7 @@ int lsa_pairing_terms(const void *g1, const void *g2, const void *const *q_preco
 }
 
 static int product_host(const void *g1, const void *g2, size_t n, void *out, bool final_exp, bool sharded) {
+    LSA_TRACE_CALL("pairing_product", n);
     int rc = require_ready();
     if (rc) return rc;
     if (!out || (n && (!g1 || !g2))) { set_error("pairing: null argument"); return LSA_ERR_INVALID; }
@@ -656,6 +660,7 @@ int lsa_pairing_product_segments(const void *g1, const void *g2, const uint64_t 
 }
 
 int lsa_fq12_product(const void *in, size_t n, void *out) {
+    LSA_TRACE_CALL("fq12_product", n);
     int rc = require_ready();
     if (rc) return rc;
     if (!out || (n && !in)) { set_error("fq12_product: null argument"); return LSA_ERR_INVALID; }
@@ -675,6 +680,7 @@ int lsa_fq12_product(const void *in, size_t n, void *out) {
     return LSA_OK;
 }
 int lsa_final_exponentiation(const void *in, size_t n, void *out, int on_device) {
+    LSA_TRACE_CALL("final_exponentiation", n);
     int rc = require_ready();
     if (rc) return rc;
     if (n == 0) return LSA_OK;
