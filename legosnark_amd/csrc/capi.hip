@@ -290,11 +290,17 @@ int copy_mode() {
     return mode;
 }
 constexpr size_t STAGE_FROM = (size_t)32 << 10;       // below: the runtime copies through its own staging buffer
+// from here on the runtime's own path (pin the caller's pages, one DMA) wins: a staged copy is sixteen and more
+// commands and six threads of memcpy -- 32 MiB: 0.3-0.4 ms later on the device than the direct copy, and the
+// fingerprint threads get less of the host.  (Buffers this large are the ones whose release stalls the GPU when the
+// runtime has pinned them: see capi_internal.h; the shim keeps them on the heap, other callers keep them alive.)
+constexpr size_t STAGE_BELOW = (size_t)16 << 20;
+static bool staged(size_t bytes) { return copy_mode() != 1 && ((bytes >= STAGE_FROM && bytes < STAGE_BELOW) || copy_mode() == 2); }
 }  // namespace
 
 int upload_host(void *d_dst, const void *h_src, size_t bytes) {
     if (bytes == 0) return LSA_OK;
-    if (copy_mode() != 1 && (bytes >= STAGE_FROM || copy_mode() == 2)) {
+    if (staged(bytes)) {
         const int rc = g_copier.run(d_dst, const_cast<void *>(h_src), bytes, false);
         if (rc <= 0) return rc;
     }
@@ -303,7 +309,7 @@ int upload_host(void *d_dst, const void *h_src, size_t bytes) {
 }
 int download_host(void *h_dst, const void *d_src, size_t bytes) {
     if (bytes == 0) return LSA_OK;
-    if (copy_mode() != 1 && (bytes >= STAGE_FROM || copy_mode() == 2)) {
+    if (staged(bytes)) {
         const int rc = g_copier.run(const_cast<void *>(d_src), h_dst, bytes, true);
         if (rc <= 0) return rc;
     }

@@ -60,14 +60,17 @@ struct StageBuf {
 };
 extern StageBuf g_stage_gather;
 
-// Pageable host memory <-> device on lsa_stream(), WITHOUT ever handing a caller's buffer to the runtime.  For
-// large pageable copies hipMemcpy pins the caller's pages in place and keeps the registration; when the caller later
-// frees that vector (munmap -- every std::vector<Fr> of 2^20 scalars is its own mapping) the driver evicts the
-// process's queues and the next submission waits 12-25 ms (measured: tools/native/h2d_vectors.cc, a CPPoly::prove-shaped
-// ladder of MSMs 29 -> 15 ms).  From 32 KiB up the copies go through pinned 2-MiB slots owned by the library; from two
-// slots up a few threads share the memcpy work.  upload_host: every copy is ON THE STREAM when it returns (then
-// asynchronous, like hipMemcpyAsync); download_host: blocking, the bytes are in h_dst when it returns.
-// LSA_H2D=direct|staged overrides the choice (direct = plain hipMemcpyAsync).
+// Pageable host memory <-> device on lsa_stream().  For a large pageable copy hipMemcpy pins the caller's pages in
+// place and keeps the registration; when the caller later frees that vector with munmap (glibc: every allocation above
+// its mmap threshold, at most 32 MiB -- a std::vector<Fr> of 2^20 scalars is just above) the driver evicts the process's
+// queues and the next submission waits 12-25 ms (measured: tools/native/h2d_vectors.cc, a CPPoly::prove-shaped ladder of
+// MSMs 29 -> 15 ms without it), and pinning 4-KiB pages is itself slow (32 MiB: 1.0-1.5 ms against 0.6 at the link rate).
+// Copies of 32 KiB .. 16 MiB therefore go through pinned 2-MiB slots owned by the library (a few threads share the
+// memcpy work from two slots up); larger ones are left to the runtime, whose single DMA from the caller's pages is
+// 0.3-0.4 ms ahead of sixteen staged commands at 32 MiB -- the shim keeps such vectors on the heap (never unmapped), other
+// callers keep them alive across calls or set LSA_H2D=staged.  upload_host: every copy is ON THE STREAM when it returns
+// (then asynchronous, like hipMemcpyAsync); download_host: blocking, the bytes are in h_dst when it returns.
+// LSA_H2D=direct|staged: plain hipMemcpyAsync always / slots at every size.
 int upload_host(void *d_dst, const void *h_src, size_t bytes);
 int download_host(void *h_dst, const void *d_src, size_t bytes);
 void upload_release();             // threads, pinned slots (lsa_shutdown)

@@ -24,6 +24,8 @@
 #include <random>
 #include <stdexcept>
 #include <cerrno>
+#include <climits>
+#include <malloc.h>
 #include <pthread.h>
 #include <sys/random.h>
 #include <sys/types.h>
@@ -768,7 +770,21 @@ public:
 
     // one-time setup (src/examples/cplink.cc:81): brings the GPU library up.  LSA_DEVICE
     // selects the device (default 0).  Fails loudly without a gfx950 device.
+    // The process's large vectors (2^20 scalars = 32 MiB, 2^20 points = 96 MiB: above glibc's mmap threshold, so each is
+    // its own mapping, faulted in page by page and unmapped on destruction) are kept on the heap instead and the heap is
+    // never trimmed: (1) the HIP runtime pins the pages of a large pageable copy, and unmapping pinned pages stalls the
+    // GPU's queues for 12-25 ms (include/../csrc/capi_internal.h); (2) the reference's own loops allocate such vectors by
+    // the dozen (src/gadgets/poly.h:57-86, src/gadgets/sumcheck.cc:41-66).  Unchanged hadamard 20: TOTAL Prove 1.70 ->
+    // 1.56 s, Lipmaa prover 134 -> 103 ms.  LSA_SHIM_MALLOC=0 leaves the allocator alone.
     static void init_public_params() {
+        const char *m = getenv("LSA_SHIM_MALLOC");
+        if (!(m && m[0] == '0')) {
+#if defined(__GLIBC__)
+            mallopt(M_MMAP_THRESHOLD, 1 << 30);
+            mallopt(M_TRIM_THRESHOLD, INT_MAX);
+            mallopt(M_TOP_PAD, 64 << 20);
+#endif
+        }
         const char *d = getenv("LSA_DEVICE");
         lsa_require(lsa_init(d ? atoi(d) : 0), "init_public_params");
     }

@@ -17,12 +17,15 @@ import oracle_lib as o  # noqa: E402
 
 def main():
     lsa.init(0)
-    out = {"mode": os.environ.get("LSA_H2D", "auto")}
-    for log2n in (16, 18, 20):
+    out = {"mode": os.environ.get("LSA_H2D", "auto"), "threads": os.environ.get("LSA_H2D_THREADS"), "chunk_kb": os.environ.get("LSA_H2D_CHUNK_KB")}
+    for log2n in [int(x) for x in os.environ.get("PROBE_LOG2N", "16,18,20").split(",")]:
         n = 1 << log2n
         bases = np.ascontiguousarray(o.arith_bases("g1", 7, 3, n))
         sc, _ = o.random_scalars(n, seed=1)
+        lsa.crs_cache_table_after(1)
         lsa.msm("g1", bases, sc)
+        lsa.msm("g1", bases, sc)
+        lsa.crs_cache_wait_tables()
         lsa.msm("g1", bases, sc)
         fresh, again, total_fresh, total_again = [], [], [], []
         bufs = []
