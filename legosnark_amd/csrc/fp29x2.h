@@ -66,16 +66,24 @@ LSA_HD F29x2 sqr(const F29x2 &a) {
 }
 
 // ------------------------------------------------------------------------------------
-struct Aff29x2 {
-    F29x2 x, y;                                            // canonical (< p)
+// Point formulas over any representation E of Fq2 that offers zero / one / limbs_zero / is_zero_mod_p / norm and the
+// free functions add_lazy, sub_k<K>, condsub4, mul<KB>, sqr<KA> with the bounds above: F29x2 (both components in one
+// lane) and F29h (fp29x2l.h: one component per lane of a pair; its predicates are uniform over the pair, so both
+// lanes take the same branches).
+template <class E>
+struct AffE {
+    E x, y;                                                // canonical (< p)
     LSA_HD bool is_inf() const { return x.limbs_zero() && y.limbs_zero(); }
 };
-struct AffPackedG2 { uint32_t w[4][8]; };                  // x.c0, x.c1, y.c0, y.c1 as 256-bit words (128 B)
-struct XYZZ29x2 {
-    F29x2 X, Y, ZZ, ZZZ;
+template <class E>
+struct XyzzE {
+    E X, Y, ZZ, ZZZ;
     LSA_HD bool is_inf() const { return ZZ.limbs_zero(); }
-    static LSA_HD XYZZ29x2 inf() { return {F29x2::zero(), F29x2::zero(), F29x2::zero(), F29x2::zero()}; }
+    static LSA_HD XyzzE inf() { return {E::zero(), E::zero(), E::zero(), E::zero()}; }
 };
+using Aff29x2 = AffE<F29x2>;
+using XYZZ29x2 = XyzzE<F29x2>;
+struct AffPackedG2 { uint32_t w[4][8]; };                  // x.c0, x.c1, y.c0, y.c1 as 256-bit words (128 B)
 LSA_HD Aff29x2 unpack_affine(const AffPackedG2 &q) {
     return {{F29::unpack256(q.w[0]), F29::unpack256(q.w[1])}, {F29::unpack256(q.w[2]), F29::unpack256(q.w[3])}};
 }
@@ -98,68 +106,72 @@ LSA_HD AffPackedG2 pack_affine_g2(const Aff<Fq2> &a) {
 }
 
 // 2*(x,y), affine canonical input (mdbl-2008-s-1)
-LSA_HD XYZZ29x2 g2_dbl_affine(const Aff29x2 &b) {
-    F29x2 U = add_lazy(b.y, b.y).norm();                               // [<2; tight]
-    F29x2 V = sqr<2>(U);
-    F29x2 W = mul<2>(U, V);                                            // 2*2*2 = 8
-    F29x2 S = mul<2>(b.x, V);
-    F29x2 xx = sqr<1>(b.x);
-    F29x2 M = add_lazy(add_lazy(xx, xx), xx).norm();                   // [<6; tight]
-    F29x2 X3 = condsub4(sub_k<4>(sqr<6>(M), add_lazy(S, S)));          // M^2 - 2S + 4p <6 -> [<4]
-    F29x2 Y3 = sub_k<2>(mul<6>(M, sub_k<4>(S, X3)), mul<1>(W, b.y));   // 2*6*6 = 72   [<4]
+template <class E>
+LSA_HD XyzzE<E> g2_dbl_affine(const AffE<E> &b) {
+    E U = add_lazy(b.y, b.y).norm();                                   // [<2; tight]
+    E V = sqr<2>(U);
+    E W = mul<2>(U, V);                                                // 2*2*2 = 8
+    E S = mul<2>(b.x, V);
+    E xx = sqr<1>(b.x);
+    E M = add_lazy(add_lazy(xx, xx), xx).norm();                       // [<6; tight]
+    E X3 = condsub4(sub_k<4>(sqr<6>(M), add_lazy(S, S)));              // M^2 - 2S + 4p <6 -> [<4]
+    E Y3 = sub_k<2>(mul<6>(M, sub_k<4>(S, X3)), mul<1>(W, b.y));       // 2*6*6 = 72   [<4]
     return {X3, Y3, V, W};
 }
 // 2*P (dbl-2008-s-1)
-LSA_HD XYZZ29x2 g2_dbl(const XYZZ29x2 &a) {
+template <class E>
+LSA_HD XyzzE<E> g2_dbl(const XyzzE<E> &a) {
     if (a.is_inf()) return a;
-    F29x2 U = condsub4(add_lazy(a.Y, a.Y).norm());                     // 2Y <8 -> [<4; tight]
-    F29x2 V = sqr<4>(U);
-    F29x2 W = mul<2>(U, V);                                            // 2*4*2 = 16
-    F29x2 S = mul<2>(a.X, V);
-    F29x2 xx = sqr<4>(a.X);
-    F29x2 M = add_lazy(add_lazy(xx, xx), xx).norm();                   // [<6; tight]
-    F29x2 X3 = condsub4(sub_k<4>(sqr<6>(M), add_lazy(S, S)));          // [<4]
-    F29x2 Y3 = sub_k<2>(mul<6>(M, sub_k<4>(S, X3)), mul<4>(W, a.Y));   // 72 ; 2*2*4 = 16   [<4]
+    E U = condsub4(add_lazy(a.Y, a.Y).norm());                         // 2Y <8 -> [<4; tight]
+    E V = sqr<4>(U);
+    E W = mul<2>(U, V);                                                // 2*4*2 = 16
+    E S = mul<2>(a.X, V);
+    E xx = sqr<4>(a.X);
+    E M = add_lazy(add_lazy(xx, xx), xx).norm();                       // [<6; tight]
+    E X3 = condsub4(sub_k<4>(sqr<6>(M), add_lazy(S, S)));              // [<4]
+    E Y3 = sub_k<2>(mul<6>(M, sub_k<4>(S, X3)), mul<4>(W, a.Y));       // 72 ; 2*2*4 = 16   [<4]
     return {X3, Y3, mul<2>(V, a.ZZ), mul<2>(W, a.ZZZ)};
 }
 // acc + (x2,y2), complete (madd-2008-s)
-LSA_HD XYZZ29x2 g2_madd(const XYZZ29x2 &a, const Aff29x2 &b) {
+template <class E>
+LSA_HD XyzzE<E> g2_madd(const XyzzE<E> &a, const AffE<E> &b) {
     if (b.is_inf()) return a;
-    if (a.is_inf()) return {b.x, b.y, F29x2::one(), F29x2::one()};
-    F29x2 U2 = mul<2>(b.x, a.ZZ);                                      // 2*1*2
-    F29x2 S2 = mul<2>(b.y, a.ZZZ);
-    F29x2 Pd = sub_k<4>(U2, a.X);                                      // [<6]
-    F29x2 R = sub_k<4>(S2, a.Y);                                       // [<6]
+    if (a.is_inf()) return {b.x, b.y, E::one(), E::one()};
+    E U2 = mul<2>(b.x, a.ZZ);                                          // 2*1*2
+    E S2 = mul<2>(b.y, a.ZZZ);
+    E Pd = sub_k<4>(U2, a.X);                                          // [<6]
+    E R = sub_k<4>(S2, a.Y);                                           // [<6]
     if (Pd.is_zero_mod_p()) {
         if (R.is_zero_mod_p()) return g2_dbl_affine(b);
-        return XYZZ29x2::inf();
+        return XyzzE<E>::inf();
     }
-    F29x2 PP = sqr<6>(Pd);                                             // (12)(12) = 144
-    F29x2 PPP = mul<2>(Pd, PP);                                        // 2*6*2 = 24
-    F29x2 Q = mul<2>(a.X, PP);                                         // 2*4*2 = 16
-    F29x2 X3 = condsub4(sub_k<6>(sqr<6>(R), add_lazy(PPP, add_lazy(Q, Q))));   // <8 -> [<4]
-    F29x2 Y3 = sub_k<2>(mul<6>(R, sub_k<4>(Q, X3)), mul<2>(a.Y, PPP));         // 2*6*6 = 72 ; 16   [<4]
+    E PP = sqr<6>(Pd);                                                 // (12)(12) = 144
+    E PPP = mul<2>(Pd, PP);                                            // 2*6*2 = 24
+    E Q = mul<2>(a.X, PP);                                             // 2*4*2 = 16
+    E X3 = condsub4(sub_k<6>(sqr<6>(R), add_lazy(PPP, add_lazy(Q, Q))));       // <8 -> [<4]
+    E Y3 = sub_k<2>(mul<6>(R, sub_k<4>(Q, X3)), mul<2>(a.Y, PPP));             // 2*6*6 = 72 ; 16   [<4]
     return {X3, Y3, mul<2>(a.ZZ, PP), mul<2>(a.ZZZ, PPP)};
 }
 // a + b, complete (add-2008-s)
-LSA_HD XYZZ29x2 g2_add(const XYZZ29x2 &a, const XYZZ29x2 &b) {
+template <class E>
+LSA_HD XyzzE<E> g2_add(const XyzzE<E> &a, const XyzzE<E> &b) {
     if (b.is_inf()) return a;
     if (a.is_inf()) return b;
-    F29x2 U1 = mul<2>(a.X, b.ZZ);                                      // 2*4*2
-    F29x2 U2 = mul<2>(b.X, a.ZZ);
-    F29x2 S1 = mul<2>(a.Y, b.ZZZ);
-    F29x2 S2 = mul<2>(b.Y, a.ZZZ);
-    F29x2 Pd = sub_k<2>(U2, U1);                                       // [<4]
-    F29x2 R = sub_k<2>(S2, S1);
+    E U1 = mul<2>(a.X, b.ZZ);                                          // 2*4*2
+    E U2 = mul<2>(b.X, a.ZZ);
+    E S1 = mul<2>(a.Y, b.ZZZ);
+    E S2 = mul<2>(b.Y, a.ZZZ);
+    E Pd = sub_k<2>(U2, U1);                                           // [<4]
+    E R = sub_k<2>(S2, S1);
     if (Pd.is_zero_mod_p()) {
         if (R.is_zero_mod_p()) return g2_dbl(a);
-        return XYZZ29x2::inf();
+        return XyzzE<E>::inf();
     }
-    F29x2 PP = sqr<4>(Pd);
-    F29x2 PPP = mul<2>(Pd, PP);
-    F29x2 Q = mul<2>(U1, PP);
-    F29x2 X3 = condsub4(sub_k<6>(sqr<4>(R), add_lazy(PPP, add_lazy(Q, Q))));
-    F29x2 Y3 = sub_k<2>(mul<6>(R, sub_k<4>(Q, X3)), mul<2>(S1, PPP));  // 2*4*6 = 48   [<4]
+    E PP = sqr<4>(Pd);
+    E PPP = mul<2>(Pd, PP);
+    E Q = mul<2>(U1, PP);
+    E X3 = condsub4(sub_k<6>(sqr<4>(R), add_lazy(PPP, add_lazy(Q, Q))));
+    E Y3 = sub_k<2>(mul<6>(R, sub_k<4>(Q, X3)), mul<2>(S1, PPP));      // 2*4*6 = 48   [<4]
     return {X3, Y3, mul<2>(mul<2>(a.ZZ, b.ZZ), PP), mul<2>(mul<2>(a.ZZZ, b.ZZZ), PPP)};
 }
 // XYZZ -> libff Jacobian: Z = ZZZ, X' = X*ZZ^2, Y' = Y*ZZZ^2

@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "curves.h"
+#include "fp29x2l.h"
 #include "fs29.h"
 #include "glv.h"
 #include "msm.h"
@@ -1007,6 +1008,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     accumulate_body<CurveG2, 1u>(bases, entries, offs, hist, perm, nperm, buckets);
 }
 
+// G2 with a PAIR of lanes per bucket, each lane on one Fq component of every coordinate (fp29x2l.h): the same entry
+// walk and the same formulas as above, half the registers per lane.  A lane fetches its own halves of the next base
+// (x.c, y.c of its component: 2 x 32 B of the 128-B record, so a pair still reads one contiguous record).
+__global__ __launch_bounds__(256) void k_accumulate_g2_pair(const AffPackedG2 *__restrict__ bases, const uint32_t *__restrict__ entries,
+                                                            const uint32_t *__restrict__ offs, const uint32_t *__restrict__ hist,
+                                                            const uint32_t *__restrict__ perm, const uint32_t *__restrict__ nperm,
+                                                            XYZZ29x2 *__restrict__ buckets) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, pr = t >> 1, part = t & 1;
+    if (pr >= *nperm) return;                               // (both lanes of a pair leave together)
+    const uint32_t g = perm[pr];
+    const uint32_t cnt = hist[g];                           // 1 .. heavy_threshold
+    const uint32_t *e = entries + offs[g];
+    struct Half { uint32_t x[8], y[8]; };
+    auto fetch = [&](uint32_t v) {
+        const AffPackedG2 &b = bases[v & 0x3fffffffu];
+        Half h;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { h.x[i] = b.w[part][i]; h.y[i] = b.w[2 + part][i]; }
+        return h;
+    };
+    XyzzE<F29h> acc = XyzzE<F29h>::inf();
+    uint32_t v = e[0];
+    Half cur = fetch(v);
+    for (uint32_t j = 0; j < cnt; j++) {
+        uint32_t vn = v;
+        Half nxt = cur;
+        if (j + 1 < cnt) { vn = e[j + 1]; nxt = fetch(vn); }
+        AffE<F29h> q = {{F29::unpack256(cur.x)}, {F29::unpack256(cur.y)}};
+        if (!q.is_inf()) {
+            if (v >> 31) q.y = sub_k<1>(F29h::zero(), q.y);  // p - y per component
+            acc = g2_madd(acc, q);
+        }
+        v = vn;
+        cur = nxt;
+    }
+    F29 *o = reinterpret_cast<F29 *>(&buckets[g]);          // X.c0, X.c1, Y.c0, Y.c1, ZZ.c0, ...
+    o[part] = acc.X.v;
+    o[2 + part] = acc.Y.v;
+    o[4 + part] = acc.ZZ.v;
+    o[6 + part] = acc.ZZZ.v;
+}
+
 // (G1 capped to 128 VGPRs / four wavefronts per SIMD spills 208 B per lane and measured 2 % slower.)
 template <class A>
 __device__ __forceinline__ A shfl_down_acc(const A &p, unsigned delta) {
@@ -1872,7 +1915,15 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     }
     mark(st);  // 4
     static const bool g2_occ2 = getenv("LSA_G2_OCC1") == nullptr;
+    // (measured equal: 3.18 ms for the pair kernel -- 160 VGPRs, no scratch, three wavefronts per SIMD, ~18 % more
+    // instructions per addition -- against 3.09 ms for the one-lane kernel at 2^20 pairs: both are instruction-issue
+    // bound, the 316 B of scratch were never the cost.  LSA_G2_PAIR=1 selects the pair kernel.)
+    static const bool g2_pair = getenv("LSA_G2_PAIR") && getenv("LSA_G2_PAIR")[0] == '1';
     if constexpr (std::is_same<C, CurveG2>::value) {
+        if (split == 1 && g2_pair) {
+            hipLaunchKernelGGL(k_accumulate_g2_pair, dim3((nb * 2 + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
+            goto acc_done;
+        }
         if (split == 1 && g2_occ2) {
             hipLaunchKernelGGL(k_accumulate_g2_occ2, dim3((nb + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
             goto acc_done;
