@@ -52,6 +52,22 @@ def spread(db_path, needle=""):
         print("%-60s %6d %10.1f %10.1f %10.1f" % (name[:60], len(v), v[0], v[len(v) // 2], v[-1]))
 
 
+def timeline(db_path, last=40):
+    """the last `last` kernel dispatches in start order: start (us, relative to the first of them), duration, gap to
+    the previous kernel's end -- where a single call's time goes between its kernels"""
+    db = sqlite3.connect(db_path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    st, en = ("start", "end") if "start" in cols else ("start_timestamp", "end_timestamp")
+    extra = ", stream_id" if "stream_id" in cols else (", queue_id" if "queue_id" in cols else "")
+    rows = db.execute("select name, %s, %s%s from kernels order by %s" % (st, en, extra, st)).fetchall()[-last:]
+    t0, prev_end = rows[0][1], rows[0][1]
+    print("%-52s %10s %10s %10s %s" % ("kernel", "start_us", "dur_us", "gap_us", "queue"))
+    for r in rows:
+        name, a, b = r[0], r[1], r[2]
+        print("%-52s %10.1f %10.1f %10.1f %s" % (short(name)[:52], (a - t0) / 1e3, (b - a) / 1e3, (a - prev_end) / 1e3, r[3] if len(r) > 3 else ""))
+        prev_end = max(prev_end, b)
+
+
 def pmc_means(db_path):
     db = sqlite3.connect(db_path)
     q = ("select kernel_name, counter_name, count(*), avg(value), avg(duration), max(vgpr_count), max(sgpr_count), "
@@ -89,7 +105,9 @@ def hbm(fetch_db, write_db, needle, out):
 
 if __name__ == "__main__":
     mode = sys.argv[1]
-    if mode == "spread":
+    if mode == "timeline":
+        timeline(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 40)
+    elif mode == "spread":
         spread(sys.argv[2], sys.argv[3] if len(sys.argv) > 3 else "")
     elif mode == "trace":
         trace(sys.argv[2])
