@@ -609,15 +609,32 @@ public:
         return Y.sqr() == X.sqr() * X + curve_b() * z6;
     }
     void print() const { std::cout << *this << "\n"; }
-    // libff "scalar * point": MSB-first double-and-add on the canonical scalar (cold path)
+    // libff "scalar * point" on the host (cold path: a verifier's handful of points; vectors of them go through
+    // lsa_mtxmultiexp / lsa_scalar_mul_batch).  The same point as libff's double-and-add; computed MSB-first over
+    // 4-bit digits with the fifteen small multiples of the base (a quarter of the additions), plain double-and-add
+    // for scalars below 2^16.
     friend G_shim operator*(const alt_bn128_Fr &k, const G_shim &p) {
         lsa_shim::StatScope scope(lsa_shim::ST_SCALAR_MUL_HOST, 1);
-        bigint<4> e = k.as_bigint();
-        Jac res = Jac::inf(), base = p.jac();
-        bool found = false;
-        for (long i = 255; i >= 0; --i) {
-            if (found) res = lsa::jac_dbl(res);
-            if (e.test_bit(i)) { found = true; res = lsa::jac_add(res, base); }
+        const bigint<4> e = k.as_bigint();
+        const Jac base = p.jac();
+        Jac res = Jac::inf();
+        long top = 255;
+        while (top >= 0 && !e.test_bit(top)) --top;
+        if (top < 16) {
+            for (long i = top; i >= 0; --i) {
+                res = lsa::jac_dbl(res);
+                if (e.test_bit(i)) res = lsa::jac_add(res, base);
+            }
+            return G_shim(res);
+        }
+        Jac tbl[16];
+        tbl[0] = Jac::inf();
+        tbl[1] = base;
+        for (int i = 2; i < 16; i++) tbl[i] = (i & 1) ? lsa::jac_add(tbl[i - 1], base) : lsa::jac_dbl(tbl[i / 2]);
+        for (long nib = top / 4; nib >= 0; --nib) {
+            if (nib != top / 4) for (int j = 0; j < 4; j++) res = lsa::jac_dbl(res);
+            const unsigned d = (unsigned)((e.data[nib / 16] >> (4 * (nib % 16))) & 15u);
+            if (d) res = lsa::jac_add(res, tbl[d]);
         }
         return G_shim(res);
     }

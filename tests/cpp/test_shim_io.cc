@@ -104,6 +104,21 @@ int main() {
     Fr_ a = Fr_::random_element(), b = Fr_::random_element();
     CHECK(a != b);
     CHECK(Fr_(a.as_bigint()) == a);
+    // scalar * point on the host (4-bit digits above 2^16): linear in the scalar, and equal to plain doublings
+    {
+        for (int t = 0; t < 6; t++) {
+            const Fr_ a = Fr_::random_element(), b = t == 0 ? Fr_(65535L) : (t == 1 ? Fr_(65536L) : Fr_::random_element());
+            CHECK((a + b) * G1_::one() == a * G1_::one() + b * G1_::one());
+            CHECK((a + b) * G2_::one() == a * G2_::one() + b * G2_::one());
+            CHECK((-a) * G1_::one() == -(a * G1_::one()));
+        }
+        G1_ p = G1_::one();
+        Fr_ two200 = Fr_::one();
+        for (int i = 0; i < 200; i++) { p = p.dbl(); two200 = two200 + two200; }
+        CHECK(two200 * G1_::one() == p);
+        CHECK((two200 + Fr_(5L)) * G1_::one() == p + Fr_(5L) * G1_::one());
+        CHECK(Fr_::zero() * G1_::one() == G1_::zero() && Fr_::one() * G2_::one() == G2_::one());
+    }
     // a pool of random bytes serves many draws: no draw repeats, every one reduced
     {
         std::vector<Fr_> rs(1000);
