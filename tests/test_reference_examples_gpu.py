@@ -104,3 +104,29 @@ def test_multiexpma_on_a_chunk_per_process_from_cpp(tmp_path):
     r = subprocess.run([exe, "12"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert '"matches_single_gpu": true' in r.stdout
+
+
+def test_shim_stats_and_call_trace_account_for_a_run():
+    """LSA_SHIM_STATS=1: the shim's exit line (calls / items / ms per kind of library call, the MSM host path's split,
+    the process's wall time); LSA_TRACE=1: one line per host-facing call from the library.  On `hadamard 8` the
+    two must agree on the number of MSMs, the time inside must be below the wall time, and every MSM of the prover's
+    ladder on the 2^8 + 1 generator copies ... is too small for the CRS cache (so no hits are reported)."""
+    import json
+    exe = os.path.join(BIN, "hadamard")
+    require_binary(exe)
+    env = dict(os.environ, LSA_SEED="7", LSA_SHIM_STATS="1", LSA_TRACE="1")
+    r = subprocess.run([exe, "8"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stderr.splitlines() if l.startswith('{"lsa_shim_stats"')]
+    assert len(lines) == 1, r.stderr[-2000:]
+    st = json.loads(lines[0])["lsa_shim_stats"]
+    traced = [l.split() for l in r.stderr.splitlines() if l.startswith("[lsa] ")]
+    n_msm = sum(1 for t in traced if t[1] == "msm")
+    assert n_msm == st["msm_g1"]["calls"] + st["msm_g2"]["calls"] > 0
+    assert sum(1 for t in traced if t[1] == "pairing_terms") == st["pairing"]["calls"] > 0
+    assert 0 < st["inside_ms"] < st["process_ms"]
+    hp = st["msm_host_path"]
+    assert hp["kernels_ms"] > 0 and hp["cache_hits"] == 0 and hp["on_pre_shifted_copies"] == 0
+    assert st["scalar_mul_host"]["calls"] > 0 and st["g2_precompute"]["calls"] > 0
+    # the reference's own output is untouched by either switch
+    assert "##had_sc TOTAL Prove" in r.stdout and "lsa_shim_stats" not in r.stdout
