@@ -27,7 +27,9 @@ multiplication rate against the measured integer ceiling, which is what really b
 `cpu_baseline` object (the oracle = libff-algorithm restatement, timed on this host) and a `configs`
 block: the other BASELINE.json configs (G2 MSM 2^20, CPpoly d=20, the 2^12-pairing product, the CPhad
 verifier shape, the CPlink prover MSM), each result-checked, each with its time, algorithmic bytes and
-field-multiplication rate (legosnark_amd/benchcfg.py).
+field-multiplication rate (legosnark_amd/benchcfg.py).  `unchanged_reference_binary`: the reference's own
+`hadamard 20` example (unchanged source, built against the shim; a child process) with ITS timers
+(`##had_sc ... Prove/Verify`, src/examples/hadamard.cc:98-105) and the time it spent inside the library.
 
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment launches its own N ranks (one child
 `python -m torch.distributed.run --nproc-per-node N bench.py ...`, started before this process
@@ -105,6 +107,36 @@ def pmc_traffic(kernel_substr="k_accumulate", exclude="heavy", timeout_s=150):
             "kernel_us_under_pmc": [vals["FETCH_SIZE"]["kernel_us"], vals["WRITE_SIZE"]["kernel_us"]],
             "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate child runs of bench.py; "
                       "bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 half-count correction, calibrated on streaming reads)"}
+
+
+def reference_binary_run(d=20):
+    """The reference's UNCHANGED `hadamard` example (built against the shim by __graft_entry__.build() where
+    /root/reference exists; build/ travels with the snapshot) run as a child process at d variables, with the
+    reference's own timers (##had_sc ... Prove/Verify: N micros, src/examples/hadamard.cc:98-105) and the shim's
+    accounting of the time spent inside the library (LSA_SHIM_STATS=1).  What a LegoSNARK user sees end to end."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "build", "reference", "hadamard")
+    if not os.path.exists(exe):
+        return {"program": "build/reference/hadamard", "status": "absent (built only where the reference's sources are)"}
+    env = dict(os.environ, LSA_SHIM_STATS="1")
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([exe, str(d)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    except subprocess.TimeoutExpired:
+        return {"program": "build/reference/hadamard %d" % d, "status": "timeout"}
+    wall = time.perf_counter() - t0
+    res = {"program": "build/reference/hadamard %d (unchanged source, libff-compatible shim)" % d, "status": "rc=%d" % r.returncode, "wall_s": round(wall, 3),
+           "timers_ms": {}}
+    for m in re.finditer(r"^##(\S+) (.*?): ([0-9.e+]+) micros", r.stdout, re.M):
+        res["timers_ms"]["%s %s" % (m.group(1), m.group(2))] = round(float(m.group(3)) / 1e3, 3)
+    for line in r.stderr.splitlines():
+        if line.startswith('{"lsa_shim_stats"'):
+            st = json.loads(line)["lsa_shim_stats"]
+            res["inside_library_ms"] = st["inside_ms"]
+            res["process_ms"] = st["process_ms"]
+            res["library_calls"] = {k: v for k, v in st.items() if isinstance(v, dict) and v.get("calls")}
+    return res
 
 
 def being_profiled():
@@ -494,6 +526,8 @@ def main():
                                               only={"g2_msm", "cppoly", "pairing", "cphad_verify"})
             if any("error" in c for c in out["configs"]):
                 raise SystemExit("bench.py: a config's result check failed: %s" % [c for c in out["configs"] if "error" in c])
+        if not args.no_configs and world == 1 and not strong and args.log2n == 20 and not being_profiled():
+            out["unchanged_reference_binary"] = reference_binary_run()
         if not args.no_cpu_baseline and world == 1 and not strong:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as o   # the checker, timed as the reported CPU baseline
