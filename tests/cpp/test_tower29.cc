@@ -35,6 +35,30 @@ int main() {
     }
     CHECK(Fs::from_mont256(rand_fq()).inverse().to_mont256() != Fq::zero(), "inv nonzero");
     { Fq a = rand_fq(); CHECK(Fs::from_mont256(a).inverse().to_mont256() == a.inverse(), "inverse"); }
+    {
+        // Fs::inverse (29-bit limbs) against Fq::inverse (another implementation: binary Euclid on 64-bit limbs, or the
+        // power a^(p-2) under -DLSA_FP_HOST32): random values, 0, +-1, powers of two and their neighbours, non-canonical inputs
+        bool ok = true;
+        for (int t = 0; t < 300; t++) { const Fq a = rand_fq(); ok = ok && Fs::from_mont256(a).inverse().to_mont256() == a.inverse(); }
+        CHECK(ok, "inverse, random");
+        CHECK(Fs::zero().inverse().to_mont256() == Fq::zero(), "inverse(0) == 0");
+        CHECK(Fs::one().inverse().to_mont256() == Fq::one(), "inverse(1)");
+        const Fq m1 = Fq::zero() - Fq::one();
+        CHECK(Fs::from_mont256(m1).inverse().to_mont256() == m1, "inverse(-1)");
+        Fq p2 = Fq::one();
+        ok = true;
+        for (int i = 0; i < 260; i++) {
+            for (const Fq &x : {p2, p2 + Fq::one(), p2 - Fq::one()}) {
+                if (x.is_zero()) continue;
+                const Fs xi = Fs::from_mont256(x).inverse();
+                ok = ok && xi.to_mont256() == x.inverse() && (xi * Fs::from_mont256(x)).to_mont256() == Fq::one();
+            }
+            p2 = p2 + p2;
+        }
+        CHECK(ok, "inverse, powers of two");
+        const Fs loose = Fs::from_mont256(m1) + Fs::from_mont256(m1);          // a representative above p
+        CHECK((loose.inverse() * loose).to_mont256() == Fq::one(), "inverse of a non-canonical representative");
+    }
     for (int t = 0; t < 20; t++) {
         Fq12 a = rand12(), b = rand12();
         F12s A = to_s(a), B = to_s(b);
