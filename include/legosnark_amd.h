@@ -80,7 +80,8 @@ int lsa_g2_msm(const void *bases_jac, const void *scalars_mont, size_t n, size_t
  * fingerprinted (64-point units, host thread pool, overlapped with the scalar upload) -- a
  * vector modified in place is a miss, never a stale result.  mode 1 (LSA_CRS_CACHE=sampled):
  * ~3*log2(n) sampled points are compared; for callers that do not modify CRS vectors in place.
- * mode 0 (LSA_CRS_CACHE=0): every call uploads and normalises its bases.  Entries are evicted
+ * mode 0 (LSA_CRS_CACHE=0): every call uploads and normalises its bases.  Vectors below 1024 points are not kept,
+ * but are recognised as prefixes of a kept one (whole 64-point units, or fewer than 64 points) and then served from it.  Entries are evicted
  * least-recently-used beyond max_bytes of device memory (0 keeps the current budget; default
  * min(1/4 of the device, 64 GiB), env LSA_CRS_CACHE_MB).  The first re-use of an entry of at
  * least the table threshold that has been hit often enough also STARTS building its pre-shifted window copies

@@ -94,10 +94,42 @@ def test_prefix_requests_cppoly_ladder_shape(fresh_cache):
     got = lsa.msm("g1", bases, sc[:4096])
     assert canon("g1", got) == canon("g1", o.multi_exp("g1", bases[:4096], sc[:4096], mode="mixed"))
     assert delta(lsa, s1) == (1, 1)
-    # small vectors bypass the cache
+    # small requests: never inserted, but looked up as prefixes of an entry -- whole 64-point units, or fewer than 64
+    # points against the per-point fingerprints of the entry's first unit (the tail of CPPoly::prove's ladder);
+    # 100 points = one unit and a partial one: not comparable, uploaded as before
     s1 = lsa.crs_cache_stats()
-    lsa.msm("g1", bases, sc[:100])
-    assert delta(lsa, s1) == (0, 0)
+    got = lsa.msm("g1", bases, sc[:100])
+    assert canon("g1", got) == canon("g1", o.multi_exp("g1", bases[:100], sc[:100], mode="mixed"))
+    assert delta(lsa, s1) == (0, 0) and lsa.msm_host_stats()["cache_hit"] == 0
+    for m in (512, 64, 37, 2, 1):
+        s1 = lsa.crs_cache_stats()
+        got = lsa.msm("g1", bases, sc[:m])
+        assert canon("g1", got) == canon("g1", o.multi_exp("g1", bases[:m], sc[:m], mode="mixed")), m
+        assert delta(lsa, s1) == (1, 0) and lsa.msm_host_stats()["cache_hit"] == 1, m
+    # the same prefixes at another address (a copy): content-addressed, still hits
+    head = bases[:512].copy()
+    s1 = lsa.crs_cache_stats()
+    assert canon("g1", lsa.msm("g1", head, sc[:37])) == canon("g1", o.multi_exp("g1", head[:37], sc[:37], mode="mixed"))
+    assert delta(lsa, s1) == (1, 0)
+    # one changed point inside the requested prefix: no hit, right answer; beyond it: hit
+    head[20] = head[3]
+    s1 = lsa.crs_cache_stats()
+    assert canon("g1", lsa.msm("g1", head, sc[:37])) == canon("g1", o.multi_exp("g1", head[:37], sc[:37], mode="mixed"))
+    assert lsa.msm_host_stats()["cache_hit"] == 0
+    assert canon("g1", lsa.msm("g1", head, sc[:512])) == canon("g1", o.multi_exp("g1", head[:512], sc[:512], mode="mixed"))
+    assert lsa.msm_host_stats()["cache_hit"] == 0
+    assert canon("g1", lsa.msm("g1", head, sc[:16])) == canon("g1", o.multi_exp("g1", head[:16], sc[:16], mode="mixed"))
+    assert lsa.msm_host_stats()["cache_hit"] == 1
+    assert delta(lsa, s1) == (1, 0)
+    # ... and on the entry's pre-shifted copies once it has them
+    lsa.crs_cache_wait_tables()
+    lsa.msm("g1", bases, sc)                      # (switches the entry if the build has just finished)
+    if lsa.msm_host_stats()["table"] == 1:
+        for m in (256, 5):
+            got = lsa.msm("g1", bases, sc[:m])
+            assert canon("g1", got) == canon("g1", o.multi_exp("g1", bases[:m], sc[:m], mode="mixed")), m
+            st = lsa.msm_host_stats()
+            assert st["cache_hit"] == 1 and st["table"] == 1, m
 
 
 def test_table_built_on_first_reuse_and_lru_eviction(fresh_cache):
@@ -119,6 +151,11 @@ def test_table_built_on_first_reuse_and_lru_eviction(fresh_cache):
     assert st["cache_hit"] == 1 and st["table"] == 1 and st["table_building"] == 0
     one = lsa.crs_cache_stats()["resident_bytes"]
     assert one % (n * 64) == 0 and one // (n * 64) >= 12      # one 64-byte copy of every point per window (+ the plain one)
+    # short prefixes of the vector (below the cache's own minimum) run over the copies too
+    for m in (512, 64, 5, 1):
+        assert canon("g1", lsa.msm("g1", vecs[0], sc[:m])) == canon("g1", o.multi_exp("g1", vecs[0][:m], sc[:m], mode="mixed")), m
+        st = lsa.msm_host_stats()
+        assert st["cache_hit"] == 1 and st["table"] == 1, m
     # without waiting: calls issued while the build runs switch over on their own, every result the same point
     lsa.crs_cache_clear()
     seen_table = False
