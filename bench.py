@@ -62,7 +62,7 @@ def cpu_model():
     return "unknown"
 
 
-def pmc_traffic(kernel_substr="k_accumulate", exclude="heavy", timeout_s=150):
+def pmc_traffic(kernel_substr="k_accumulate", exclude="heavy", timeout_s=150, extra_args=("--no-configs",), expect_us=None):
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC counters, collected as
     /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc
     passes (they do not fit one pass), each over a short child run of this same script; both
@@ -84,7 +84,7 @@ def pmc_traffic(kernel_substr="k_accumulate", exclude="heavy", timeout_s=150):
         try:
             env = dict(os.environ, TMPDIR="/tmp")
             cmd = [exe, "--pmc", ctr, "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-host-path", "--no-pmc"]
+                   "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-host-path", "--no-pmc"] + list(extra_args)
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             if r.returncode != 0 or not dbs:
@@ -193,6 +193,8 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
     ap.add_argument("--no-configs", action="store_true", help="skip the `configs` block (the other BASELINE.json configs)")
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1: print the launch command and exit")
+    ap.add_argument("--only-configs", default="", help="comma-separated names of legosnark_amd.benchcfg configs: run only those (the PMC child "
+                                                       "passes behind a config's counter traffic use this) and print their lines")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -202,11 +204,26 @@ def main():
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         raise SystemExit("WORLD_SIZE (%s) != --gpus (%d): this run would not measure what it was asked to" % (os.environ.get("WORLD_SIZE", "unset"), args.gpus))
 
+    if args.only_configs:
+        import numpy as np
+        import torch
+        import legosnark_amd as lsa
+        from legosnark_amd import benchcfg
+        lsa.init(0)
+        torch.cuda.set_device(0)
+        print(json.dumps({"configs": benchcfg.measure(lsa, torch, np, torch.device("cuda", 0), log2n=args.log2n, d=20, log2pairs=12, reps=3,
+                                                      only=set(args.only_configs.split(",")))}), flush=True)
+        return
+
     # roofline.traffic: two short profiled child runs of this script, before this process
     # initialises the GPU (or even imports torch)
     traffic = None
+    pairing_traffic = None
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_pmc and not args.total_log2n and args.log2n == 20 and not being_profiled():
         traffic = pmc_traffic()
+        if not args.no_configs:
+            # the same two counter passes for the dominant kernel of BASELINE configs[4] (2^12 fresh pairs: k_miller_fused)
+            pairing_traffic = pmc_traffic(kernel_substr="k_miller_fused", exclude="\x00", extra_args=("--only-configs", "pairing"))
 
     import numpy as np
     import torch
@@ -477,6 +494,16 @@ def main():
     if rank == 0:
         acc_ms = stages["accumulate"]
         fmuls_per_pair = fm_per_pair
+        if traffic:
+            # the counter sample must be the launches this line is about: the same kernel at the same size (its
+            # duration under the serialising PMC passes within 15 % of the live HIP-event figure) -- else null
+            us = traffic["kernel_us_under_pmc"]
+            traffic["kernel_us_live"] = acc_ms * 1e3
+            if acc_ms <= 0 or any(abs(u - acc_ms * 1e3) > 0.15 * acc_ms * 1e3 for u in us):
+                traffic["rejected"] = "kernel duration under PMC differs from the live figure by more than 15 %: not the same launches"
+            else:
+                traffic["ratio_to_algorithmic_bytes"] = {"corrected": traffic["bytes_per_launch"] / (n_local * ALG_BYTES_PER_PAIR),
+                                                         "raw": traffic["raw_bytes_per_launch"] / (n_local * ALG_BYTES_PER_PAIR)}
         achieved = n_local * ALG_BYTES_PER_PAIR / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         gf = n_local * fmuls_per_pair / (acc_ms * 1e-3) / 1e9 if acc_ms > 0 else 0.0
         if strong:
@@ -502,7 +529,7 @@ def main():
             "result_checked_by_identity": checked,
             "roofline": {"kernel": "k_accumulate<CurveG1>", "bound": "hbm", "limited_by": "integer VALU (see valu)", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic["bytes_per_launch"] if traffic else None, "traffic_detail": traffic,
+                         "traffic": traffic["bytes_per_launch"] if traffic and "rejected" not in traffic else None, "traffic_detail": traffic,
                          "algorithmic_bytes_per_launch": n_local * ALG_BYTES_PER_PAIR,
                          "kernel_ms": acc_ms, "calls_averaged": stages["calls"],
                          "valu": {"achieved_Gfmul_s": gf, "peak_Gfmul_s": FMUL_PEAK_G, "frac": gf / FMUL_PEAK_G,
@@ -524,6 +551,11 @@ def main():
             from legosnark_amd import benchcfg
             out["configs"] = benchcfg.measure(lsa, torch, np, dev, log2n=20, d=20, log2pairs=12, reps=5,
                                               only={"g2_msm", "cppoly", "pairing", "cphad_verify"})
+            for c in out["configs"]:
+                if c["config"].startswith("pairing product") and "error" not in c:
+                    # 192 B in per pair; 384 B out per workgroup of five pairs (the partial products the tree continues from)
+                    c["traffic"] = pairing_traffic["bytes_per_launch"] if pairing_traffic else None
+                    c["traffic_detail"] = pairing_traffic
             if any("error" in c for c in out["configs"]):
                 raise SystemExit("bench.py: a config's result check failed: %s" % [c for c in out["configs"] if "error" in c])
         if not args.no_configs and world == 1 and not strong and args.log2n == 20 and not being_profiled():

@@ -16,6 +16,8 @@
 #include <thread>
 #include <vector>
 
+#include <sys/random.h>
+
 #include "capi_internal.h"
 #include "tower.h"
 
@@ -30,6 +32,66 @@ void set_error(const char *fmt, ...) {
 }
 
 State g;
+
+// ---- keyed content fingerprints (the CRS cache and the G2 line-table cache): see hash_words below
+namespace {
+constexpr size_t NH_KEY_WORDS = 4096;           // 32 KiB: longer messages are hashed block by block
+struct NhKey {
+    uint64_t k[NH_KEY_WORDS + 8];
+    NhKey() {
+        size_t got = 0;
+        while (got < sizeof k) {
+            const ssize_t r = getrandom((char *)k + got, sizeof k - got, 0);
+            if (r <= 0) break;
+            got += (size_t)r;
+        }
+        if (got < sizeof k) {                   // no CSPRNG (never seen on Linux >= 3.17): time- and address-seeded xorshift
+            uint64_t x = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ (uint64_t)(uintptr_t)this;
+            for (size_t i = got / 8; i < sizeof k / 8; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; k[i] = x * 0x9E3779B97F4A7C15ull; }
+        }
+        for (size_t i = NH_KEY_WORDS; i < NH_KEY_WORDS + 8; i++) k[i] |= 1;     // multipliers of the block chain / the fold: odd
+    }
+};
+const NhKey &nh_key() { static const NhKey key; return key; }
+}  // namespace
+void keyed_hash128(const void *bytes, size_t nbytes, uint64_t tweak, uint64_t out[2]) {
+    typedef unsigned __int128 u128;
+    const NhKey &K = nh_key();
+    const uint64_t *w = (const uint64_t *)bytes;
+    const size_t nw = nbytes / 8;
+    // the length and the tweak enter as a message pair of their own, so lengths and kinds never collide by construction
+    u128 acc = (u128)(K.k[NH_KEY_WORDS + 1] + (uint64_t)nbytes) * (K.k[NH_KEY_WORDS + 2] + tweak);
+    const u128 chain = ((u128)K.k[NH_KEY_WORDS + 3] << 64) | K.k[NH_KEY_WORDS];
+    for (size_t base = 0; base < nw; base += NH_KEY_WORDS) {
+        const size_t m = nw - base < NH_KEY_WORDS ? nw - base : NH_KEY_WORDS;
+        const uint64_t *p = w + base;
+        u128 a0 = 0, a1 = 0;                    // two independent sums: the multiplier pipe stays full
+        size_t i = 0;
+        for (; i + 4 <= m; i += 4) {
+            a0 += (u128)(p[i] + K.k[i]) * (p[i + 1] + K.k[i + 1]);
+            a1 += (u128)(p[i + 2] + K.k[i + 2]) * (p[i + 3] + K.k[i + 3]);
+        }
+        for (; i + 2 <= m; i += 2) a0 += (u128)(p[i] + K.k[i]) * (p[i + 1] + K.k[i + 1]);
+        if (i < m) a0 += (u128)(p[i] + K.k[i]) * K.k[i + 1];                    // odd tail: the missing word is zero
+        acc = acc * chain + a0 + a1;
+    }
+    if (nbytes & 7) {                            // trailing bytes (never the case for the callers here)
+        uint64_t t = 0;
+        memcpy(&t, (const char *)bytes + nw * 8, nbytes & 7);
+        acc += (u128)(t + K.k[NH_KEY_WORDS + 4]) * K.k[NH_KEY_WORDS + 5];
+    }
+    out[0] = (uint64_t)acc;
+    out[1] = (uint64_t)(acc >> 64);
+}
+uint64_t keyed_hash64(const void *bytes, size_t nbytes, uint64_t tweak) {
+    uint64_t h[2];
+    keyed_hash128(bytes, nbytes, tweak, h);
+    // 128 -> 64 bits by a keyed multilinear map (high half of lo * a + hi * b)
+    const NhKey &K = nh_key();
+    typedef unsigned __int128 u128;
+    const u128 t = (u128)h[0] * K.k[NH_KEY_WORDS + 6] + (u128)h[1] * K.k[NH_KEY_WORDS + 7];
+    return (uint64_t)(t >> 64);
+}
 
 int require_ready() {
     if (!g.ready) {
@@ -502,21 +564,13 @@ constexpr size_t CRS_TASK_UNITS = 64;           // units per hashing task (4096 
 constexpr unsigned CRS_TABLE_AFTER_DEFAULT = 23;
 constexpr size_t CRS_MIN_POINTS = 1024;         // smaller vectors are cheaper to re-upload than to look up
 
-inline uint64_t hash_words(const uint64_t *w, size_t nwords) {
-    // four independent multiply-xor lanes ((h ^ w) * K is a bijection in w and in h: one changed
-    // word always changes its lane), folded at the end
-    uint64_t h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull, h2 = 0xA4093822299F31D0ull, h3 = 0x082EFA98EC4E6C89ull;
-    const uint64_t K = 0x9E3779B97F4A7C15ull;
-    size_t i = 0;
-    for (; i + 4 <= nwords; i += 4) {
-        h0 = (h0 ^ w[i]) * K; h1 = (h1 ^ w[i + 1]) * K; h2 = (h2 ^ w[i + 2]) * K; h3 = (h3 ^ w[i + 3]) * K;
-    }
-    for (; i < nwords; i++) h0 = (h0 ^ w[i]) * K;
-    auto rotl = [](uint64_t x, int k) { return (x << k) | (x >> (64 - k)); };
-    uint64_t h = h0 ^ rotl(h1, 17) ^ rotl(h2, 31) ^ rotl(h3, 47);
-    h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
-    return h;
-}
+// Content fingerprints are KEYED: NH (the inner hash of UMAC, here on 64-bit words with 128-bit sums:
+//   sum_i ((m_2i + k_2i) mod 2^64) * ((m_2i+1 + k_2i+1) mod 2^64) mod 2^128)
+// under a per-process key drawn from the kernel's CSPRNG at first use.  For two distinct messages of the same length the
+// collision probability over the key is <= 2^-64 whatever the messages are, so a caller who can choose the bytes of a
+// vector (or of a G2 point handed to a verifier) but cannot read this process's memory cannot aim at the resident
+// entry of another vector.  One multiplication per 16 bytes: faster than the unkeyed multiply-xor lanes it replaces.
+inline uint64_t hash_words(const uint64_t *w, size_t nwords) { return lsa::keyed_hash64(w, nwords * 8, 0); }
 
 // persistent workers hashing the chunks of one vector; the caller thread joins in at finish()
 class HashPool {

@@ -27,6 +27,11 @@ extern State g;
 
 int require_ready();
 
+// Keyed content fingerprints (NH under a per-process random key, capi.hip): for two distinct inputs of the same
+// length the collision probability over the key is <= 2^-64 (128-bit form), whatever the inputs are.
+void keyed_hash128(const void *bytes, size_t nbytes, uint64_t tweak, uint64_t out[2]);
+uint64_t keyed_hash64(const void *bytes, size_t nbytes, uint64_t tweak);
+
 // LSA_TRACE=1: one line on stderr per host-facing call -- name, size, wall time (what a caller's profile of the
 // library looks like from outside; off: one predictable branch).
 bool trace_on();

@@ -79,33 +79,20 @@ struct Key128 {
 };
 struct Key128Hash { size_t operator()(const Key128 &k) const { return (size_t)(k.a ^ (k.b * 0x9E3779B97F4A7C15ull)); } };
 
-// 128-bit fingerprint: two sets of four multiply-xor lanes with different multipliers and seeds ((h ^ w) * K is
-// a bijection in w: one changed word always changes both halves).  NOT cryptographic: it guards against stale
-// or coinciding inputs of an honest caller, not against chosen collisions.
+// 128-bit KEYED fingerprint (capi.hip: NH under a per-process random key): a verifier's results depend on which
+// table a point resolves to, so the key of a table must not be something a prover can aim at -- for two distinct
+// points (or blobs) the collision probability over the key is <= 2^-64 whatever their bytes are.
 Key128 fingerprint(const void *bytes, size_t nbytes, uint64_t kind) {
-    const uint64_t *w = (const uint64_t *)bytes;
-    const size_t nw = nbytes / 8;
-    const uint64_t K1 = 0x9E3779B97F4A7C15ull, K2 = 0xC2B2AE3D27D4EB4Full;
-    uint64_t h[4] = {0x243F6A8885A308D3ull ^ kind, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull};
-    uint64_t q[4] = {0x452821E638D01377ull, 0xBE5466CF34E90C6Cull ^ kind, 0xC0AC29B7C97C50DDull, 0x3F84D5B5B5470917ull};
-    size_t i = 0;
-    for (; i + 4 <= nw; i += 4)
-        for (int l = 0; l < 4; l++) { h[l] = (h[l] ^ w[i + l]) * K1; q[l] = (q[l] ^ w[i + (l + 1) % 4]) * K2; q[l] ^= q[l] >> 29; }
-    for (; i < nw; i++) { h[0] = (h[0] ^ w[i]) * K1; q[0] = (q[0] ^ w[i]) * K2; q[0] ^= q[0] >> 29; }
-    auto rotl = [](uint64_t x, int k) { return (x << k) | (x >> (64 - k)); };
-    Key128 r;
-    r.a = h[0] ^ rotl(h[1], 17) ^ rotl(h[2], 31) ^ rotl(h[3], 47);
-    r.b = q[0] ^ rotl(q[1], 13) ^ rotl(q[2], 29) ^ rotl(q[3], 43);
-    r.a ^= r.a >> 32; r.a *= 0xD6E8FEB86659FD93ull; r.a ^= r.a >> 32;
-    r.b ^= r.b >> 31; r.b *= 0xFF51AFD7ED558CCDull; r.b ^= r.b >> 33;
-    return r;
+    uint64_t h[2];
+    keyed_hash128(bytes, nbytes, kind, h);
+    return Key128{h[0], h[1]};
 }
 
 struct TableCache {
     static constexpr size_t BLOCK = 128;                  // tables per device allocation
     size_t max_tables = 4096;                             // 90 MB; LSA_G2_TABLES / lsa_g2_table_cache
     std::vector<void *> blocks;
-    struct Slot { Key128 key; uint64_t tick; bool used; };
+    struct Slot { Key128 key; uint64_t tick; bool used; bool pending; };      // pending: promised by a prefetch, not built yet
     std::vector<Slot> slots;
     std::unordered_map<Key128, uint32_t, Key128Hash> map;
     uint64_t tick = 0, hits = 0, misses = 0, evictions = 0;
@@ -131,32 +118,51 @@ struct TableCache {
         slots[it->second].tick = tick;
         return (long)it->second;
     }
-    // a free slot for `key` (the least recently used one that no term of the current call refers to), -1 if none
-    long insert(const Key128 &key) {
+    // a free slot for `key` (a released one, a new one, or the least recently used one that neither a term of the
+    // current call nor an unbuilt promise of an earlier prefetch refers to), -1 if none
+    long insert(const Key128 &key, bool pending = false) {
         long s = -1;
-        if (slots.size() < max_tables) {
+        if (!free_slots.empty()) {
+            s = (long)free_slots.back();
+            free_slots.pop_back();
+            slots[(size_t)s] = Slot{key, tick, true, pending};
+        } else if (slots.size() < max_tables) {
             if (slots.size() == blocks.size() * BLOCK) {
                 void *b = nullptr;
                 if (hipMalloc(&b, BLOCK * g2_table_words() * 4) != hipSuccess) { (void)hipGetLastError(); return -1; }
                 blocks.push_back(b);
             }
-            slots.push_back(Slot{key, tick, true});
+            slots.push_back(Slot{key, tick, true, pending});
             s = (long)slots.size() - 1;
         } else {
             uint64_t best = tick;
             for (size_t i = 0; i < slots.size(); i++)
-                if (slots[i].tick < best) { best = slots[i].tick; s = (long)i; }
+                if (slots[i].used && !slots[i].pending && slots[i].tick < best) { best = slots[i].tick; s = (long)i; }
             if (s < 0) return -1;
             map.erase(slots[(size_t)s].key);
             evictions++;
-            slots[(size_t)s] = Slot{key, tick, true};
+            slots[(size_t)s] = Slot{key, tick, true, pending};
         }
         map[key] = (uint32_t)s;
         return s;
     }
+    // forgets `key` (a table that was promised or begun and never finished: a later lookup must miss, not read it)
+    void erase(const Key128 &key) {
+        auto it = map.find(key);
+        if (it == map.end()) return;
+        const uint32_t s = it->second;
+        map.erase(it);
+        slots[s].used = false; slots[s].pending = false; slots[s].tick = 0;
+        free_slots.push_back(s);
+    }
+    void built(const Key128 &key) {
+        auto it = map.find(key);
+        if (it != map.end()) slots[it->second].pending = false;
+    }
+    std::vector<uint32_t> free_slots;
     void clear() {
         for (void *b : blocks) (void)hipFree(b);
-        blocks.clear(); slots.clear(); map.clear();
+        blocks.clear(); slots.clear(); map.clear(); free_slots.clear();
         if (ident) (void)hipFree(ident);
         ident = nullptr;
     }
@@ -170,20 +176,30 @@ struct TableCache {
 struct PendingTables {
     std::vector<Jac<Fq2>> pts;
     std::vector<uint64_t> dst;
+    std::vector<Key128> keys;
     StageBuf dev;
     static constexpr size_t BATCH = 5;
+    int build(const std::vector<char> &h, size_t m) {
+        if (dev.ensure(h.size())) { set_error("g2_tables_prefetch: staging allocation failed"); return LSA_ERR_NOMEM; }
+        LSA_UPLOAD(dev.p, h.data(), h.size());
+        return g2_precomp_device(dev.p, m, (uint32_t *const *)((const char *)dev.p + m * sizeof(Jac<Fq2>)), g.stream);
+    }
     int flush() {
         const size_t m = pts.size();
         if (m == 0) return LSA_OK;
         std::vector<char> h(m * (sizeof(Jac<Fq2>) + 8));
         memcpy(h.data(), pts.data(), m * sizeof(Jac<Fq2>));
         memcpy(h.data() + m * sizeof(Jac<Fq2>), dst.data(), m * 8);
+        const std::vector<Key128> ks = keys;
         pts.clear();
         dst.clear();
-        if (dev.ensure(h.size())) { set_error("g2_tables_prefetch: staging allocation failed"); return LSA_ERR_NOMEM; }
-        LSA_UPLOAD(dev.p, h.data(), h.size());
-        return g2_precomp_device(dev.p, m, (uint32_t *const *)((const char *)dev.p + m * sizeof(Jac<Fq2>)), g.stream);
+        keys.clear();
+        const int rc = build(h, m);
+        // a promise that could not be kept is withdrawn: its key must miss from now on, not resolve to an unwritten table
+        for (const Key128 &k : ks) { if (rc) g_tabs.erase(k); else g_tabs.built(k); }
+        return rc;
     }
+    void drop() { pts.clear(); dst.clear(); keys.clear(); }
 } g_pending;
 
 // ---------------------------------------------------------------- one job description
@@ -332,15 +348,33 @@ int run_miller(const Terms &t, void **d_res) {
     std::vector<uint32_t> need_imp;        // terms whose table has to be imported from a precomp blob
     size_t scratch_used = 0;
     std::unordered_map<Key128, uint64_t, Key128Hash> seen;   // within this call
+    std::unordered_map<const void *, uint64_t> seen_blob;   // cache bypassed: equal blob POINTERS still share one table
     auto scratch_slot = [&](size_t k) { return (uint64_t)(uintptr_t)((uint32_t *)g_pair_scratch_tabs.p + k * TW); };
-    // uncached terms take scratch tables: count them first (the scratch buffer must not move afterwards)
-    size_t scratch_need = 0;
-    if (!use_cache) scratch_need = n;
-    else scratch_need = n;                 // worst case: the cache is full of this call's own tables
+    // every term is validated BEFORE the cache is touched: a call that fails half-way must not leave keys behind
+    for (size_t i = 0; i < n; i++)
+        if (!(t.qpre && t.qpre[i]) && !t.g2) { set_error("pairing: term %zu has neither a point nor a precomputed table", i); return LSA_ERR_INVALID; }
+    // uncached terms take scratch tables: count them first (the scratch buffer must not move afterwards).  With the
+    // cache: at worst all n (the cache full of this call's own tables, n <= 1024); without: one per point term and one
+    // per DISTINCT blob (verifyLin3or4 scaled up: 2^16 terms over a handful of key blobs are a handful of tables)
+    size_t scratch_need = n;
+    if (!use_cache && t.qpre) {
+        std::unordered_map<const void *, uint64_t> distinct;
+        scratch_need = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (!t.qpre[i]) scratch_need++;
+            else if (distinct.emplace(t.qpre[i], 0).second) scratch_need++;
+        }
+    }
     if (g_pair_scratch_tabs.ensure(std::max<size_t>(scratch_need, 1) * TW * 4)) { set_error("pairing: table scratch allocation failed"); return LSA_ERR_NOMEM; }
+    // keys this call inserts: withdrawn again on ANY error return below (their tables would be unwritten or partial, and
+    // the next call with the same Q would run its Miller loop over them)
+    struct InsertGuard {
+        std::vector<Key128> keys;
+        bool ok = false;
+        ~InsertGuard() { if (!ok) for (const Key128 &k : keys) g_tabs.erase(k); }
+    } guard;
     for (size_t i = 0; i < n; i++) {
         const void *blob = t.qpre ? t.qpre[i] : nullptr;
-        if (!blob && !t.g2) { set_error("pairing: term %zu has neither a point nor a precomputed table", i); return LSA_ERR_INVALID; }
         uint64_t dev = 0;
         if (use_cache) {
             const Key128 key = blob ? fingerprint(blob, PUB, 2) : fingerprint((const char *)t.g2 + i * sizeof(Jac<Fq2>), sizeof(Jac<Fq2>), 1);
@@ -351,14 +385,23 @@ int run_miller(const Terms &t, void **d_res) {
                 if (s >= 0) dev = (uint64_t)(uintptr_t)g_tabs.ptr((uint32_t)s);
                 else {
                     s = g_tabs.insert(key);
+                    if (s >= 0) guard.keys.push_back(key);
                     dev = s >= 0 ? (uint64_t)(uintptr_t)g_tabs.ptr((uint32_t)s) : scratch_slot(scratch_used++);
                     (blob ? need_imp : need_pre).push_back((uint32_t)i);
                 }
                 seen.emplace(key, dev);
             }
+        } else if (blob) {
+            auto it = seen_blob.find(blob);
+            if (it != seen_blob.end()) dev = it->second;
+            else {
+                dev = scratch_slot(scratch_used++);
+                seen_blob.emplace(blob, dev);
+                need_imp.push_back((uint32_t)i);
+            }
         } else {
             dev = scratch_slot(scratch_used++);
-            (blob ? need_imp : need_pre).push_back((uint32_t)i);
+            need_pre.push_back((uint32_t)i);
         }
         h_tab[i] = dev;
     }
@@ -369,7 +412,9 @@ int run_miller(const Terms &t, void **d_res) {
     if (use_cache && !t.qpre && !need_pre.empty() && g_force_m == 0 && force_kernel() != 5) {
         std::vector<uint64_t> emit(n, 0);
         for (uint32_t i : need_pre) emit[i] = h_tab[i];
-        return run_fused(t, emit, d_res);
+        const int rcf = run_fused(t, emit, d_res);
+        guard.ok = rcf == LSA_OK;
+        return rcf;
     }
 
     // ---- uploads
@@ -427,6 +472,7 @@ int run_miller(const Terms &t, void **d_res) {
     int rc = miller_tab_device(d_g1, (const uint32_t *const *)(dm + off_tab), (const uint8_t *)(dm + off_flag), (const uint32_t *)(dm + off_acc), nacc, M,
                                g_tabs.ident, g_pair_f.p, g.stream);
     if (rc) return rc;
+    guard.ok = true;           // every new table is on the stream, ahead of anything that reads it
     // ---- products over the accumulators of each product
     if (nacc == nprod) { *d_res = g_pair_f.p; return LSA_OK; }
     if (nprod == 1) {
@@ -478,7 +524,7 @@ void pairing_release() {
     g_pin_meta.release(); g_pin_q.release();
     if (g_uploaded) { (void)hipEventDestroy(g_uploaded); g_uploaded = nullptr; }
     g_upload_pending = false;
-    g_pending.pts.clear(); g_pending.dst.clear(); g_pending.dev.release();
+    g_pending.drop(); g_pending.dev.release();
     g_tabs.clear();
 }
 }  // namespace lsa
@@ -530,12 +576,13 @@ int lsa_g2_tables_prefetch(const void *g2_jac, size_t n) {
         const char *q = (const char *)g2_jac + i * sizeof(Jac<Fq2>);
         const Key128 key = fingerprint(q, sizeof(Jac<Fq2>), 1);
         if (g_tabs.lookup(key) >= 0) continue;
-        const long s = g_tabs.insert(key);
+        const long s = g_tabs.insert(key, true);                    // pending: no later insert may evict it before it is built
         if (s < 0) continue;                                        // full of tables of this very call: leave it to the Miller call
         Jac<Fq2> pt;
         memcpy(&pt, q, sizeof pt);
         g_pending.pts.push_back(pt);
         g_pending.dst.push_back((uint64_t)(uintptr_t)g_tabs.ptr((uint32_t)s));
+        g_pending.keys.push_back(key);
     }
     // (a cache smaller than a batch could hand a promised slot to somebody else before it is built)
     if (g_pending.pts.size() >= PendingTables::BATCH || g_tabs.max_tables < 4 * PendingTables::BATCH) return g_pending.flush();
@@ -550,8 +597,7 @@ int lsa_pairing_set_chunk(unsigned pairs_per_accumulator) {
 int lsa_g2_table_cache(size_t max_tables) {
     int rc = require_ready();
     if (rc) return rc;
-    g_pending.pts.clear();                                      // their slots go with the cache
-    g_pending.dst.clear();
+    g_pending.drop();                                           // their slots go with the cache
     HIPCHK(hipStreamSynchronize(g.stream));
     g_tabs.env_read = true;
     g_tabs.clear();
