@@ -417,6 +417,12 @@ static int bases_create(const void *bases_jac, size_t n, int src_on_device, int 
         // table that does not fit falls back to the plain layout.
         const char *pe = getenv("LSA_PRECOMPUTE");
         bool table = allow_table && n >= msm_merge_min() && !(pe && pe[0] == '0');
+        // G1 handles of up to 2^16 points: all copies in ONE kernel (msm_compact.hip: one inversion per point instead
+        // of 25, ~1.2 ms whatever n) -- cheap enough that every such handle carries them unless a threshold was set
+        // explicitly, and their MSMs of up to msm_compact_max() pairs take the four-launch pipeline
+        const bool fast_build = group == 1 && n <= ((size_t)1 << 16) && allow_table && !(pe && pe[0] == '0') &&
+                                (table || !msm_merge_min_is_explicit());
+        if (fast_build) table = true;
         const size_t tw = msm_table_windows(group, n);
         if (table && (uint64_t)n * tw >= (1u << 30)) table = false;
         if (table && hipMalloc(&b->d_aff, tw * n * msm_base_bytes(group)) != hipSuccess) { (void)hipGetLastError(); b->d_aff = nullptr; table = false; }
@@ -438,12 +444,18 @@ static int bases_create(const void *bases_jac, size_t n, int src_on_device, int 
             d_in = (const Jac<F> *)tmp;
         }
         rc = prepare_bases<F>(d_in, b->d_aff, n, g.stream);
-        if (!rc && table) {
+        void *scratch = nullptr;
+        if (!rc && table && fast_build) {
+            if (hipMalloc(&scratch, table_build_scratch_bytes(n)) != hipSuccess) { (void)hipGetLastError(); scratch = nullptr; set_error("bases_create: scratch allocation failed"); rc = LSA_ERR_NOMEM; }
+            if (!rc) rc = table_build_g1_device(b->d_aff, n, n, scratch, g.stream);
+            if (!rc) b->table_stride = n;
+        } else if (!rc && table) {
             rc = precompute_windows<F>(b->d_aff, n, g.stream);
             if (!rc) b->table_stride = n;
         }
         hipError_t e = hipStreamSynchronize(g.stream);
         if (tmp) (void)hipFree(tmp);
+        if (scratch) (void)hipFree(scratch);
         if (rc || e != hipSuccess) {
             if (!rc) { set_error("bases_create: kernel failed: %s", hipGetErrorString(e)); rc = LSA_ERR_HIP; }
             (void)hipFree(b->d_aff); delete b;
@@ -532,11 +544,11 @@ int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars, siz
 }  // extern "C"
 // grow-only device staging buffers of the host-buffer entry points (StageBuf, capi_internal.h)
 namespace {
-StageBuf g_stage_jac, g_stage_bases, g_stage_scalars;
+StageBuf g_stage_jac, g_stage_bases, g_stage_scalars, g_stage_prefix_scratch;
 }  // namespace
 namespace lsa { StageBuf g_stage_gather; }
 static void release_stage_buffers() {
-    g_stage_jac.release(); g_stage_bases.release(); g_stage_scalars.release(); g_stage_gather.release();
+    g_stage_jac.release(); g_stage_bases.release(); g_stage_scalars.release(); g_stage_gather.release(); g_stage_prefix_scratch.release();
     pairing_release();
 }
 
@@ -768,6 +780,10 @@ struct CrsEntry {
     // plain layout until the build has finished, then switches; nobody ever waits for the 26 copies
     std::shared_ptr<TableBuild> build;
     void *small = nullptr;                          // the plain bases after the switch (an MSM queued earlier may still read them)
+    // G1: pre-shifted copies of the entry's first prefix_n points only, built in one kernel on lsa_stream() when the first
+    // request that fits arrives (crs_prefix_table): the tails of the reference's prefix ladders run over them
+    void *prefix = nullptr;
+    size_t prefix_n = 0;
     bool building() const { return build && build->state.load() == 0; }
 };
 
@@ -824,6 +840,8 @@ void crs_release_entry(CrsEntry &e) {
     }
     if (e.small) (void)hipFree(e.small);
     e.small = nullptr;
+    if (e.prefix) (void)hipFree(e.prefix);
+    e.prefix = nullptr; e.prefix_n = 0;
 }
 bool crs_entry_building(const lsa_bases *b) {
     for (auto &x : g_crs.entries) if (x.b == b) return x.building();
@@ -1049,6 +1067,45 @@ static lsa_bases *crs_lookup_small(const void *bases_jac, size_t n, int group) {
     return nullptr;
 }
 
+// The copies of the first points of a G1 entry that has no full table (yet): CPPoly::prove asks for MSMs over prefixes
+// 2^(d-1) .. 1 of its key vector (src/gadgets/poly.h:76-88) and most of those calls are small.  On the plain layout
+// such an MSM is 0.9 ms (a fold over 127 dependent doublings, ~25 launches); over copies of the prefix it takes the
+// four-launch pipeline of msm_compact.hip.  One kernel, ~1.2 ms, on lsa_stream() ahead of the MSM that asked for it;
+// paid back by the second small call.  LSA_CRS_PREFIX_TABLE=0 turns it off.
+static size_t crs_prefix_max() {
+    static const size_t v = [] {
+        const char *e = getenv("LSA_CRS_PREFIX_TABLE");
+        const size_t want = e ? (size_t)atoll(e) : (size_t)1 << 14;
+        return want > ((size_t)1 << 16) ? (size_t)1 << 16 : want;
+    }();
+    return v;
+}
+static int crs_prefix_table(lsa_bases *b, size_t n_req, const void **d_bases, size_t *stride) {
+    const char *pe = getenv("LSA_PRECOMPUTE");
+    if (b->group != 1 || b->table_stride || n_req == 0 || n_req > crs_prefix_max() || n_req > msm_compact_max() || (pe && pe[0] == '0') ||
+        msm_merge_min_is_explicit())
+        return LSA_OK;
+    CrsEntry *e = nullptr;
+    for (auto &x : g_crs.entries) if (x.b == b) e = &x;
+    if (!e) return LSA_OK;
+    if (!e->prefix) {
+        const size_t pn = std::min(e->n, crs_prefix_max());
+        const size_t bytes = (size_t)msm_table_windows(1, pn) * pn * msm_base_bytes(1);
+        void *t = nullptr;
+        if (hipMalloc(&t, bytes) != hipSuccess) { (void)hipGetLastError(); return LSA_OK; }          // no memory: the plain layout serves
+        if (g_stage_prefix_scratch.ensure(table_build_scratch_bytes(pn))) { (void)hipFree(t); return LSA_OK; }
+        HIPCHK(hipMemcpyAsync(t, b->d_aff, pn * msm_base_bytes(1), hipMemcpyDeviceToDevice, g.stream));
+        const int rc = table_build_g1_device(t, pn, pn, g_stage_prefix_scratch.p, g.stream);
+        if (rc) { (void)hipStreamSynchronize(g.stream); (void)hipFree(t); return rc; }
+        e->prefix = t;
+        e->prefix_n = pn;
+        e->bytes += bytes;
+        g_crs.bytes += bytes;
+    }
+    if (n_req <= e->prefix_n) { *d_bases = e->prefix; *stride = e->prefix_n; }
+    return LSA_OK;
+}
+
 static inline double ms_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
@@ -1087,6 +1144,9 @@ static int msm_host_local(const void *bases_jac, const void *scalars, size_t n, 
         st.table_building = crs_entry_building(b) ? 1 : 0;
         d_bases = b->d_aff;
         table_stride = b->table_stride;
+        rc = crs_prefix_table(b, n, &d_bases, &table_stride);
+        if (rc) return rc;
+        if (table_stride && !b->table_stride) st.table = 2;           // the entry's prefix table
     } else if (lsa_bases *pb = crs_lookup_small<F>(bases_jac, n, group)) {
         auto t0 = std::chrono::steady_clock::now();
         rc = upload_host(g_stage_scalars.p, scalars, n * sizeof(Fr));
@@ -1097,6 +1157,9 @@ static int msm_host_local(const void *bases_jac, const void *scalars, size_t n, 
         st.table_building = crs_entry_building(pb) ? 1 : 0;
         d_bases = pb->d_aff;
         table_stride = pb->table_stride;
+        rc = crs_prefix_table(pb, n, &d_bases, &table_stride);
+        if (rc) return rc;
+        if (table_stride && !pb->table_stride) st.table = 2;
     } else {
         if (g_stage_jac.ensure(n * sizeof(Jac<F>)) || g_stage_bases.ensure(n * msm_base_bytes(group))) {
             set_error("msm: staging allocation failed");

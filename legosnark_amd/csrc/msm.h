@@ -45,6 +45,7 @@ unsigned msm_field_mults_per_pair(size_t n, size_t table_n);
 size_t msm_merge_min();
 bool msm_uses_table(size_t n);    // an MSM of n pairs on a table-carrying handle takes the wide-window pipeline
 void msm_set_merge_min(size_t n);
+bool msm_merge_min_is_explicit();  // lsa_msm_set_table_threshold(n != 0) is in force
 // fills windows 1.. of a table whose window 0 holds the n prepared bases
 template <class F>
 int precompute_windows(void *d_table, size_t n, hipStream_t st);
@@ -84,6 +85,30 @@ int final_exp_device(const void *d_in_fq12, size_t n, void *d_out_fq12, hipStrea
 int fq12_product_device(void *d_buf, void *d_scratch, size_t n, void **result, hipStream_t st);
 int fq12_segment_products_device(const void *d_in, const uint64_t *d_off, size_t nseg, void *d_out, hipStream_t st);
 size_t fq12_bytes();
+
+// msm_compact.hip: a whole MSM of n <= msm_compact_max() pairs over a table-carrying handle in four launches (G1)
+template <class F>
+int msm_compact_device(const void *d_table, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride);
+size_t msm_compact_max();
+// all pre-shifted copies of n points in one kernel: d_table holds msm_table_windows() * stride packed points, copy 0
+// (points [0, n)) filled; d_scratch: table_build_scratch_bytes(n)
+int table_build_g1_device(void *d_table, size_t n, size_t stride, void *d_scratch, hipStream_t st);
+size_t table_build_scratch_bytes(size_t n);
+
+// The tail slots of the MSM pipelines (msm.hip): a call's front runs on the caller's stream, its tail on the slot's
+// internal stream with the slot's workspace; results are ordered again at msm_join().
+struct MsmSlot {
+    hipStream_t tail;     // the slot's stream (the caller's stream itself under LSA_NO_OVERLAP=1)
+    void *ws;             // >= the bytes asked for; owned by this call until its tail has run
+    void *aux;            // 4 KiB that only msm_compact_device uses: zero at creation, left zero by every call
+    int index;
+};
+// picks the next slot, grows its workspace, makes `st` wait for the slot's previous tail
+int msm_slot_begin(hipStream_t st, size_t ws_bytes, const void *d_out, MsmSlot *slot);
+// the front (on st) is issued: the slot's stream continues from here (and behind any earlier tail that writes d_out)
+int msm_slot_handover(MsmSlot *slot, hipStream_t st);
+// the tail is issued
+int msm_slot_end(MsmSlot *slot, hipStream_t st);
 
 // Orders the results of earlier msm_device calls (whose tails run on an internal stream) on `st`.
 int msm_join(hipStream_t st);

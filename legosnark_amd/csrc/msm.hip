@@ -44,6 +44,7 @@
 #include "fs29.h"
 #include "glv.h"
 #include "msm.h"
+#include "msm_plan.h"
 
 namespace lsa {
 
@@ -409,74 +410,11 @@ __global__ __launch_bounds__(1024) void k_tile_scan_rows(const uint16_t *__restr
 // ------------------------------------------------------------------------------------
 #define WIDE_FINE_BITS 7u
 #define MSM_MAX_SEGMENTS 64u
-struct WidePlan {
-    unsigned nwin;        // digits per scalar
-    unsigned c;           // widest window: 2^(c-1) buckets
-    unsigned copy_step;   // window k gathers from table copy k * copy_step
-    unsigned start[32];   // window k covers bits [start[k], start[k] + width[k])
-    unsigned width[32];
-};
 // scalar slices of a segmented call: segment j = scalars[off[j] .. off[j+1]) against bases[0 .. len_j)
 struct SegList {
     uint32_t nseg;
     uint32_t off[MSM_MAX_SEGMENTS + 1];
 };
-
-// Signed digits of one scalar, produced one window at a time (the carry chain is sequential) and
-// handed to `use(k, sd)` with sd = +-(segment * B + |digit|), 0 for a zero digit -- no digit
-// array: the ranking pass and the scatter pass both recompute them from the scalar (a Montgomery
-// reduction and a few shifts per scalar) instead of writing 4 B per digit to HBM and reading
-// them back twice.
-template <class Use>
-__device__ __forceinline__ void wide_digits(const Fr &scalar, const WidePlan &pl, uint32_t seg_base, Use use) {
-    uint32_t s[8];
-    scalar.to_canonical(s);
-    // balanced representative: s > (r-1)/2 is recoded as -(r - s), i.e. the digits of r - s with
-    // every sign flipped.  Same sum; "small negative" scalars (r - 1, r - 2, ...: ten of their
-    // thirteen digits would be the digits of r, the same ten buckets for every such scalar) become
-    // small digits, and the top window never exceeds a quarter of its range.
-    bool flip;
-    {
-        uint32_t t[8];
-        uint64_t br = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {                  // t = r - s
-            const uint64_t x = (uint64_t)LSA_R[i] - s[i] - br;
-            t[i] = (uint32_t)x;
-            br = (x >> 32) & 1;
-        }
-        br = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) br = (((uint64_t)t[i] - s[i] - br) >> 32) & 1;      // borrow out <=> t < s <=> 2 s > r
-        flip = br != 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) s[i] = flip ? t[i] : s[i];
-    }
-    // consume the limbs through a 64-bit bit buffer (static limb index: no register-array indexing)
-    uint64_t buf = 0;
-    unsigned have = 0, k = 0;
-    uint32_t carry = 0;
-#pragma unroll
-    for (int limb = 0; limb < 8; limb++) {
-        buf |= (uint64_t)s[limb] << have;
-        have += 32;
-        while (k < pl.nwin && (have >= pl.width[k] || limb == 7)) {
-            const unsigned width = pl.width[k];
-            uint32_t d = (uint32_t)buf & ((1u << width) - 1);
-            buf >>= width;
-            have = have >= width ? have - width : 0;
-            d += carry;
-            int32_t sd;
-            // the top window is never recoded: scalars are < 2^254 and the windows cover 255 bits, so
-            // its raw value is < 2^(width-1) and the carry keeps it <= 2^(width-1) <= B
-            if (k + 1 < pl.nwin && d >= (1u << (width - 1))) { sd = (int32_t)d - (int32_t)(1u << width); carry = 1; }
-            else { sd = (int32_t)d; carry = 0; }
-            if (sd != 0) { const int32_t m = (int32_t)seg_base + (sd < 0 ? -sd : sd); sd = (sd < 0) != flip ? -m : m; }
-            use(k, sd);
-            k++;
-        }
-    }
-}
 
 // Scalars per workgroup of the wide path's ranking / scatter passes: a tile's entries (nwin per
 // scalar) must fit the u16 counters even when every one of them lands in the same bin
@@ -1421,6 +1359,8 @@ struct TailBuf {
     hipStream_t stream = nullptr;
     bool pending = false;          // a tail has been issued on this slot
     bool unjoined = false;         // ... and the caller's stream has not waited for it yet
+    void *aux = nullptr;           // 4 KiB of msm_compact_device's (zero between calls)
+    const void *out = nullptr;     // where the slot's last tail writes its result
 };
 static TailBuf g_tail[NTAIL];
 static unsigned g_slot = 0;
@@ -1468,6 +1408,8 @@ void msm_release_workspace() {
     for (auto &t : g_tail) {
         if (t.stream) { (void)hipStreamSynchronize(t.stream); (void)hipStreamDestroy(t.stream); t.stream = nullptr; }
         t.ws.release();
+        if (t.aux) (void)hipFree(t.aux);
+        t.aux = nullptr; t.out = nullptr;
         if (t.done) (void)hipEventDestroy(t.done);
         if (t.front_done) (void)hipEventDestroy(t.front_done);
         t.done = nullptr; t.front_done = nullptr; t.pending = false; t.unjoined = false;
@@ -1496,6 +1438,58 @@ int msm_profile_last(float ms[LSA_MSM_STAGES]) {
 }
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int tail_slots_ready() {
+    if (g_overlap < 0) g_overlap = getenv("LSA_NO_OVERLAP") ? 0 : 1;
+    if (!g_tail[0].done) {
+        for (auto &t : g_tail) {
+            HIPCHK(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&t.front_done, hipEventDisableTiming));
+            if (g_overlap) HIPCHK(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
+            HIPCHK(hipMalloc(&t.aux, 4096));
+            HIPCHK(hipMemset(t.aux, 0, 4096));
+        }
+    }
+    return LSA_OK;
+}
+
+// ---- the slot interface other pipelines (msm_compact.hip) run their tails through
+int msm_slot_begin(hipStream_t st, size_t ws_bytes, const void *d_out, MsmSlot *slot) {
+    int rc = tail_slots_ready();
+    if (rc) return rc;
+    TailBuf &tb = g_tail[g_slot];
+    if (ws_bytes > tb.ws.cap) {
+        if (tb.pending) HIPCHK(hipEventSynchronize(tb.done));          // about to reallocate: the old tail must be finished
+        if (tb.ws.ensure(ws_bytes) != 0) { set_error("msm: tail workspace allocation of %zu bytes failed", ws_bytes); return LSA_ERR_NOMEM; }
+    }
+    if (tb.pending) HIPCHK(hipStreamWaitEvent(st, tb.done, 0));        // the front may not overwrite what the slot's last tail still reads
+    slot->tail = g_overlap ? tb.stream : st;
+    slot->ws = tb.ws.ptr;
+    slot->aux = tb.aux;
+    slot->index = (int)g_slot;
+    tb.out = d_out;
+    return LSA_OK;
+}
+int msm_slot_handover(MsmSlot *slot, hipStream_t st) {
+    TailBuf &tb = g_tail[slot->index];
+    if (slot->tail == st) return LSA_OK;
+    HIPCHK(hipEventRecord(tb.front_done, st));
+    HIPCHK(hipStreamWaitEvent(slot->tail, tb.front_done, 0));
+    // results appear in call order wherever two calls write the same place: behind every earlier tail with this destination
+    for (int i = 0; i < NTAIL; i++) {
+        TailBuf &o = g_tail[i];
+        if (i != slot->index && o.pending && o.out == tb.out) HIPCHK(hipStreamWaitEvent(slot->tail, o.done, 0));
+    }
+    return LSA_OK;
+}
+int msm_slot_end(MsmSlot *slot, hipStream_t st) {
+    TailBuf &tb = g_tail[slot->index];
+    HIPCHK(hipEventRecord(tb.done, slot->tail));
+    tb.pending = true;
+    tb.unjoined = slot->tail != st;
+    g_slot = (g_slot + 1) % NTAIL;
+    return LSA_OK;
+}
 
 size_t msm_base_bytes(int group) { return group == 1 ? sizeof(CurveG1::Base) : sizeof(CurveG2::Base); }
 
@@ -1564,48 +1558,13 @@ template int normalize_to_affine<Fq2>(const Jac<Fq2> *, Aff<Fq2> *, size_t, hipS
 // Price: 26 (24) x the base memory (G1 64 B, G2 128 B per point and copy) and one pass of 255
 // doublings + 25 batch normalisations per key.
 // ------------------------------------------------------------------------------------
-// Copy j of the table holds 2^(pos[j]) * P.  The positions are the starts of 13 (12 from 6*2^20
-// points on) wide windows that split the 255 scalar bits as evenly as possible (8 x 20 + 5 x 19
-// bits; 3 x 22 + 9 x 21) plus the midpoint of each: wide digits use every other copy, narrow
-// digits (10 or 9 bits; 11 or 10) all of them.  Even widths matter: a short window concentrates
-// its digits on few buckets, and the longest bucket list bounds the accumulate kernel.
-struct TableGrid {
-    unsigned ncopies;
-    unsigned pos[33];     // pos[ncopies] = 255
-};
-static TableGrid table_grid(size_t n_table) {
-    TableGrid t;
-    const unsigned nbig = n_table >= ((size_t)6 << 20) ? 12u : 13u;
-    const unsigned base = 255 / nbig, rem = 255 % nbig;
-    unsigned bit = 0;
-    for (unsigned k = 0; k < nbig; k++) {
-        const unsigned w = base + (k < rem ? 1u : 0u);
-        t.pos[2 * k] = bit;
-        t.pos[2 * k + 1] = bit + (w + 1) / 2;
-        bit += w;
-    }
-    t.ncopies = 2 * nbig;
-    t.pos[t.ncopies] = 255;
-    return t;
-}
 static unsigned table_copies(size_t n_table) { return table_grid(n_table).ncopies; }
 static size_t wide_big_min() {
     static const size_t v = getenv("LSA_WIDE_BIG_MIN") ? (size_t)atoll(getenv("LSA_WIDE_BIG_MIN")) : (size_t)1 << 16;
     return v;
 }
 static WidePlan wide_plan(size_t n_table, size_t n_call, unsigned nseg) {
-    const TableGrid t = table_grid(n_table);
-    WidePlan pl = {};
-    const bool big = nseg == 1 && n_call >= wide_big_min();
-    pl.copy_step = big ? 2 : 1;
-    pl.nwin = t.ncopies / pl.copy_step;
-    pl.c = 0;
-    for (unsigned k = 0; k < pl.nwin; k++) {
-        pl.start[k] = t.pos[k * pl.copy_step];
-        pl.width[k] = t.pos[(k + 1) * pl.copy_step] - pl.start[k];
-        if (pl.width[k] > pl.c) pl.c = pl.width[k];
-    }
-    return pl;
+    return wide_plan_for(n_table, nseg == 1 && n_call >= wide_big_min());
 }
 unsigned msm_table_windows(int /*group*/, size_t n) { return table_copies(n); }
 
@@ -1621,6 +1580,7 @@ size_t msm_merge_min() {
     }
     return g_merge_min;
 }
+bool msm_merge_min_is_explicit() { return g_merge_min_explicit; }
 static size_t table_use_min() { return g_merge_min_explicit ? msm_merge_min() : 1; }
 // whether an MSM of n pairs on a handle that carries the copies runs over them (the wide-window pipeline)
 bool msm_uses_table(size_t n) { return n >= table_use_min(); }
@@ -1785,14 +1745,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     size_t o_coffs = carve(fine ? (size_t)Bc * 4 : 0);
     if (g_ws.ensure(off) != 0) { set_error("msm: workspace allocation of %zu bytes failed", off); return LSA_ERR_NOMEM; }
     // tail buffers of this call parity
-    if (g_overlap < 0) g_overlap = getenv("LSA_NO_OVERLAP") ? 0 : 1;
-    if (!g_tail[0].done) {
-        for (auto &t : g_tail) {
-            HIPCHK(hipEventCreateWithFlags(&t.done, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&t.front_done, hipEventDisableTiming));
-            if (g_overlap) HIPCHK(hipStreamCreateWithFlags(&t.stream, hipStreamNonBlocking));
-        }
-    }
+    { int rcs = tail_slots_ready(); if (rcs) return rcs; }
     // (Running the sort of call i+1 beside the accumulate of call i on a third stream was measured
     // and rejected: with enough hardware queues for real concurrency both kernels slow each other
     // down by more than the overlap gains -- 1.87 ms per step against 1.70 -- because the
@@ -1814,6 +1767,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
         if (t.ws.ensure(toff) != 0) { set_error("msm: tail workspace allocation of %zu bytes failed", toff); return LSA_ERR_NOMEM; }
     }
     if (tb.pending) HIPCHK(hipStreamWaitEvent(st, tb.done, 0));        // the front may not overwrite buckets a tail still reads
+    tb.out = d_out;
     char *tws = (char *)tb.ws.ptr;
     char *ws = (char *)g_ws.ptr;
     uint32_t *hist = (uint32_t *)(ws + o_hist);
@@ -1993,6 +1947,12 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         HIPCHK(hipMemcpyAsync(d_out, &inf, sizeof inf, hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
         return LSA_OK;
+    }
+    if constexpr (std::is_same<F, Fq>::value) {
+        // small and medium calls over a table: the four-launch pipeline of msm_compact.hip (LSA_NO_COMPACT=1: never)
+        static const bool allow_compact = getenv("LSA_NO_COMPACT") == nullptr;
+        if (allow_compact && table_stride != 0 && n >= table_use_min() && n <= msm_compact_max())
+            return msm_compact_device<Fq>(d_bases_v, first, d_scalars, n, d_out, st, table_stride);
     }
     SegList segs;
     segs.nseg = 1;
