@@ -152,7 +152,7 @@ int lsa_init(int device) {
     g.device = device;
     g.ready = true;
     upload_prepare();
-    return LSA_OK;
+    return msm_warmup(g.stream);
 }
 
 void lsa_shutdown(void) {
@@ -529,13 +529,21 @@ int lsa_commit_run_async(const lsa_bases *g1_bases, const lsa_bases *g2_bases, c
     return msm_device<Fq2>(g2_bases->d_aff, 0, (const Fr *)d_scalars, n, (Jac<Fq2> *)d_out_g2, g.stream, g2_bases->table_stride);
 }
 
+// Blocking: the tail runs on lsa_stream() itself and the last kernel writes the point straight into pinned host memory
+// (no cross-stream hand-over, no copy command behind the kernels: ~35 us of a small call's latency).
 int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars, size_t n, void *out_jac) {
-    int rc = lsa_msm_run_async(bases, first, d_scalars, n, g.d_result);
+    int rc = require_ready();
     if (rc) return rc;
-    rc = msm_join(g.stream);
+    if (!bases || !out_jac || (n && !d_scalars)) { set_error("msm_run: null argument"); return LSA_ERR_INVALID; }
+    if (first > bases->n || n > bases->n - first) { set_error("msm_run: range [%zu,%zu) exceeds %zu bases", first, first + n, bases->n); return LSA_ERR_INVALID; }
+    rc = msm_join(g.stream);                       // earlier asynchronous calls publish before this one (call order)
+    if (rc) return rc;
+    if (bases->group == 1)
+        rc = msm_device<Fq>(bases->d_aff, first, (const Fr *)d_scalars, n, (Jac<Fq> *)g.h_result, g.stream, bases->table_stride, true);
+    else
+        rc = msm_device<Fq2>(bases->d_aff, first, (const Fr *)d_scalars, n, (Jac<Fq2> *)g.h_result, g.stream, bases->table_stride, true);
     if (rc) return rc;
     size_t bytes = bases->group == 1 ? sizeof(Jac<Fq>) : sizeof(Jac<Fq2>);
-    HIPCHK(hipMemcpyAsync(g.h_result, g.d_result, bytes, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     memcpy(out_jac, g.h_result, bytes);
     return LSA_OK;
@@ -1113,7 +1121,7 @@ static inline double ms_since(std::chrono::steady_clock::time_point t0) {
 // this process's MSM into g.d_result (stream-ordered, tails joined); the host-side wall-clock split in `st`
 template <class F>
 static int msm_host_local(const void *bases_jac, const void *scalars, size_t n, int group, lsa_host_stats &st,
-                          std::chrono::steady_clock::time_point &t_msm) {
+                          std::chrono::steady_clock::time_point &t_msm, bool to_host) {
     int rc = LSA_OK;
     crs_configure_from_env();
     const bool cached = g_crs.mode != 0 && n >= CRS_MIN_POINTS;
@@ -1180,9 +1188,10 @@ static int msm_host_local(const void *bases_jac, const void *scalars, size_t n, 
         d_bases = g_stage_bases.p;
     }
     t_msm = std::chrono::steady_clock::now();
-    rc = msm_device<F>(d_bases, 0, (const Fr *)g_stage_scalars.p, n, (Jac<F> *)g.d_result, g.stream, table_stride);
+    rc = msm_join(g.stream);
     if (rc) return rc;
-    return msm_join(g.stream);
+    // blocking call: tail on lsa_stream(); unless the partials still have to be exchanged, the result lands in pinned host memory
+    return msm_device<F>(d_bases, 0, (const Fr *)g_stage_scalars.p, n, (Jac<F> *)(to_host ? g.h_result : g.d_result), g.stream, table_stride, true);
 }
 
 template <class F>
@@ -1196,7 +1205,7 @@ static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *
     lsa_host_stats st = {};
     st.n = n;
     auto t0 = std::chrono::steady_clock::now();
-    rc = msm_host_local<F>(bases_jac, scalars, n, group, st, t0);
+    rc = msm_host_local<F>(bases_jac, scalars, n, group, st, t0, !sharded);
     if (sharded) {
         // this rank's slice is one libff chunk: all-gather the partials, sum them in rank order.  A rank whose
         // local part failed still takes part (with the point at infinity: all-zero bytes) and reports its error
@@ -1211,7 +1220,7 @@ static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *
         rc = sum_points_device<F>((const Jac<F> *)g_stage_gather.p, world, (Jac<F> *)g.d_result, g.stream);
     }
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(g.h_result, g.d_result, sizeof(Jac<F>), hipMemcpyDeviceToHost, g.stream));
+    if (sharded) HIPCHK(hipMemcpyAsync(g.h_result, g.d_result, sizeof(Jac<F>), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     memcpy(out_jac, g.h_result, sizeof(Jac<F>));
     if (!g_crs.garbage.empty()) crs_collect_garbage();     // lsa_stream() has just drained

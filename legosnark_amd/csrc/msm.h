@@ -29,8 +29,11 @@ size_t msm_base_bytes(int group);
 // (entry k*table_stride + i = 2^(s_k) * P_i, k < msm_table_windows(group, table_stride); the
 // window starts s_k are a function of table_stride alone) built by precompute_windows(); used
 // when n >= msm_merge_min() ("wide windows", msm.hip).
+// blocking: the caller synchronises right after this call, so the tail runs on `st` itself (two cross-stream
+// hand-overs of ~13 us less on the critical path of a lone call) and d_out may be pinned host memory
 template <class F>
-int msm_device(const void *d_bases, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride = 0);
+int msm_device(const void *d_bases, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride = 0,
+               bool blocking = false);
 // nseg independent MSMs over prefixes of the same table-carrying bases in one pass (msm.hip):
 // result j = sum_i d_scalars[seg_off[j] + i] * bases[first + i], i < seg_off[j+1] - seg_off[j].
 template <class F>
@@ -88,7 +91,8 @@ size_t fq12_bytes();
 
 // msm_compact.hip: a whole MSM of n <= msm_compact_max() pairs over a table-carrying handle in four launches (G1)
 template <class F>
-int msm_compact_device(const void *d_table, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride);
+int msm_compact_device(const void *d_table, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride,
+                       bool blocking = false);
 size_t msm_compact_max();
 // all pre-shifted copies of n points in one kernel: d_table holds msm_table_windows() * stride packed points, copy 0
 // (points [0, n)) filled; d_scratch: table_build_scratch_bytes(n)
@@ -104,7 +108,7 @@ struct MsmSlot {
     int index;
 };
 // picks the next slot, grows its workspace, makes `st` wait for the slot's previous tail
-int msm_slot_begin(hipStream_t st, size_t ws_bytes, const void *d_out, MsmSlot *slot);
+int msm_slot_begin(hipStream_t st, size_t ws_bytes, const void *d_out, MsmSlot *slot, bool inline_tail = false);
 // the front (on st) is issued: the slot's stream continues from here (and behind any earlier tail that writes d_out)
 int msm_slot_handover(MsmSlot *slot, hipStream_t st);
 // the tail is issued
@@ -115,6 +119,7 @@ int msm_join(hipStream_t st);
 // Makes `other` wait for them instead and leaves `st` alone.
 int msm_join_to(hipStream_t other);
 
+int msm_warmup(hipStream_t st);       // lsa_init: streams, events, function attributes, code object, first workspaces
 void msm_release_workspace();
 void msm_profile_enable(bool on);
 int msm_profile_last(float ms[LSA_MSM_STAGES]);

@@ -1453,8 +1453,47 @@ static int tail_slots_ready() {
     return LSA_OK;
 }
 
+static int msm_func_attrs() {
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {   // > 64 KiB of dynamic LDS needs an explicit opt-in
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partition), hipFuncAttributeMaxDynamicSharedMemorySize, 13 * PART_TILE * 4));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fine_sort_part), hipFuncAttributeMaxDynamicSharedMemorySize, 155648));
+        lds_attr_set = true;
+    }
+    return LSA_OK;
+}
+
+// What the first MSM of a process used to pay inside its own call (17-20 ms whatever its size: the library's code object
+// loaded on the first kernel launch, four streams and their events, the function attributes, the first workspace
+// allocations) is paid by lsa_init instead -- a prover's init_public_params(), not its first multiExpMA.  The workspaces
+// are sized for one G1 MSM of 2^20 pairs (~0.5 GB of the 288); LSA_WARM=0 skips all of it, LSA_WARM_MB sets the size.
+int msm_warmup(hipStream_t st) {
+    const char *w = getenv("LSA_WARM");
+    if (w && w[0] == '0') return LSA_OK;
+    int rc = tail_slots_ready();
+    if (rc) return rc;
+    rc = msm_func_attrs();
+    if (rc) return rc;
+    const char *mb = getenv("LSA_WARM_MB");
+    const size_t front = (mb ? (size_t)atoll(mb) : 192) << 20, tailb = front / 2;
+    if (front) {
+        if (g_ws.ensure(front) != 0) (void)hipGetLastError();          // (no memory: the first call will say so)
+        for (auto &t : g_tail) if (t.ws.ensure(tailb) != 0) (void)hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u);      // loads the code object
+    for (auto &t : g_tail) if (t.stream) hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, t.stream, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
+    HIPCHK(hipDeviceSynchronize());
+    return LSA_OK;
+}
+
 // ---- the slot interface other pipelines (msm_compact.hip) run their tails through
-int msm_slot_begin(hipStream_t st, size_t ws_bytes, const void *d_out, MsmSlot *slot) {
+int msm_slot_begin(hipStream_t st, size_t ws_bytes, const void *d_out, MsmSlot *slot, bool inline_tail) {
     int rc = tail_slots_ready();
     if (rc) return rc;
     TailBuf &tb = g_tail[g_slot];
@@ -1463,7 +1502,7 @@ int msm_slot_begin(hipStream_t st, size_t ws_bytes, const void *d_out, MsmSlot *
         if (tb.ws.ensure(ws_bytes) != 0) { set_error("msm: tail workspace allocation of %zu bytes failed", ws_bytes); return LSA_ERR_NOMEM; }
     }
     if (tb.pending) HIPCHK(hipStreamWaitEvent(st, tb.done, 0));        // the front may not overwrite what the slot's last tail still reads
-    slot->tail = g_overlap ? tb.stream : st;
+    slot->tail = (g_overlap && !inline_tail) ? tb.stream : st;
     slot->ws = tb.ws.ptr;
     slot->aux = tb.aux;
     slot->index = (int)g_slot;
@@ -1472,9 +1511,10 @@ int msm_slot_begin(hipStream_t st, size_t ws_bytes, const void *d_out, MsmSlot *
 }
 int msm_slot_handover(MsmSlot *slot, hipStream_t st) {
     TailBuf &tb = g_tail[slot->index];
-    if (slot->tail == st) return LSA_OK;
-    HIPCHK(hipEventRecord(tb.front_done, st));
-    HIPCHK(hipStreamWaitEvent(slot->tail, tb.front_done, 0));
+    if (slot->tail != st) {
+        HIPCHK(hipEventRecord(tb.front_done, st));
+        HIPCHK(hipStreamWaitEvent(slot->tail, tb.front_done, 0));
+    }
     // results appear in call order wherever two calls write the same place: behind every earlier tail with this destination
     for (int i = 0; i < NTAIL; i++) {
         TailBuf &o = g_tail[i];
@@ -1642,7 +1682,7 @@ unsigned msm_field_mults_per_pair(size_t n, size_t table_n) {
 // d_out receives nseg points.
 template <class F>
 static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars, const SegList &segs, Jac<F> *d_out, hipStream_t st,
-                        size_t table_stride, bool reuse_sort = false) {
+                        size_t table_stride, bool reuse_sort = false, bool blocking = false) {
     using C = typename CurveOf<F>::type;
     using A = typename C::Acc;
     const typename C::Base *d_bases = (const typename C::Base *)d_bases_v + first;
@@ -1752,7 +1792,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     // accumulate kernel alone already fills every SIMD's issue slots and register file.)
     TailBuf &tb = g_tail[g_slot];
     TailBuf &prev = g_tail[(g_slot + NTAIL - 1) % NTAIL];
-    hipStream_t tail = g_overlap ? tb.stream : st;
+    hipStream_t tail = (g_overlap && !blocking) ? tb.stream : st;
     size_t toff = 0;
     auto tcarve = [&](size_t bytes) { size_t o = toff; toff = align_up(toff + bytes, 256); return o; };
     size_t o_buckets = tcarve((size_t)nb * split * sizeof(A));
@@ -1800,18 +1840,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     auto mark = [&](hipStream_t s_) { if (g_profile) (void)hipEventRecord(g_ev[evslot][evi++], s_); };
 
     mark(st);  // 0
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {   // > 64 KiB of dynamic LDS needs an explicit opt-in
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<0>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_wide<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_rank), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist_wide), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_partition), hipFuncAttributeMaxDynamicSharedMemorySize, 13 * PART_TILE * 4));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fine_sort_part), hipFuncAttributeMaxDynamicSharedMemorySize, 155648));
-        lds_attr_set = true;
-    }
+    { int rca = msm_func_attrs(); if (rca) return rca; }
     if (reuse_sort) {
         // second MSM of a commitment pair: the entries, populations and offsets of the call just
         // issued on this stream (same scalars, same digit plan, same table stride) are still in the
@@ -1939,12 +1968,12 @@ acc_done:
 }
 
 template <class F>
-int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride) {
+int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride, bool blocking) {
     if (n == 0) {
         int jr = msm_join(st);
         if (jr) return jr;
         Jac<F> inf = Jac<F>::inf();
-        HIPCHK(hipMemcpyAsync(d_out, &inf, sizeof inf, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_out, &inf, sizeof inf, hipMemcpyDefault, st));       // (d_out may be pinned host memory: blocking callers)
         HIPCHK(hipStreamSynchronize(st));
         return LSA_OK;
     }
@@ -1952,13 +1981,13 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         // small and medium calls over a table: the four-launch pipeline of msm_compact.hip (LSA_NO_COMPACT=1: never)
         static const bool allow_compact = getenv("LSA_NO_COMPACT") == nullptr;
         if (allow_compact && table_stride != 0 && n >= table_use_min() && n <= msm_compact_max())
-            return msm_compact_device<Fq>(d_bases_v, first, d_scalars, n, d_out, st, table_stride);
+            return msm_compact_device<Fq>(d_bases_v, first, d_scalars, n, d_out, st, table_stride, blocking);
     }
     SegList segs;
     segs.nseg = 1;
     segs.off[0] = 0;
     segs.off[1] = (uint32_t)n;
-    return msm_pipeline<F>(d_bases_v, first, d_scalars, segs, d_out, st, table_stride);
+    return msm_pipeline<F>(d_bases_v, first, d_scalars, segs, d_out, st, table_stride, false, blocking);
 }
 
 // nseg independent MSMs in one pass: result j = sum_i scalars[off[j] + i] * bases[first + i],
@@ -2004,7 +2033,7 @@ int msm_commit_pair_device(const void *d_g1_bases, const void *d_g2_bases, const
 template int msm_segments_device<Fq>(const void *, size_t, const Fr *, const uint64_t *, size_t, Jac<Fq> *, hipStream_t, size_t);
 template int msm_segments_device<Fq2>(const void *, size_t, const Fr *, const uint64_t *, size_t, Jac<Fq2> *, hipStream_t, size_t);
 
-template int msm_device<Fq>(const void *, size_t, const Fr *, size_t, Jac<Fq> *, hipStream_t, size_t);
-template int msm_device<Fq2>(const void *, size_t, const Fr *, size_t, Jac<Fq2> *, hipStream_t, size_t);
+template int msm_device<Fq>(const void *, size_t, const Fr *, size_t, Jac<Fq> *, hipStream_t, size_t, bool);
+template int msm_device<Fq2>(const void *, size_t, const Fr *, size_t, Jac<Fq2> *, hipStream_t, size_t, bool);
 
 }  // namespace lsa

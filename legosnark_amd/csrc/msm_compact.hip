@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void k_cmp_accumulate(const typename C::Base *
     A a = A::inf();
 #pragma unroll 1
     for (uint32_t j = 0; j < 4; j++) {
-        const uint32_t l = 4 * qd + j;
+        const uint32_t l = qd + 16 * j;                             // strided: with few sums the later trips add nothing anywhere
         A o = A::inf();
         if (l < used) o = cmp_load(reinterpret_cast<const A *>(&tree[wv][l * PITCH]));
         a = quad_add(a, o, sub);
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(512) void k_cmp_bits(const typename C::Acc *__restr
     A a = A::inf();
 #pragma unroll 1
     for (uint32_t j = 0; j < 4; j++) {
-        const uint32_t idx = g * CMP_BITS_BLOCK + wv * 64 + 4 * qd + j;
+        const uint32_t idx = g * CMP_BITS_BLOCK + wv * 64 + qd + 16 * j;
         A o = A::inf();
         if (idx < W && ((item_w[idx] >> bit) & 1u)) o = cmp_load(&items[idx]);
         a = quad_add(a, o, sub);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64) void k_cmp_final(const typename C::Acc *__restr
     A a = A::inf();
 #pragma unroll 1
     for (uint32_t j = 0; j < 4; j++) {
-        const uint32_t idx = 4 * qd + j;
+        const uint32_t idx = qd + 16 * j;
         A o = A::inf();
         if (idx < nparts) o = cmp_load(&part[idx]);
         a = quad_add(a, o, sub);
@@ -341,7 +341,7 @@ size_t msm_compact_max() { return cmp_max() < CMP_TILE * CMP_MAXTILES ? cmp_max(
 static inline size_t cmp_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 template <class F>
-int msm_compact_device(const void *d_table, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride) {
+int msm_compact_device(const void *d_table, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride, bool blocking) {
     using C = typename CurveOf<F>::type;
     using A = typename C::Acc;
     if (n == 0 || n > msm_compact_max() || table_stride == 0) { set_error("msm_compact: not applicable (n = %zu)", n); return LSA_ERR_INVALID; }
@@ -369,7 +369,7 @@ int msm_compact_device(const void *d_table, size_t first, const Fr *d_scalars, s
     const size_t o_n = carve(4);
     const size_t o_part = carve((size_t)64 * sizeof(A));
     MsmSlot slot;
-    int rc = msm_slot_begin(st, off, d_out, &slot);
+    int rc = msm_slot_begin(st, off, d_out, &slot, blocking);
     if (rc) return rc;
     char *ws = (char *)slot.ws;
     uint32_t *ghist = (uint32_t *)slot.aux;                     // zero between the calls of a slot (k_cmp_final clears it)
@@ -393,7 +393,7 @@ int msm_compact_device(const void *d_table, size_t first, const Fr *d_scalars, s
     HIPCHK(hipGetLastError());
     return msm_slot_end(&slot, st);
 }
-template int msm_compact_device<Fq>(const void *, size_t, const Fr *, size_t, Jac<Fq> *, hipStream_t, size_t);
+template int msm_compact_device<Fq>(const void *, size_t, const Fr *, size_t, Jac<Fq> *, hipStream_t, size_t, bool);
 
 // ------------------------------------------------------------------------------------ table builder
 // All pre-shifted copies of a point in ONE kernel: lane i doubles P_i 255 times, parks the 25 (23) multiples it
