@@ -224,6 +224,8 @@ def _after_torch(*tensors):
     if not any(hasattr(t, "data_ptr") and getattr(t, "is_cuda", False) for t in tensors):
         return
     import torch
+    if torch.cuda.current_stream().query():
+        return                       # nothing pending on torch's stream: no event, no cross-stream wait in front of the call
     dev = torch.cuda.current_device()
     h = lib().lsa_stream()
     key = (dev, h)

@@ -1083,7 +1083,7 @@ static lsa_bases *crs_lookup_small(const void *bases_jac, size_t n, int group) {
 static size_t crs_prefix_max() {
     static const size_t v = [] {
         const char *e = getenv("LSA_CRS_PREFIX_TABLE");
-        const size_t want = e ? (size_t)atoll(e) : (size_t)1 << 14;
+        const size_t want = e ? (size_t)atoll(e) : (size_t)1 << 16;
         return want > ((size_t)1 << 16) ? (size_t)1 << 16 : want;
     }();
     return v;

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(64) void k_cmp_final(const typename C::Acc *__restr
 
 // ------------------------------------------------------------------------------------ host
 static size_t cmp_max() {
-    static const size_t v = getenv("LSA_COMPACT_MAX") ? (size_t)atoll(getenv("LSA_COMPACT_MAX")) : (size_t)1 << 14;
+    static const size_t v = getenv("LSA_COMPACT_MAX") ? (size_t)atoll(getenv("LSA_COMPACT_MAX")) : (size_t)1 << 16;   // 2^15: 0.31 ms against 0.45 on the general pipeline, 2^16: 0.44 / 0.67
     return v;
 }
 size_t msm_compact_max() { return cmp_max() < CMP_TILE * CMP_MAXTILES ? cmp_max() : CMP_TILE * CMP_MAXTILES; }
