@@ -191,6 +191,59 @@ struct F29 {
         return r;
     }
 
+    // (a0*b0 + a1*b1 + a2*b2 + a3*b3) / 2^261 mod p with ONE reduction.  All limbs tight (< 2^29, top limbs as their values
+    // allow): 36 + 9 limb products of < 2^58 per column stay below 2^64.  With T = sum a_i*b_i the result is
+    // < T / 2^261 + p, i.e. < 4p for T < 507 p^2 (callers state their T).  [tight]
+    friend LSA_HD F29 dot4(const F29 &a0, const F29 &b0, const F29 &a1, const F29 &b1, const F29 &a2, const F29 &b2, const F29 &a3, const F29 &b3) {
+        uint64_t acc = 0;
+        uint32_t m[9];
+        F29 r;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+#pragma unroll
+            for (int i = 0; i <= k; i++) {
+                acc += (uint64_t)a0.l[i] * b0.l[k - i];
+                acc += (uint64_t)a1.l[i] * b1.l[k - i];
+                acc += (uint64_t)a2.l[i] * b2.l[k - i];
+                acc += (uint64_t)a3.l[i] * b3.l[k - i];
+            }
+#pragma unroll
+            for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * p(k - i);
+            m[k] = ((uint32_t)acc * PINV) & MASK;
+            acc += (uint64_t)m[k] * p(0);
+            acc >>= 29;
+        }
+#pragma unroll
+        for (int k = 9; k < 17; k++) {
+#pragma unroll
+            for (int i = k - 8; i < 9; i++) {
+                acc += (uint64_t)a0.l[i] * b0.l[k - i];
+                acc += (uint64_t)a1.l[i] * b1.l[k - i];
+                acc += (uint64_t)a2.l[i] * b2.l[k - i];
+                acc += (uint64_t)a3.l[i] * b3.l[k - i];
+            }
+#pragma unroll
+            for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * p(k - i);
+            r.l[k - 9] = (uint32_t)acc & MASK;
+            acc >>= 29;
+        }
+        r.l[8] = (uint32_t)acc;
+        return r;
+    }
+    // cu*u + cv*v + K*p for small signed cu, cv and K >= 0 chosen by the caller so that the value is non-negative
+    // (u, v tight); carry-normalised: limbs < 2^29, the value must stay below 2^261.  [tight]
+    friend LSA_HD F29 lin2(const F29 &u, int cu, const F29 &v, int cv, int K) {
+        F29 r;
+        int64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int64_t t = (int64_t)cu * (int64_t)u.l[i] + (int64_t)cv * (int64_t)v.l[i] + (int64_t)K * (int64_t)p(i) + c;
+            if (i < 8) { r.l[i] = (uint32_t)t & MASK; c = t >> 29; }
+            else r.l[i] = (uint32_t)t;
+        }
+        return r;
+    }
+
     // value == 0 (mod p) for a tight value < 16p.  Necessary condition first: a multiple
     // k*p has low limb k*p_0, so k = l0 * p_0^-1 mod 2^29 must be < 16 (false positives
     // 2^-25); the exact comparison runs only then.

@@ -79,7 +79,7 @@ static __device__ __forceinline__ Fs *w12_fq_ref(Fq2S *slot, unsigned l) {
     const unsigned t = l >> 1, k = 2 * (t % 3) + t / 3;
     return (l & 1) ? &slot[k].c1 : &slot[k].c0;
 }
-__global__ __launch_bounds__(128) void k_final_exp_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
+__global__ __launch_bounds__(192) void k_final_exp_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
     __shared__ Fq2S lds[W12_LDS_FQ2];
     const size_t e = blockIdx.x;
     if (e >= n) return;
@@ -436,7 +436,11 @@ int miller_device(const void *d_g1, const void *d_g2, size_t n, void *d_out, hip
 int final_exp_device(const void *d_in, size_t n, void *d_out, hipStream_t st) {
     if (n == 0) return LSA_OK;
     if (n < 16384)   // fewer elements than lanes to fill the chip: one wavefront per element
-        hipLaunchKernelGGL(k_final_exp_wave, dim3((unsigned)n), dim3(128), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);   // two wavefronts per element
+    {
+        // three wavefronts per element: the one-phase row product of w12.h (LSA_FINAL_EXP_LANES=128: the two-phase product)
+        static const unsigned lanes = getenv("LSA_FINAL_EXP_LANES") ? (unsigned)atoi(getenv("LSA_FINAL_EXP_LANES")) : 192u;
+        hipLaunchKernelGGL(k_final_exp_wave, dim3((unsigned)n), dim3(lanes == 128 ? 128 : 192), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);
+    }
     else
         hipLaunchKernelGGL(k_final_exp, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);
     HIPCHK(hipGetLastError());

@@ -26,7 +26,7 @@ namespace lsa {
 using Fq2S = Fq2T<Fs>;
 using Fq12S = Fq12T<Fs>;
 
-static constexpr int W12_SLOTS = 12;                     // Fq12 registers in LDS
+static constexpr int W12_SLOTS = 15;                     // Fq12 registers in LDS
 static constexpr int W12_LDS_FQ2 = W12_SLOTS * 6 + 36;   // + the 36 partial products
 
 // Fq2 product with two fused reductions (fp29x2.h: c0 = a0*b0 + a1*(20p - b1),
@@ -149,6 +149,147 @@ LSA_HD Fq2S &w12_tower_ref(Fq12S &t, int k) {
     return (k >> 1) == 0 ? h.c0 : ((k >> 1) == 1 ? h.c1 : h.c2);
 }
 
+// Granger-Scott squaring of a cyclotomic element in the polynomial basis, one Fq component of the result per lane as ONE
+// fused dot product (fp29.h dot4) -- no second reduction phase, no barrier inside.  With f = sum a_k w^k (a_k = tower
+// coefficient: a0, a2, a4 = c0.c0, c0.c1, c0.c2; a1, a3, a5 = c1.c0, c1.c1, c1.c2) libff's cyclotomic_squared reads
+//   a0' = 3 (a0^2 + xi a3^2) - 2 a0     a3' = 6 a0 a3 + 2 a3          (pair x = a0, y = a3)
+//   a2' = 3 (a1^2 + xi a4^2) - 2 a2     a5' = 6 a1 a4 + 2 a5          (pair x = a1, y = a4)
+//   a4' = 3 (a2^2 + xi a5^2) - 2 a4     a1' = 6 xi a2 a5 + 2 a1       (pair x = a2, y = a5)
+// and each Fq component is sum_i L_i * R_i + (+-2) * s with L_i one component of x or y (or x0 + x1) and R_i a small
+// integer combination of two components plus a multiple of p that keeps it non-negative:
+//   E.c0 = (x0 + x1)(3x0 - 3x1) + y0 (27y0 - 6y1) - 27 y1^2 - 2 s0        E.c1 = 6 x0 x1 + y0 (3y0 + 54y1) - 3 y1^2 - 2 s1
+//   O.c0 = 6 x0 y0 - 6 x1 y1 + 2 s0                                        O.c1 = 6 x0 y1 + 6 x1 y0 + 2 s1
+//   X.c0 = x0 (54y0 - 6y1) - x1 (6y0 + 54y1) + 2 s0                        X.c1 = x0 (6y0 + 54y1) + x1 (54y0 - 6y1) + 2 s1
+// Inputs < 2p (tight): every R_i < 120p < 2^261, T = sum L_i R_i < 484 p^2, so the one reduction leaves < 3.87p and one
+// conditional subtraction of 2p restores < 2p.  ~800 instructions on 12 lanes against ~430 + ~350 on 72 + 12 lanes and a
+// workgroup barrier in between for the general product.
+struct W12SqTerm { int8_t la, fa, lb, fb, ra, ca, rb, cb, K; };    // L = fa * comp[la] + fb * comp[lb];  R = ca * comp[ra] + cb * comp[rb] + K p
+struct W12SqRow { W12SqTerm t[3]; int8_t lin; };                    // + lin * s   (comp: 0 x0, 1 x1, 2 y0, 3 y1; a zero factor drops a term)
+LSA_HD const W12SqRow &w12_sq_row(unsigned type, unsigned part) {
+    // type 0: E, 1: O, 2: X
+    static constexpr W12SqRow ROWS[6] = {
+        {{{0, 1, 1, 1, 0, 3, 1, -3, 6}, {2, 1, 2, 0, 2, 27, 3, -6, 12}, {3, 1, 3, 0, 3, -27, 3, 0, 54}}, -2},     // E.c0
+        {{{0, 1, 0, 0, 1, 6, 1, 0, 0}, {2, 1, 2, 0, 2, 3, 3, 54, 0}, {3, 1, 3, 0, 3, -3, 3, 0, 6}}, -2},           // E.c1
+        {{{0, 1, 0, 0, 2, 6, 2, 0, 0}, {1, 1, 1, 0, 3, -6, 3, 0, 12}, {0, 0, 0, 0, 0, 0, 0, 0, 0}}, 2},            // O.c0
+        {{{0, 1, 0, 0, 3, 6, 3, 0, 0}, {1, 1, 1, 0, 2, 6, 2, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0}}, 2},              // O.c1
+        {{{0, 1, 0, 0, 2, 54, 3, -6, 12}, {1, 1, 1, 0, 2, -6, 3, -54, 120}, {0, 0, 0, 0, 0, 0, 0, 0, 0}}, 2},      // X.c0
+        {{{0, 1, 0, 0, 2, 6, 3, 54, 0}, {1, 1, 1, 0, 2, 54, 3, -6, 12}, {0, 0, 0, 0, 0, 0, 0, 0, 0}}, 2},          // X.c1
+    };
+    return ROWS[type * 2 + part];
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// ------------------------------------------------------------------------------------------------------------------
+// The Fq12 product in ONE phase (device only; W12::mul takes it when the workgroup has 192 lanes).  The two-phase
+// product above costs its first wavefront ~430 + ~350 instructions and two workgroup barriers with an LDS round trip
+// between them: ~3 us for a chain link whose arithmetic is one Fq product deep.  Here a ROW of 16 lanes owns one Fq
+// component of the result (12 rows = three wavefronts): lane r < 12 of row (k, part) computes the plain integer
+// product L * R of ONE pair of 29-bit-limb operands -- 81 multiply-adds into 17 column sums, no reduction -- where L is
+// a component of a_i and R the matching combination of b_j's components (i = r / 2, j = k - i mod 6; terms with
+// i + j >= 6 carry the factor xi = 9 + u on the b side):
+//   part 0:  a_i0 * ( b0)        + a_i1 * (-b1)          wrapped:  a_i0 * (9 b0 - b1)  + a_i1 * (-b0 - 9 b1)
+//   part 1:  a_i0 * ( b1)        + a_i1 * ( b0)          wrapped:  a_i0 * (b0 + 9 b1)  + a_i1 * (9 b0 - b1)
+// (R made non-negative with a multiple of p: < 22p).  The lane carries its columns into 18 tight limbs, the row adds
+// them up with four DPP butterfly steps (one carry pass in the middle keeps the sums in 32 bits), and every lane of the
+// row runs the ONE Montgomery reduction of the sum: T < 12 * 44 p^2 gives < 4p, one conditional subtraction < 2p.
+// ~550 instructions, one barrier (two when the destination aliases an operand).
+// ------------------------------------------------------------------------------------------------------------------
+// t.l[q] += t.l[q] of the lane the permutation names, all 18 limbs: one v_add_u32_dpp each, written as ONE asm block (the
+// intrinsic leaves a v_mov per limb behind; inside the block consecutive instructions touch different registers, the
+// leading s_nop covers the DPP read-after-VALU-write hazard against whatever the compiler scheduled before it)
+#define W12_DPP18(T, CTRL)                                                                                                  \
+    asm volatile("s_nop 1\n"                                                                                               \
+                 "v_add_u32_dpp %0, %0, %0 " CTRL "\nv_add_u32_dpp %1, %1, %1 " CTRL "\nv_add_u32_dpp %2, %2, %2 " CTRL "\n"   \
+                 "v_add_u32_dpp %3, %3, %3 " CTRL "\nv_add_u32_dpp %4, %4, %4 " CTRL "\nv_add_u32_dpp %5, %5, %5 " CTRL "\n"   \
+                 "v_add_u32_dpp %6, %6, %6 " CTRL "\nv_add_u32_dpp %7, %7, %7 " CTRL "\nv_add_u32_dpp %8, %8, %8 " CTRL "\n"   \
+                 "v_add_u32_dpp %9, %9, %9 " CTRL "\nv_add_u32_dpp %10, %10, %10 " CTRL "\nv_add_u32_dpp %11, %11, %11 " CTRL "\n" \
+                 "v_add_u32_dpp %12, %12, %12 " CTRL "\nv_add_u32_dpp %13, %13, %13 " CTRL "\nv_add_u32_dpp %14, %14, %14 " CTRL "\n" \
+                 "v_add_u32_dpp %15, %15, %15 " CTRL "\nv_add_u32_dpp %16, %16, %16 " CTRL "\nv_add_u32_dpp %17, %17, %17 " CTRL "\n" \
+                 : "+v"((T).l[0]), "+v"((T).l[1]), "+v"((T).l[2]), "+v"((T).l[3]), "+v"((T).l[4]), "+v"((T).l[5]), "+v"((T).l[6]),     \
+                   "+v"((T).l[7]), "+v"((T).l[8]), "+v"((T).l[9]), "+v"((T).l[10]), "+v"((T).l[11]), "+v"((T).l[12]), "+v"((T).l[13]), \
+                   "+v"((T).l[14]), "+v"((T).l[15]), "+v"((T).l[16]), "+v"((T).l[17]))
+struct W12Limbs18 { uint32_t l[18]; };
+// plain product a * b of two tight 9-limb values as 18 tight limbs (a * b < 2^522)
+__device__ __forceinline__ W12Limbs18 w12_wide_mul(const F29 &a, const F29 &b) {
+    W12Limbs18 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const int j = k - i;
+            if (j >= 0 && j < 9) acc += (uint64_t)a.l[i] * b.l[j];
+        }
+        r.l[k] = (uint32_t)acc & F29::MASK;
+        acc >>= 29;
+    }
+    r.l[17] = (uint32_t)acc;
+    return r;
+}
+__device__ __forceinline__ void w12_carry18(W12Limbs18 &t) {        // limbs < 2^32 -> tight (the value fits 18 limbs)
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        const uint64_t v = (uint64_t)t.l[k] + c;
+        t.l[k] = (uint32_t)v & F29::MASK;
+        c = (uint32_t)(v >> 29);
+    }
+    t.l[17] += c;
+}
+// T / 2^261 mod p for T = sum t_k 2^(29k) with loose limbs (< 2^31): < T / 2^261 + p, limbs tight
+__device__ __forceinline__ F29 w12_redc18(const W12Limbs18 &t) {
+    uint64_t acc = 0;
+    uint32_t m[9];
+    F29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        acc += t.l[k];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F29::p(k - i);
+        m[k] = ((uint32_t)acc * F29::PINV) & F29::MASK;
+        acc += (uint64_t)m[k] * F29::p(0);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+        acc += t.l[k];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * F29::p(k - i);
+        r.l[k - 9] = (uint32_t)acc & F29::MASK;
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc + t.l[17];
+    return r;
+}
+// d = a * b for slots of 6 Fq2S each; 192 lanes; see above
+__device__ __noinline__ void w12_mul_rows(Fq2S *D, const Fq2S *A, const Fq2S *B) {
+    const unsigned lane = threadIdx.x, row = lane >> 4, r = lane & 15;
+    const unsigned k = row >> 1, part = row & 1, i = r >> 1, h = r & 1;
+    const unsigned iw = i < 6 ? i : 0, j = (k + 6 - iw) % 6;
+    const bool wrapped = iw > k;
+    // R = c0 * b_j0 + c1 * b_j1 + K p
+    int c0, c1, K;
+    if (!wrapped) { c0 = (part ^ h) ? 0 : 1; c1 = (part ^ h) ? (part ? 1 : -1) : 0; K = (part == 0 && h == 1) ? 2 : 0; }
+    else if (part == 0) { c0 = h ? -1 : 9; c1 = h ? -9 : -1; K = h ? 20 : 2; }
+    else { c0 = h ? 9 : 1; c1 = h ? -1 : 9; K = h ? 2 : 0; }
+    F29 L = w12_load(&w12_comp(A[iw], h)).v;
+    const Fq2S bj = w12_load(&B[j]);
+    __syncthreads();                                   // every lane holds its operands: D may alias A or B from here on
+    const uint32_t live = w12_mask(0u - (uint32_t)(r < 12));
+#pragma unroll
+    for (int q = 0; q < 9; q++) L.l[q] &= live;          // lanes 12..15 of a row add nothing
+    W12Limbs18 t = w12_wide_mul(L, lin2(bj.c0.v, c0, bj.c1.v, c1, K));
+    W12_DPP18(t, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    W12_DPP18(t, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");         // sums of four (< 2^31)
+    w12_carry18(t);
+    W12_DPP18(t, "row_half_mirror row_mask:0xf bank_mask:0xf");
+    W12_DPP18(t, "row_mirror row_mask:0xf bank_mask:0xf");                  // the row's sum in every lane (< 2^31 per limb)
+    const Fs res = {condsub2(w12_redc18(t))};
+    if (r == 0) w12_store(&w12_comp(D[k], part), res);
+    __syncthreads();
+}
+#endif
+
 template <class X>
 struct W12 {
     X &x;
@@ -166,6 +307,9 @@ struct W12 {
     // whole Fq2 products and a xi step in the reduction.
     LSA_HD_NOINLINE void mul(int d, int a, int b) {
         Fq2S *A = slot(a), *B = slot(b), *D = slot(d), *Pp = P;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (x.nlanes() >= 192) { w12_mul_rows(D, A, B); return; }      // (workgroup-uniform)
+#endif
         const unsigned nl = x.nlanes();
         x.par([=](unsigned lane) {
             for (unsigned t = lane; t < 72; t += nl) {
@@ -194,6 +338,36 @@ struct W12 {
         });
     }
     LSA_HD void sqr(int d, int a) { mul(d, a, a); }
+    // d = a^2 for a in the cyclotomic subgroup (every squaring of the hard part); d != a
+    LSA_HD_NOINLINE void csqr(int d, int a) {
+        Fq2S *A = slot(a), *D = slot(d);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (x.nlanes() >= 192) { w12_mul_rows(D, A, A); return; }      // the row product is shorter than twelve fused lanes
+#endif
+        x.par([=](unsigned lane) {
+            if (lane < 12) {
+                const unsigned k = lane >> 1, part = lane & 1;
+                // output coefficient k: its pair (x, y) = (a_xi, a_(xi+3)) and its formula
+                const unsigned xi = (0x120120u >> (4 * k)) & 15u;              // k = 0..5 -> 0, 2, 1, 0, 2, 1
+                const unsigned type = (0x101020u >> (4 * k)) & 15u;            // k = 0..5 -> E, X, E, O, E, O = 0, 2, 0, 1, 0, 1
+                const W12SqRow &row = w12_sq_row(type, part);
+                // component c of the pair, by address (an index into a register array would live in scratch)
+                auto comp = [&](int c) { return w12_load(&w12_comp(A[xi + 3 * (unsigned)(c >> 1)], (unsigned)(c & 1))).v; };
+                F29 L[3], R[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const W12SqTerm &t = row.t[i];
+                    L[i] = lin2(comp(t.la), t.fa, comp(t.lb), t.fb, 0);
+                    R[i] = lin2(comp(t.ra), t.ca, comp(t.rb), t.cb, t.K);
+                }
+                const F29 two = add_lazy(F29::one(), F29::one());              // Montgomery form of 2 (< 2p)
+                const F29 lin = lin2(two, row.lin > 0 ? 1 : -1, F29::zero(), 0, row.lin > 0 ? 0 : 2);     // +-2
+                const F29 sv = w12_load(&w12_comp(A[k], part)).v;
+                const Fs r = {condsub2(dot4(L[0], R[0], L[1], R[1], L[2], R[2], sv, lin))};
+                w12_store(&w12_comp(D[k], part), r);
+            }
+        });
+    }
     LSA_HD void copy(int d, int a) {
         Fq2S *A = slot(a), *D = slot(d);
         x.par([=](unsigned lane) { if (lane < 6) D[lane] = A[lane]; });
@@ -267,17 +441,31 @@ struct W12 {
     LSA_HD void exp_by_neg_z(int d, int a, int tmp) {
         static constexpr int8_t NAF3[63] = {1, 0, 0, 0, -1, 0, 0, 0, 0, -3, 0, 0, 1, 0, 0, 0, 1, 0, 0, -3, 0, 0, 0, -3, 0, 0, 3, 0, 0, 0, 1,
                                             0, 0, 0, -3, 0, 0, 0, 3, 0, 0, 1, 0, 0, 1, 0, 0, 3, 0, 0, 0, -3, 0, 0, 0, 0, -3, 0, 0, 1, 0, 0, 1};
-        const int acc = tmp, a3 = tmp + 1, neg = tmp + 2;
-        sqr(neg, a);
-        mul(a3, neg, a);                    // a^3
-        copy(acc, a);                       // top digit (bit 62) is +1
-        for (int i = 61; i >= 0; --i) {
-            sqr(acc, acc);
+        // every squaring is a cyclotomic one (csqr: d != a, so the accumulator alternates between two slots); the
+        // inverses a^-1, a^-3 (conjugates) are made once.  Uses slots tmp .. tmp + 5.
+        int acc = tmp, alt = tmp + 3;
+        const int a3 = tmp + 1, na = tmp + 2, na3 = tmp + 4, sq = tmp + 5;
+        csqr(sq, a);
+        mul(a3, sq, a);                     // a^3
+        conj(na, a);
+        conj(na3, a3);
+        csqr(alt, a);                       // top digit (bit 62) is +1: the accumulator starts as a, the first squaring reads it in place
+        {
+            const int dg = NAF3[61];
+            if (dg == 1) mul(acc, alt, a);
+            else if (dg == 3) mul(acc, alt, a3);
+            else if (dg == -1) mul(acc, alt, na);
+            else if (dg == -3) mul(acc, alt, na3);
+            else { const int t = acc; acc = alt; alt = t; }
+        }
+        for (int i = 60; i >= 0; --i) {
+            csqr(alt, acc);
             const int dg = NAF3[i];
-            if (dg == 1) mul(acc, acc, a);
-            else if (dg == 3) mul(acc, acc, a3);
-            else if (dg == -1) { conj(neg, a); mul(acc, acc, neg); }
-            else if (dg == -3) { conj(neg, a3); mul(acc, acc, neg); }
+            if (dg == 1) mul(acc, alt, a);
+            else if (dg == 3) mul(acc, alt, a3);
+            else if (dg == -1) mul(acc, alt, na);
+            else if (dg == -3) mul(acc, alt, na3);
+            else { const int t = acc; acc = alt; alt = t; }
         }
         conj(d, acc);
     }
@@ -285,7 +473,7 @@ struct W12 {
     // libff alt_bn128_final_exponentiation on slot 0 -> slot 0 (same chain as final_exp_one in
     // pairing.hip).  Uses every slot.
     LSA_HD void final_exponentiation() {
-        enum { ELT = 0, FIRST, A, B, C, D, E, F, G, T0, T1, T2 };
+        enum { ELT = 0, FIRST, A, B, C, D, E, F, G, T0, T1, T2, T3, T4, T5 };      // (exp_by_neg_z uses T0 .. T5)
         conj(A, ELT);             // conj(f): f^(p^6)
         mul(C, ELT, A);           // f * conj(f), an element of Fq6
         inverse6(D, C);
@@ -294,11 +482,11 @@ struct W12 {
         frobenius<2>(D, C);
         mul(FIRST, D, C);
         exp_by_neg_z(A, FIRST, T0);
-        sqr(B, A);
-        sqr(C, B);
+        csqr(B, A);
+        csqr(C, B);
         mul(D, C, B);
         exp_by_neg_z(E, D, T0);
-        sqr(F, E);
+        csqr(F, E);
         exp_by_neg_z(G, F, T0);
         conj(T2, D);              // H
         conj(G, G);               // I

@@ -55,6 +55,23 @@ int main() {
             CHECK(w.load_tower(8) == fq12_pow_u64(a, 0x1234567ull), "pow");
         }
     }
+    // Granger-Scott squaring on twelve lanes against the tower's cyclotomic and general squarings, on elements of the
+    // cyclotomic subgroup (f^((p^6-1)(p^2+1))), chained (outputs < 2p feed the next squaring)
+    for (int t = 0; t < 6; t++) {
+        Fq12S a = rand12();
+        Fq12S e = fq12_mul(a.unitary_inverse(), fq12_inverse(a));           // f^(p^6-1)
+        e = fq12_mul(fq12_frobenius<2>(e), e);                              // ^(p^2+1)
+        w.store_tower(1, e);
+        Fq12S want = e;
+        int cur = 1, nxt = 2;
+        for (int r = 0; r < 5; r++) {
+            w.csqr(nxt, cur);
+            want = fq12_sqr(want);
+            CHECK(w.load_tower(nxt) == want, "cyclotomic squaring vs general squaring");
+            CHECK(fq12_cyclotomic_sqr(w.load_tower(cur)) == want, "tower cyclotomic squaring");
+            std::swap(cur, nxt);
+        }
+    }
     for (int t = 0; t < 2; t++) {
         Fq12S a = rand12();
         w.store_tower(0, a);
