@@ -211,15 +211,23 @@ LSA_HD const W12SqRow &w12_sq_row(unsigned type, unsigned part) {
 struct W12Limbs18 { uint32_t l[18]; };
 // plain product a * b of two tight 9-limb values as 18 tight limbs (a * b < 2^522)
 __device__ __forceinline__ W12Limbs18 w12_wide_mul(const F29 &a, const F29 &b) {
+    // the 17 column sums are independent of each other (< 9 * 2^58 each): accumulated apart and carried afterwards, so
+    // that a lone wavefront can interleave their multiply-adds instead of waiting on one accumulator
     W12Limbs18 r;
-    uint64_t acc = 0;
+    uint64_t col[17];
 #pragma unroll
     for (int k = 0; k < 17; k++) {
+        col[k] = 0;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
             const int j = k - i;
-            if (j >= 0 && j < 9) acc += (uint64_t)a.l[i] * b.l[j];
+            if (j >= 0 && j < 9) col[k] += (uint64_t)a.l[i] * b.l[j];
         }
+    }
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        acc += col[k];
         r.l[k] = (uint32_t)acc & F29::MASK;
         acc >>= 29;
     }
