@@ -130,6 +130,18 @@ def reference_binary_run(d=20):
            "timers_ms": {}}
     for m in re.finditer(r"^##(\S+) (.*?): ([0-9.e+]+) micros", r.stdout, re.M):
         res["timers_ms"]["%s %s" % (m.group(1), m.group(2))] = round(float(m.group(3)) / 1e3, 3)
+    # rc 0 says little (the reference's verifiers print nothing when a check fails): the verifier side of
+    # the same build is checked beside it -- legosnark_amd/shim/checks/pairing_check.cc runs the reference's own
+    # simple_pairing_check on true and false statements and its unchanged CPPoly::verify, deferred and call by call
+    chk = os.path.join(ROOT, "build", "reference", "pairing_check")
+    if os.path.exists(chk):
+        try:
+            c = subprocess.run([chk, "12"], env=dict(os.environ, LSA_SEED="11"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+            last = json.loads(c.stdout.strip().splitlines()[-1]) if c.stdout.strip() else {}
+            res["verifier_check"] = {"program": "build/reference/pairing_check 12", "rc": c.returncode, "failures": last.get("failures"),
+                                     "cppoly_verify": last.get("cppoly_verify"), "cppoly_verify_ms": last.get("cppoly_verify_ms")}
+        except Exception as e:                               # a broken check is reported, not hidden
+            res["verifier_check"] = {"program": "build/reference/pairing_check 12", "error": str(e)[:200]}
     for line in r.stderr.splitlines():
         if line.startswith('{"lsa_shim_stats"'):
             st = json.loads(line)["lsa_shim_stats"]
@@ -560,6 +572,9 @@ def main():
                 raise SystemExit("bench.py: a config's result check failed: %s" % [c for c in out["configs"] if "error" in c])
         if not args.no_configs and world == 1 and not strong and args.log2n == 20 and not being_profiled():
             out["unchanged_reference_binary"] = reference_binary_run()
+            vc = out["unchanged_reference_binary"].get("verifier_check")
+            if vc and (vc.get("rc") != 0 or vc.get("failures") != 0 or "error" in vc):
+                raise SystemExit("bench.py: the verifier check beside the unchanged reference binary failed: %s" % vc)
         if not args.no_cpu_baseline and world == 1 and not strong:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as o   # the checker, timed as the reported CPU baseline

@@ -575,6 +575,7 @@ class G_shim {
 public:
     F X, Y, Z;   // libff layout: Jacobian, Montgomery limbs
     using Jac = lsa::Jac<F>;
+    using scalar_field = alt_bn128_Fr;     // (libff: typedef alt_bn128_Fr scalar_field)
     G_shim() { *this = zero(); }
     G_shim(const F &x, const F &y, const F &z) : X(x), Y(y), Z(z) {}
     G_shim(const Jac &j) : X(j.X), Y(j.Y), Z(j.Z) {}
@@ -968,18 +969,67 @@ std::vector<alt_bn128_G1> lsa_scalar_mul_batch(const std::vector<alt_bn128_G1> &
     return out;
 }
 
-// fixed-base tables: the GPU builds its own table per call, so the "table" only carries
-// the base point (get_window_table + batch_exp always travel together in the reference:
-// src/utils/util.h:125-133, src/prototools/interp.h:45-58).
+// fixed-base tables.  libff: `template<typename T> using window_table = std::vector<std::vector<T>>` with
+// powers_of_g[outer][inner] = inner * 2^(outer * window) * g (get_window_table).  The GPU builds its own table inside
+// batch_exp, so get_window_table + batch_exp (which always travel together in the reference: src/utils/util.h:125-133,
+// src/prototools/interp.h:45-58) only need the base point -- but a caller that INDEXES the table must find libff's
+// entries there: the rows are materialised on first access (one lsa_g{1,2}_batch_exp over the scalars
+// inner * 2^(outer * window), rows x columns and the short last row exactly as libff lays them out) and behave like
+// the vector of vectors from then on.
 template <typename T>
 struct window_table {
+    using row_type = std::vector<T>;
+    using value_type = row_type;
     T base;
     size_t scalar_size = 0, window = 0;
+
+    window_table() = default;
+    window_table(const T &g, size_t bits, size_t w) : base(g), scalar_size(bits), window(w) {}
+    size_t size() const { return window ? (scalar_size + window - 1) / window : 0; }
+    bool empty() const { return size() == 0; }
+    const row_type &operator[](size_t outer) const { return rows()[outer]; }
+    const row_type &at(size_t outer) const { return rows().at(outer); }
+    typename std::vector<row_type>::const_iterator begin() const { return rows().begin(); }
+    typename std::vector<row_type>::const_iterator end() const { return rows().end(); }
+    const std::vector<row_type> &rows() const {
+        if (!built_) {
+            using FieldT = typename T::scalar_field;
+            const size_t outerc = size(), in_window = size_t(1) << window;
+            const size_t last_in_window = outerc ? size_t(1) << (scalar_size - (outerc - 1) * window) : 0;
+            std::vector<FieldT> sc;
+            sc.reserve(outerc * in_window);
+            FieldT outer_step = FieldT::one();                       // 2^(outer * window)
+            FieldT two_w = FieldT::one();
+            for (size_t b = 0; b < window; b++) two_w = two_w + two_w;
+            for (size_t outer = 0; outer < outerc; outer++) {
+                const size_t cur = outer == outerc - 1 ? last_in_window : in_window;
+                FieldT v = FieldT::zero();
+                for (size_t inner = 0; inner < in_window; inner++) {
+                    sc.push_back(inner < cur ? v : FieldT::zero());  // libff leaves the tail of the last row at T::zero()
+                    v = v + outer_step;
+                }
+                outer_step = outer_step * two_w;
+            }
+            std::vector<T> flat(sc.size());
+            if (!sc.empty()) {
+                if (detail::group_id<T>::value == 1) lsa_require(lsa_g1_batch_exp(&base, sc.data(), sc.size(), flat.data(), 0), "get_window_table<G1>");
+                else lsa_require(lsa_g2_batch_exp(&base, sc.data(), sc.size(), flat.data(), 0), "get_window_table<G2>");
+            }
+            rows_.assign(outerc, row_type());
+            for (size_t outer = 0; outer < outerc; outer++) rows_[outer].assign(flat.begin() + outer * in_window, flat.begin() + (outer + 1) * in_window);
+            built_ = true;
+        }
+        return rows_;
+    }
+
+  private:
+    mutable std::vector<row_type> rows_;
+    mutable bool built_ = false;
 };
 template <typename T>
 size_t get_exp_window_size(const size_t num_scalars) { return num_scalars >= (size_t(1) << 16) ? 12 : 8; }
 template <typename T>
-window_table<T> get_window_table(const size_t scalar_size, const size_t window, const T &g) { return window_table<T>{g, scalar_size, window}; }
+window_table<T> get_window_table(const size_t scalar_size, const size_t window, const T &g) { return window_table<T>(g, scalar_size, window); }
 template <typename T, typename FieldT>
 std::vector<T> batch_exp(const size_t scalar_size, const size_t window, const window_table<T> &table, const std::vector<FieldT> &v) {
     (void)scalar_size; (void)window;

@@ -43,3 +43,29 @@ def test_a_failed_multi_rank_run_is_a_failed_bench():
     r = run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-pmc", "--no-cpu-baseline", "--no-host-path", "--no-configs"])
     assert r.returncode != 0
     assert '"metric"' not in r.stdout
+
+
+def test_config_4_launch_and_its_shards():
+    """BASELINE.json configs[3]: ONE CPlink-prover MSM over 2^24 + 2 pairs on the 8 GPUs of a node.  The launcher hands
+    every rank `--total-log2n 24`, and lsa_shard_range (libff's chunk rule, /root/reference/src/utils/globl.h:67-77:
+    n / chunks each, the last takes the remainder) tiles [0, 2^24 + 2) exactly, in rank order, like the Python mirror."""
+    r = run(["--gpus", "8", "--total-log2n", "24", "--dry-launch"])
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["launch"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    tail = cmd[cmd.index(BENCH) + 1:]
+    assert tail == ["--gpus", "8", "--total-log2n", "24"]
+    import legosnark_amd as lsa
+    from legosnark_amd import sharded
+    n = (1 << 24) + 2
+    for world in (8, 2, 1, 7):
+        edges = [lsa.shard_range(n, world, rank) for rank in range(world)]
+        assert edges[0][0] == 0 and edges[-1][1] == n
+        for rank in range(world):
+            assert edges[rank] == sharded.shard_range(n, world, rank)
+            if rank:
+                assert edges[rank][0] == edges[rank - 1][1]
+            if rank < world - 1:
+                assert edges[rank][1] - edges[rank][0] == n // world
+    # fewer pairs than ranks: libff runs the inner loop unchunked -- rank 0 owns everything
+    assert [lsa.shard_range(5, 8, rank) for rank in range(8)] == [(0, 5)] + [(5, 5)] * 7

@@ -97,7 +97,7 @@ import legosnark_amd as lsa
 import oracle_lib as o
 assert lsa.LIB_PATH.endswith("liblegosnark_amd_loopback.so")
 lsa.init(0)
-W = 3
+W = %(world)d
 lsa.comm_init(0, 1, lsa.comm_unique_id())
 assert lsa.comm_world() == W
 n = 5000
@@ -119,8 +119,19 @@ assert o.g1_canonical_affine(lsa.msm_sharded("g1", bases, sc)) == want
 q = o.arith_bases("g2", 3, 11, 4)
 p = o.arith_bases("g1", 9, 2, 4)
 e1 = lsa.pairing_product(p, q)
-e3 = o.fq12_mul(o.fq12_mul(e1, e1), e1)
-assert np.array_equal(lsa.pairing_product_sharded(p, q), e3)
+eW = e1
+for _ in range(W - 1):
+    eW = o.fq12_mul(eW, e1)
+assert np.array_equal(lsa.pairing_product_sharded(p, q), eW)
+# G2: the 192-byte partials through the same exchange step
+b2 = o.arith_bases("g2", 7, 3, 700)
+s2, _ = o.random_scalars(700, seed=5)
+one2 = o.multi_exp("g2", b2, s2, mode="mixed")
+want2 = o.g2_canonical_affine(o.g2_mul(one2, o.fr_mont(W)))
+assert o.g2_canonical_affine(lsa.msm_sharded("g2", b2, s2)) == want2
+B2 = lsa.Bases("g2", b2)
+assert o.g2_canonical_affine(B2.msm_sharded(torch.from_numpy(s2.view(np.int64)).to("cuda:0"))) == want2
+B2.close()
 B.close()
 lsa.comm_destroy()
 print("LOOPBACK OK")
@@ -128,7 +139,8 @@ print("LOOPBACK OK")
 
 
 @pytest.mark.gpu
-def test_multi_rank_step_on_one_gpu_with_loopback_peers():
+@pytest.mark.parametrize("world", [3, 8])
+def test_multi_rank_step_on_one_gpu_with_loopback_peers(world):
     """The TEST build of the library (liblegosnark_amd_loopback.so: comm.hip compiled with LSA_COMM_TEST_LOOPBACK;
     the product library has no such hook) with LSA_COMM_LOOPBACK=W: a one-rank communicator that behaves as rank 0
     of W ranks whose peers contribute this rank's own partial (W device copies instead of ncclAllGather).  Runs the
@@ -137,8 +149,8 @@ def test_multi_rank_step_on_one_gpu_with_loopback_peers():
     the local ones.  In its own process: the variant is chosen when the library is loaded."""
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LSA_LIB_VARIANT="loopback", LSA_COMM_LOOPBACK="3")
-    body = _LOOPBACK_BODY % {"tests": os.path.join(root, "tests"), "root": root}
+    env = dict(os.environ, LSA_LIB_VARIANT="loopback", LSA_COMM_LOOPBACK=str(world))     # 8: BASELINE.json configs[3]'s node
+    body = _LOOPBACK_BODY % {"tests": os.path.join(root, "tests"), "root": root, "world": world}
     r = subprocess.run([sys.executable, "-c", body], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "LOOPBACK OK" in r.stdout, r.stdout[-3000:]
 

@@ -83,6 +83,15 @@ def test_verifier_side_through_the_shim_deferred_equals_call_by_call():
     assert outs[0]["cppoly_verify"] == outs[1]["cppoly_verify"]
 
 
+def test_libff_surface_the_examples_do_not_reach():
+    """legosnark_amd/shim/checks/shim_check.cc: libff's window_table indexed like the vector of vectors it is upstream
+    (rows, columns, the short last row, iteration, batch_exp over the same object), and libfqfft's
+    get_evaluation_domain refusing a size that is not a power of two with a message instead of rounding it."""
+    r = run("shim_check")
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "shim_check: 0 failure(s)" in r.stdout and "FAIL" not in r.stdout
+
+
 def test_cplink_built_by_the_references_own_cmake_verifies():
     """The reference's unchanged CMakeLists.txt with depends/libsnark and depends/fmt replaced by
     legosnark_amd/shim/cmake (targets snark, ff, fmt::fmt-header-only)."""
