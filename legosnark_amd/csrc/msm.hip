@@ -1351,7 +1351,7 @@ static Workspace g_prep_ws;   // prepare_bases staging
 // a front, so several run at once.  Each tail computes its result into the slot and publishes
 // it to the caller's buffer with a 96/192-byte copy that waits for the previous call's copy:
 // results appear in call order even when a later tail finishes first.
-static constexpr int NTAIL = 4;
+static constexpr int NTAIL = 8;
 struct TailBuf {
     Workspace ws;
     hipEvent_t done = nullptr;     // recorded after the slot's result has been published

@@ -50,11 +50,12 @@ namespace lsa {
 static constexpr uint32_t CMP_TILE = 256;          // scalars per sort workgroup
 static constexpr uint32_t CMP_MAXB = 1024;         // buckets: 2^(c-1), c = 10 (11 for tables of 6*2^20 points and more)
 static constexpr uint32_t CMP_MAXWIN = 26;
-static constexpr uint32_t CMP_MAXTILES = 256;      // n <= 65536
+static constexpr uint32_t CMP_MAXTILES = 1024;     // n <= 262144
+static constexpr uint32_t CMP_TILES_PER_LANE = CMP_MAXTILES / 64;
 static constexpr uint32_t CMP_BITS_BLOCK = 512;    // items per workgroup of k_cmp_bits
 
 // ------------------------------------------------------------------------------------ 1: tile sort
-// entry = index of the scalar inside the call (16 bits) | window << 16 | sign << 31
+// entry = index of the scalar inside the call (20 bits) | window << 20 | sign << 31
 __global__ __launch_bounds__(CMP_TILE) void k_cmp_sort(const Fr *__restrict__ scalars, uint32_t n, WidePlan pl, uint32_t B, uint32_t ent_stride,
                                                        uint32_t *__restrict__ ent, uint16_t *__restrict__ toff, uint32_t *__restrict__ ghist) {
     __shared__ uint32_t cnt[CMP_MAXB], off[CMP_MAXB + 1], wsum[4];
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(CMP_TILE) void k_cmp_sort(const Fr *__restrict__ sc
     __syncthreads();
     for (uint32_t k = 0; k < pl.nwin; k++) {
         const uint32_t c = code[k * CMP_TILE + tid];
-        if (c != 0xffffffffu) sorted[off[c & 0x7fffu] + (c >> 16)] = i | (k << 16) | ((c & 0x8000u) << 16);
+        if (c != 0xffffffffu) sorted[off[c & 0x7fffu] + (c >> 16)] = i | (k << 20) | ((c & 0x8000u) << 16);
     }
     __syncthreads();
     const uint32_t total = off[B];
@@ -157,9 +158,14 @@ __global__ __launch_bounds__(256) void k_cmp_accumulate(const typename C::Base *
     using A = typename C::Acc;
     constexpr uint32_t AW = sizeof(A) / 4, PITCH = AW + 1;          // (+1 word: the 64 lanes' rows start in different banks)
     __shared__ uint32_t istart[CMP_MAXB + 1], gcnt[CMP_MAXB], wsum[4];
-    __shared__ uint32_t tpre[4][CMP_MAXTILES + 1];                  // per wavefront: exclusive prefix of its bucket's run lengths over the tiles
-    __shared__ uint16_t tstart[4][CMP_MAXTILES];                    // ... and where the run starts inside each tile
-    __shared__ uint32_t tree[4][64 * PITCH];
+    // per wavefront, one region used twice: first the exclusive prefix of its bucket's run lengths over the tiles (tpre) and
+    // where the run starts inside each tile (tstart), then -- all entries fetched -- the 64 lane sums of the tree (a
+    // wavefront's LDS operations execute in order, and the region is its own)
+    constexpr uint32_t WREG = (64 * PITCH > CMP_MAXTILES + 1 + CMP_MAXTILES / 2 ? 64 * PITCH : CMP_MAXTILES + 1 + CMP_MAXTILES / 2);
+    __shared__ uint32_t wave_region[4][WREG];
+#define tpre_(w) (wave_region[w])
+#define tstart_(w) (reinterpret_cast<uint16_t *>(wave_region[w] + CMP_MAXTILES + 1))
+#define tree_(w) (wave_region[w])
     const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     {
         const uint32_t per = B / 256, b0 = tid * per;
@@ -196,18 +202,21 @@ __global__ __launch_bounds__(256) void k_cmp_accumulate(const typename C::Base *
         b = lo;
         e0 = (item - istart[b]) * chunk;
         e1 = gcnt[b] < e0 + chunk ? gcnt[b] : e0 + chunk;
-        // run lengths of bucket b per tile: lane owns tiles [4 * lane, 4 * lane + 4)
-        uint32_t len[4], st[4], sum = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {
-            const uint32_t t = 4 * lane + q;
-            len[q] = 0; st[q] = 0;
+        // run lengths of bucket b per tile: lane owns the tiles [TPL * lane, TPL * lane + TPL)
+        constexpr uint32_t TPL = CMP_TILES_PER_LANE;
+        uint32_t sum = 0;
+#pragma unroll 4
+        for (uint32_t q = 0; q < TPL; q++) {
+            const uint32_t t = TPL * lane + q;
+            uint32_t st = 0, len = 0;
             if (t < ntiles) {
                 const uint16_t *o = toff + (size_t)t * (B + 1) + b;
-                st[q] = o[0];
-                len[q] = (uint32_t)o[1] - st[q];
+                st = o[0];
+                len = (uint32_t)o[1] - st;
             }
-            sum += len[q];
+            tstart_(wv)[t] = (uint16_t)st;
+            tpre_(wv)[t] = len;                        // (turned into the exclusive prefix below)
+            sum += len;
         }
         uint32_t incl = sum;
 #pragma unroll
@@ -216,13 +225,12 @@ __global__ __launch_bounds__(256) void k_cmp_accumulate(const typename C::Base *
             if ((int)lane >= d) incl += u;
         }
         uint32_t run = incl - sum;
-#pragma unroll
-        for (uint32_t q = 0; q < 4; q++) {
-            tpre[wv][4 * lane + q] = run;
-            tstart[wv][4 * lane + q] = (uint16_t)st[q];
-            run += len[q];
+        for (uint32_t q = 0; q < TPL; q++) {
+            const uint32_t len = tpre_(wv)[TPL * lane + q];
+            tpre_(wv)[TPL * lane + q] = run;
+            run += len;
         }
-        if (lane == 63) tpre[wv][CMP_MAXTILES] = run;
+        if (lane == 63) tpre_(wv)[CMP_MAXTILES] = run;
     }
     __syncthreads();
     A acc = C::inf();
@@ -230,12 +238,12 @@ __global__ __launch_bounds__(256) void k_cmp_accumulate(const typename C::Base *
         // entry e of the bucket's list -> (tile t with tpre[t] <= e < tpre[t + 1]) -> the tile's sorted run
         auto fetch_entry = [&](uint32_t e) {
             uint32_t lo = 0, hi = CMP_MAXTILES;                     // the last t with tpre[t] <= e (empty runs repeat a value: the last one wins)
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tpre[wv][mid] <= e) lo = mid; else hi = mid; }
-            return ent[(size_t)lo * ent_stride + tstart[wv][lo] + (e - tpre[wv][lo])];
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tpre_(wv)[mid] <= e) lo = mid; else hi = mid; }
+            return ent[(size_t)lo * ent_stride + tstart_(wv)[lo] + (e - tpre_(wv)[lo])];
         };
         // one mixed-addition site; the next entry's two dependent loads (entry, then its 64-byte point) are in flight
         // while the current addition runs
-        auto base_of = [&](uint32_t v) { return table[(size_t)((v >> 16) & 31u) * win_stride + (v & 0xffffu)]; };
+        auto base_of = [&](uint32_t v) { return table[(size_t)((v >> 20) & 31u) * win_stride + (v & 0xfffffu)]; };
         uint32_t e = e0 + lane;
         if (e < e1) {
             uint32_t v = fetch_entry(e);
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(256) void k_cmp_accumulate(const typename C::Base *
                 cur = nxt;
             }
         }
-        uint32_t *row = &tree[wv][lane * PITCH];
+        uint32_t *row = &tree_(wv)[lane * PITCH];
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&acc);
 #pragma unroll
         for (uint32_t w = 0; w < AW; w++) row[w] = src[w];
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(256) void k_cmp_accumulate(const typename C::Base *
     for (uint32_t j = 0; j < 4; j++) {
         const uint32_t l = qd + 16 * j;                             // strided: with few sums the later trips add nothing anywhere
         A o = A::inf();
-        if (l < used) o = cmp_load(reinterpret_cast<const A *>(&tree[wv][l * PITCH]));
+        if (l < used) o = cmp_load(reinterpret_cast<const A *>(&tree_(wv)[l * PITCH]));
         a = quad_add(a, o, sub);
     }
     a = cmp_quad_tree(a, lane);
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(64) void k_cmp_final(const typename C::Acc *__restr
 
 // ------------------------------------------------------------------------------------ host
 static size_t cmp_max() {
-    static const size_t v = getenv("LSA_COMPACT_MAX") ? (size_t)atoll(getenv("LSA_COMPACT_MAX")) : (size_t)1 << 16;   // 2^15: 0.31 ms against 0.45 on the general pipeline, 2^16: 0.44 / 0.67
+    static const size_t v = getenv("LSA_COMPACT_MAX") ? (size_t)atoll(getenv("LSA_COMPACT_MAX")) : (size_t)1 << 17;   // 2^15: 0.31 ms against 0.45 on the general pipeline, 2^16: 0.44 / 0.67
     return v;
 }
 size_t msm_compact_max() { return cmp_max() < CMP_TILE * CMP_MAXTILES ? cmp_max() : CMP_TILE * CMP_MAXTILES; }

@@ -200,3 +200,30 @@ def test_prefix_table_behind_the_host_entry_point(lsa):
     got = canon(lsa.msm("g1", bases2[:512], sc[:512]))
     assert got == canon(o.multi_exp("g1", bases2[:512], sc[:512], mode="mixed"))
     lsa.crs_cache_clear()
+
+
+def test_compact_at_its_upper_end_over_a_stepwise_table(lsa):
+    """n = 2^17 (512 tiles, 52 mixed additions per lane) and sizes around it on a handle of 2^17 + 300 points whose copies
+    come from the 25-step builder (more than 2^16 points): uniform scalars, u[i] = i, one repeated scalar; checked by
+    the known-discrete-log identity."""
+    n = (1 << 17) + 300
+    a, b = 0xABCDEF << 70 | 3, 0x13579B << 33 | 1
+    bases = o.arith_bases("g1", a, b, n)
+    lsa.set_table_threshold(1)
+    try:
+        B = lsa.Bases("g1", bases)
+        if not B.has_table():
+            pytest.skip("tables disabled")
+        g = o.generator("g1")
+        sc, ints = o.random_scalars(n, seed=17)
+        d_s = dev(sc)
+        for m in ((1 << 17), (1 << 17) - 1, 70000, (1 << 16) + 1):
+            k = sum(s * (a + i * b) for i, s in enumerate(ints[:m])) % R
+            assert canon(B.msm(d_s, n=m)) == canon(o.g1_mul(g, o.fr_mont(k))), m
+        m = 1 << 17
+        for name, vals in (("i", list(range(m))), ("repeated", [0x1234567890ABCDEF % R] * m)):
+            k = sum(s * (a + i * b) for i, s in enumerate(vals)) % R
+            assert canon(B.msm(dev(o.fr_mont_array(vals)), n=m)) == canon(o.g1_mul(g, o.fr_mont(k))), name
+        B.close()
+    finally:
+        lsa.set_table_threshold(0)
