@@ -103,7 +103,9 @@ int lsa_crs_cache_stats(uint64_t *hits, uint64_t *misses, uint64_t *resident_byt
 typedef struct {
     size_t n;
     int cache_hit;               /* 1: bases were resident */
-    int table;                   /* 1: the call used pre-shifted window copies */
+    int table;                   /* 1: the call used the entry's pre-shifted window copies; 2: the copies of the entry's first
+                                  * points only (a G1 entry without full copies serving a request of <= 2^16 pairs: built in one
+                                  * kernel on the first such request, LSA_CRS_PREFIX_TABLE) */
     double h2d_scalars_ms;       /* pageable host -> device copy of n x 32 B */
     double fingerprint_wait_ms;  /* what was left of the fingerprint pass after that copy */
     double bases_prepare_ms;     /* miss: upload + normalise (+ table on first re-use); hit: lookup */
@@ -117,7 +119,11 @@ int lsa_msm_host_stats(lsa_host_stats *out);
 /* The CRS vectors passed to multiExpMA are fixed per key (crs->P at
  * src/gadgets/subspace.cc:82, g1s/g2s at src/prototools/commit.h:154-155), so they are
  * uploaded once, batch-normalised to affine in HBM (64 B / 128 B per point) and reused.
- * `bases_jac` may be a host pointer or (src_on_device != 0) a device pointer. */
+ * `bases_jac` may be a host pointer or (src_on_device != 0) a device pointer.
+ * Handles of >= 2^19 points (LSA_PRECOMPUTE_MIN, lsa_msm_set_table_threshold) also keep 26 (24) pre-shifted copies of
+ * every point (lsa_bases_has_table); so do G1 handles of up to 2^16 points -- their copies come from ONE kernel, ~1.2 ms --
+ * unless a threshold was set explicitly.  G1 MSMs of up to 2^17 pairs over such a handle take a four-launch pipeline
+ * (csrc/msm_compact.hip: 0.12-0.25 ms blocking for n <= 2^14). */
 typedef struct lsa_bases lsa_bases;
 int lsa_g1_bases_create(const void *bases_jac, size_t n, int src_on_device, lsa_bases **out);
 int lsa_g2_bases_create(const void *bases_jac, size_t n, int src_on_device, lsa_bases **out);
@@ -144,7 +150,8 @@ const void *lsa_bases_device_ptr(const lsa_bases *b);
 
 /* MSM over bases[first .. first+n) with scalars already resident in HBM
  * (d_scalars_mont: device pointer, n x 32 B, Montgomery Fr).  out_jac is a HOST buffer
- * (96 B / 192 B); the call returns after the result has landed there. */
+ * (96 B / 192 B); the call returns after the result has landed there (the whole call runs on lsa_stream() and its last
+ * kernel writes into pinned host memory: no cross-stream hand-over, no copy command behind the kernels). */
 int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars_mont, size_t n, void *out_jac);
 /* Same, asynchronous: result is written to the DEVICE buffer d_out_jac; it is ordered on
  * lsa_stream() after lsa_stream_join() (or any synchronous call). */

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     import legosnark_amd
     if not os.path.exists(legosnark_amd.LIB_PATH):
         legosnark_amd.build()
-    lib = ctypes.CDLL(legosnark_amd.LIB_PATH)
+    lib = legosnark_amd.lib()          # (loads torch first when it is installed: one RCCL build per process, see lib())
     missing = [s for s in declared_symbols() if not hasattr(lib, s)]
     assert not missing, missing
 
