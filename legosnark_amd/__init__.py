@@ -734,6 +734,14 @@ def pairing_terms(g1, offsets, g2=None, tables=None, index=None, flags=None, fin
     return out
 
 
+def g2_tables_prefetch(g2):
+    """Promise the line tables of these G2 points to the device's cache (built asynchronously, five at a time or when the
+    next Miller call arrives): what the shim's precompute_G2 does."""
+    g2 = np.ascontiguousarray(g2, dtype=np.uint64).reshape(-1, 24)
+    lib().lsa_g2_tables_prefetch.argtypes = [C.c_void_p, C.c_size_t]
+    _check(lib().lsa_g2_tables_prefetch(_host_ptr(g2), len(g2)))
+
+
 def g2_table_cache(max_tables):
     """Capacity of the device's G2 line-table cache (0: off; clears it)."""
     _check(lib().lsa_g2_table_cache(int(max_tables)))

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(64) void k_miller_g12(const Jac<Fq> *__restrict__ g
 }
 
 // out[b] = prod in[8b .. 8b+7], one wavefront per group of 8 (W12 products)
-__global__ __launch_bounds__(128) void k_fq12_prod8_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
+__global__ __launch_bounds__(192) void k_fq12_prod8_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
     __shared__ Fq2S lds[W12_LDS_FQ2];
     const size_t lo = (size_t)blockIdx.x * 8;
     if (lo >= n) return;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(128) void k_fq12_prod8_wave(const Fq12 *__restrict_
 // out[j] = prod in[off[j] .. off[j+1]) (1 for an empty segment), one workgroup per segment: the
 // verifiers' many short products (CPPoly::verify multiplies 2-3 Miller values per final
 // exponentiation, /root/reference/src/gadgets/poly.h:105-122)
-__global__ __launch_bounds__(128) void k_fq12_prod_seg_wave(const Fq12 *__restrict__ in, const uint64_t *__restrict__ off, Fq12 *__restrict__ out) {
+__global__ __launch_bounds__(192) void k_fq12_prod_seg_wave(const Fq12 *__restrict__ in, const uint64_t *__restrict__ off, Fq12 *__restrict__ out) {
     __shared__ Fq2S lds[W12_LDS_FQ2];
     const size_t lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
     const unsigned lane = threadIdx.x;
@@ -453,7 +453,7 @@ int fq12_product_device(void *d_buf, void *d_scratch, size_t n, void **result, h
     Fq12 *a = (Fq12 *)d_buf, *b = (Fq12 *)d_scratch;
     while (n > 1) {
         size_t m = (n + 7) / 8;
-        if (m < 16384) hipLaunchKernelGGL(k_fq12_prod8_wave, dim3((unsigned)m), dim3(128), 0, st, a, n, b);
+        if (m < 16384) hipLaunchKernelGGL(k_fq12_prod8_wave, dim3((unsigned)m), dim3(192), 0, st, a, n, b);      // three wavefronts: the one-phase row product (w12.h)
         else hipLaunchKernelGGL(k_fq12_prod8, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, a, n, b);
         Fq12 *t = a; a = b; b = t;
         n = m;
@@ -466,7 +466,7 @@ int fq12_product_device(void *d_buf, void *d_scratch, size_t n, void **result, h
 // d_out[j] = prod d_in[off[j] .. off[j+1]), j < nseg; d_off: nseg + 1 offsets on the device
 int fq12_segment_products_device(const void *d_in, const uint64_t *d_off, size_t nseg, void *d_out, hipStream_t st) {
     if (nseg == 0) return LSA_OK;
-    hipLaunchKernelGGL(k_fq12_prod_seg_wave, dim3((unsigned)nseg), dim3(128), 0, st, (const Fq12 *)d_in, d_off, (Fq12 *)d_out);
+    hipLaunchKernelGGL(k_fq12_prod_seg_wave, dim3((unsigned)nseg), dim3(192), 0, st, (const Fq12 *)d_in, d_off, (Fq12 *)d_out);
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }

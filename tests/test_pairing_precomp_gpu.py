@@ -175,3 +175,38 @@ def test_large_batch_bypasses_the_cache_and_shares_accumulators(lsa):
         lsa.pairing_set_chunk(0)
     assert np.array_equal(got, want)
     assert np.array_equal(lsa.pairing_product_segments(ps, qs, off, final_exp=False), want)
+
+
+def test_a_failed_call_leaves_no_half_built_table_behind(lsa):
+    """A call that names blobs 0 .. k-1 and then a term with neither a table nor a point fails with LSA_ERR_INVALID --
+    and must not leave the keys of the blobs it had already looked at pointing at unwritten tables: the next valid call
+    with the same blobs gives the oracle's Miller values, and the cache holds no more tables than that call built.
+    Then: a prefetch that promises more tables than the cache can pin is still served correctly."""
+    import legosnark_amd
+    ps = o.arith_bases("g1", 31, 5, 5)
+    qs = _g2_points(5, 404)
+    want = o.miller_loop_batch(ps, qs)
+    try:
+        lsa.g2_table_cache(64)
+        tabs = lsa.g2_precompute(qs)
+        off = np.arange(6, dtype=np.uint64)
+        with pytest.raises(legosnark_amd.LsaError):
+            lsa.pairing_terms(ps, off, g2=None, tables=tabs, index=[0, 1, 2, -1, 4], final_exp=False)      # term 3: nothing
+        assert lsa.g2_table_cache_stats()["resident"] == 0                    # validated before the cache was touched
+        got = lsa.pairing_terms(ps, off, tables=tabs, index=[0, 1, 2, 3, 4], final_exp=False)
+        assert np.array_equal(got, want)
+        assert lsa.g2_table_cache_stats()["resident"] == 5
+        # points: a second, valid call over the same Q after an invalid one
+        lsa.g2_table_cache(64)
+        with pytest.raises(legosnark_amd.LsaError):
+            lsa.pairing_terms(ps, np.array([0, 3, 2, 5], dtype=np.uint64), g2=qs, final_exp=False)       # offsets decrease
+        assert np.array_equal(lsa.miller_loop(ps, qs), want)
+        # a tiny cache and prefetches one by one: promised slots are pinned until built, never handed to another point
+        lsa.g2_table_cache(8)
+        more = o.arith_bases("g2", 777, 3, 12)
+        pm = o.arith_bases("g1", 8, 9, 12)
+        for q in more:
+            lsa.g2_tables_prefetch(q.reshape(1, 24))
+        assert np.array_equal(lsa.miller_loop(pm, more), o.miller_loop_batch(pm, more))
+    finally:
+        lsa.g2_table_cache(4096)
