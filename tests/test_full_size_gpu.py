@@ -14,6 +14,8 @@ on the host by the oracle's Fr arithmetic) or against oracle samples -- none is 
         one GPU, and the same input through the two-rank sharded path at 2^23 per rank
         (configs[3] minus the other seven GPUs; src/gadgets/subspace.cc:78-85)
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -204,6 +206,12 @@ def test_cplink_prover_shape_2pow24_and_two_rank_split(lsa):
     lo1, hi1 = sharded.shard_range(n, 2, 1)
     assert (lo0, hi0, lo1, hi1) == (0, n // 2, n // 2, n) and hi0 - lo0 >= 1 << 23
     peer = B.msm(d_w[lo1:hi1], n=hi1 - lo1, first=lo1)
+    # short MSMs over the same handle: 24 copies and 11-bit digits here (tables of 6 * 2^20 points and more: 1024 buckets,
+    # eleven weight bits in the compact pipeline of msm_compact.hip), prefixes and an offset range
+    if B.has_table():
+        for first, m in ((0, 1), (0, 300), (0, 4096), (0, 1 << 16), (12345, 5000)):
+            got_s = B.msm(d_w[first:first + m], n=m, first=first)
+            assert canon("g1", got_s) == k_times_gen("g1", o.fr_dot(w[first:first + m], x[first:first + m])), (first, m)
     B.close()
     d_peer = to_dev(peer)
 
@@ -217,4 +225,10 @@ def test_cplink_prover_shape_2pow24_and_two_rank_split(lsa):
     job = sharded.make_gpu_sharded(lsa, "g1", B0, 2, 0, dist=FakeDist())
     res = job.run(d_w[lo0:hi0])
     assert canon("g1", job.result_host(res)) == want
+    # (the handle of 2^23 + 1 points carries 24 copies -- the full one above is too large for 30-bit entries)
+    assert B0.has_table() == (os.environ.get("LSA_PRECOMPUTE", "1")[:1] != "0")
+    if B0.has_table():
+        for first, m in ((0, 1), (0, 300), (0, 4096), (0, 1 << 16), (12345, 5000)):
+            got_s = B0.msm(d_w[first:first + m], n=m, first=first)
+            assert canon("g1", got_s) == k_times_gen("g1", o.fr_dot(w[first:first + m], x[first:first + m])), (first, m)
     B0.close()
