@@ -1301,6 +1301,86 @@ __device__ __forceinline__ void emit_body(const A *__restrict__ window_sums, J *
 __global__ __launch_bounds__(64) void k_emit_g1(const XYZZ29 *__restrict__ window_sums, Jac<Fq> *__restrict__ out) { emit_body(window_sums, out); }
 __global__ __launch_bounds__(64) void k_emit_g2(const XYZZ29x2 *__restrict__ window_sums, Jac<Fq2> *__restrict__ out) { emit_body(window_sums, out); }
 
+// ------------------------------------------------------------------------------------
+// The upper reduction levels as bit trees (wide path, one bucket space).  After the first k_reduce2 level m = 4096
+// (ACC, RUN) pairs are left, pair t covering 2^lm buckets:  total = sum_t ACC_t + 2^lm * sum_t t * RUN_t.  Three more
+// 16-ary levels are three dependent chains of 9 + log_mult quad operations each (53 + 61 + 67 us of a lone call's
+// 1.55 ms); written as  sum_t t * RUN_t = sum_j 2^j * T_j,  T_j = sum of the RUN_t whose index has bit j,  the twelve
+// T_j and the sum of the ACC_t are thirteen INDEPENDENT tree sums (k_reduce_bits_a: eight wavefronts per 512 pairs,
+// 7 + 3 quad additions), each weighted by its own lm + j doublings (k_reduce_bits_b: one wavefront per tree) and added
+// up by one wavefront that also converts the result (k_reduce_bits_c): ~75 us.  Same quad arithmetic (quad29.h); 13 x
+// the reads of the level it replaces, but that level is 4096 pairs: 832 short wavefronts against the 4096 of the level
+// before it.
+// ------------------------------------------------------------------------------------
+template <class A>
+__device__ __forceinline__ A bits_quad_tree(A a, unsigned lane, unsigned first_d) {
+    const unsigned sub = lane & 3, qd = lane >> 2;
+#pragma unroll 1
+    for (unsigned d = first_d; d >= 1; d >>= 1) {
+        A o = shfl_down_acc(a, 4 * d);
+        if (qd + d >= 16) o = A::inf();
+        a = quad_add(a, o, sub);
+    }
+    return a;
+}
+template <class C>
+__global__ __launch_bounds__(512) void k_reduce_bits_a(const typename C::Acc *__restrict__ pairs, uint32_t m, uint32_t nbits, uint32_t G,
+                                                       typename C::Acc *__restrict__ part) {
+    using A = typename C::Acc;
+    constexpr uint32_t AW = sizeof(A) / 4;
+    __shared__ uint32_t wave_sum[8][AW];
+    const uint32_t bit = blockIdx.x, g = blockIdx.y;
+    const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, sub = lane & 3, qd = lane >> 2;
+    A a = A::inf();
+#pragma unroll 1
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t t = g * 512 + wv * 64 + qd + 16 * j;
+        A o = A::inf();
+        if (t < m) {
+            if (bit == nbits) o = pairs[2 * (size_t)t];                              // the ACC tree
+            else if ((t >> bit) & 1u) o = pairs[2 * (size_t)t + 1];                  // RUN_t into T_bit
+        }
+        a = quad_add(a, o, sub);
+    }
+    a = bits_quad_tree(a, lane, 8);
+    if (lane == 0) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&a);
+#pragma unroll
+        for (uint32_t w = 0; w < AW; w++) wave_sum[wv][w] = src[w];
+    }
+    __syncthreads();
+    if (wv != 0) return;
+    a = A::inf();
+    if (qd < 8) a = *reinterpret_cast<const A *>(&wave_sum[qd][0]);
+    a = bits_quad_tree(a, lane, 4);
+    if (lane == 0) part[bit * G + g] = a;
+}
+// one wavefront per tree: the G <= 16 partials of tree `bit`, then its weight 2^(lm + bit) (the ACC tree: none)
+template <class C>
+__global__ __launch_bounds__(64) void k_reduce_bits_b(const typename C::Acc *__restrict__ part, uint32_t nbits, uint32_t G, uint32_t lm,
+                                                      typename C::Acc *__restrict__ weighted) {
+    using A = typename C::Acc;
+    const uint32_t bit = blockIdx.x;
+    const unsigned lane = threadIdx.x, sub = lane & 3, qd = lane >> 2;
+    A a = A::inf();
+    if (qd < G) a = part[bit * G + qd];
+    a = bits_quad_tree(a, lane, 8);
+    const uint32_t dbl = bit == nbits ? 0u : lm + bit;
+#pragma unroll 1
+    for (uint32_t i = 0; i < dbl; i++) a = quad_dbl(a, sub);
+    if (lane == 0) weighted[bit] = a;
+}
+// the sum of the nbits + 1 <= 16 weighted trees, as libff's Jacobian point
+template <class C>
+__global__ __launch_bounds__(64) void k_reduce_bits_c(const typename C::Acc *__restrict__ weighted, uint32_t count, Jac<typename C::Field> *__restrict__ out) {
+    using A = typename C::Acc;
+    const unsigned lane = threadIdx.x, qd = lane >> 2;
+    A a = A::inf();
+    if (qd < count) a = weighted[qd];
+    a = bits_quad_tree(a, lane, 8);
+    if (lane == 0) *out = C::to_jac(a);
+}
+
 // publishes a slot's result(s) into the caller's buffer (a 96/192-byte hipMemcpyAsync costs ~30 us
 // as a runtime copy kernel; this is one small workgroup)
 __global__ __launch_bounds__(256) void k_publish(const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, unsigned words) {
@@ -1351,7 +1431,7 @@ static Workspace g_prep_ws;   // prepare_bases staging
 // a front, so several run at once.  Each tail computes its result into the slot and publishes
 // it to the caller's buffer with a 96/192-byte copy that waits for the previous call's copy:
 // results appear in call order even when a later tail finishes first.
-static constexpr int NTAIL = 8;
+static constexpr int NTAIL = 8;      // slots that exist; tail_slots() of them are used (LSA_TAIL_SLOTS)
 struct TailBuf {
     Workspace ws;
     hipEvent_t done = nullptr;     // recorded after the slot's result has been published
@@ -1364,6 +1444,14 @@ struct TailBuf {
 };
 static TailBuf g_tail[NTAIL];
 static unsigned g_slot = 0;
+static unsigned tail_slots() {
+    static const unsigned v = [] {
+        const char *e = getenv("LSA_TAIL_SLOTS");
+        const int want = e ? atoi(e) : NTAIL;
+        return (unsigned)(want < 2 ? 2 : (want > NTAIL ? NTAIL : want));
+    }();
+    return v;
+}
 static int g_overlap = -1;
 
 // (Measured and rejected: keeping the tail of call i back until call i+1 has issued its sort, so
@@ -1527,7 +1615,7 @@ int msm_slot_end(MsmSlot *slot, hipStream_t st) {
     HIPCHK(hipEventRecord(tb.done, slot->tail));
     tb.pending = true;
     tb.unjoined = slot->tail != st;
-    g_slot = (g_slot + 1) % NTAIL;
+    g_slot = (g_slot + 1) % tail_slots();
     return LSA_OK;
 }
 
@@ -1791,7 +1879,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     // down by more than the overlap gains -- 1.87 ms per step against 1.70 -- because the
     // accumulate kernel alone already fills every SIMD's issue slots and register file.)
     TailBuf &tb = g_tail[g_slot];
-    TailBuf &prev = g_tail[(g_slot + NTAIL - 1) % NTAIL];
+    TailBuf &prev = g_tail[(g_slot + tail_slots() - 1) % tail_slots()];
     hipStream_t tail = (g_overlap && !blocking) ? tb.stream : st;
     size_t toff = 0;
     auto tcarve = [&](size_t bytes) { size_t o = toff; toff = align_up(toff + bytes, 256); return o; };
@@ -1934,17 +2022,36 @@ acc_done:
             hipLaunchKernelGGL((k_reduce1<C>), dim3(kw * wpw), dim3(64), 0, tail, buckets, B, L, logL, wpw, split, wave_out);
         A *lvl_in = wave_out, *lvl_out = window_sums;
         uint32_t m = wpw, lm = big ? logL : logL + 4;    // m pairs per window, each covering 2^lm buckets
+        // one bucket space of 2^19 and more buckets: after the first 16-ary level the rest are bit trees (above)
+        static const bool allow_bits = getenv("LSA_NO_REDUCE_BITS") == nullptr;
+        const bool bits_tail = allow_bits && big && kw == 1 && nseg == 1 && m >= 4096 && (m / 16) <= 8192;
+        bool converted = false;
+        Jac<F> *res = tail != st ? (Jac<F> *)(tws + res_off) : d_out;
         do {                                             // at least one k_reduce2 level (it leaves the sum in slot 0)
             const uint32_t m_out = (m + 15) / 16;
             hipLaunchKernelGGL((k_reduce2<C>), dim3(kw * m_out), dim3(64), 0, tail, lvl_in, m, m_out, lm, lvl_out);
             std::swap(lvl_in, lvl_out);
             m = m_out;
             lm += 4;
+            if (bits_tail && m > 1) {
+                uint32_t nbits = 0;
+                while ((1u << nbits) < m) nbits++;        // indices 0 .. m - 1
+                const uint32_t G = (m + 511) / 512;       // <= 16
+                A *part = lvl_out;                        // (the level just consumed: (nbits + 1) * G + 16 values fit its m_in * 2)
+                A *weighted = part + (size_t)(nbits + 1) * G;
+                hipLaunchKernelGGL((k_reduce_bits_a<C>), dim3(nbits + 1, G), dim3(512), 0, tail, lvl_in, m, nbits, G, part);
+                hipLaunchKernelGGL((k_reduce_bits_b<C>), dim3(nbits + 1), dim3(64), 0, tail, part, nbits, G, lm, weighted);
+                if (profile) (void)hipEventRecord(ev6, tail);  // 6
+                hipLaunchKernelGGL((k_reduce_bits_c<C>), dim3(1), dim3(64), 0, tail, weighted, nbits + 1, res);
+                converted = true;
+                break;
+            }
         } while (m > 1);
-        if (profile) (void)hipEventRecord(ev6, tail);  // 6
+        if (!converted && profile) (void)hipEventRecord(ev6, tail);  // 6
         // lvl_in[2*k] = sum of window k (pairs of (ACC,RUN): stride 2)
-        Jac<F> *res = tail != st ? (Jac<F> *)(tws + res_off) : d_out;
-        if (wide && nseg > 1) {   // every segment's bucket space is a finished sum: convert
+        if (converted) {
+            // (the bit trees end in the Jacobian point)
+        } else if (wide && nseg > 1) {   // every segment's bucket space is a finished sum: convert
             if constexpr (std::is_same<C, CurveG1>::value) hipLaunchKernelGGL(k_emit_g1, dim3(nseg), dim3(64), 0, tail, lvl_in, res);
             else hipLaunchKernelGGL(k_emit_g2, dim3(nseg), dim3(64), 0, tail, lvl_in, res);
         } else if constexpr (std::is_same<C, CurveG1>::value) {   // (wide, one segment: kw = 1, the fold only converts -- with a quad of lanes)
@@ -1961,7 +2068,7 @@ acc_done:
     }
     tb.pending = true;
     tb.unjoined = (tail != st);
-    g_slot = (g_slot + 1) % NTAIL;
+    g_slot = (g_slot + 1) % tail_slots();
     HIPCHK(hipGetLastError());
     if (g_profile) g_ev_calls++;
     return LSA_OK;

@@ -1,0 +1,23 @@
+#!/bin/bash
+# the round's profile set (GPU box): rocprofv3 kernel traces of the bench command, of the other configs, of the
+# unchanged hadamard 20, time vs n, one isolated compact call; everything under gpurun_out/<tag>_*
+cd "$(dirname "$0")/.." || exit 1
+TAG=${TAG:-r04_v3}
+export TMPDIR=/tmp
+OUT=$(pwd)/gpurun_out
+mkdir -p "$OUT"
+sh tools/profile_spread.sh $TAG > /dev/null 2>&1
+# the other configs
+mkdir -p "$OUT/prof_cfg"
+rocprofv3 --kernel-trace --stats -d "$OUT/prof_cfg" -o trace -- python3 bench.py --only-configs g2_msm,cppoly,pairing,cphad_verify > "$OUT/${TAG}_configs.json" 2> /dev/null
+DB=$(find "$OUT/prof_cfg" -name '*.db' | head -1)
+python3 tools/rocpd_summary.py trace "$DB" > "$OUT/${TAG}_configs_kernel_trace_stats.txt"
+python3 tools/rocpd_summary.py spread "$DB" > "$OUT/${TAG}_configs_kernel_spread.txt"
+rm -rf "$OUT/prof_cfg"
+# the unchanged reference binary
+TAG=$TAG sh tools/run_hadamard.sh 12 16 20 > /dev/null 2>&1
+python3 tools/msm_vs_n.py > "$OUT/${TAG}_msm_vs_n.txt" 2>&1
+sh tools/profile_cmd_timeline.sh ${TAG}_compact_n4096 12 tools/single_call_trace.py 4096 > /dev/null 2>&1
+sh tools/profile_cmd_timeline.sh ${TAG}_single_call 30 tools/single_call_trace.py > /dev/null 2>&1
+python3 tools/final_exp_probe.py > "$OUT/${TAG}_final_exp.txt" 2>&1
+ls -la "$OUT" | grep "$TAG" | awk '{print $5, $9}'
