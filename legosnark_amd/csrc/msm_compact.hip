@@ -398,7 +398,13 @@ int msm_compact_device(const void *d_table, size_t first, const Fr *d_scalars, s
                        item_w, nitems);
     hipLaunchKernelGGL((k_cmp_bits<C>), dim3(nbits, G), dim3(512), 0, tail, items, item_w, nitems, G, part);
     hipLaunchKernelGGL((k_cmp_final<C>), dim3(1), dim3(64), 0, tail, part, nbits * G, ghist, B, d_out);
-    HIPCHK(hipGetLastError());
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+        // a launch that did not happen may leave the slot's bucket totals behind: the slot's next call must count from zero
+        (void)hipMemsetAsync(slot.aux, 0, CMP_MAXB * 4, tail);
+        (void)msm_slot_end(&slot, st);
+        set_error("msm_compact: kernel launch failed: %s", hipGetErrorString(e));
+        return LSA_ERR_HIP;
+    }
     return msm_slot_end(&slot, st);
 }
 template int msm_compact_device<Fq>(const void *, size_t, const Fr *, size_t, Jac<Fq> *, hipStream_t, size_t, bool);
