@@ -1575,20 +1575,22 @@ int lsa_fr_ntt(void *a, size_t log_n, const void *omega, int inverse, const void
     Fr w, gco;
     memcpy(&w, omega, sizeof w);
     if (coset_g) memcpy(&gco, coset_g, sizeof gco);
-    DevBuf d_tw, d_a;
-    if (d_tw.alloc((n / 2 + 1) * sizeof(Fr))) { set_error("fr_ntt: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    // grow-only staging for the twiddle table and (host callers) the data: two hipMalloc / hipFree pairs per call cost a
+    // 2^20-point transform of an unchanged prover more than its kernels (the shim's evaluation_domain calls this 7 times
+    // per Lipmaa proof)
+    static StageBuf s_tw, s_a;
+    if (s_tw.ensure((n / 2 + 1) * sizeof(Fr))) { set_error("fr_ntt: hipMalloc failed"); return LSA_ERR_NOMEM; }
     Fr *da = (Fr *)a;
     if (!on_device) {
-        if (d_a.alloc(n * sizeof(Fr))) { set_error("fr_ntt: hipMalloc failed"); return LSA_ERR_NOMEM; }
-        LSA_UPLOAD(d_a.p, a, n * sizeof(Fr));
-        da = (Fr *)d_a.p;
+        if (s_a.ensure(n * sizeof(Fr))) { set_error("fr_ntt: hipMalloc failed"); return LSA_ERR_NOMEM; }
+        LSA_UPLOAD(s_a.p, a, n * sizeof(Fr));
+        da = (Fr *)s_a.p;
     }
-    rc = fr_ntt_device(da, (unsigned)log_n, w, inverse != 0, coset_g ? &gco : nullptr, (Fr *)d_tw.p, g.stream);
+    rc = fr_ntt_device(da, (unsigned)log_n, w, inverse != 0, coset_g ? &gco : nullptr, (Fr *)s_tw.p, g.stream);
     if (rc) return rc;
-    // the twiddle table is freed on return: the download (blocking, behind the kernels on the same stream) or an
-    // explicit wait drains the stream first.  (The download is enqueued BEHIND the kernels, not after a wait for them:
-    // the first device -> host copy a process issues on an idle stream costs it 8 ms of copy-engine set-up on this stack.)
-    if (!on_device) LSA_DOWNLOAD(a, d_a.p, n * sizeof(Fr));
+    // (The download is enqueued BEHIND the kernels, not after a wait for them: the first device -> host copy a process
+    // issues on an idle stream costs it 8 ms of copy-engine set-up on this stack.)
+    if (!on_device) LSA_DOWNLOAD(a, s_a.p, n * sizeof(Fr));
     else HIPCHK(hipStreamSynchronize(g.stream));
     return LSA_OK;
 }
