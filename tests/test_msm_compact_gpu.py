@@ -227,3 +227,47 @@ def test_compact_at_its_upper_end_over_a_stepwise_table(lsa):
         B.close()
     finally:
         lsa.set_table_threshold(0)
+
+
+def test_compact_and_general_pipelines_interleaved(lsa):
+    """Asynchronous calls that alternate between the two pipelines on one handle (2^18 + 7 points: calls above 2^17 pairs take
+    the general pipeline, the others the compact one) plus a segmented call, sharing the eight tail slots and writing some
+    results to the same buffer: every result by the discrete-log identity, the shared buffer holds the LAST call's point."""
+    import torch
+    n = (1 << 18) + 7
+    a, b = 0x5A5A5A << 90 | 7, 0x3C3C << 50 | 9
+    bases = o.arith_bases("g1", a, b, n)
+    lsa.set_table_threshold(1)
+    try:
+        B = lsa.Bases("g1", bases)
+        if not B.has_table():
+            pytest.skip("tables disabled")
+        sc, ints = o.random_scalars(n, seed=606)
+        d_s = dev(sc)
+        sizes = [n, 5000, 1 << 18, 1, 100000, (1 << 17) + 1, 64, 1 << 17, 200000, 777]
+        outs = torch.zeros((len(sizes), 12), dtype=torch.int64, device="cuda:0")
+        same = torch.zeros(12, dtype=torch.int64, device="cuda:0")
+        seg = torch.zeros((3, 12), dtype=torch.int64, device="cuda:0")
+        for rep in range(2):
+            for i, m in enumerate(sizes):
+                B.msm_async(d_s, outs[i], n=m)
+                B.msm_async(d_s, same, n=m)
+                if i == 4:
+                    B.msm_segments_async(d_s, np.array([0, 300, 300, 5000], dtype=np.uint64), seg)
+        lsa.synchronize()
+        g = o.generator("g1")
+        pre = [0]
+        for i in range(n):
+            pre.append((pre[-1] + ints[i] * (a + i * b)) % R)
+        got = outs.cpu().numpy().view(np.uint64)
+        for i, m in enumerate(sizes):
+            assert canon(got[i]) == canon(o.g1_mul(g, o.fr_mont(pre[m]))), (i, m)
+        assert canon(same.cpu().numpy().view(np.uint64)) == canon(o.g1_mul(g, o.fr_mont(pre[sizes[-1]])))
+        sg = seg.cpu().numpy().view(np.uint64)
+        assert canon(sg[0]) == canon(o.g1_mul(g, o.fr_mont(pre[300])))
+        assert canon(sg[1]) is None
+        k2 = sum(ints[300 + i] * (a + i * b) for i in range(4700)) % R            # a segment multiplies a PREFIX of the bases
+        assert canon(sg[2]) == canon(o.g1_mul(g, o.fr_mont(k2)))
+        B.close()
+    finally:
+        lsa.set_table_threshold(0)
