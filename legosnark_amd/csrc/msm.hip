@@ -1558,9 +1558,9 @@ static int msm_func_attrs() {
 }
 
 // What the first MSM of a process used to pay inside its own call (17-20 ms whatever its size: the library's code object
-// loaded on the first kernel launch, four streams and their events, the function attributes, the first workspace
+// loaded on the first kernel launch, eight streams and their events, the function attributes, the first workspace
 // allocations) is paid by lsa_init instead -- a prover's init_public_params(), not its first multiExpMA.  The workspaces
-// are sized for one G1 MSM of 2^20 pairs (~0.5 GB of the 288); LSA_WARM=0 skips all of it, LSA_WARM_MB sets the size.
+// are sized for one G1 MSM of 2^20 pairs (192 MB + 8 x 96 MB of the 288 GB); LSA_WARM=0 skips all of it, LSA_WARM_MB sets the size.
 int msm_warmup(hipStream_t st) {
     const char *w = getenv("LSA_WARM");
     if (w && w[0] == '0') return LSA_OK;
