@@ -1188,6 +1188,46 @@ __global__ __launch_bounds__(64) void k_reduce1_lane(const typename C::Acc *__re
     out[2 * (size_t)t + 1] = run;
 }
 
+// The first 16-ary level over the 65536 (ACC, RUN) pairs of k_reduce1_lane, ONE LANE per group of sixteen (wide path, calls
+// whose tail hides under the next call's front).  The quad version of this level (k_reduce2) is the shortest chain --
+// 9 + log_mult quad operations -- but every quad operation keeps four lanes busy for one addition and carries ~40 % of
+// selects and broadcasts: 4096 wavefronts x ~20 000 instructions = 82 M wavefront-instructions per MSM, as much as a
+// sixth of the accumulate kernel, on a chip whose issue slots are the bottleneck of a pipelined step.  A lane-private
+// running sum does the same arithmetic in 48 general additions per lane: 64 wavefronts x ~190 000 instructions = 12 M.
+// Seven times less work, 0.2 ms more latency -- the right trade exactly when nobody waits for this call alone.
+//   ACC = sum_j acc_j + 2^log_mult * sum_j j * run_j,  RUN = sum_j run_j   (j = 0 .. 15, as quadwave_weighted)
+template <class C>
+__global__ __launch_bounds__(64) void k_reduce2_lane(const typename C::Acc *__restrict__ in, uint32_t m_in, uint32_t m_out, uint32_t log_mult,
+                                                     typename C::Acc *__restrict__ out) {
+    using A = typename C::Acc;
+    const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= m_out) return;
+    A acc = A::inf(), run = A::inf(), wsum = A::inf();
+    // trips per input pair through ONE addition site (see k_reduce1_lane): acc += acc_j; run += run_j; wsum += run (j >= 1)
+#pragma unroll 1
+    for (int j = 15; j >= 0; j--) {
+        const uint32_t idx = 16 * t + (uint32_t)j;
+        const bool have = idx < m_in;
+        const uint32_t trips = j ? 3u : 2u;
+#pragma unroll 1
+        for (uint32_t h = 0; h < trips; h++) {
+            uint32_t m0 = h == 0 ? 0xffffffffu : 0u, m1 = h == 1 ? 0xffffffffu : 0u;
+            asm volatile("" : "+v"(m0), "+v"(m1));
+            A rhs = run;                                                    // h == 2: wsum += run
+            if (h < 2) rhs = have ? in[2 * (size_t)idx + h] : A::inf();
+            const A lhs = select_acc(m0, acc, select_acc(m1, run, wsum));
+            const A r = C::add(lhs, rhs);
+            acc = select_acc(m0, r, acc);
+            run = select_acc(m1, r, run);
+            wsum = select_acc(~(m0 | m1), r, wsum);
+        }
+    }
+#pragma unroll 1
+    for (uint32_t i = 0; i < log_mult; i++) wsum = C::dbl(wsum);
+    out[2 * (size_t)t] = C::add(acc, wsum);
+    out[2 * (size_t)t + 1] = run;
+}
+
 // Level 1: T = B/L quads per window; quad t owns buckets [t*L, (t+1)*L) (their `split` partial
 // sums are folded in here).  Writes one (ACC,RUN) pair per wavefront (16 quads = 16*L buckets).
 template <class C>
@@ -2029,8 +2069,15 @@ acc_done:
         const bool bits_tail = allow_bits && blocking && big && kw == 1 && nseg == 1 && m >= 4096 && (m / 16) <= 8192;
         bool converted = false;
         Jac<F> *res = tail != st ? (Jac<F> *)(tws + res_off) : d_out;
+        // pipelined wide calls: the first 16-ary level lane-private (k_reduce2_lane: a seventh of the quad level's work)
+        static const bool allow_lane_l1 = getenv("LSA_NO_LANE_L1") == nullptr;
+        bool lane_l1 = allow_lane_l1 && !blocking && big && kw == 1 && nseg == 1 && m >= 16384;
         do {                                             // at least one k_reduce2 level (it leaves the sum in slot 0)
             const uint32_t m_out = (m + 15) / 16;
+            if (lane_l1) {
+                hipLaunchKernelGGL((k_reduce2_lane<C>), dim3((m_out + 63) / 64), dim3(64), 0, tail, lvl_in, m, m_out, lm, lvl_out);
+                lane_l1 = false;
+            } else
             hipLaunchKernelGGL((k_reduce2<C>), dim3(kw * m_out), dim3(64), 0, tail, lvl_in, m, m_out, lm, lvl_out);
             std::swap(lvl_in, lvl_out);
             m = m_out;

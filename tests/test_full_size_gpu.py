@@ -83,6 +83,38 @@ def test_generator_copies_2pow20(lsa, group):
     B.close()
 
 
+@pytest.mark.parametrize("group", ["g1", "g2"])
+def test_pipelined_calls_of_2pow18_pairs_agree_with_blocking_ones(lsa, group):
+    """Queued calls above the compact pipeline's range (2^17 pairs) reduce their 2^19 buckets with a lane-private first level
+    (k_reduce2_lane, msm.hip) where a blocking call uses the quad level and the bit trees: both
+    tails on the same inputs, and the known-discrete-log identity on top."""
+    import torch
+    n = 1 << 18
+    rng = synth.Xoshiro256ss(seed=synth.SEED ^ 0x17)
+    a, b = rng.fr_int(), rng.fr_int()
+    x = synth.arith_fr_mont(a, b, n)
+    bases = lsa.batch_exp(group, curve.generator(group), to_dev(x))
+    B = lsa.Bases(group, bases, on_device=True)
+    del bases
+    sizes = [n, n - 4097, (1 << 17) + 1, n - 1]
+    scs = [rng.uniform_fr(m) for m in sizes]
+    dev = [to_dev(s) for s in scs]
+    words = 12 if group == "g1" else 24
+    outs = torch.zeros((2 * len(sizes), words), dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    for rep in range(2):
+        for i, m in enumerate(sizes):
+            B.msm_async(dev[i], outs[rep * len(sizes) + i], n=m)
+    lsa.synchronize()
+    got = to_host(outs)
+    for i, m in enumerate(sizes):
+        want = canon(group, B.msm(dev[i], n=m))
+        assert canon(group, got[i]) == want, (i, m)
+        assert canon(group, got[len(sizes) + i]) == want, (i, m)
+        assert want == k_times_gen(group, o.fr_dot(scs[i], x[:m])), (i, m)
+    B.close()
+
+
 def test_cppoly_d20_commit_and_ladder(lsa):
     import torch
     d = 20

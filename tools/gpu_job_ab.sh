@@ -1,10 +1,9 @@
 #!/bin/bash
-# A/B of an environment switch on the headline bench line, alternating on one box:  tools/gpu_job_ab.sh VAR=val [reps]
+# A/B of one environment switch on the headline step: tools/gpu_job_ab.sh VAR [steps] [reps]
 cd "$(dirname "$0")/.." || exit 1
-SW=$1; REPS=${2:-3}
-for rep in $(seq 1 $REPS); do
-  for mode in default "$SW"; do
-    if [ "$mode" = default ]; then E=""; else E="$SW"; fi
-    env $E python bench.py --no-pmc --no-configs --no-host-path --no-cpu-baseline 2>/dev/null | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('$mode', round(d['value']/1e8,3), 'ms/step', round(d['ms_per_step'],4), 'single', round(d['single_call_latency_ms'],3), 'cplink', round(d['cplink_prover_ms'],3))"
-  done
+VAR=$1; STEPS=${2:-200}; REPS=${3:-3}
+one() { python bench.py --no-configs --steps $STEPS --warmup 10 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.4f ms/step  kernel %.4f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"; }
+for r in $(seq $REPS); do
+  echo -n "default      : "; one
+  echo -n "$VAR=1 : "; env $VAR=1 python bench.py --no-configs --steps $STEPS --warmup 10 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.4f ms/step  kernel %.4f' % (d['ms_per_step'], d['roofline']['kernel_ms']))"
 done
