@@ -237,7 +237,15 @@ struct F29 {
         int64_t c = 0;
 #pragma unroll
         for (int i = 0; i < 9; i++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            // three signed 32 x 32 + 64 multiply-adds per limb (left to itself the compiler splits every term in two)
+            int64_t t = c;
+            asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(t) : "v"(K), "v"((int32_t)p(i)) : "vcc");
+            asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(t) : "v"(cu), "v"((int32_t)u.l[i]) : "vcc");
+            asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(t) : "v"(cv), "v"((int32_t)v.l[i]) : "vcc");
+#else
             const int64_t t = (int64_t)cu * (int64_t)u.l[i] + (int64_t)cv * (int64_t)v.l[i] + (int64_t)K * (int64_t)p(i) + c;
+#endif
             if (i < 8) { r.l[i] = (uint32_t)t & MASK; c = t >> 29; }
             else r.l[i] = (uint32_t)t;
         }

@@ -65,27 +65,39 @@ __global__ __launch_bounds__(64) void k_final_exp(const Fq12 *__restrict__ in, s
 
 // One wavefront per element (w12.h): 36-lane Fq12 products out of LDS.  ~10x shorter chain than
 // k_final_exp; used whenever fewer elements than the chip has lanes are in flight.
-struct WaveExec {
+// (the lane count is a compile-time constant: W12 asks for it in every product, and blockDim.x is a load from the
+// dispatch packet -- a round trip to L2, 0.2-0.5 us depending on the CU, in front of each of the ~300 chain links)
+template <unsigned LANES>
+struct WaveExecN {
     template <class F>
     __device__ __forceinline__ void par(F f) {
         f(threadIdx.x);
         __syncthreads();
     }
-    __device__ __forceinline__ unsigned nlanes() const { return blockDim.x; }
+    __device__ __forceinline__ unsigned nlanes() const { return LANES; }
 };
+using WaveExec = WaveExecN<64>;
+using WaveExec192 = WaveExecN<192>;
 // libff Fq12 layout (c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2, each Fq2 = 2 Fq) <-> slot: lane
 // l < 12 moves Fq number l, which is part l%2 of tower coefficient t = l/2, i.e. of w^(2*(t%3) + t/3).
 static __device__ __forceinline__ Fs *w12_fq_ref(Fq2S *slot, unsigned l) {
     const unsigned t = l >> 1, k = 2 * (t % 3) + t / 3;
     return (l & 1) ? &slot[k].c1 : &slot[k].c0;
 }
-__global__ __launch_bounds__(192) void k_final_exp_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
+template <unsigned LANES>
+__global__ __launch_bounds__(LANES) void k_final_exp_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out, unsigned long long *dbg) {
     __shared__ Fq2S lds[W12_LDS_FQ2];
     const size_t e = blockIdx.x;
     if (e >= n) return;
     const unsigned lane = threadIdx.x;
-    WaveExec ex;
-    W12<WaveExec> w{ex, lds, lds + 6 * W12_SLOTS};
+    WaveExecN<LANES> ex;
+    W12<WaveExecN<LANES>> w{ex, lds, lds + 6 * W12_SLOTS};
+    w.dbg = dbg;
+    if (dbg && (lane & 63) == 0) {
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        dbg[12 + (lane >> 6)] = hw;
+    }
     if (lane < 12) *w12_fq_ref(w.slot(0), lane) = Fs::from_mont256(reinterpret_cast<const Fq *>(&in[e])[lane]);
     __syncthreads();
     w.final_exponentiation();
@@ -152,9 +164,9 @@ __global__ __launch_bounds__(192) void k_fq12_prod8_wave(const Fq12 *__restrict_
     const size_t lo = (size_t)blockIdx.x * 8;
     if (lo >= n) return;
     const unsigned lane = threadIdx.x;
-    WaveExec ex;
-    W12<WaveExec> w{ex, lds, lds + 6 * W12_SLOTS};
-    for (unsigned x = lane; x < 96; x += blockDim.x) {  // 8 elements x 12 Fq
+    WaveExec192 ex;
+    W12<WaveExec192> w{ex, lds, lds + 6 * W12_SLOTS};
+    for (unsigned x = lane; x < 96; x += 192) {  // 8 elements x 12 Fq
         const unsigned e = x / 12, l = x % 12;
         Fs v = (l == 0) ? Fs::one() : Fs::zero();       // missing inputs = 1
         if (lo + e < n) v = Fs::from_mont256(reinterpret_cast<const Fq *>(&in[lo + e])[l]);
@@ -172,8 +184,8 @@ __global__ __launch_bounds__(192) void k_fq12_prod_seg_wave(const Fq12 *__restri
     __shared__ Fq2S lds[W12_LDS_FQ2];
     const size_t lo = off[blockIdx.x], hi = off[blockIdx.x + 1];
     const unsigned lane = threadIdx.x;
-    WaveExec ex;
-    W12<WaveExec> w{ex, lds, lds + 6 * W12_SLOTS};
+    WaveExec192 ex;
+    W12<WaveExec192> w{ex, lds, lds + 6 * W12_SLOTS};
     if (lane < 12) {
         Fs v = (lane == 0) ? Fs::one() : Fs::zero();
         if (lo < hi) v = Fs::from_mont256(reinterpret_cast<const Fq *>(&in[lo])[lane]);
@@ -439,7 +451,21 @@ int final_exp_device(const void *d_in, size_t n, void *d_out, hipStream_t st) {
     {
         // three wavefronts per element: the one-phase row product of w12.h (LSA_FINAL_EXP_LANES=128: the two-phase product)
         static const unsigned lanes = getenv("LSA_FINAL_EXP_LANES") ? (unsigned)atoi(getenv("LSA_FINAL_EXP_LANES")) : 192u;
-        hipLaunchKernelGGL(k_final_exp_wave, dim3((unsigned)n), dim3(lanes == 128 ? 128 : 192), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);
+        static unsigned long long *dbg = nullptr;
+        static int dbg_calls = 0;
+        if (getenv("LSA_FE_STAMPS") && !dbg) (void)hipHostMalloc((void **)&dbg, 16 * 8, 0);
+        if (lanes == 128) hipLaunchKernelGGL(k_final_exp_wave<128>, dim3((unsigned)n), dim3(128), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out, dbg);
+        else hipLaunchKernelGGL(k_final_exp_wave<192>, dim3((unsigned)n), dim3(192), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out, dbg);
+        if (dbg && n == 1) {
+            (void)hipStreamSynchronize(st);
+            if (++dbg_calls > 100 && dbg_calls < 110) {
+                fprintf(stderr, "fe stamps (us at 100 MHz?):");
+                for (int i = 1; i < 12; i++) fprintf(stderr, " %d:%.1f", i, (double)(dbg[i] - dbg[i - 1]));
+                fprintf(stderr, " total %.1f", (double)(dbg[11] - dbg[0]));
+                for (int w = 0; w < 3; w++) fprintf(stderr, " | se %u cu %u simd %u wave %u", (unsigned)(dbg[12 + w] >> 13) & 7, (unsigned)(dbg[12 + w] >> 8) & 15, (unsigned)(dbg[12 + w] >> 4) & 3, (unsigned)dbg[12 + w] & 15);
+                fprintf(stderr, "\n");
+            }
+        }
     }
     else
         hipLaunchKernelGGL(k_final_exp, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);

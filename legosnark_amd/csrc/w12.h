@@ -20,6 +20,7 @@
 #include "fp29x2.h"
 #include "fs29.h"
 #include "tower.h"
+#include "frob_rows.h"
 
 namespace lsa {
 
@@ -234,68 +235,90 @@ __device__ __forceinline__ W12Limbs18 w12_wide_mul(const F29 &a, const F29 &b) {
     r.l[17] = (uint32_t)acc;
     return r;
 }
-__device__ __forceinline__ void w12_carry18(W12Limbs18 &t) {        // limbs < 2^32 -> tight (the value fits 18 limbs)
-    uint32_t c = 0;
+// (T + U) / 2^261 mod p for T = sum t_k 2^(29k), U = sum u_k 2^(29k) with loose limbs (any 32-bit values): < (T + U) / 2^261 + p,
+// limbs tight.  Written column-wise for a LONE wavefront: m_k goes into the eight later columns as soon as it is known --
+// eight independent multiply-adds the scheduler can place between the dependent instructions of the one serial chain
+// (column + carry -> m_k -> carry) -- instead of 81 multiply-adds accumulated one after the other into the same register
+// pair (a dependent v_mad_u64_u32 issues every 11 cycles, an independent one every 6: tools/ubench_clock.hip).
+__device__ __forceinline__ F29 w12_redc18(const W12Limbs18 &t, const W12Limbs18 &u) {
+    uint64_t col[17];
 #pragma unroll
-    for (int k = 0; k < 17; k++) {
-        const uint64_t v = (uint64_t)t.l[k] + c;
-        t.l[k] = (uint32_t)v & F29::MASK;
-        c = (uint32_t)(v >> 29);
-    }
-    t.l[17] += c;
-}
-// T / 2^261 mod p for T = sum t_k 2^(29k) with loose limbs (< 2^31): < T / 2^261 + p, limbs tight
-__device__ __forceinline__ F29 w12_redc18(const W12Limbs18 &t) {
-    uint64_t acc = 0;
-    uint32_t m[9];
+    for (int k = 0; k < 17; k++) col[k] = (uint64_t)t.l[k] + u.l[k];
+    uint64_t carry = 0;
     F29 r;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-        acc += t.l[k];
+        uint64_t acc = col[k] + carry;
+        const uint32_t m = ((uint32_t)acc * F29::PINV) & F29::MASK;
+        acc += (uint64_t)m * F29::p(0);
+        carry = acc >> 29;
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F29::p(k - i);
-        m[k] = ((uint32_t)acc * F29::PINV) & F29::MASK;
-        acc += (uint64_t)m[k] * F29::p(0);
-        acc >>= 29;
+        for (int j = 1; j < 9; j++) col[k + j] += (uint64_t)m * F29::p(j);
     }
 #pragma unroll
     for (int k = 9; k < 17; k++) {
-        acc += t.l[k];
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * F29::p(k - i);
+        const uint64_t acc = col[k] + carry;
         r.l[k - 9] = (uint32_t)acc & F29::MASK;
-        acc >>= 29;
+        carry = acc >> 29;
     }
-    r.l[8] = (uint32_t)acc + t.l[17];
+    r.l[8] = (uint32_t)carry + t.l[17] + u.l[17];
     return r;
 }
-// d = a * b for slots of 6 Fq2S each; 192 lanes; see above
-__device__ __noinline__ void w12_mul_rows(Fq2S *D, const Fq2S *A, const Fq2S *B) {
+// the same lanes' limbs as seen through a DPP permutation (v_mov_b32_dpp, all 18 limbs, one asm block as W12_DPP18)
+#define W12_DPP18_MOV(D, T, CTRL)                                                                                          \
+    asm volatile("s_nop 1\n"                                                                                               \
+                 "v_mov_b32_dpp %0, %18 " CTRL "\nv_mov_b32_dpp %1, %19 " CTRL "\nv_mov_b32_dpp %2, %20 " CTRL "\n"          \
+                 "v_mov_b32_dpp %3, %21 " CTRL "\nv_mov_b32_dpp %4, %22 " CTRL "\nv_mov_b32_dpp %5, %23 " CTRL "\n"          \
+                 "v_mov_b32_dpp %6, %24 " CTRL "\nv_mov_b32_dpp %7, %25 " CTRL "\nv_mov_b32_dpp %8, %26 " CTRL "\n"          \
+                 "v_mov_b32_dpp %9, %27 " CTRL "\nv_mov_b32_dpp %10, %28 " CTRL "\nv_mov_b32_dpp %11, %29 " CTRL "\n"        \
+                 "v_mov_b32_dpp %12, %30 " CTRL "\nv_mov_b32_dpp %13, %31 " CTRL "\nv_mov_b32_dpp %14, %32 " CTRL "\n"       \
+                 "v_mov_b32_dpp %15, %33 " CTRL "\nv_mov_b32_dpp %16, %34 " CTRL "\nv_mov_b32_dpp %17, %35 " CTRL "\n"       \
+                 : "=&v"((D).l[0]), "=&v"((D).l[1]), "=&v"((D).l[2]), "=&v"((D).l[3]), "=&v"((D).l[4]), "=&v"((D).l[5]),       \
+                   "=&v"((D).l[6]), "=&v"((D).l[7]), "=&v"((D).l[8]), "=&v"((D).l[9]), "=&v"((D).l[10]), "=&v"((D).l[11]),    \
+                   "=&v"((D).l[12]), "=&v"((D).l[13]), "=&v"((D).l[14]), "=&v"((D).l[15]), "=&v"((D).l[16]), "=&v"((D).l[17]) \
+                 : "v"((T).l[0]), "v"((T).l[1]), "v"((T).l[2]), "v"((T).l[3]), "v"((T).l[4]), "v"((T).l[5]), "v"((T).l[6]),   \
+                   "v"((T).l[7]), "v"((T).l[8]), "v"((T).l[9]), "v"((T).l[10]), "v"((T).l[11]), "v"((T).l[12]), "v"((T).l[13]), \
+                   "v"((T).l[14]), "v"((T).l[15]), "v"((T).l[16]), "v"((T).l[17]))
+template <bool FROB>
+__device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, const uint32_t *frob) {
     const unsigned lane = threadIdx.x, row = lane >> 4, r = lane & 15;
     const unsigned k = row >> 1, part = row & 1, i = r >> 1, h = r & 1;
-    const unsigned iw = i < 6 ? i : 0, j = (k + 6 - iw) % 6;
-    const bool wrapped = iw > k;
-    // R = c0 * b_j0 + c1 * b_j1 + K p
-    int c0, c1, K;
-    if (!wrapped) { c0 = (part ^ h) ? 0 : 1; c1 = (part ^ h) ? (part ? 1 : -1) : 0; K = (part == 0 && h == 1) ? 2 : 0; }
-    else if (part == 0) { c0 = h ? -1 : 9; c1 = h ? -9 : -1; K = h ? 20 : 2; }
-    else { c0 = h ? 9 : 1; c1 = h ? -1 : 9; K = h ? 2 : 0; }
-    F29 L = w12_load(&w12_comp(A[iw], h)).v;
-    const Fq2S bj = w12_load(&B[j]);
-    __syncthreads();                                   // every lane holds its operands: D may alias A or B from here on
-    const uint32_t live = w12_mask(0u - (uint32_t)(r < 12));
+    F29 L, Rv;
+    if (FROB) {
+        static constexpr uint32_t ZERO9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        L = w12_load(&w12_comp(A[k], h)).v;
+        const uint32_t *c = r < 2 ? frob + ((k * 2 + part) * 2 + h) * 9 : ZERO9;      // lanes 2..15 of a row add nothing
 #pragma unroll
-    for (int q = 0; q < 9; q++) L.l[q] &= live;          // lanes 12..15 of a row add nothing
-    W12Limbs18 t = w12_wide_mul(L, lin2(bj.c0.v, c0, bj.c1.v, c1, K));
+        for (int q = 0; q < 9; q++) Rv.l[q] = c[q];
+    } else {
+        const unsigned iw = i < 6 ? i : 0;
+        const bool wrapped = iw > k;
+        const unsigned j = k - iw + (wrapped ? 6u : 0u);
+        // R = c0 * b_j0 + c1 * b_j1 + K p, the three small integers looked up by (wrapped, part, h) in packed bytes:
+        //   plain:    part 0: (1, 0, 0), (0, -1, 2)       part 1: (0, 1, 0), (1, 0, 0)
+        //   wrapped:  part 0: (9, -1, 2), (-1, -9, 20)    part 1: (1, 9, 0), (9, -1, 2)
+        // (all zero for lanes 12..15 of a row: they add nothing)
+        const unsigned sh = 8u * ((wrapped ? 4u : 0u) | (part << 1) | h);
+        const int lv = r < 12 ? -1 : 0;
+        const int c0 = (int)(int8_t)(0x0901ff0901000001ull >> sh) & lv, c1 = (int)(int8_t)(0xff09f7ff0001ff00ull >> sh) & lv, K = (int)(int8_t)(0x0200140200000200ull >> sh) & lv;
+        L = w12_load(&w12_comp(A[iw], h)).v;
+        const Fq2S bj = w12_load(&B[j]);
+        Rv = lin2(bj.c0.v, c0, bj.c1.v, c1, K);
+    }
+    __syncthreads();                                   // every lane holds its operands: D may alias A or B from here on
+    W12Limbs18 t = w12_wide_mul(L, Rv), u;
     W12_DPP18(t, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
     W12_DPP18(t, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");         // sums of four (< 2^31)
-    w12_carry18(t);
-    W12_DPP18(t, "row_half_mirror row_mask:0xf bank_mask:0xf");
-    W12_DPP18(t, "row_mirror row_mask:0xf bank_mask:0xf");                  // the row's sum in every lane (< 2^31 per limb)
-    const Fs res = {condsub2(w12_redc18(t))};
+    W12_DPP18(t, "row_half_mirror row_mask:0xf bank_mask:0xf");             // sums of eight (< 2^32: tight limbs)
+    W12_DPP18_MOV(u, t, "row_mirror row_mask:0xf bank_mask:0xf");           // the other half of the row: added inside the reduction
+    const Fs res = {condsub2(w12_redc18(t, u))};
     if (r == 0) w12_store(&w12_comp(D[k], part), res);
     __syncthreads();
 }
+// LEAF functions (no calls inside, so no return address to park in a spilled VGPR: a product that calls a product
+// function pays one scratch store and one scratch load with their waits -- a round trip to L2 -- per chain link)
+__device__ __noinline__ void w12_mul_rows(Fq2S *D, const Fq2S *A, const Fq2S *B) { w12_rows<false>(D, A, B, nullptr); }
+__device__ __noinline__ void w12_frob_rows(Fq2S *D, const Fq2S *A, const uint32_t *frob) { w12_rows<true>(D, A, nullptr, frob); }
 #endif
 
 template <class X>
@@ -303,6 +326,12 @@ struct W12 {
     X &x;
     Fq2S *R;   // W12_SLOTS x 6 coefficients
     Fq2S *P;   // 36 partial products
+    unsigned long long *dbg = nullptr;
+    LSA_HD void stamp(int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (dbg && threadIdx.x == 0) dbg[i] = __builtin_readcyclecounter();
+#endif
+    }
 
     LSA_HD Fq2S *slot(int s) const { return R + 6 * s; }
 
@@ -313,11 +342,14 @@ struct W12 {
     // that coefficient k is the plain sum of six partial products and one reduction by a
     // Montgomery product with 1.  ~430 + ~350 instructions per lane instead of ~600 + ~500 for
     // whole Fq2 products and a xi step in the reduction.
-    LSA_HD_NOINLINE void mul(int d, int a, int b) {
-        Fq2S *A = slot(a), *B = slot(b), *D = slot(d), *Pp = P;
+    LSA_HD void mul(int d, int a, int b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (x.nlanes() >= 192) { w12_mul_rows(D, A, B); return; }      // (workgroup-uniform)
+        if (x.nlanes() >= 192) { w12_mul_rows(slot(d), slot(a), slot(b)); return; }      // (a compile-time constant on the device)
 #endif
+        mul_lanes(d, a, b);
+    }
+    LSA_HD_NOINLINE void mul_lanes(int d, int a, int b) {
+        Fq2S *A = slot(a), *B = slot(b), *D = slot(d), *Pp = P;
         const unsigned nl = x.nlanes();
         x.par([=](unsigned lane) {
             for (unsigned t = lane; t < 72; t += nl) {
@@ -347,11 +379,14 @@ struct W12 {
     }
     LSA_HD void sqr(int d, int a) { mul(d, a, a); }
     // d = a^2 for a in the cyclotomic subgroup (every squaring of the hard part); d != a
-    LSA_HD_NOINLINE void csqr(int d, int a) {
-        Fq2S *A = slot(a), *D = slot(d);
+    LSA_HD void csqr(int d, int a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        if (x.nlanes() >= 192) { w12_mul_rows(D, A, A); return; }      // the row product is shorter than twelve fused lanes
+        if (x.nlanes() >= 192) { w12_mul_rows(slot(d), slot(a), slot(a)); return; }      // the row product is shorter than twelve fused lanes
 #endif
+        csqr_lanes(d, a);
+    }
+    LSA_HD_NOINLINE void csqr_lanes(int d, int a) {
+        Fq2S *A = slot(a), *D = slot(d);
         x.par([=](unsigned lane) {
             if (lane < 12) {
                 const unsigned k = lane >> 1, part = lane & 1;
@@ -419,6 +454,10 @@ struct W12 {
     template <int POWER>
     LSA_HD void frobenius(int d, int a) {
         Fq2S *A = slot(a), *D = slot(d);
+#if defined(__HIP_DEVICE_COMPILE__)
+        static_assert(POWER >= 1 && POWER <= 3, "frob_rows.h holds the maps of a final exponentiation");
+        if (x.nlanes() >= 192) { w12_frob_rows(D, A, &LSA_FROB_ROWS[POWER - 1][0][0][0][0]); return; }   // one row product (constants: frob_rows.h)
+#endif
         x.par([=](unsigned lane) {
             if (lane < 6) {
                 Fq2S v = fq2_frobenius<POWER>(A[lane]);
@@ -447,8 +486,10 @@ struct W12 {
     // z (digits 0, +-1, +-3; 18 non-zero of 63) -- inverses are conjugations here, so a^z costs
     // 62 squarings + 17 products + 2 for a^3 instead of 62 + 27.  Uses slots tmp, tmp+1, tmp+2.
     LSA_HD void exp_by_neg_z(int d, int a, int tmp) {
-        static constexpr int8_t NAF3[63] = {1, 0, 0, 0, -1, 0, 0, 0, 0, -3, 0, 0, 1, 0, 0, 0, 1, 0, 0, -3, 0, 0, 0, -3, 0, 0, 3, 0, 0, 0, 1,
-                                            0, 0, 0, -3, 0, 0, 0, 3, 0, 0, 1, 0, 0, 1, 0, 0, 3, 0, 0, 0, -3, 0, 0, 0, 0, -3, 0, 0, 1, 0, 0, 1};
+        // the digits as four bit masks (bit i set: digit i is +1 / +3 / -1 / -3): a table in memory costs the chain one
+        // load round trip per squaring
+        constexpr uint64_t D_P1 = 0x4800120040011001ull, D_P3 = 0x0000804004000000ull, D_M1 = 0x0000000000000010ull, D_M3 = 0x0108000400880200ull;
+        static_assert(D_P1 + 3 * D_P3 - D_M1 - 3 * D_M3 == 0x44e992b44a6909f1ull && (D_P1 >> 62) == 1, "width-3 NAF of z");
         // every squaring is a cyclotomic one (csqr: d != a, so the accumulator alternates between two slots); the
         // inverses a^-1, a^-3 (conjugates) are made once.  Uses slots tmp .. tmp + 5.
         int acc = tmp, alt = tmp + 3;
@@ -458,21 +499,12 @@ struct W12 {
         conj(na, a);
         conj(na3, a3);
         csqr(alt, a);                       // top digit (bit 62) is +1: the accumulator starts as a, the first squaring reads it in place
-        {
-            const int dg = NAF3[61];
-            if (dg == 1) mul(acc, alt, a);
-            else if (dg == 3) mul(acc, alt, a3);
-            else if (dg == -1) mul(acc, alt, na);
-            else if (dg == -3) mul(acc, alt, na3);
-            else { const int t = acc; acc = alt; alt = t; }
-        }
-        for (int i = 60; i >= 0; --i) {
-            csqr(alt, acc);
-            const int dg = NAF3[i];
-            if (dg == 1) mul(acc, alt, a);
-            else if (dg == 3) mul(acc, alt, a3);
-            else if (dg == -1) mul(acc, alt, na);
-            else if (dg == -3) mul(acc, alt, na3);
+        for (int i = 61; i >= 0; --i) {
+            if (i != 61) csqr(alt, acc);
+            if ((D_P1 >> i) & 1) mul(acc, alt, a);
+            else if ((D_P3 >> i) & 1) mul(acc, alt, a3);
+            else if ((D_M1 >> i) & 1) mul(acc, alt, na);
+            else if ((D_M3 >> i) & 1) mul(acc, alt, na3);
             else { const int t = acc; acc = alt; alt = t; }
         }
         conj(d, acc);
@@ -482,20 +514,28 @@ struct W12 {
     // pairing.hip).  Uses every slot.
     LSA_HD void final_exponentiation() {
         enum { ELT = 0, FIRST, A, B, C, D, E, F, G, T0, T1, T2, T3, T4, T5 };      // (exp_by_neg_z uses T0 .. T5)
+        stamp(0);
         conj(A, ELT);             // conj(f): f^(p^6)
         mul(C, ELT, A);           // f * conj(f), an element of Fq6
+        stamp(1);
         inverse6(D, C);
+        stamp(2);
         mul(B, A, D);             // f^-1 = conj(f) / (f * conj(f))
         mul(C, A, B);             // f^(p^6 - 1)
+        stamp(3);
         frobenius<2>(D, C);
+        stamp(4);
         mul(FIRST, D, C);
+        stamp(5);
         exp_by_neg_z(A, FIRST, T0);
+        stamp(6);
         csqr(B, A);
         csqr(C, B);
         mul(D, C, B);
         exp_by_neg_z(E, D, T0);
         csqr(F, E);
         exp_by_neg_z(G, F, T0);
+        stamp(7);
         conj(T2, D);              // H
         conj(G, G);               // I
         mul(G, G, E);             // J = I * E
@@ -503,14 +543,18 @@ struct W12 {
         mul(T2, G, B);            // L = K * B
         mul(T0, G, E);            // M = K * E
         mul(T0, T0, FIRST);       // N = M * first
+        stamp(8);
         frobenius<1>(T1, T2);     // O = frob1(L)
+        stamp(9);
         mul(T0, T1, T0);          // P = O * N
         frobenius<2>(T1, G);      // Q = frob2(K)
         mul(T0, T1, T0);          // R = Q * P
         conj(T1, FIRST);          // S
         mul(T1, T1, T2);          // T = S * L
         frobenius<3>(T1, T1);     // U
+        stamp(10);
         mul(ELT, T1, T0);         // U * R
+        stamp(11);
     }
 };
 
