@@ -107,10 +107,30 @@ LSA_HD Inv256 inv_mod_p(const Inv256 &y) {
             ah = (exact_a & sm) | (approx_a & ~sm);
             bh = (exact_b & sm) | (approx_b & ~sm);
         }
-        // ---- 31 inner steps on the approximations
-        int64_t f0 = 1, g0 = 0, f1 = 0, g1 = 1;
+        // ---- 31 inner steps on the approximations.  After k steps |f|, |g| <= 2^k: the first 30 steps keep the factors in
+        // 32-bit registers (half the instructions of 64-bit ones on this machine), the last one runs on 64 bits because
+        // 2^31 itself does occur (g1 after 31 halvings of an even a).
+        int64_t f0, g0, f1, g1;
+        {
+            uint32_t F0 = 1, G0 = 0, F1 = 0, G1 = 1;
 #pragma unroll 1
-        for (int j = 0; j < 31; j++) {
+            for (int j = 0; j < 30; j++) {
+                const uint32_t odd = 0u - ((uint32_t)ah & 1u);
+                const uint32_t sw = odd & (0u - (uint32_t)(ah < bh));
+                const uint64_t sw64 = (uint64_t)(int64_t)(int32_t)sw, odd64 = (uint64_t)(int64_t)(int32_t)odd;
+                const uint64_t t = (ah ^ bh) & sw64; ah ^= t; bh ^= t;
+                uint32_t ti = (F0 ^ F1) & sw; F0 ^= ti; F1 ^= ti;
+                ti = (G0 ^ G1) & sw; G0 ^= ti; G1 ^= ti;
+                ah -= bh & odd64;
+                F0 -= F1 & odd;
+                G0 -= G1 & odd;
+                ah >>= 1;
+                F1 <<= 1;
+                G1 <<= 1;
+            }
+            f0 = (int64_t)(int32_t)F0; g0 = (int64_t)(int32_t)G0; f1 = (int64_t)(int32_t)F1; g1 = (int64_t)(int32_t)G1;
+        }
+        {
             const uint64_t odd = (uint64_t)0 - (ah & 1u);
             const uint64_t lt = (uint64_t)0 - (uint64_t)(ah < bh);
             const uint64_t sw = odd & lt;

@@ -85,19 +85,13 @@ static __device__ __forceinline__ Fs *w12_fq_ref(Fq2S *slot, unsigned l) {
     return (l & 1) ? &slot[k].c1 : &slot[k].c0;
 }
 template <unsigned LANES>
-__global__ __launch_bounds__(LANES) void k_final_exp_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out, unsigned long long *dbg) {
+__global__ __launch_bounds__(LANES) void k_final_exp_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
     __shared__ Fq2S lds[W12_LDS_FQ2];
     const size_t e = blockIdx.x;
     if (e >= n) return;
     const unsigned lane = threadIdx.x;
     WaveExecN<LANES> ex;
     W12<WaveExecN<LANES>> w{ex, lds, lds + 6 * W12_SLOTS};
-    w.dbg = dbg;
-    if (dbg && (lane & 63) == 0) {
-        uint32_t hw;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        dbg[12 + (lane >> 6)] = hw;
-    }
     if (lane < 12) *w12_fq_ref(w.slot(0), lane) = Fs::from_mont256(reinterpret_cast<const Fq *>(&in[e])[lane]);
     __syncthreads();
     w.final_exponentiation();
@@ -451,21 +445,8 @@ int final_exp_device(const void *d_in, size_t n, void *d_out, hipStream_t st) {
     {
         // three wavefronts per element: the one-phase row product of w12.h (LSA_FINAL_EXP_LANES=128: the two-phase product)
         static const unsigned lanes = getenv("LSA_FINAL_EXP_LANES") ? (unsigned)atoi(getenv("LSA_FINAL_EXP_LANES")) : 192u;
-        static unsigned long long *dbg = nullptr;
-        static int dbg_calls = 0;
-        if (getenv("LSA_FE_STAMPS") && !dbg) (void)hipHostMalloc((void **)&dbg, 16 * 8, 0);
-        if (lanes == 128) hipLaunchKernelGGL(k_final_exp_wave<128>, dim3((unsigned)n), dim3(128), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out, dbg);
-        else hipLaunchKernelGGL(k_final_exp_wave<192>, dim3((unsigned)n), dim3(192), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out, dbg);
-        if (dbg && n == 1) {
-            (void)hipStreamSynchronize(st);
-            if (++dbg_calls > 100 && dbg_calls < 110) {
-                fprintf(stderr, "fe stamps (us at 100 MHz?):");
-                for (int i = 1; i < 12; i++) fprintf(stderr, " %d:%.1f", i, (double)(dbg[i] - dbg[i - 1]));
-                fprintf(stderr, " total %.1f", (double)(dbg[11] - dbg[0]));
-                for (int w = 0; w < 3; w++) fprintf(stderr, " | se %u cu %u simd %u wave %u", (unsigned)(dbg[12 + w] >> 13) & 7, (unsigned)(dbg[12 + w] >> 8) & 15, (unsigned)(dbg[12 + w] >> 4) & 3, (unsigned)dbg[12 + w] & 15);
-                fprintf(stderr, "\n");
-            }
-        }
+        if (lanes == 128) hipLaunchKernelGGL(k_final_exp_wave<128>, dim3((unsigned)n), dim3(128), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);
+        else hipLaunchKernelGGL(k_final_exp_wave<192>, dim3((unsigned)n), dim3(192), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);
     }
     else
         hipLaunchKernelGGL(k_final_exp, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);

@@ -279,6 +279,14 @@ __device__ __forceinline__ F29 w12_redc18(const W12Limbs18 &t, const W12Limbs18 
                  : "v"((T).l[0]), "v"((T).l[1]), "v"((T).l[2]), "v"((T).l[3]), "v"((T).l[4]), "v"((T).l[5]), "v"((T).l[6]),   \
                    "v"((T).l[7]), "v"((T).l[8]), "v"((T).l[9]), "v"((T).l[10]), "v"((T).l[11]), "v"((T).l[12]), "v"((T).l[13]), \
                    "v"((T).l[14]), "v"((T).l[15]), "v"((T).l[16]), "v"((T).l[17]))
+// Keep a value computed by EVERY lane: its only use is a store by one lane of the row, and left alone the compiler sinks
+// the whole computation under that lane's EXEC mask.  A lone wavefront runs instructions with a sparse EXEC mask slower
+// than with all lanes on -- 1.1x to 2.1x, depending on the CU it landed on (tools/ubench_placement.hip, "one active
+// lane per wavefront"; every CU runs the dense version at the same speed) -- so the arithmetic stays dense and only
+// the store is predicated.
+__device__ __forceinline__ void w12_pin(F29 &v) {
+    asm volatile("" : "+v"(v.l[0]), "+v"(v.l[1]), "+v"(v.l[2]), "+v"(v.l[3]), "+v"(v.l[4]), "+v"(v.l[5]), "+v"(v.l[6]), "+v"(v.l[7]), "+v"(v.l[8]));
+}
 template <bool FROB>
 __device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, const uint32_t *frob) {
     const unsigned lane = threadIdx.x, row = lane >> 4, r = lane & 15;
@@ -311,7 +319,8 @@ __device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, 
     W12_DPP18(t, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");         // sums of four (< 2^31)
     W12_DPP18(t, "row_half_mirror row_mask:0xf bank_mask:0xf");             // sums of eight (< 2^32: tight limbs)
     W12_DPP18_MOV(u, t, "row_mirror row_mask:0xf bank_mask:0xf");           // the other half of the row: added inside the reduction
-    const Fs res = {condsub2(w12_redc18(t, u))};
+    Fs res = {condsub2(w12_redc18(t, u))};
+    w12_pin(res.v);                                    // (dense: see w12_pin)
     if (r == 0) w12_store(&w12_comp(D[k], part), res);
     __syncthreads();
 }
@@ -319,6 +328,36 @@ __device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, 
 // function pays one scratch store and one scratch load with their waits -- a round trip to L2 -- per chain link)
 __device__ __noinline__ void w12_mul_rows(Fq2S *D, const Fq2S *A, const Fq2S *B) { w12_rows<false>(D, A, B, nullptr); }
 __device__ __noinline__ void w12_frob_rows(Fq2S *D, const Fq2S *A, const uint32_t *frob) { w12_rows<true>(D, A, nullptr, frob); }
+// slot d <- conj(slot a ^ z) for a in the cyclotomic subgroup (W12::exp_by_neg_z, which explains the digits), 192 lanes:
+// the whole loop as ONE block of code -- both row products inlined, the factor of a multiplication chosen by slot
+// number, no calls in the 62 trips.  A free function of the register file's base R (slot s = R + 6 s), NOT a member:
+// a member that is not inlined takes `this`, the W12 object then lives in scratch memory, and every slot address in the
+// caller and here becomes a load from it -- a round trip to L2 in front of each chain link.
+__device__ __noinline__ void w12_exp_by_neg_z_rows(Fq2S *R, int d, int a, int tmp) {
+    constexpr uint64_t D_P1 = 0x4800120040011001ull, D_P3 = 0x0000804004000000ull, D_M1 = 0x0000000000000010ull, D_M3 = 0x0108000400880200ull;
+    const unsigned lane = threadIdx.x;
+    auto slot = [R](int s) { return R + 6 * s; };
+    auto conj = [&](int dd, int aa) {
+        if (lane < 6) { const Fq2S v = slot(aa)[lane]; slot(dd)[lane] = (lane & 1) ? v.neg() : v; }
+        __syncthreads();
+    };
+    int acc = tmp, alt = tmp + 3;
+    const int a3 = tmp + 1, na = tmp + 2, na3 = tmp + 4, sq = tmp + 5;
+    w12_rows<false>(slot(sq), slot(a), slot(a), nullptr);
+    w12_rows<false>(slot(a3), slot(sq), slot(a), nullptr);        // a^3
+    conj(na, a);
+    conj(na3, a3);
+#pragma unroll 1
+    for (int i = 61; i >= 0; --i) {
+        w12_rows<false>(slot(alt), slot(i == 61 ? a : acc), slot(i == 61 ? a : acc), nullptr);
+        const unsigned p1 = (unsigned)(D_P1 >> i) & 1u, p3 = (unsigned)(D_P3 >> i) & 1u, m1 = (unsigned)(D_M1 >> i) & 1u, m3 = (unsigned)(D_M3 >> i) & 1u;
+        if (p1 | p3 | m1 | m3) {
+            const int f = p1 ? a : (p3 ? a3 : (m1 ? na : na3));
+            w12_rows<false>(slot(acc), slot(alt), slot(f), nullptr);
+        } else { const int t = acc; acc = alt; alt = t; }
+    }
+    conj(d, acc);
+}
 #endif
 
 template <class X>
@@ -326,12 +365,6 @@ struct W12 {
     X &x;
     Fq2S *R;   // W12_SLOTS x 6 coefficients
     Fq2S *P;   // 36 partial products
-    unsigned long long *dbg = nullptr;
-    LSA_HD void stamp(int i) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if (dbg && threadIdx.x == 0) dbg[i] = __builtin_readcyclecounter();
-#endif
-    }
 
     LSA_HD Fq2S *slot(int s) const { return R + 6 * s; }
 
@@ -438,8 +471,30 @@ struct W12 {
     // representatives say): the tower's Fq6 inversion on lane 0 (15 Fq2 products and one Fermat
     // inversion in Fq).  The final exponentiation inverts f as conj(f) * (f * conj(f))^-1 with it:
     // two products of the parallel engine instead of four Fq6 products on one lane.
-    LSA_HD void inverse6(int d, int a) {
+    LSA_HD void inverse6(int d, int a, int tmp = -1) {
         Fq2S *A = slot(a), *D = slot(d);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (x.nlanes() >= 192 && tmp >= 0) {
+            // on the row engine: a^-1 = a^(q^2) a^(q^4) / N, N = a a^(q^2) a^(q^4) the norm down to Fq2 (coefficient 0) -- two
+            // Frobenius maps and three row products around ONE Fq2 inversion on lane 0, instead of the tower's 33 Fq
+            // products on that lane.  The same field element as the tower code's, so the same canonical bytes.  Uses
+            // slots tmp, tmp + 1; d may be a.
+            Fq2S *T = slot(tmp), *U = slot(tmp + 1);
+            w12_frob_rows(T, A, &LSA_FROB_ROWS[1][0][0][0][0]);       // a^(q^2)
+            w12_frob_rows(U, T, &LSA_FROB_ROWS[1][0][0][0][0]);       // a^(q^4)
+            w12_mul_rows(T, T, U);
+            w12_mul_rows(U, A, T);                                    // N (odd and higher coefficients are 0 mod p)
+            x.par([=](unsigned lane) {
+                Fq2S inv = w12_load(&U[0]).inverse();           // every lane the same inversion: no sparse EXEC mask (w12_pin)
+                w12_pin(inv.c0.v);
+                w12_pin(inv.c1.v);
+                if (lane == 0) U[0] = inv;
+                else if (lane < 6) U[lane] = Fq2S::zero();
+            });
+            w12_mul_rows(D, T, U);
+            return;
+        }
+#endif
         x.par([=](unsigned lane) {
             if (lane == 0) {
                 const Fq6T<Fs> r = fq6_inverse(Fq6T<Fs>{A[0], A[2], A[4]});
@@ -486,6 +541,9 @@ struct W12 {
     // z (digits 0, +-1, +-3; 18 non-zero of 63) -- inverses are conjugations here, so a^z costs
     // 62 squarings + 17 products + 2 for a^3 instead of 62 + 27.  Uses slots tmp, tmp+1, tmp+2.
     LSA_HD void exp_by_neg_z(int d, int a, int tmp) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (x.nlanes() >= 192) { w12_exp_by_neg_z_rows(R, d, a, tmp); return; }
+#endif
         // the digits as four bit masks (bit i set: digit i is +1 / +3 / -1 / -3): a table in memory costs the chain one
         // load round trip per squaring
         constexpr uint64_t D_P1 = 0x4800120040011001ull, D_P3 = 0x0000804004000000ull, D_M1 = 0x0000000000000010ull, D_M3 = 0x0108000400880200ull;
@@ -514,28 +572,20 @@ struct W12 {
     // pairing.hip).  Uses every slot.
     LSA_HD void final_exponentiation() {
         enum { ELT = 0, FIRST, A, B, C, D, E, F, G, T0, T1, T2, T3, T4, T5 };      // (exp_by_neg_z uses T0 .. T5)
-        stamp(0);
         conj(A, ELT);             // conj(f): f^(p^6)
         mul(C, ELT, A);           // f * conj(f), an element of Fq6
-        stamp(1);
-        inverse6(D, C);
-        stamp(2);
+        inverse6(D, C, T0);
         mul(B, A, D);             // f^-1 = conj(f) / (f * conj(f))
         mul(C, A, B);             // f^(p^6 - 1)
-        stamp(3);
         frobenius<2>(D, C);
-        stamp(4);
         mul(FIRST, D, C);
-        stamp(5);
         exp_by_neg_z(A, FIRST, T0);
-        stamp(6);
         csqr(B, A);
         csqr(C, B);
         mul(D, C, B);
         exp_by_neg_z(E, D, T0);
         csqr(F, E);
         exp_by_neg_z(G, F, T0);
-        stamp(7);
         conj(T2, D);              // H
         conj(G, G);               // I
         mul(G, G, E);             // J = I * E
@@ -543,18 +593,14 @@ struct W12 {
         mul(T2, G, B);            // L = K * B
         mul(T0, G, E);            // M = K * E
         mul(T0, T0, FIRST);       // N = M * first
-        stamp(8);
         frobenius<1>(T1, T2);     // O = frob1(L)
-        stamp(9);
         mul(T0, T1, T0);          // P = O * N
         frobenius<2>(T1, G);      // Q = frob2(K)
         mul(T0, T1, T0);          // R = Q * P
         conj(T1, FIRST);          // S
         mul(T1, T1, T2);          // T = S * L
         frobenius<3>(T1, T1);     // U
-        stamp(10);
         mul(ELT, T1, T0);         // U * R
-        stamp(11);
     }
 };
 

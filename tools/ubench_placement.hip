@@ -32,6 +32,18 @@ __global__ __launch_bounds__(192) void k_work(uint32_t iters, uint64_t *out, uin
         } else if (KIND == 4) {
 #pragma unroll
             for (int k = 0; k < 8; k++) { asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b)); __syncthreads(); }
+        } else if (KIND == 6) {     // the same dependent chain with ONE active lane per wavefront (sparse EXEC)
+            if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+                for (int k = 0; k < 64; k++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(b), "v"(a) : "vcc");
+#pragma unroll
+                for (int k = 0; k < 64; k++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b));
+            }
+        } else if (KIND == 7) {     // and with all lanes active
+#pragma unroll
+            for (int k = 0; k < 64; k++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(b), "v"(a) : "vcc");
+#pragma unroll
+            for (int k = 0; k < 64; k++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b));
         } else {                    // a loop body of 4.8 KB (600 x 8 bytes): does the instruction cache hold it?
 #pragma unroll
             for (int k = 0; k < 600; k++) asm volatile("v_add_u32_e64 %0, %0, %1" : "+v"(a) : "v"(b));
@@ -77,5 +89,7 @@ int main(int argc, char **argv) {
     run<3>("v_add_u32_dpp", between, d_out, d_tmp);
     run<4>("barriers", between, d_out, d_tmp);
     run<5>("4.8-KB loop body", between, d_out, d_tmp);
+    run<6>("mads + adds, one active lane per wavefront", between, d_out, d_tmp);
+    run<7>("mads + adds, all lanes", between, d_out, d_tmp);
     return 0;
 }
