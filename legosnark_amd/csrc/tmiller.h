@@ -772,16 +772,25 @@ struct WTabMiller {
         });
         if (mode) {
             x.par([=](unsigned lane) {
-                if (lane >= 12) return;
-                const unsigned k = lane >> 1, part = lane & 1;
-                const F29 mine = coeff_part(m, k, part);
+                // twelve results, but EVERY lane computes one (lane l the same as lane l mod 12): with only twelve lanes on,
+                // a lone wavefront runs this phase 1.1-2.1x slower, depending on the CU (w12.h: w12_pin) -- only the
+                // stores are predicated
+                const unsigned k = (lane >> 1) % 6u, part = lane & 1;
+                F29 mine = coeff_part(m, k, part);
 #if defined(__HIP_DEVICE_COMPILE__)
                 const F29 other = wt_swap(mine);
 #else
                 const F29 other = coeff_part(m, k, part ^ 1u);
 #endif
-                w12_store(&w12_comp(m[WT_F + k], part), Fs{mine});
-                w12_store(&w12_comp(m[WT_XF + k], part), Fs{wt_xi_comp(part, mine, other)});    // [< 20]
+                F29 xf = wt_xi_comp(part, mine, other);                                           // [< 20]
+#if defined(__HIP_DEVICE_COMPILE__)
+                w12_pin(mine);
+                w12_pin(xf);
+#endif
+                if (lane < 12) {
+                    w12_store(&w12_comp(m[WT_F + k], part), Fs{mine});
+                    w12_store(&w12_comp(m[WT_XF + k], part), Fs{xf});
+                }
             });
         }
     }
@@ -839,5 +848,62 @@ struct WTabMiller {
         return t;
     }
 };
+
+static constexpr int RT_MAXM = 2;
+enum { RT_F = 0, RT_PXY = 6, RT_LINES = RT_PXY + RT_MAXM, RT_LDS_FQ2 = RT_LINES + RT_MAXM * ATE_NUM_COEFFS * 3 };
+#if defined(__HIP_DEVICE_COMPILE__)
+// ------------------------------------------------------------------------------------------------------------------
+// The same job on the row engine of w12.h (192 lanes, up to RT_MAXM pairs per accumulator): the latency shape for the
+// verifiers' lone pairing checks.  WTabMiller's round is two phases (42 + 12 lanes, an LDS round trip and a barrier
+// between them, the line of the next round scaled by four helper lanes on the side): ~780 instructions and two barriers
+// per round, 2.1 us.  Here
+//   * the lines are made ONCE, before the loop: all 102 rows of a pair's table are unpacked, ell_VW scaled by py and
+//     ell_VV by px (612 values per pair, four batches of one Fq product per lane) and parked in LDS (22 KB per pair);
+//   * a round is ONE row product (w12_rows): f <- f * f, or f <- f * line with the line's three coefficients (0, 3, 4
+//     of the polynomial basis: libff mul_by_024) as a sparse second factor -- ~600 instructions, 1.15 us.
+// Same field elements as WTabMiller's (products commute, values leave canonical), 64 + 102 M rounds.
+// ------------------------------------------------------------------------------------------------------------------
+// m: RT_LDS_FQ2 values in LDS; tab, P, neg: RT_MAXM entries each (pairs >= cnt: the identity table); result in m[RT_F .. RT_F + 5]
+__device__ __forceinline__ void rt_miller_run(Fq2S *m, const uint32_t *const *tab, const Jac<Fq> *const *P, const uint8_t *neg, unsigned cnt, unsigned M) {
+    const unsigned lane = threadIdx.x;
+    {   // (px, py) of every pair, computed by every lane (no sparse EXEC mask: w12_pin), stored by one
+        const unsigned i = lane & (RT_MAXM - 1);
+        Fq2S pxy[2];
+        tm_setup_g1(i < cnt, P[i], neg[i] != 0, pxy);
+        w12_pin(pxy[0].c0.v);
+        w12_pin(pxy[1].c0.v);
+        if (lane < (unsigned)RT_MAXM) m[RT_PXY + lane] = Fq2S{pxy[0].c0, pxy[1].c0};        // (px, py) as the two halves of one slot
+        if (lane < 6) m[RT_F + lane] = lane == 0 ? Fq2S::one() : Fq2S::zero();
+    }
+    __syncthreads();
+    // the lines: value (pair i, entry e, component c) = table word group c of row e, times py (ell_VW) or px (ell_VV)
+    for (unsigned idx = lane; idx < M * (unsigned)ATE_NUM_COEFFS * 6u; idx += 192u) {
+        const unsigned i = idx / (ATE_NUM_COEFFS * 6u), rem = idx % (ATE_NUM_COEFFS * 6u), e = rem / 6u, c = rem % 6u;
+        const uint32_t *src = tab[i] + e * TM_ROW_WORDS + c * 8;
+        uint32_t w[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) w[q] = src[q];
+        F29 v = F29::unpack256(w);
+        if (c >= 2) {
+            const Fs s = w12_load(&w12_comp(m[RT_PXY + i], c < 4 ? 1u : 0u));       // ell_VW * py, ell_VV * px
+            v = mul(v, s.v);
+        }
+        w12_store(&w12_comp(m[RT_LINES + (i * ATE_NUM_COEFFS + e) * 3 + (c >> 1)], c & 1u), Fs{v});
+    }
+    __syncthreads();
+    unsigned u = 0;
+#pragma unroll 1
+    for (int ph = 0; ph < 66; ph++) {
+        const bool dbl = ph < 64;
+        const int lines = dbl ? 1 + ate_bit(63 - ph) : 1;
+        if (dbl) w12_rows<W12_MUL>(m + RT_F, m + RT_F, m + RT_F, nullptr);
+#pragma unroll 1
+        for (int li = 0; li < lines; li++, u++) {
+#pragma unroll 1
+            for (unsigned i = 0; i < M; i++) w12_rows<W12_LINE>(m + RT_F, m + RT_F, m + RT_LINES + (i * ATE_NUM_COEFFS + u) * 3, nullptr);
+        }
+    }
+}
+#endif
 
 }  // namespace lsa

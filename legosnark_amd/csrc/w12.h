@@ -287,12 +287,13 @@ __device__ __forceinline__ F29 w12_redc18(const W12Limbs18 &t, const W12Limbs18 
 __device__ __forceinline__ void w12_pin(F29 &v) {
     asm volatile("" : "+v"(v.l[0]), "+v"(v.l[1]), "+v"(v.l[2]), "+v"(v.l[3]), "+v"(v.l[4]), "+v"(v.l[5]), "+v"(v.l[6]), "+v"(v.l[7]), "+v"(v.l[8]));
 }
-template <bool FROB>
+enum { W12_MUL = 0, W12_FROB = 1, W12_LINE = 2 };
+template <int MODE>
 __device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, const uint32_t *frob) {
     const unsigned lane = threadIdx.x, row = lane >> 4, r = lane & 15;
     const unsigned k = row >> 1, part = row & 1, i = r >> 1, h = r & 1;
     F29 L, Rv;
-    if (FROB) {
+    if (MODE == W12_FROB) {
         static constexpr uint32_t ZERO9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         L = w12_load(&w12_comp(A[k], h)).v;
         const uint32_t *c = r < 2 ? frob + ((k * 2 + part) * 2 + h) * 9 : ZERO9;      // lanes 2..15 of a row add nothing
@@ -307,10 +308,15 @@ __device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, 
         //   wrapped:  part 0: (9, -1, 2), (-1, -9, 20)    part 1: (1, 9, 0), (9, -1, 2)
         // (all zero for lanes 12..15 of a row: they add nothing)
         const unsigned sh = 8u * ((wrapped ? 4u : 0u) | (part << 1) | h);
-        const int lv = r < 12 ? -1 : 0;
+        int lv = r < 12 ? -1 : 0;
+        unsigned jb = j;
+        if (MODE == W12_LINE) {                          // B = {ell_0, ell_VW', ell_VV'}: coefficients 0, 3, 4 of a line (libff mul_by_024), the others are zero
+            lv &= (j == 0 || j == 3 || j == 4) ? -1 : 0;
+            jb = j == 0 ? 0u : (j == 3 ? 1u : 2u);
+        }
         const int c0 = (int)(int8_t)(0x0901ff0901000001ull >> sh) & lv, c1 = (int)(int8_t)(0xff09f7ff0001ff00ull >> sh) & lv, K = (int)(int8_t)(0x0200140200000200ull >> sh) & lv;
         L = w12_load(&w12_comp(A[iw], h)).v;
-        const Fq2S bj = w12_load(&B[j]);
+        const Fq2S bj = w12_load(&B[jb]);
         Rv = lin2(bj.c0.v, c0, bj.c1.v, c1, K);
     }
     __syncthreads();                                   // every lane holds its operands: D may alias A or B from here on
@@ -326,8 +332,8 @@ __device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, 
 }
 // LEAF functions (no calls inside, so no return address to park in a spilled VGPR: a product that calls a product
 // function pays one scratch store and one scratch load with their waits -- a round trip to L2 -- per chain link)
-__device__ __noinline__ void w12_mul_rows(Fq2S *D, const Fq2S *A, const Fq2S *B) { w12_rows<false>(D, A, B, nullptr); }
-__device__ __noinline__ void w12_frob_rows(Fq2S *D, const Fq2S *A, const uint32_t *frob) { w12_rows<true>(D, A, nullptr, frob); }
+__device__ __noinline__ void w12_mul_rows(Fq2S *D, const Fq2S *A, const Fq2S *B) { w12_rows<W12_MUL>(D, A, B, nullptr); }
+__device__ __noinline__ void w12_frob_rows(Fq2S *D, const Fq2S *A, const uint32_t *frob) { w12_rows<W12_FROB>(D, A, nullptr, frob); }
 // slot d <- conj(slot a ^ z) for a in the cyclotomic subgroup (W12::exp_by_neg_z, which explains the digits), 192 lanes:
 // the whole loop as ONE block of code -- both row products inlined, the factor of a multiplication chosen by slot
 // number, no calls in the 62 trips.  A free function of the register file's base R (slot s = R + 6 s), NOT a member:
@@ -343,17 +349,17 @@ __device__ __noinline__ void w12_exp_by_neg_z_rows(Fq2S *R, int d, int a, int tm
     };
     int acc = tmp, alt = tmp + 3;
     const int a3 = tmp + 1, na = tmp + 2, na3 = tmp + 4, sq = tmp + 5;
-    w12_rows<false>(slot(sq), slot(a), slot(a), nullptr);
-    w12_rows<false>(slot(a3), slot(sq), slot(a), nullptr);        // a^3
+    w12_rows<W12_MUL>(slot(sq), slot(a), slot(a), nullptr);
+    w12_rows<W12_MUL>(slot(a3), slot(sq), slot(a), nullptr);        // a^3
     conj(na, a);
     conj(na3, a3);
 #pragma unroll 1
     for (int i = 61; i >= 0; --i) {
-        w12_rows<false>(slot(alt), slot(i == 61 ? a : acc), slot(i == 61 ? a : acc), nullptr);
+        w12_rows<W12_MUL>(slot(alt), slot(i == 61 ? a : acc), slot(i == 61 ? a : acc), nullptr);
         const unsigned p1 = (unsigned)(D_P1 >> i) & 1u, p3 = (unsigned)(D_P3 >> i) & 1u, m1 = (unsigned)(D_M1 >> i) & 1u, m3 = (unsigned)(D_M3 >> i) & 1u;
         if (p1 | p3 | m1 | m3) {
             const int f = p1 ? a : (p3 ? a3 : (m1 ? na : na3));
-            w12_rows<false>(slot(acc), slot(alt), slot(f), nullptr);
+            w12_rows<W12_MUL>(slot(acc), slot(alt), slot(f), nullptr);
         } else { const int t = acc; acc = alt; alt = t; }
     }
     conj(d, acc);
