@@ -25,11 +25,12 @@ namespace lsa {
 // a quad of lanes (quad29.h: 3 dependency levels per doubling instead of 9 products).
 template <class C>
 __global__ __launch_bounds__(64) void k_bexp_powers(Jac<typename C::Field> base, typename C::Acc *__restrict__ pw, unsigned w, unsigned nwin) {
-    if (threadIdx.x >= 4 || blockIdx.x != 0) return;
+    // (every quad of the wavefront runs the chain, lane 0 stores: four lanes alone run it 1.1-2.1x slower -- tools/ubench_exec_mask.hip)
+    if (blockIdx.x != 0) return;
     const unsigned q = threadIdx.x & 3;
     typename C::Acc cur = C::from_jac(base);
     for (unsigned j = 0; j < nwin; j++) {
-        if (q == 0) pw[j] = cur;
+        if (threadIdx.x == 0) pw[j] = cur;
         for (unsigned i = 0; i < w; i++) cur = quad_dbl(cur, q);
     }
 }

@@ -1307,7 +1307,9 @@ __device__ __forceinline__ void pin_vgpr(A &a) {
 // ------------------------------------------------------------------------------------
 template <class A, class J>
 __device__ __forceinline__ void fold_quad_body(const A *__restrict__ window_sums, unsigned nwin, unsigned c, J *__restrict__ out) {
-    if (threadIdx.x >= 4 || blockIdx.x != 0) return;
+    // EVERY quad of the wavefront runs the same fold (one of them would do): with four lanes on, a lone wavefront executes
+    // the chain 1.1-2.1x slower, depending on the CU it landed on (tools/ubench_exec_mask.hip); lane 0 stores
+    if (blockIdx.x != 0) return;
     const unsigned q = threadIdx.x & 3;
     // window_sums holds (ACC,RUN) pairs of the last reduction level: window k at index 2k
     A r = window_sums[2 * (nwin - 1)];
@@ -1318,10 +1320,11 @@ __device__ __forceinline__ void fold_quad_body(const A *__restrict__ window_sums
         pin_vgpr(w);
         r = quad_add(r, w, q);
     }
-    if (q == 0) {
-        if constexpr (std::is_same<A, XYZZ29>::value) *out = xyzz29_to_jac(r);
-        else *out = g2_to_jac(r);
-    }
+    J res;
+    if constexpr (std::is_same<A, XYZZ29>::value) res = xyzz29_to_jac(r);
+    else res = g2_to_jac(r);
+    pin_vgpr(res);
+    if (threadIdx.x == 0) *out = res;
 }
 __global__ __launch_bounds__(64) void k_fold_quad(const XYZZ29 *__restrict__ window_sums, unsigned nwin, unsigned c, Jac<Fq> *__restrict__ out) {
     fold_quad_body(window_sums, nwin, c, out);
