@@ -20,4 +20,6 @@ python3 tools/msm_vs_n.py > "$OUT/${TAG}_msm_vs_n.txt" 2>&1
 sh tools/profile_cmd_timeline.sh ${TAG}_compact_n4096 12 tools/single_call_trace.py 4096 > /dev/null 2>&1
 sh tools/profile_cmd_timeline.sh ${TAG}_single_call 30 tools/single_call_trace.py > /dev/null 2>&1
 python3 tools/final_exp_probe.py > "$OUT/${TAG}_final_exp.txt" 2>&1
+python3 tools/pairing_check_probe.py > "$OUT/${TAG}_pairing_check.txt" 2>&1
+sh tools/profile_cmd_timeline.sh ${TAG}_pairing_check 9 tools/pairing_check_probe.py > /dev/null 2>&1
 ls -la "$OUT" | grep "$TAG" | awk '{print $5, $9}'
