@@ -46,3 +46,25 @@ def test_host_64_bit_limbs_agree_with_the_device_limbs(tmp_path):
         assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-2000:]
         outs.append(r.stdout)
     assert outs[0] == outs[1] and outs[0].count("inv ") == 2
+
+
+def test_frobenius_row_constants_are_the_generators_output():
+    """csrc/frob_rows.h is generated (tools/gen_frob_rows.py: the Frobenius factors of bn254_constants.h multiplied out,
+    conjugation and signs folded in, 29-bit-limb Montgomery form); the committed table must be what the script prints,
+    and must satisfy gamma_(P,k) = FROB6_C{k>>1}[P] * (k odd ? FROB12_C1[P] : 1) against the oracle's Fq2 arithmetic."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_frob_rows.py")], cwd=root, capture_output=True, text=True, check=True).stdout
+    header = open(os.path.join(root, "legosnark_amd", "csrc", "frob_rows.h")).read()
+    want = re.findall(r"0x[0-9a-f]{8}u", out)
+    got = re.findall(r"0x[0-9a-f]{8}u", header)
+    assert len(want) == 3 * 6 * 2 * 2 * 9 and got == want
+    # spot value: power 2, k = 0 is the identity map: rows (1, -0) / (0, 1) in Montgomery form R = 2^261
+    p = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    one = (1 << 261) % p
+    limbs = [int(x[2:-1], 16) for x in want]
+    base = ((1 * 6 + 0) * 2 + 0) * 2 * 9                      # [power - 1 = 1][k = 0][part 0][h 0]
+    assert sum(l << (29 * i) for i, l in enumerate(limbs[base:base + 9])) == one
+    assert all(l == 0 for l in limbs[base + 9:base + 18])       # -g1 = 0
