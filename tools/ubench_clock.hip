@@ -24,6 +24,18 @@ __global__ __launch_bounds__(64) void k_chain(uint32_t iters, uint64_t *out, uin
         } else if (KIND == 2) {     // 16 dependent v_mad_u64_u32
 #pragma unroll
             for (int k = 0; k < 16; k++) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(b), "v"(c) : "vcc");
+        } else if (KIND == 4) {     // 16 dependent v_cndmask_b32 (VOP2: the mask in VCC)
+            asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a), "v"(b) : "vcc");
+#pragma unroll
+            for (int k = 0; k < 16; k++) asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a) : "v"(b) : "vcc");
+        } else if (KIND == 5) {     // 16 dependent v_cndmask_b32 (VOP3: the mask in an SGPR pair)
+            uint64_t m;
+            asm volatile("v_cmp_lt_u32 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+#pragma unroll
+            for (int k = 0; k < 16; k++) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a) : "v"(b), "s"(m));
+        } else if (KIND == 6) {     // 16 dependent v_bfi_b32 (select by mask register)
+#pragma unroll
+            for (int k = 0; k < 16; k++) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(a) : "v"(c), "v"(b));
         } else {                    // a carry step: add, and, shift (dependent triple) x 5 + 1
 #pragma unroll
             for (int k = 0; k < 5; k++)
@@ -62,6 +74,9 @@ int main() {
         run<1>("v_add_u32, 4 chains", blocks, d_out);
         run<2>("dependent v_mad_u64_u32", blocks, d_out);
         run<3>("carry step (add, and, shr)", blocks, d_out);
+        run<4>("dependent v_cndmask_b32_e32 (vcc)", blocks, d_out);
+        run<5>("dependent v_cndmask_b32_e64", blocks, d_out);
+        run<6>("dependent v_bfi_b32", blocks, d_out);
     }
     // sixteen lone workgroups one after the other: successive dispatches start on successive XCDs
     printf("lone workgroup, dependent v_add_u32, dispatch after dispatch:\n");
