@@ -2074,7 +2074,11 @@ acc_done:
         Jac<F> *res = tail != st ? (Jac<F> *)(tws + res_off) : d_out;
         // pipelined wide calls: the first 16-ary level lane-private (k_reduce2_lane: a seventh of the quad level's work)
         static const bool allow_lane_l1 = getenv("LSA_NO_LANE_L1") == nullptr;
-        bool lane_l1 = allow_lane_l1 && !blocking && big && kw == 1 && nseg == 1 && m >= 16384;
+        // (G1 only: 48 sequential G2 additions are 1.2 ms of latency; and only when the previous call's tail is still in
+        // flight, i.e. calls really are queued back to back: a pair that is waited for right away -- CPpoly's commit --
+        // pays the lane kernel's 0.2 ms of extra latency instead: 6.0 -> 6.25 ms)
+        bool lane_l1 = allow_lane_l1 && std::is_same<C, CurveG1>::value && !blocking && big && kw == 1 && nseg == 1 && m >= 16384 && tail != st &&
+                       prev.pending && &prev != &tb && hipEventQuery(prev.done) == hipErrorNotReady;
         do {                                             // at least one k_reduce2 level (it leaves the sum in slot 0)
             const uint32_t m_out = (m + 15) / 16;
             if (lane_l1) {
