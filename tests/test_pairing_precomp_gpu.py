@@ -5,6 +5,7 @@ is compared byte-for-byte with the oracle (oracle/bn254.c: oracle_precompute_g2 
 oracle_miller_loop restate libff's alt_bn128_ate_precompute_G2 / alt_bn128_ate_miller_loop).
 Reference call sites: /root/reference/src/gadgets/subspace.cc:48,66-70,152-166,
 src/gadgets/lipmaa.cc:187-207, src/gadgets/poly.h:97-121, src/utils/globl.h:94-105."""
+import os
 import random
 
 import numpy as np
@@ -210,3 +211,40 @@ def test_a_failed_call_leaves_no_half_built_table_behind(lsa):
         assert np.array_equal(lsa.miller_loop(pm, more), o.miller_loop_batch(pm, more))
     finally:
         lsa.g2_table_cache(4096)
+
+
+@pytest.mark.parametrize("switch", ["LSA_MILLER_ROWS=0", "LSA_FINAL_EXP_LANES=128"])
+def test_the_older_kernels_behind_their_switches_give_the_same_bytes(lsa, switch):
+    """k_miller_wtab (two-phase rounds) and the two-wavefront final exponentiation stay in the library behind A/B
+    switches that are read once per process: a child process under the switch must return the bytes this process does
+    (a two-term check with a conjugated term, and the Miller values alone)."""
+    import subprocess
+    import sys
+    ps = o.arith_bases("g1", 321, 7, 2)
+    qs = _g2_points(2, 55)
+    tabs = lsa.g2_precompute(qs)
+    off = np.array([0, 2], dtype=np.uint64)
+    flags = np.array([0, 1], dtype=np.uint8)
+    here = lsa.pairing_terms(ps, off, tables=tabs, index=[0, 1], flags=flags, final_exp=True)
+    mill = lsa.miller_loop_precomp(ps, tabs, [0, 1])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # the child rebuilds the same inputs through this module's helpers
+    code = (
+        "import sys, os, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import legosnark_amd as lsa, oracle_lib as o\n"
+        "import test_pairing_precomp_gpu as t\n"
+        "lsa.init(0)\n"
+        "ps = o.arith_bases('g1', 321, 7, 2); qs = t._g2_points(2, 55); tabs = lsa.g2_precompute(qs)\n"
+        "a = lsa.pairing_terms(ps, np.array([0, 2], dtype=np.uint64), tables=tabs, index=[0, 1], flags=np.array([0, 1], dtype=np.uint8), final_exp=True)\n"
+        "b = lsa.miller_loop_precomp(ps, tabs, [0, 1])\n"
+        "sys.stdout.write(a.tobytes().hex() + ' ' + b.tobytes().hex())\n"
+    ) % (root, os.path.join(root, "tests"))
+    env = dict(os.environ)
+    k, v = switch.split("=")
+    env[k] = v
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    a_hex, b_hex = out.stdout.strip().split()[-2:]
+    assert a_hex == here.tobytes().hex()
+    assert b_hex == mill.tobytes().hex()
