@@ -29,6 +29,7 @@ int g2_table_export_device(const uint32_t *const *d_tabs, size_t n, void *d_publ
 int g2_table_import_device(const void *d_public, size_t n, uint32_t *const *d_tabs, hipStream_t st);
 int g2_table_identity_device(uint32_t *d_tab, hipStream_t st);
 unsigned miller_tab_max_pairs();
+void miller_split_release();
 int miller_tab_device(const void *d_g1, const uint32_t *const *d_tabs, const uint8_t *d_flags, const uint32_t *d_acc_off, size_t nacc, unsigned M,
                       const uint32_t *d_ident, void *d_out, hipStream_t st);
 int miller_fused_device(const void *d_g1, const void *d_g2, const uint8_t *d_flags, uint32_t *const *d_tabs, size_t n, void *d_out, hipStream_t st);
@@ -539,6 +540,7 @@ void pairing_release() {
     if (g_uploaded) { (void)hipEventDestroy(g_uploaded); g_uploaded = nullptr; }
     g_upload_pending = false;
     g_pending.drop(); g_pending.dev.release();
+    miller_split_release();
     g_tabs.clear();
 }
 }  // namespace lsa

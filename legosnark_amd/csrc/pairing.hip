@@ -405,14 +405,17 @@ __global__ __launch_bounds__(64) void k_miller_wtab(const Jac<Fq> *__restrict__ 
 }
 
 // One accumulator per workgroup of 192 lanes, at most RT_MAXM pairs each (tmiller.h, rt_miller_run): the row-engine version.
+// K > 1: K workgroups per accumulator (blockIdx = a * K + r), out[a * K + r] = the factor of the steps r mod K
 __global__ __launch_bounds__(192) void k_miller_rtab(const Jac<Fq> *__restrict__ g1, const uint32_t *const *__restrict__ tabs,
                                                      const uint8_t *__restrict__ flags, const uint32_t *__restrict__ acc_off, size_t nacc,
-                                                     unsigned M, const uint32_t *__restrict__ ident, Fq12 *__restrict__ out) {
+                                                     unsigned M, const uint32_t *__restrict__ ident, Fq12 *__restrict__ out, unsigned K) {
     __shared__ Fq2S lds[RT_LDS_FQ2];
     __shared__ const uint32_t *tp[RT_MAXM];
     __shared__ const Jac<Fq> *pp[RT_MAXM];
     __shared__ uint8_t ng[RT_MAXM];
-    const size_t a = blockIdx.x;
+    __shared__ uint8_t own[ATE_NUM_COEFFS + 2];
+    const size_t a = blockIdx.x / K;
+    const unsigned r = blockIdx.x % K;
     if (a >= nacc) return;
     const unsigned lane = threadIdx.x;
     const unsigned lo = acc_off[a], len = acc_off[a + 1] - lo;
@@ -424,12 +427,12 @@ __global__ __launch_bounds__(192) void k_miller_rtab(const Jac<Fq> *__restrict__
     }
     __syncthreads();
 #if defined(__HIP_DEVICE_COMPILE__)
-    rt_miller_run(lds, tp, pp, ng, len, M);
+    rt_miller_run(lds, tp, pp, ng, len, M, K, r, own);
 #endif
     if (lane < 12) {
         const unsigned k = lane >> 1, part = lane & 1, t = (k & 1) * 3 + (k >> 1);
         const Fq2S cf = lds[RT_F + k];
-        reinterpret_cast<Fq *>(&out[a])[2 * t + part] = (part ? cf.c1 : cf.c0).to_mont256();
+        reinterpret_cast<Fq *>(&out[blockIdx.x])[2 * t + part] = (part ? cf.c1 : cf.c0).to_mont256();
     }
 }
 
@@ -543,6 +546,8 @@ int miller_fused_device(const void *d_g1, const void *d_g2, const uint8_t *d_fla
     return LSA_OK;
 }
 unsigned miller_tab_max_pairs() { return (unsigned)TM_MAXM; }
+static void *g_rt_parts = nullptr;         // the factors of split Miller loops (32 accumulators x 8 workgroups)
+void miller_split_release() { if (g_rt_parts) { (void)hipFree(g_rt_parts); g_rt_parts = nullptr; } }
 int miller_tab_device(const void *d_g1, const uint32_t *const *d_tabs, const uint8_t *d_flags, const uint32_t *d_acc_off, size_t nacc, unsigned M,
                       const uint32_t *d_ident, void *d_out, hipStream_t st) {
     if (nacc == 0) return LSA_OK;
@@ -553,10 +558,19 @@ int miller_tab_device(const void *d_g1, const uint32_t *const *d_tabs, const uin
     const bool wave = force ? force == 1 : nacc <= 2048;
     // few accumulators of one or two pairs (the verifiers' lone checks): the row engine, 0.2 ms against 0.35 (LSA_MILLER_ROWS=0: off)
     static const bool rows = getenv("LSA_MILLER_ROWS") == nullptr || atoi(getenv("LSA_MILLER_ROWS")) != 0;
-    if (wave && rows && M <= (unsigned)RT_MAXM && nacc <= 512)
-        hipLaunchKernelGGL(k_miller_rtab, dim3((unsigned)nacc), dim3(192), 0, st, (const Jac<Fq> *)d_g1, d_tabs, d_flags, d_acc_off, nacc, M, d_ident,
-                           (Fq12 *)d_out);
-    else if (wave)
+    if (wave && rows && M <= (unsigned)RT_MAXM && nacc <= 512) {
+        // a handful of accumulators: eight workgroups share each loop's line products (rt_miller_run), k_fq12_prod8_wave
+        // multiplies their eight factors -- 64 + 102 M / 8 chain links instead of 64 + 102 M (LSA_MILLER_SPLIT=1: off)
+        static const unsigned split = getenv("LSA_MILLER_SPLIT") ? (unsigned)atoi(getenv("LSA_MILLER_SPLIT")) : 8u;
+        if (split == 8 && nacc <= 32) {
+            if (!g_rt_parts && hipMalloc(&g_rt_parts, 32 * 8 * sizeof(Fq12)) != hipSuccess) { g_rt_parts = nullptr; set_error("miller_tab: hipMalloc failed"); return LSA_ERR_NOMEM; }
+            hipLaunchKernelGGL(k_miller_rtab, dim3((unsigned)nacc * 8), dim3(192), 0, st, (const Jac<Fq> *)d_g1, d_tabs, d_flags, d_acc_off, nacc, M, d_ident,
+                               (Fq12 *)g_rt_parts, 8u);
+            hipLaunchKernelGGL(k_fq12_prod8_wave, dim3((unsigned)nacc), dim3(192), 0, st, (const Fq12 *)g_rt_parts, nacc * 8, (Fq12 *)d_out);
+        } else
+            hipLaunchKernelGGL(k_miller_rtab, dim3((unsigned)nacc), dim3(192), 0, st, (const Jac<Fq> *)d_g1, d_tabs, d_flags, d_acc_off, nacc, M, d_ident,
+                               (Fq12 *)d_out, 1u);
+    } else if (wave)
         hipLaunchKernelGGL(k_miller_wtab, dim3((unsigned)nacc), dim3(64), 0, st, (const Jac<Fq> *)d_g1, d_tabs, d_flags, d_acc_off, nacc, M, d_ident,
                            (Fq12 *)d_out);
     else

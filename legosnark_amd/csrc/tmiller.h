@@ -863,9 +863,21 @@ enum { RT_F = 0, RT_PXY = 6, RT_LINES = RT_PXY + RT_MAXM, RT_LDS_FQ2 = RT_LINES 
 //     of the polynomial basis: libff mul_by_024) as a sparse second factor -- ~600 instructions, 1.15 us.
 // Same field elements as WTabMiller's (products commute, values leave canonical), 64 + 102 M rounds.
 // ------------------------------------------------------------------------------------------------------------------
-// m: RT_LDS_FQ2 values in LDS; tab, P, neg: RT_MAXM entries each (pairs >= cnt: the identity table); result in m[RT_F .. RT_F + 5]
-__device__ __forceinline__ void rt_miller_run(Fq2S *m, const uint32_t *const *tab, const Jac<Fq> *const *P, const uint8_t *neg, unsigned cnt, unsigned M) {
+// m: RT_LDS_FQ2 values in LDS; tab, P, neg: RT_MAXM entries each (pairs >= cnt: the identity table); result in m[RT_F .. RT_F + 5].
+// K > 1: ONE OF K workgroups that share the loop.  With F_s the product of the lines of step s, the loop computes
+// f = prod_s F_s^(2^(63 - s)) (times the two closing lines) by f <- f^2 * F_s; the factors of the steps s = r mod K alone
+// obey the same recurrence -- g <- g^2 every step, g <- g * F_s on the workgroup's own steps -- and the K results
+// multiply to f.  The 64 squarings stay (they are the chain), the 102 M line products are shared out: 64 + 102 M / K
+// links instead of 64 + 102 M, on K otherwise idle CUs; `own` (104 bytes of LDS) marks the entries of the own steps.
+__device__ __forceinline__ void rt_miller_run(Fq2S *m, const uint32_t *const *tab, const Jac<Fq> *const *P, const uint8_t *neg, unsigned cnt, unsigned M,
+                                              unsigned K, unsigned r, uint8_t *own) {
     const unsigned lane = threadIdx.x;
+    if (lane < 66) {                                      // lane = step: its entries are [first, first + lines)
+        unsigned first = 0;
+        for (unsigned s = 0; s < lane; s++) first += s < 64 ? 1u + (unsigned)ate_bit(63 - (int)s) : 1u;
+        const unsigned lines = lane < 64 ? 1u + (unsigned)ate_bit(63 - (int)lane) : 1u;
+        for (unsigned l = 0; l < lines; l++) own[first + l] = (uint8_t)(lane % K == r);
+    }
     {   // (px, py) of every pair, computed by every lane (no sparse EXEC mask: w12_pin), stored by one
         const unsigned i = lane & (RT_MAXM - 1);
         Fq2S pxy[2];
@@ -879,6 +891,7 @@ __device__ __forceinline__ void rt_miller_run(Fq2S *m, const uint32_t *const *ta
     // the lines: value (pair i, entry e, component c) = table word group c of row e, times py (ell_VW) or px (ell_VV)
     for (unsigned idx = lane; idx < M * (unsigned)ATE_NUM_COEFFS * 6u; idx += 192u) {
         const unsigned i = idx / (ATE_NUM_COEFFS * 6u), rem = idx % (ATE_NUM_COEFFS * 6u), e = rem / 6u, c = rem % 6u;
+        if (!own[e]) continue;
         const uint32_t *src = tab[i] + e * TM_ROW_WORDS + c * 8;
         uint32_t w[8];
 #pragma unroll
@@ -897,8 +910,10 @@ __device__ __forceinline__ void rt_miller_run(Fq2S *m, const uint32_t *const *ta
         const bool dbl = ph < 64;
         const int lines = dbl ? 1 + ate_bit(63 - ph) : 1;
         if (dbl) w12_rows<W12_MUL>(m + RT_F, m + RT_F, m + RT_F, nullptr);
+        const bool mine = (unsigned)ph % K == r;
 #pragma unroll 1
         for (int li = 0; li < lines; li++, u++) {
+            if (!mine) continue;
 #pragma unroll 1
             for (unsigned i = 0; i < M; i++) w12_rows<W12_LINE>(m + RT_F, m + RT_F, m + RT_LINES + (i * ATE_NUM_COEFFS + u) * 3, nullptr);
         }
