@@ -199,7 +199,7 @@ namespace lsa {
 namespace {
 class HostCopier {
     static constexpr size_t SLOT = (size_t)2 << 20;
-    static constexpr unsigned MAX_WORKERS = 8, SLOTS_PER_WORKER = 2;
+    static constexpr unsigned MAX_WORKERS = 12, SLOTS_PER_WORKER = 2;
     struct Slot { void *p = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
     struct Worker { Slot slot[SLOTS_PER_WORKER]; unsigned turn = 0; };
     Worker w_[MAX_WORKERS];
@@ -229,7 +229,8 @@ class HostCopier {
         if (arena_) return true;
         const unsigned hw = std::thread::hardware_concurrency();
         const char *e = getenv("LSA_H2D_THREADS");
-        unsigned want = e ? (unsigned)atoi(e) : (hw > 8 ? 6 : (hw > 2 ? hw / 2 : 1));
+        // one thread moves ~10 GB/s through a pinned slot; the link takes ~55: ten on a host with cores to spare
+        unsigned want = e ? (unsigned)atoi(e) : (hw >= 32 ? 10 : (hw > 8 ? 6 : (hw > 2 ? hw / 2 : 1)));
         if (want < 1) want = 1;
         if (want > MAX_WORKERS) want = MAX_WORKERS;
         if (hipHostMalloc(&arena_, (size_t)want * SLOTS_PER_WORKER * SLOT, hipHostMallocDefault) != hipSuccess) { arena_ = nullptr; return false; }
@@ -367,16 +368,46 @@ constexpr size_t STAGE_FROM = (size_t)32 << 10;       // below: the runtime copi
 // runtime has pinned them: see capi_internal.h; the shim keeps them on the heap, other callers keep them alive.)
 constexpr size_t STAGE_BELOW = (size_t)16 << 20;
 static bool staged(size_t bytes) { return copy_mode() != 1 && ((bytes >= STAGE_FROM && bytes < STAGE_BELOW) || copy_mode() == 2); }
+// A host range the library has NOT been handed before (the reference's provers: one multiExpMA per key vector and
+// process, src/gadgets/subspace.cc:78-85; fresh std::vectors of scalars per call) is the other case: the runtime's direct
+// path first has to pin its pages, 4 KiB at a time unless the kernel backs the range with huge pages -- 5-20 ms per
+// 96 MiB depending on the box, where the slots move it at the link rate whatever the pages are.  The last few large
+// ranges are remembered; a range goes through the slots until it has been seen LSA_H2D_DIRECT_AFTER (default 2) times,
+// from then on the runtime's registration is worth its price (bench loops, provers that keep their vectors).
+struct SeenRange { const void *p = nullptr; size_t bytes = 0; unsigned count = 0; uint64_t tick = 0; };
+static SeenRange g_seen[16];
+static uint64_t g_seen_tick = 0;
+static unsigned direct_after() {
+    static const unsigned v = [] { const char *e = getenv("LSA_H2D_DIRECT_AFTER"); return e ? (unsigned)atoi(e) : 2u; }();
+    return v;
+}
+static bool large_copy_staged(const void *h, size_t bytes) {
+    if (copy_mode() == 1) return false;
+    if (copy_mode() == 2) return true;
+    SeenRange *slot = &g_seen[0];
+    for (auto &r : g_seen) {
+        if (r.p == h && r.bytes == bytes) { r.tick = ++g_seen_tick; return r.count++ < direct_after(); }
+        if (r.tick < slot->tick) slot = &r;
+    }
+    *slot = SeenRange{h, bytes, 1, ++g_seen_tick};
+    return direct_after() > 0;
+}
 }  // namespace
 
-int upload_host(void *d_dst, const void *h_src, size_t bytes) {
+bool upload_takes_slots(const void *h_src, size_t bytes) {
+    return staged(bytes) || (bytes >= STAGE_BELOW && large_copy_staged(h_src, bytes));
+}
+int upload_host_as(void *d_dst, const void *h_src, size_t bytes, bool slots) {
     if (bytes == 0) return LSA_OK;
-    if (staged(bytes)) {
+    if (slots) {
         const int rc = g_copier.run(d_dst, const_cast<void *>(h_src), bytes, false);
         if (rc <= 0) return rc;
     }
     HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, g.stream));
     return LSA_OK;
+}
+int upload_host(void *d_dst, const void *h_src, size_t bytes) {
+    return upload_host_as(d_dst, h_src, bytes, bytes != 0 && upload_takes_slots(h_src, bytes));
 }
 int download_host(void *h_dst, const void *d_src, size_t bytes) {
     if (bytes == 0) return LSA_OK;
@@ -410,6 +441,7 @@ void upload_prepare() {
 extern "C" {
 // ---------------------------------------------------------------- bases
 }  // extern "C"
+static int stage_jac_ensure(size_t bytes, void **p);      // g_stage_jac (below)
 template <class F>
 static int bases_create(const void *bases_jac, size_t n, int src_on_device, int group, lsa_bases **out, bool allow_table = true) {
     int rc = require_ready();
@@ -440,19 +472,42 @@ static int bases_create(const void *bases_jac, size_t n, int src_on_device, int 
             set_error("bases_create: hipMalloc of %zu bytes failed", n * msm_base_bytes(group));
             return LSA_ERR_NOMEM;
         }
+        bool prepared = false;
         if (src_on_device) {
             d_in = (const Jac<F> *)bases_jac;
         } else {
-            if (hipMalloc(&tmp, n * sizeof(Jac<F>)) != hipSuccess) {
-                (void)hipFree(b->d_aff); delete b;
-                set_error("bases_create: hipMalloc of %zu bytes failed", n * sizeof(Jac<F>));
-                return LSA_ERR_NOMEM;
+            // the Jacobian staging area: the library's grow-only buffer up to 512 MiB (no hipMalloc / hipFree -- each an
+            // implicit device synchronisation and 0.5-2 ms -- inside a prover's first MSM), a temporary beyond
+            const size_t jbytes = n * sizeof(Jac<F>);
+            void *d_stage = nullptr;
+            if (jbytes <= ((size_t)512 << 20)) {
+                if (stage_jac_ensure(jbytes, &d_stage)) d_stage = nullptr;
             }
-            const int urc = upload_host(tmp, bases_jac, n * sizeof(Jac<F>));
-            if (urc) { (void)hipStreamSynchronize(g.stream); (void)hipFree(tmp); (void)hipFree(b->d_aff); delete b; return urc; }
-            d_in = (const Jac<F> *)tmp;
+            if (!d_stage) {
+                if (hipMalloc(&tmp, jbytes) != hipSuccess) {
+                    (void)hipFree(b->d_aff); delete b;
+                    set_error("bases_create: hipMalloc of %zu bytes failed", jbytes);
+                    return LSA_ERR_NOMEM;
+                }
+                d_stage = tmp;
+            }
+            d_in = (const Jac<F> *)d_stage;
+            // In waves: while the host threads fill the pinned slots of wave k + 1, the copy engine moves wave k and
+            // the normalisation kernel of wave k - 1 runs (affine coordinates are unique: the same bytes as one
+            // prepare_bases over the whole vector).  One wave for short vectors.
+            // A vector the runtime has pinned by now (seen several times) goes as one direct copy, as before.
+            const bool slots = upload_takes_slots(bases_jac, jbytes);
+            const size_t wave_pts = slots ? ((((size_t)16 << 20) / sizeof(Jac<F>)) & ~(size_t)4095) : n;
+            int urc = LSA_OK;
+            for (size_t lo = 0; lo < n && !urc; lo += wave_pts) {
+                const size_t cnt = n - lo < wave_pts ? n - lo : wave_pts;
+                urc = upload_host_as((char *)d_stage + lo * sizeof(Jac<F>), (const char *)bases_jac + lo * sizeof(Jac<F>), cnt * sizeof(Jac<F>), slots);
+                if (!urc) urc = prepare_bases<F>(d_in + lo, (char *)b->d_aff + lo * msm_base_bytes(group), cnt, g.stream);
+            }
+            if (urc) { (void)hipStreamSynchronize(g.stream); if (tmp) (void)hipFree(tmp); (void)hipFree(b->d_aff); delete b; return urc; }
+            prepared = true;
         }
-        rc = prepare_bases<F>(d_in, b->d_aff, n, g.stream);
+        if (!prepared) rc = prepare_bases<F>(d_in, b->d_aff, n, g.stream);
         void *scratch = nullptr;
         if (!rc && table && fast_build) {
             if (hipMalloc(&scratch, table_build_scratch_bytes(n)) != hipSuccess) { (void)hipGetLastError(); scratch = nullptr; set_error("bases_create: scratch allocation failed"); rc = LSA_ERR_NOMEM; }
@@ -564,6 +619,11 @@ namespace {
 StageBuf g_stage_jac, g_stage_bases, g_stage_scalars, g_stage_prefix_scratch;
 }  // namespace
 namespace lsa { StageBuf g_stage_gather; }
+static int stage_jac_ensure(size_t bytes, void **p) {
+    if (g_stage_jac.ensure(bytes)) return -1;
+    *p = g_stage_jac.p;
+    return 0;
+}
 static void release_stage_buffers() {
     g_stage_jac.release(); g_stage_bases.release(); g_stage_scalars.release(); g_stage_gather.release(); g_stage_prefix_scratch.release();
     pairing_release();

@@ -77,6 +77,10 @@ extern StageBuf g_stage_gather;
 // (then asynchronous, like hipMemcpyAsync); download_host: blocking, the bytes are in h_dst when it returns.
 // LSA_H2D=direct|staged: plain hipMemcpyAsync always / slots at every size.
 int upload_host(void *d_dst, const void *h_src, size_t bytes);
+// the two halves of upload_host for callers that cut one host range into several copies: the decision (recorded once
+// per range: a large range goes through the slots until it has been seen LSA_H2D_DIRECT_AFTER times) and the copy
+bool upload_takes_slots(const void *h_src, size_t bytes);
+int upload_host_as(void *d_dst, const void *h_src, size_t bytes, bool slots);
 int download_host(void *h_dst, const void *d_src, size_t bytes);
 void upload_release();             // threads, pinned slots (lsa_shutdown)
 void upload_prepare();             // the same, created (lsa_init)

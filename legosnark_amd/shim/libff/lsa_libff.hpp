@@ -21,6 +21,7 @@
 #include <cstring>
 #include <iostream>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <stdexcept>
 #include <cerrno>
@@ -38,6 +39,15 @@
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
+// The reference's -DMULTICORE=ON build (/root/reference/CMakeLists.txt:35-39,57-59,78-80: -fopenmp -DMULTICORE=1) calls
+// omp_get_max_threads() without including <omp.h> itself (src/utils/globl.h:52,68; src/utils/sparsemexp.cc:6,17): libff's
+// headers pull it in under that macro [upstream, recalled: libff/algebra/scalar_multiplication/multiexp.tcc], so this one
+// does too.  `chunks` is then the OpenMP thread count; the GPU computes the same sum whatever its value.  The four
+// `#pragma omp parallel for` loops of src/gadgets/lipmaa.cc:125-172 run this header's Fr operators concurrently: they are
+// pure functions of their operands (no shared state; random_element's pool is thread_local, the statistics are atomics).
+#ifdef MULTICORE
+#include <omp.h>
+#endif
 
 namespace libff {
 
@@ -105,6 +115,18 @@ struct StatScope {
 inline void lsa_require(int rc, const char *what) {
     if (rc != 0) throw std::runtime_error(std::string(what) + ": " + lsa_last_error());
 }
+
+// The C-ABI is written for ONE calling thread at a time (SURVEY.md section 8b "Threading"; the reference never issues two
+// library calls concurrently, MULTICORE or not).  Every forwarding site of this header takes this lock, so that a caller
+// who does reach the library from several threads (an OpenMP loop around commitments, say) is serialised instead of racing
+// on the library's stream and staging buffers.  Recursive: window_table::rows() forwards from inside batch_exp's callers.
+namespace lsa_shim {
+inline std::recursive_mutex &gpu_mutex() { static std::recursive_mutex m; return m; }
+struct GpuLock {
+    std::lock_guard<std::recursive_mutex> g;
+    GpuLock() : g(gpu_mutex()) {}
+};
+}  // namespace lsa_shim
 
 // ---------------------------------------------------------------- profiling stubs (libff/common/profiling.hpp)
 inline bool &inhibit_profiling_info_ref() { static bool b = false; return b; }
@@ -458,15 +480,32 @@ struct PairExpr {
     lsa::Fq12 cst = lsa::Fq12::one();      // product of the already evaluated factors
     bool has_cst = false;
     bool final_exp = false;
-    mutable bool done = false;             // every copy of a deferred value shares its node, hence its result
+    // every copy of a deferred value shares its node, hence its result.  `done` is published with release order after
+    // `result` is written (under gpu_mutex): copies of one value may be looked at from several threads.
+    mutable std::atomic<bool> done{false};
     mutable lsa::Fq12 result;
+    PairExpr() = default;
+    PairExpr(const PairExpr &o) : terms(o.terms), cst(o.cst), has_cst(o.has_cst), final_exp(o.final_exp) {
+        if (o.done.load(std::memory_order_acquire)) { result = o.result; done.store(true, std::memory_order_release); }
+    }
+    PairExpr &operator=(const PairExpr &o) {
+        if (this != &o) {
+            terms = o.terms; cst = o.cst; has_cst = o.has_cst; final_exp = o.final_exp;
+            const bool d = o.done.load(std::memory_order_acquire);
+            if (d) result = o.result;
+            done.store(d, std::memory_order_release);
+        }
+        return *this;
+    }
 };
 inline bool eager() {
     static const bool e = getenv("LSA_SHIM_EAGER") && getenv("LSA_SHIM_EAGER")[0] == '1';
     return e;
 }
 inline const lsa::Fq12 &evaluate(const PairExpr &e) {
-    if (e.done) return e.result;
+    if (e.done.load(std::memory_order_acquire)) return e.result;
+    GpuLock lock;
+    if (e.done.load(std::memory_order_acquire)) return e.result;
     StatScope scope(ST_PAIRING, e.terms.size());
     lsa::Fq12 out = e.cst;
     const size_t n = e.terms.size();
@@ -484,14 +523,14 @@ inline const lsa::Fq12 &evaluate(const PairExpr &e) {
         lsa_require(lsa_final_exponentiation(&in, 1, &out, 0), "final_exponentiation");
     }
     e.result = out;
-    e.done = true;
+    e.done.store(true, std::memory_order_release);
     return e.result;
 }
 }  // namespace lsa_shim
 
 class alt_bn128_Fq12 {
-    mutable lsa::Fq12 v_;
-    mutable std::shared_ptr<const lsa_shim::PairExpr> e_;      // non-null: v_ is not there yet
+    lsa::Fq12 v_;
+    std::shared_ptr<const lsa_shim::PairExpr> e_;      // non-null: the value lives in the node (evaluated on demand)
 public:
     alt_bn128_Fq12() : v_(lsa::Fq12::one()) { v_.c0.c0 = lsa::Fq2::zero(); }
     alt_bn128_Fq12(const lsa::Fq12 &x) : v_(x) {}
@@ -499,21 +538,19 @@ public:
         if (lsa_shim::eager()) val();
     }
     // the twelve field elements (libff layout); evaluates a deferred value
-    const lsa::Fq12 &val() const {
-        if (e_) { v_ = lsa_shim::evaluate(*e_); e_.reset(); }
-        return v_;
-    }
-    bool deferred() const { return e_ != nullptr; }
+    // (a const object is never written: concurrent readers of one value, or of copies of it, are safe)
+    const lsa::Fq12 &val() const { return e_ ? lsa_shim::evaluate(*e_) : v_; }
+    bool deferred() const { return e_ != nullptr && !e_->done.load(std::memory_order_acquire); }
     static alt_bn128_Fq12 one() { return alt_bn128_Fq12(lsa::Fq12::one()); }
     static alt_bn128_Fq12 zero() { return alt_bn128_Fq12(); }
     bool operator==(const alt_bn128_Fq12 &o) const { return val() == o.val(); }
     bool operator!=(const alt_bn128_Fq12 &o) const { return !(val() == o.val()); }
     alt_bn128_Fq12 operator*(const alt_bn128_Fq12 &o) const {
-        if (!e_ && !o.e_) return alt_bn128_Fq12(lsa::fq12_mul(v_, o.v_));
+        if (!deferred() && !o.deferred()) return alt_bn128_Fq12(lsa::fq12_mul(val(), o.val()));
         // a deferred factor that is not final-exponentiated contributes its terms; anything else its value
         auto r = std::make_shared<lsa_shim::PairExpr>();
         for (const alt_bn128_Fq12 *f : {this, &o}) {
-            if (f->e_ && !f->e_->final_exp && !f->e_->done) {
+            if (f->deferred() && !f->e_->final_exp) {
                 r->terms.insert(r->terms.end(), f->e_->terms.begin(), f->e_->terms.end());
                 if (f->e_->has_cst) { r->cst = r->has_cst ? lsa::fq12_mul(r->cst, f->e_->cst) : f->e_->cst; r->has_cst = true; }
             } else {
@@ -531,7 +568,7 @@ public:
     // conjugation over Fq6 (the inverse of a unitary element).  It is a field automorphism, and the conjugate of a
     // Miller loop on (P, Q) is the Miller loop on (-P, Q): a deferred product conjugates term by term
     alt_bn128_Fq12 unitary_inverse() const {
-        if (!e_ || e_->final_exp || e_->done) return alt_bn128_Fq12(val().unitary_inverse());
+        if (!deferred() || e_->final_exp) return alt_bn128_Fq12(val().unitary_inverse());
         auto r = std::make_shared<lsa_shim::PairExpr>(*e_);
         for (auto &t : r->terms) t.conj ^= 1;
         if (r->has_cst) r->cst = r->cst.unitary_inverse();
@@ -540,10 +577,10 @@ public:
     // libff final_exponentiation (alt_bn128_pp::final_exponentiation forwards here)
     alt_bn128_Fq12 final_exponentiated() const {
         auto r = std::make_shared<lsa_shim::PairExpr>();
-        if (e_ && !e_->final_exp && !e_->done) *r = *e_;
+        if (deferred() && !e_->final_exp) *r = *e_;
         else { r->cst = val(); r->has_cst = true; }
         r->final_exp = true;
-        r->done = false;
+        r->done.store(false, std::memory_order_release);
         return alt_bn128_Fq12(std::shared_ptr<const lsa_shim::PairExpr>(std::move(r)));
     }
     alt_bn128_Fq12 operator^(const bigint<4> &e) const {
@@ -729,6 +766,7 @@ struct alt_bn128_G2_precomp {
     alt_bn128_G2 Q;                                       // Z == 1 or the point at infinity
     mutable std::shared_ptr<std::vector<uint8_t>> blob;   // LSA_G2_PRECOMP_BYTES: QX, QY, coefficients (lazy)
     const std::vector<uint8_t> &bytes() const {
+        lsa_shim::GpuLock lock;
         if (!blob) {
             blob = std::make_shared<std::vector<uint8_t>>(LSA_G2_PRECOMP_BYTES);
             lsa_require(lsa_g2_precompute(&Q, 1, blob->data()), "precompute_G2");
@@ -804,6 +842,7 @@ public:
 #endif
         }
         const char *d = getenv("LSA_DEVICE");
+        lsa_shim::GpuLock lock;
         lsa_require(lsa_init(d ? atoi(d) : 0), "init_public_params");
     }
     static alt_bn128_G1_precomp precompute_G1(const alt_bn128_G1 &P) {
@@ -817,6 +856,7 @@ public:
         lsa_shim::StatScope scope(lsa_shim::ST_G2_PRECOMP, 1);
         alt_bn128_G2 a = Q;
         a.to_affine_coordinates();
+        lsa_shim::GpuLock lock;
         lsa_require(lsa_g2_tables_prefetch(&a, 1), "precompute_G2");
         return {a, nullptr};
     }
@@ -885,6 +925,7 @@ T msm_forward(typename std::vector<T>::const_iterator vec_start, typename std::v
     assert((size_t)(scalar_end - scalar_start) == n);
     (void)scalar_end;
     T out;
+    lsa_shim::GpuLock lock;
     lsa_shim::StatScope scope(group_id<T>::value == 1 ? lsa_shim::ST_MSM_G1 : lsa_shim::ST_MSM_G2, n);
     const void *b = n ? (const void *)&*vec_start : nullptr;
     const void *s = n ? (const void *)&*scalar_start : nullptr;
@@ -956,6 +997,7 @@ void lsa_mtxmultiexp(std::vector<alt_bn128_G1> &out, const std::vector<FieldT> &
         col_ptr[j + 1] = vals.size();
     }
     out.assign(m.size(), alt_bn128_G1::zero());
+    lsa_shim::GpuLock lock;
     lsa_shim::StatScope scope(lsa_shim::ST_SPARSE_MSM, nnz);
     lsa_require(lsa_g1_sparse_matrix_msm(vals.data(), rows.data(), col_ptr.data(), m.size(), exps.data(), exps.size(), out.data()),
                 "mtxmultiexp");
@@ -965,6 +1007,7 @@ template <class FieldT>
 std::vector<alt_bn128_G1> lsa_scalar_mul_batch(const std::vector<alt_bn128_G1> &pts, const std::vector<FieldT> &scalars) {
     const size_t n = pts.size() < scalars.size() ? pts.size() : scalars.size();
     std::vector<alt_bn128_G1> out(n, alt_bn128_G1::zero());
+    lsa_shim::GpuLock lock;
     lsa_require(lsa_g1_scalar_mul_batch(pts.data(), scalars.data(), n, out.data(), 0), "scalar_mul_batch");
     return out;
 }
@@ -992,6 +1035,7 @@ struct window_table {
     typename std::vector<row_type>::const_iterator begin() const { return rows().begin(); }
     typename std::vector<row_type>::const_iterator end() const { return rows().end(); }
     const std::vector<row_type> &rows() const {
+        lsa_shim::GpuLock lock;
         if (!built_) {
             using FieldT = typename T::scalar_field;
             const size_t outerc = size(), in_window = size_t(1) << window;
@@ -1035,6 +1079,7 @@ std::vector<T> batch_exp(const size_t scalar_size, const size_t window, const wi
     (void)scalar_size; (void)window;
     std::vector<T> out(v.size());
     if (v.empty()) return out;
+    lsa_shim::GpuLock lock;
     lsa_shim::StatScope scope(lsa_shim::ST_BATCH_EXP, v.size());
     if (detail::group_id<T>::value == 1) lsa_require(lsa_g1_batch_exp(&table.base, v.data(), v.size(), out.data(), 0), "batch_exp<G1>");
     else lsa_require(lsa_g2_batch_exp(&table.base, v.data(), v.size(), out.data(), 0), "batch_exp<G2>");
@@ -1047,6 +1092,7 @@ T windowed_exp(const size_t scalar_size, const size_t window, const window_table
 template <typename T>
 void batch_to_special(std::vector<T> &vec) {
     if (vec.empty()) return;
+    lsa_shim::GpuLock lock;
     lsa_shim::StatScope scope(lsa_shim::ST_NORMALIZE, vec.size());
     if (detail::group_id<T>::value == 1) lsa_require(lsa_g1_normalize(vec.data(), vec.size(), vec.data()), "batch_to_special");
     else lsa_require(lsa_g2_normalize(vec.data(), vec.size(), vec.data()), "batch_to_special");

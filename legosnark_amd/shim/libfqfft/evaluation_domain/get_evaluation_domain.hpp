@@ -26,6 +26,7 @@ public:
     size_t log_m() const { size_t l = 0; while ((size_t(1) << l) < m) l++; return l; }
     void ntt(std::vector<FieldT> &a, int inverse, const FieldT *g) {
         check(a);
+        libff::lsa_shim::GpuLock lock;
         libff::lsa_require(lsa_fr_ntt(a.data(), log_m(), &omega, inverse, g, 0), "evaluation_domain FFT");
     }
     virtual void FFT(std::vector<FieldT> &a) { ntt(a, 0, nullptr); }

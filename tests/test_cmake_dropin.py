@@ -31,3 +31,28 @@ def test_reference_cmake_builds_cplink_against_the_dropin_packages(tmp_path):
     assert os.path.exists(exe)
     needed = subprocess.check_output(["readelf", "-d", exe], text=True)
     assert "liblegosnark_amd.so" in needed
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="reference checkout not present")
+@pytest.mark.parametrize("src", ["gadgets/lipmaa.cc", "gadgets/subspace.cc", "utils/sparsemexp.cc", "examples/hadamard.cc"])
+def test_reference_sources_compile_in_the_multicore_configuration(src, tmp_path):
+    """-DMULTICORE=ON (/root/reference/CMakeLists.txt:35-39,57-59,78-80) = -fopenmp -DMULTICORE=1 under the reference's
+    own warning flags: src/utils/globl.h:52,68 and src/utils/sparsemexp.cc:6,17 call omp_get_max_threads() without
+    including <omp.h> -- libff's headers do under that macro, so the shim's must."""
+    R = os.path.join(REF, "src")
+    cmd = ["g++", "-std=c++17", "-O0", "-Wall", "-Wextra", "-Wfatal-errors", "-pthread", "-fopenmp", "-DMULTICORE=1",
+           "-DBN_SUPPORT_SNARK=1", "-DCURVE_BN128", "-DNO_PROCPS", "-I", os.path.join(ROOT, "legosnark_amd", "shim")]
+    for d in ("", "gadgets", "prototools", "examples", "utils"):
+        cmd += ["-I", os.path.join(R, d)]
+    r = subprocess.run(cmd + ["-c", os.path.join(R, src), "-o", str(tmp_path / "o.o")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    syms = subprocess.check_output(["nm", "-u", str(tmp_path / "o.o")], text=True)
+    if src != "examples/hadamard.cc":
+        assert "omp_get_max_threads" in syms or "GOMP_parallel" in syms
+
+
+def test_shim_header_has_no_openmp_dependency_without_multicore(tmp_path):
+    """The default configuration must not need libgomp: <omp.h> is only pulled in under MULTICORE."""
+    src = tmp_path / "t.cc"
+    src.write_text('#include "libff/lsa_libff.hpp"\n#ifdef _OMP_H\n#error omp.h included without MULTICORE\n#endif\nint main() { return 0; }\n')
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "legosnark_amd", "shim"), str(src)])

@@ -14,6 +14,9 @@ BIN = os.path.join(ROOT, "build", "reference")
 
 
 CMAKE_BIN = os.path.join(ROOT, "build", "reference_cmake", "src", "examples")
+# the reference's -DMULTICORE=ON configuration (-fopenmp -DMULTICORE=1): Makefile- and CMake-built
+BIN_MC = os.path.join(ROOT, "build", "reference_mc")
+CMAKE_BIN_MC = os.path.join(ROOT, "build", "reference_cmake_mc", "src", "examples")
 
 
 def require_binary(exe):
@@ -33,10 +36,10 @@ def require_binary(exe):
     pytest.skip("%s missing and not in the build manifest: run __graft_entry__.build() where /root/reference exists" % exe)
 
 
-def run(name, *args, seed="7", bindir=BIN):
+def run(name, *args, seed="7", bindir=BIN, **extra_env):
     exe = os.path.join(bindir, name)
     require_binary(exe)
-    env = dict(os.environ, LSA_SEED=seed)
+    env = dict(os.environ, LSA_SEED=seed, **extra_env)
     return subprocess.run([exe, *args], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, text=True)
 
 
@@ -139,3 +142,49 @@ def test_shim_stats_and_call_trace_account_for_a_run():
     assert st["scalar_mul_host"]["calls"] > 0 and st["g2_precompute"]["calls"] > 0
     # the reference's own output is untouched by either switch
     assert "##had_sc TOTAL Prove" in r.stdout and "lsa_shim_stats" not in r.stdout
+
+
+# ---- the reference's -DMULTICORE=ON configuration (/root/reference/CMakeLists.txt:35-39,57-59,78-80)
+
+@pytest.mark.parametrize("bindir", [BIN_MC, CMAKE_BIN_MC], ids=["makefile", "cmake"])
+def test_multicore_cplink_verifies_with_eight_chunks(bindir):
+    """multiExpMA passes chunks = omp_get_max_threads() (src/utils/globl.h:67-72) and prints it; the unchanged cplink
+    must still pass its own MYREQUIRE(verify): prover MSM (chunks = 8) <-> keygen <-> pairings."""
+    r = run("cplink", bindir=bindir, OMP_NUM_THREADS="8")
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "NCHUNKS : 8" in r.stdout and "NCHUNKS : 1" not in r.stdout
+    assert "Error!" not in r.stdout
+    r = run("cplink", bindir=bindir, OMP_NUM_THREADS="3")
+    assert r.returncode == 0 and "NCHUNKS : 3" in r.stdout, r.stdout[-2000:]
+
+
+def test_multicore_hadamard_and_pairing_check():
+    """hadamard 12 runs lipmaa.cc's four `#pragma omp parallel for` loops over the shim's Fr on eight threads (its
+    Lipmaa verifier and the sumcheck verifiers return their own verdicts); pairing_check's failure count stays 0."""
+    import json
+    r = run("hadamard", "12", bindir=BIN_MC, OMP_NUM_THREADS="8")
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "had_lipmaa Prove" in r.stdout and "NCHUNKS : 8" in r.stdout
+    r = run("hadamard", "10", bindir=CMAKE_BIN_MC, OMP_NUM_THREADS="8")
+    assert r.returncode == 0, r.stdout[-2000:]
+    r = run("matrixsc", "3", bindir=BIN_MC, OMP_NUM_THREADS="8")
+    assert r.returncode == 0, r.stdout[-2000:]
+    r = run("pairing_check", "6", bindir=BIN_MC, seed="11", OMP_NUM_THREADS="8")
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["failures"] == 0
+    r = run("keygen_check", "10", "128", bindir=BIN_MC, OMP_NUM_THREADS="8")
+    assert r.returncode == 0 and '"mismatches": 0' in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("bindir,threads", [(BIN_MC, "8"), (BIN_MC, "2"), (BIN, "1")], ids=["multicore-8", "multicore-2", "single"])
+def test_omp_check_same_points_whatever_the_thread_count(bindir, threads):
+    """legosnark_amd/shim/checks/omp_check.cc: multiExpMA(chunks = threads) returns the point multi_exp(chunks = 1)
+    and the host sum return; lipmaa.cc's loop bodies, random_element, host scalar multiplications, one deferred GT value
+    read from every thread, and MSMs issued from several threads at once all equal their serial results."""
+    import json
+    r = run("omp_check", "3000", bindir=bindir, OMP_NUM_THREADS=threads)
+    assert r.returncode == 0, r.stdout[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])["omp_check"]
+    assert line["failures"] == 0 and line["threads"] == int(threads)
+    assert line["multicore"] is (bindir == BIN_MC)
+    assert ("NCHUNKS : %s" % threads) in r.stdout
