@@ -198,7 +198,7 @@ int lsa_profile_last_msm(float ms[LSA_MSM_STAGES]) { return msm_profile_last(ms)
 namespace lsa {
 namespace {
 class HostCopier {
-    static constexpr size_t SLOT = (size_t)2 << 20;
+    size_t SLOT = (size_t)2 << 20;                    // LSA_H2D_SLOT_KB (experiments)
     static constexpr unsigned MAX_WORKERS = 12, SLOTS_PER_WORKER = 2;
     struct Slot { void *p = nullptr; hipEvent_t ev = nullptr; bool pending = false; };
     struct Worker { Slot slot[SLOTS_PER_WORKER]; unsigned turn = 0; };
@@ -218,6 +218,16 @@ class HostCopier {
 
     void *arena_ = nullptr;                           // every slot, one pinned allocation
     unsigned nworkers_ = 0;
+    // Uploads of two slots and more leave lsa_stream(): worker i issues its copies on copy stream i % ncs_, so that
+    // several copy engines run at once (one stream = one engine at a time: 23 GB/s measured, against 40-50 for the
+    // runtime's own large copy) and a kernel the caller queues on lsa_stream() between two uploads (the normalisation
+    // of the previous wave of a CRS vector) does not hold the next copies back.  run() orders the streams: they wait
+    // for what lsa_stream() holds at the start (`order_after`), lsa_stream() waits for them at the end.
+    static constexpr unsigned MAX_STREAMS = 4;
+    hipStream_t cs_[MAX_STREAMS] = {};
+    hipEvent_t ev_begin_ = nullptr, ev_done_[MAX_STREAMS] = {};
+    unsigned ncs_ = 0;
+    bool on_cs_ = false;
     bool slot_ready(Slot &s) {
         if (!s.p || !s.ev) return false;
         if (s.pending) { if (hipEventSynchronize(s.ev) != hipSuccess) return false; s.pending = false; }
@@ -233,6 +243,7 @@ class HostCopier {
         unsigned want = e ? (unsigned)atoi(e) : (hw >= 32 ? 10 : (hw > 8 ? 6 : (hw > 2 ? hw / 2 : 1)));
         if (want < 1) want = 1;
         if (want > MAX_WORKERS) want = MAX_WORKERS;
+        if (const char *sk = getenv("LSA_H2D_SLOT_KB")) { const size_t kb = (size_t)atol(sk); if (kb >= 64 && kb <= 16384) SLOT = kb << 10; }
         if (hipHostMalloc(&arena_, (size_t)want * SLOTS_PER_WORKER * SLOT, hipHostMallocDefault) != hipSuccess) { arena_ = nullptr; return false; }
         for (unsigned i = 0; i < want; i++)
             for (unsigned k = 0; k < SLOTS_PER_WORKER; k++) {
@@ -242,6 +253,22 @@ class HostCopier {
                 if (hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) { s.ev = nullptr; return false; }
             }
         nworkers_ = want;
+        const char *se = getenv("LSA_H2D_STREAMS");
+        // ONE copy stream by default: enough to run the copies beside the kernels of lsa_stream() (96 MiB of first-sight
+        // bases: 3.3 ms, 4.3 on lsa_stream() itself); with two to four, 40 % of the first calls of fresh processes took
+        // another 7 ms (more copy engines and queues brought up lazily, in whichever call first overlaps enough copies)
+        unsigned ns = se ? (unsigned)atoi(se) : 1u;
+        if (ns > MAX_STREAMS) ns = MAX_STREAMS;
+        if (ns > want) ns = want;
+        ncs_ = 0;
+        if (ns && hipEventCreateWithFlags(&ev_begin_, hipEventDisableTiming) == hipSuccess) {
+            for (unsigned k = 0; k < ns; k++) {
+                if (hipStreamCreateWithFlags(&cs_[k], hipStreamNonBlocking) != hipSuccess) { cs_[k] = nullptr; break; }
+                if (hipEventCreateWithFlags(&ev_done_[k], hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(cs_[k]); cs_[k] = nullptr; ev_done_[k] = nullptr; break; }
+                ncs_ = k + 1;
+            }
+        }
+        (void)hipGetLastError();
         for (unsigned i = 1; i < want; i++) th_.emplace_back([this, i] { loop(i); });
         return true;
     }
@@ -259,8 +286,9 @@ class HostCopier {
                     hipEventSynchronize(s.ev) != hipSuccess) { err_ = 1; continue; }
                 memcpy(host_ + lo, s.p, len);
             } else {
+                hipStream_t st = on_cs_ ? cs_[id % ncs_] : g.stream;
                 memcpy(s.p, host_ + lo, len);
-                if (hipMemcpyAsync(dev_ + lo, s.p, len, hipMemcpyHostToDevice, g.stream) != hipSuccess || hipEventRecord(s.ev, g.stream) != hipSuccess) { err_ = 1; continue; }
+                if (hipMemcpyAsync(dev_ + lo, s.p, len, hipMemcpyHostToDevice, st) != hipSuccess || hipEventRecord(s.ev, st) != hipSuccess) { err_ = 1; continue; }
                 s.pending = true;
             }
         }
@@ -285,7 +313,7 @@ class HostCopier {
   public:
     ~HostCopier() { stop_threads(); }
     // 0: done (up: every copy is on the stream; down: the bytes are in host memory), 1: not taken, < 0: LSA error
-    int run(void *dev, void *host, size_t bytes, bool down) {
+    int run(void *dev, void *host, size_t bytes, bool down, bool order_after = true) {
         if (broken_) return 1;
         dev_ = (char *)dev; host_ = (char *)host; bytes_ = bytes; down_ = down;
         // whole slots for large copies; a copy of 0.5 .. 4 MiB (the points of a 2^12-pair product: 0.4 + 0.8 MiB) is cut into
@@ -304,6 +332,12 @@ class HostCopier {
             std::lock_guard<std::mutex> lk(m_);
             if (!prepare_locked()) { broken_ = true; return 1; }
             if (th_.empty()) alone = true;
+            on_cs_ = !down && !alone && ncs_ > 0;
+            if (on_cs_ && order_after) {
+                bool ok = hipEventRecord(ev_begin_, g.stream) == hipSuccess;
+                for (unsigned k = 0; k < ncs_ && ok; k++) ok = hipStreamWaitEvent(cs_[k], ev_begin_, 0) == hipSuccess;
+                if (!ok) { (void)hipGetLastError(); on_cs_ = false; }
+            }
             if (!alone) {
                 active_ = (unsigned)th_.size();
                 gen_++;
@@ -314,6 +348,11 @@ class HostCopier {
         if (!alone) {
             std::unique_lock<std::mutex> lk(m_);
             cv_done_.wait(lk, [&] { return active_ == 0; });
+        }
+        if (on_cs_) {
+            for (unsigned k = 0; k < ncs_; k++)
+                if (hipEventRecord(ev_done_[k], cs_[k]) != hipSuccess || hipStreamWaitEvent(g.stream, ev_done_[k], 0) != hipSuccess) err_ = 1;
+            on_cs_ = false;
         }
         if (err_.load()) {
             broken_ = true;
@@ -339,6 +378,26 @@ class HostCopier {
         std::lock_guard<std::mutex> lk(m_);
         if (!prepare_locked()) broken_ = true;
     }
+    // the first pinned transfer on a stream sets up that stream's copy-engine queue (~7 ms each, measured inside the
+    // first CRS upload of a process): paid in lsa_init, per copy stream and per size class a slot can carry
+    // (the runtime adds copy engines when copies overlap, and each new engine is another such set-up: the warm-up keeps
+    // every copy stream busy at the same time, ordered against lsa_stream() exactly as run() orders them)
+    void warm_streams() {
+        std::lock_guard<std::mutex> lk(m_);
+        if (!arena_ || !ncs_) return;
+        void *d = nullptr;
+        if (hipMalloc(&d, (size_t)ncs_ * SLOT) != hipSuccess) { (void)hipGetLastError(); return; }
+        (void)hipEventRecord(ev_begin_, g.stream);
+        for (unsigned k = 0; k < ncs_; k++) (void)hipStreamWaitEvent(cs_[k], ev_begin_, 0);
+        for (int rep = 0; rep < 12; rep++)
+            for (unsigned k = 0; k < ncs_; k++)
+                (void)hipMemcpyAsync((char *)d + (size_t)k * SLOT, (char *)arena_ + (size_t)k * SLOT, rep & 1 ? SLOT / 4 : SLOT, hipMemcpyHostToDevice, cs_[k]);
+        for (unsigned k = 0; k < ncs_; k++) { (void)hipEventRecord(ev_done_[k], cs_[k]); (void)hipStreamWaitEvent(g.stream, ev_done_[k], 0); }
+        (void)hipStreamSynchronize(g.stream);
+        for (unsigned k = 0; k < ncs_; k++) (void)hipStreamSynchronize(cs_[k]);
+        (void)hipFree(d);
+        (void)hipGetLastError();
+    }
     void release() {
         stop_threads();
         for (auto &w : w_)
@@ -346,6 +405,14 @@ class HostCopier {
                 if (s.ev) { if (s.pending) (void)hipEventSynchronize(s.ev); (void)hipEventDestroy(s.ev); }
                 s = Slot();
             }
+        for (unsigned k = 0; k < MAX_STREAMS; k++) {
+            if (cs_[k]) { (void)hipStreamSynchronize(cs_[k]); (void)hipStreamDestroy(cs_[k]); }
+            if (ev_done_[k]) (void)hipEventDestroy(ev_done_[k]);
+            cs_[k] = nullptr; ev_done_[k] = nullptr;
+        }
+        if (ev_begin_) (void)hipEventDestroy(ev_begin_);
+        ev_begin_ = nullptr;
+        ncs_ = 0;
         if (arena_) (void)hipHostFree(arena_);
         arena_ = nullptr;
         nworkers_ = 0;
@@ -397,17 +464,17 @@ static bool large_copy_staged(const void *h, size_t bytes) {
 bool upload_takes_slots(const void *h_src, size_t bytes) {
     return staged(bytes) || (bytes >= STAGE_BELOW && large_copy_staged(h_src, bytes));
 }
-int upload_host_as(void *d_dst, const void *h_src, size_t bytes, bool slots) {
+int upload_host_as(void *d_dst, const void *h_src, size_t bytes, bool slots, bool order_after) {
     if (bytes == 0) return LSA_OK;
     if (slots) {
-        const int rc = g_copier.run(d_dst, const_cast<void *>(h_src), bytes, false);
+        const int rc = g_copier.run(d_dst, const_cast<void *>(h_src), bytes, false, order_after);
         if (rc <= 0) return rc;
     }
     HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, g.stream));
     return LSA_OK;
 }
 int upload_host(void *d_dst, const void *h_src, size_t bytes) {
-    return upload_host_as(d_dst, h_src, bytes, bytes != 0 && upload_takes_slots(h_src, bytes));
+    return upload_host_as(d_dst, h_src, bytes, bytes != 0 && upload_takes_slots(h_src, bytes), true);
 }
 int download_host(void *h_dst, const void *d_src, size_t bytes) {
     if (bytes == 0) return LSA_OK;
@@ -428,6 +495,7 @@ void upload_prepare() {
     // HSA_ENABLE_SDMA=0): pay that here for every size a slot can carry, not inside a caller's first NTT
     void *d = nullptr;
     if (hipMalloc(&d, (size_t)4 << 20) != hipSuccess) { (void)hipGetLastError(); return; }
+    g_copier.warm_streams();
     std::vector<char> h((size_t)4 << 20, 0);
     for (size_t bytes = STAGE_FROM; bytes <= ((size_t)4 << 20); bytes <<= 1) {
         if (upload_host(d, h.data(), bytes) != LSA_OK) break;
@@ -461,7 +529,8 @@ static int bases_create(const void *bases_jac, size_t n, int src_on_device, int 
         // G1 handles of up to 2^16 points: all copies in ONE kernel (msm_compact.hip: one inversion per point instead
         // of 25, ~1.2 ms whatever n) -- cheap enough that every such handle carries them unless a threshold was set
         // explicitly, and their MSMs of up to msm_compact_max() pairs take the four-launch pipeline
-        const bool fast_build = group == 1 && n <= ((size_t)1 << 16) && allow_table && !(pe && pe[0] == '0') &&
+        // (G2 handles too since round 5: CommScheme::commit's second half, src/prototools/commit.h:155)
+        const bool fast_build = n <= ((size_t)1 << 16) && allow_table && !(pe && pe[0] == '0') &&
                                 (table || !msm_merge_min_is_explicit());
         if (fast_build) table = true;
         const size_t tw = msm_table_windows(group, n);
@@ -501,7 +570,7 @@ static int bases_create(const void *bases_jac, size_t n, int src_on_device, int 
             int urc = LSA_OK;
             for (size_t lo = 0; lo < n && !urc; lo += wave_pts) {
                 const size_t cnt = n - lo < wave_pts ? n - lo : wave_pts;
-                urc = upload_host_as((char *)d_stage + lo * sizeof(Jac<F>), (const char *)bases_jac + lo * sizeof(Jac<F>), cnt * sizeof(Jac<F>), slots);
+                urc = upload_host_as((char *)d_stage + lo * sizeof(Jac<F>), (const char *)bases_jac + lo * sizeof(Jac<F>), cnt * sizeof(Jac<F>), slots, lo == 0);
                 if (!urc) urc = prepare_bases<F>(d_in + lo, (char *)b->d_aff + lo * msm_base_bytes(group), cnt, g.stream);
             }
             if (urc) { (void)hipStreamSynchronize(g.stream); if (tmp) (void)hipFree(tmp); (void)hipFree(b->d_aff); delete b; return urc; }
@@ -510,8 +579,8 @@ static int bases_create(const void *bases_jac, size_t n, int src_on_device, int 
         if (!prepared) rc = prepare_bases<F>(d_in, b->d_aff, n, g.stream);
         void *scratch = nullptr;
         if (!rc && table && fast_build) {
-            if (hipMalloc(&scratch, table_build_scratch_bytes(n)) != hipSuccess) { (void)hipGetLastError(); scratch = nullptr; set_error("bases_create: scratch allocation failed"); rc = LSA_ERR_NOMEM; }
-            if (!rc) rc = table_build_g1_device(b->d_aff, n, n, scratch, g.stream);
+            if (hipMalloc(&scratch, table_build_scratch_bytes(n, group)) != hipSuccess) { (void)hipGetLastError(); scratch = nullptr; set_error("bases_create: scratch allocation failed"); rc = LSA_ERR_NOMEM; }
+            if (!rc) rc = group == 1 ? table_build_g1_device(b->d_aff, n, n, scratch, g.stream) : table_build_g2_device(b->d_aff, n, n, scratch, g.stream);
             if (!rc) b->table_stride = n;
         } else if (!rc && table) {
             rc = precompute_windows<F>(b->d_aff, n, g.stream);
@@ -861,6 +930,7 @@ struct CrsEntry {
     // request that fits arrives (crs_prefix_table): the tails of the reference's prefix ladders run over them
     void *prefix = nullptr;
     size_t prefix_n = 0;
+    unsigned prefix_asks = 0;                       // G2: requests a prefix table would have served (it is built at the second)
     bool building() const { return build && build->state.load() == 0; }
 };
 
@@ -1157,22 +1227,36 @@ static size_t crs_prefix_max() {
     }();
     return v;
 }
+// G2 entries (CommScheme::commit's second MSM, src/prototools/commit.h:155; InterpCommScheme::commit, src/gadgets/lipmaa.cc:27)
+// get theirs at the SECOND request that could use one (LSA_CRS_PREFIX_AFTER_G2 requests are served from the plain layout
+// first; the G2 builder's 255 Fq2 doublings per point are ~3x the G1 kernel, and a vector used once never pays for them).
+static unsigned crs_prefix_after_g2() {
+    static const unsigned v = [] { const char *e = getenv("LSA_CRS_PREFIX_AFTER_G2"); return e ? (unsigned)atoi(e) : 1u; }();
+    return v;
+}
 static int crs_prefix_table(lsa_bases *b, size_t n_req, const void **d_bases, size_t *stride) {
     const char *pe = getenv("LSA_PRECOMPUTE");
-    if (b->group != 1 || b->table_stride || n_req == 0 || n_req > crs_prefix_max() || n_req > msm_compact_max() || (pe && pe[0] == '0') ||
-        msm_merge_min_is_explicit())
+    const int grp = b->group;
+    if (b->table_stride || n_req == 0 || n_req > crs_prefix_max() || n_req > (grp == 1 ? msm_compact_max() : msm_compact_max_g2()) ||
+        (pe && pe[0] == '0') || msm_merge_min_is_explicit())
         return LSA_OK;
     CrsEntry *e = nullptr;
     for (auto &x : g_crs.entries) if (x.b == b) e = &x;
     if (!e) return LSA_OK;
     if (!e->prefix) {
+        if (grp == 2 && e->prefix_asks++ < crs_prefix_after_g2()) return LSA_OK;
         const size_t pn = std::min(e->n, crs_prefix_max());
-        const size_t bytes = (size_t)msm_table_windows(1, pn) * pn * msm_base_bytes(1);
+        const size_t bytes = (size_t)msm_table_windows(grp, pn) * pn * msm_base_bytes(grp);
         void *t = nullptr;
         if (hipMalloc(&t, bytes) != hipSuccess) { (void)hipGetLastError(); return LSA_OK; }          // no memory: the plain layout serves
-        if (g_stage_prefix_scratch.ensure(table_build_scratch_bytes(pn))) { (void)hipFree(t); return LSA_OK; }
-        HIPCHK(hipMemcpyAsync(t, b->d_aff, pn * msm_base_bytes(1), hipMemcpyDeviceToDevice, g.stream));
-        const int rc = table_build_g1_device(t, pn, pn, g_stage_prefix_scratch.p, g.stream);
+        if (g_stage_prefix_scratch.ensure(table_build_scratch_bytes(pn, grp))) { (void)hipFree(t); return LSA_OK; }
+        if (hipMemcpyAsync(t, b->d_aff, pn * msm_base_bytes(grp), hipMemcpyDeviceToDevice, g.stream) != hipSuccess) {
+            set_error("crs_prefix_table: copy failed: %s", hipGetErrorString(hipGetLastError()));
+            (void)hipFree(t);
+            return LSA_ERR_HIP;
+        }
+        const int rc = grp == 1 ? table_build_g1_device(t, pn, pn, g_stage_prefix_scratch.p, g.stream)
+                                : table_build_g2_device(t, pn, pn, g_stage_prefix_scratch.p, g.stream);
         if (rc) { (void)hipStreamSynchronize(g.stream); (void)hipFree(t); return rc; }
         e->prefix = t;
         e->prefix_n = pn;

@@ -80,7 +80,9 @@ int upload_host(void *d_dst, const void *h_src, size_t bytes);
 // the two halves of upload_host for callers that cut one host range into several copies: the decision (recorded once
 // per range: a large range goes through the slots until it has been seen LSA_H2D_DIRECT_AFTER times) and the copy
 bool upload_takes_slots(const void *h_src, size_t bytes);
-int upload_host_as(void *d_dst, const void *h_src, size_t bytes, bool slots);
+// (order_after = false: the destination is not touched by anything queued on lsa_stream() since the previous piece of
+// the same range went out -- the copy streams then do not wait for the kernels queued in between)
+int upload_host_as(void *d_dst, const void *h_src, size_t bytes, bool slots, bool order_after);
 int download_host(void *h_dst, const void *d_src, size_t bytes);
 void upload_release();             // threads, pinned slots (lsa_shutdown)
 void upload_prepare();             // the same, created (lsa_init)

@@ -9,6 +9,7 @@
 #pragma once
 #include "fp29.h"
 #include "inv29.h"
+#include "fp29x2.h"
 
 namespace lsa {
 
@@ -90,5 +91,12 @@ struct Fs {
         return acc;
     }
 };
+
+// 1 / (a0 + a1 u) = (a0 - a1 u) / (a0^2 + a1^2): one inversion in Fq.  Components < 2p, tight, in and out.
+LSA_HD F29x2 f29x2_inverse(const F29x2 &a) {
+    const F29 nrm = condsub2(add_lazy(sqr(a.c0), sqr(a.c1)).norm());                   // a0^2 + a1^2  [< 2p]
+    const F29 ni = Fs{nrm}.inverse().v;
+    return {mul(a.c0, ni), mul(sub_k<2>(F29::zero(), a.c1), ni)};
+}
 
 }  // namespace lsa

@@ -90,15 +90,17 @@ int fq12_product_device(void *d_buf, void *d_scratch, size_t n, void **result, h
 int fq12_segment_products_device(const void *d_in, const uint64_t *d_off, size_t nseg, void *d_out, hipStream_t st);
 size_t fq12_bytes();
 
-// msm_compact.hip: a whole MSM of n <= msm_compact_max() pairs over a table-carrying handle in four launches (G1)
+// msm_compact.hip: a whole MSM of n <= msm_compact_max() pairs over a table-carrying handle in four launches (G1, G2)
 template <class F>
 int msm_compact_device(const void *d_table, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride,
                        bool blocking = false);
 size_t msm_compact_max();
+size_t msm_compact_max_g2();
 // all pre-shifted copies of n points in one kernel: d_table holds msm_table_windows() * stride packed points, copy 0
 // (points [0, n)) filled; d_scratch: table_build_scratch_bytes(n)
 int table_build_g1_device(void *d_table, size_t n, size_t stride, void *d_scratch, hipStream_t st);
-size_t table_build_scratch_bytes(size_t n);
+int table_build_g2_device(void *d_table, size_t n, size_t stride, void *d_scratch, hipStream_t st);
+size_t table_build_scratch_bytes(size_t n, int group = 1);
 
 // The tail slots of the MSM pipelines (msm.hip): a call's front runs on the caller's stream, its tail on the slot's
 // internal stream with the slot's workspace; results are ordered again at msm_join().

@@ -157,6 +157,56 @@ __global__ __launch_bounds__(256) void k_prepare_g1(const Jac<Fq> *__restrict__ 
     }
 }
 
+// G2: the same on Fq2 over the 29-bit limbs (fp29x2.h), K points per inversion (through the norm: one Fq inversion).
+// k_normalize<Fq2, 8> + k_convert_bases, which this replaces, kept 656 bytes of scratch per lane: 344 MB for a full
+// grid, far above what the runtime keeps allocated between dispatches, so EVERY launch paid a scratch allocation --
+// 1-10 ms per launch depending on the box, twelve launches per streamed first-sight G2 vector.
+template <int K>
+__global__ __launch_bounds__(256) void k_prepare_g2(const Jac<Fq2> *__restrict__ in, AffPackedG2 *__restrict__ out, size_t n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, base = t * K;
+    if (base >= n) return;
+    const Fq2 one256 = Fq2::one();
+    F29x2 prod[K];
+    F29x2 acc = F29x2::one();
+    bool need_inv = false;
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        if (base + i < n) {
+            const Fq2 z = in[base + i].Z;
+            if (!z.is_zero() && z != one256) { acc = mul<2>(acc, f29x2_from_mont256(z)); need_inv = true; }   // [< 2]
+        }
+        prod[i] = acc;
+    }
+    F29x2 inv = need_inv ? f29x2_inverse(acc) : F29x2::one();
+#pragma unroll
+    for (int i = K - 1; i >= 0; i--) {
+        if (base + i >= n) continue;
+        const Jac<Fq2> p = in[base + i];
+        AffPackedG2 r;
+        if (p.Z.is_zero()) {
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int w = 0; w < 8; w++) r.w[c][w] = 0;
+        } else {
+            F29x2 x = f29x2_from_mont256(p.X), y = f29x2_from_mont256(p.Y);
+            if (p.Z != one256) {
+                const F29x2 zi = mul<2>(inv, i == 0 ? F29x2::one() : prod[i - 1]);      // 1 / Z_i
+                inv = mul<2>(inv, f29x2_from_mont256(p.Z));
+                const F29x2 zi2 = sqr<2>(zi);
+                x = mul<2>(x, zi2);
+                y = mul<2>(y, mul<2>(zi2, zi));
+            }
+            const F29x2 xc = x.canonical(), yc = y.canonical();
+            xc.c0.pack256(r.w[0]);
+            xc.c1.pack256(r.w[1]);
+            yc.c0.pack256(r.w[2]);
+            yc.c1.pack256(r.w[3]);
+        }
+        out[base + i] = r;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // kernels 1a-1c: digits, LDS ranking, tile prefix.  No global atomics.
 //   1a k_digits     scalars (Montgomery Fr, read once, coalesced) -> canonical -> signed
@@ -1685,6 +1735,16 @@ int prepare_bases(const Jac<F> *d_in, void *d_out, size_t n, hipStream_t st) {
         HIPCHK(hipGetLastError());
         return LSA_OK;
     }
+    if constexpr (std::is_same<F, Fq2>::value) {
+        static const bool old_path = getenv("LSA_G2_PREPARE_OLD") != nullptr;      // A/B: k_normalize + k_convert_bases
+        if (!old_path) {
+            constexpr int KG = 4;
+            const unsigned gblocks = (unsigned)(((n + KG - 1) / KG + 255) / 256);
+            hipLaunchKernelGGL((k_prepare_g2<KG>), dim3(gblocks), dim3(256), 0, st, d_in, (AffPackedG2 *)d_out, n);
+            HIPCHK(hipGetLastError());
+            return LSA_OK;
+        }
+    }
     // staging buffer for the normalised affine points: grow-only, reused across calls
     // (every user is ordered on the same stream)
     if (g_prep_ws.ensure(n * sizeof(Aff<F>)) != 0) { set_error("prepare_bases: staging allocation failed"); return LSA_ERR_NOMEM; }
@@ -2140,11 +2200,14 @@ int msm_device(const void *d_bases_v, size_t first, const Fr *d_scalars, size_t 
         HIPCHK(hipStreamSynchronize(st));
         return LSA_OK;
     }
-    if constexpr (std::is_same<F, Fq>::value) {
-        // small and medium calls over a table: the four-launch pipeline of msm_compact.hip (LSA_NO_COMPACT=1: never)
+    {
+        // small and medium calls over a table: the four-launch pipeline of msm_compact.hip (LSA_NO_COMPACT=1: never;
+        // LSA_NO_COMPACT_G2=1: G1 only, the round-4 state)
         static const bool allow_compact = getenv("LSA_NO_COMPACT") == nullptr;
-        if (allow_compact && table_stride != 0 && n >= table_use_min() && n <= msm_compact_max())
-            return msm_compact_device<Fq>(d_bases_v, first, d_scalars, n, d_out, st, table_stride, blocking);
+        static const bool allow_g2 = getenv("LSA_NO_COMPACT_G2") == nullptr;
+        const size_t cmax = std::is_same<F, Fq>::value ? msm_compact_max() : msm_compact_max_g2();
+        if (allow_compact && (std::is_same<F, Fq>::value || allow_g2) && table_stride != 0 && n >= table_use_min() && n <= cmax)
+            return msm_compact_device<F>(d_bases_v, first, d_scalars, n, d_out, st, table_stride, blocking);
     }
     SegList segs;
     segs.nseg = 1;

@@ -30,6 +30,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 #include "curves.h"
 #include "fs29.h"
@@ -345,6 +346,11 @@ static size_t cmp_max() {
     return v;
 }
 size_t msm_compact_max() { return cmp_max() < CMP_TILE * CMP_MAXTILES ? cmp_max() : CMP_TILE * CMP_MAXTILES; }
+// G2: up to 2^16 pairs (from there on the wide digits of the general pipeline do half the additions)
+size_t msm_compact_max_g2() {
+    static const size_t v = getenv("LSA_COMPACT_MAX_G2") ? (size_t)atoll(getenv("LSA_COMPACT_MAX_G2")) : (size_t)1 << 16;
+    return v < CMP_TILE * CMP_MAXTILES ? v : CMP_TILE * CMP_MAXTILES;
+}
 
 static inline size_t cmp_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -352,7 +358,7 @@ template <class F>
 int msm_compact_device(const void *d_table, size_t first, const Fr *d_scalars, size_t n, Jac<F> *d_out, hipStream_t st, size_t table_stride, bool blocking) {
     using C = typename CurveOf<F>::type;
     using A = typename C::Acc;
-    if (n == 0 || n > msm_compact_max() || table_stride == 0) { set_error("msm_compact: not applicable (n = %zu)", n); return LSA_ERR_INVALID; }
+    if (n == 0 || n > (std::is_same<F, Fq>::value ? msm_compact_max() : msm_compact_max_g2()) || table_stride == 0) { set_error("msm_compact: not applicable (n = %zu)", n); return LSA_ERR_INVALID; }
     const WidePlan pl = wide_plan_for(table_stride, false);
     const uint32_t B = 1u << (pl.c - 1);
     if (B > CMP_MAXB || B < 256 || pl.nwin > CMP_MAXWIN) { set_error("msm_compact: digit plan out of range"); return LSA_ERR_INVALID; }
@@ -408,6 +414,9 @@ int msm_compact_device(const void *d_table, size_t first, const Fr *d_scalars, s
     return msm_slot_end(&slot, st);
 }
 template int msm_compact_device<Fq>(const void *, size_t, const Fr *, size_t, Jac<Fq> *, hipStream_t, size_t, bool);
+// G2 (CommScheme::commit's second half, /root/reference/src/prototools/commit.h:155; InterpCommScheme::commit,
+// src/gadgets/lipmaa.cc:27): the same four launches over 128-byte bases and 288-byte accumulators
+template int msm_compact_device<Fq2>(const void *, size_t, const Fr *, size_t, Jac<Fq2> *, hipStream_t, size_t, bool);
 
 // ------------------------------------------------------------------------------------ table builder
 // All pre-shifted copies of a point in ONE kernel: lane i doubles P_i 255 times, parks the 25 (23) multiples it
@@ -457,7 +466,64 @@ __global__ __launch_bounds__(64) void k_cmp_build_table(AffPacked *__restrict__ 
         table[(size_t)j * stride + i] = o;
     }
 }
-size_t table_build_scratch_bytes(size_t n) { return (size_t)(table_grid(n).ncopies - 1) * n * sizeof(CmpBuildRec); }
+// The same for G2: Fq2 doublings (fp29x2.h), the one inversion through the norm (1 / (a + b u) = (a - b u) / (a^2 + b^2)).
+struct CmpBuildRecG2 {
+    XYZZ29x2 p;
+    F29x2 pre;
+};
+__global__ __launch_bounds__(64) void k_cmp_build_table_g2(AffPackedG2 *__restrict__ table, uint32_t n, uint32_t stride, TableGrid grid,
+                                                           CmpBuildRecG2 *__restrict__ scratch) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const Aff29x2 p0 = unpack_affine(table[i]);
+    if (p0.is_inf()) {
+        AffPackedG2 z;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int w = 0; w < 8; w++) z.w[c][w] = 0;
+        for (unsigned j = 1; j < grid.ncopies; j++) table[(size_t)j * stride + i] = z;
+        return;
+    }
+    XYZZ29x2 cur = {p0.x, p0.y, F29x2::one(), F29x2::one()};
+    F29x2 prod = F29x2::one();
+#pragma unroll 1
+    for (unsigned j = 1; j < grid.ncopies; j++) {
+        const unsigned nd = grid.pos[j] - grid.pos[j - 1];
+#pragma unroll 1
+        for (unsigned d = 0; d < nd; d++) cur = g2_dbl(cur);
+        CmpBuildRecG2 r;
+        r.p = cur;
+        r.pre = prod;
+        scratch[(size_t)(j - 1) * n + i] = r;
+        prod = mul<2>(prod, cur.ZZZ);                      // [< 2]
+    }
+    F29x2 inv = f29x2_inverse(prod);                       // [< 2]
+#pragma unroll 1
+    for (unsigned j = grid.ncopies - 1; j >= 1; j--) {
+        const CmpBuildRecG2 r = scratch[(size_t)(j - 1) * n + i];
+        const F29x2 i3 = mul<2>(inv, r.pre);               // 1 / ZZZ_j
+        inv = mul<2>(inv, r.p.ZZZ);
+        const F29x2 izz = sqr<2>(mul<2>(r.p.ZZ, i3));      // ZZ^3 = ZZZ^2  =>  1 / ZZ = (ZZ / ZZZ)^2
+        const F29x2 x = mul<2>(r.p.X, izz).canonical(), y = mul<2>(r.p.Y, i3).canonical();     // X, Y < 4: 2*4*2 = 16
+        AffPackedG2 o;
+        x.c0.pack256(o.w[0]);
+        x.c1.pack256(o.w[1]);
+        y.c0.pack256(o.w[2]);
+        y.c1.pack256(o.w[3]);
+        table[(size_t)j * stride + i] = o;
+    }
+}
+size_t table_build_scratch_bytes(size_t n, int group) {
+    return (size_t)(table_grid(n).ncopies - 1) * n * (group == 1 ? sizeof(CmpBuildRec) : sizeof(CmpBuildRecG2));
+}
+int table_build_g2_device(void *d_table, size_t n, size_t stride, void *d_scratch, hipStream_t st) {
+    if (n == 0) return LSA_OK;
+    hipLaunchKernelGGL(k_cmp_build_table_g2, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (AffPackedG2 *)d_table, (uint32_t)n, (uint32_t)stride, table_grid(stride),
+                       (CmpBuildRecG2 *)d_scratch);
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
 // d_table: ncopies * stride packed points, copy 0 (the first n of them) filled; fills copies 1.. for points [0, n)
 int table_build_g1_device(void *d_table, size_t n, size_t stride, void *d_scratch, hipStream_t st) {
     if (n == 0) return LSA_OK;

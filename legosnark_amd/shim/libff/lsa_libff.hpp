@@ -36,6 +36,8 @@
 #include "../../../include/legosnark_amd.h"
 #include "../../csrc/ec.h"
 #include "../../csrc/tower.h"
+#include "../../csrc/fixed_base.h"
+#include <future>
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
@@ -627,6 +629,26 @@ public:
     }
     static G_shim random_element() { return alt_bn128_Fr::random_element() * one(); }
     static size_t size_in_bits() { return GROUP == 1 ? 255 : 509; }
+    // Fixed-base table of the generator (csrc/fixed_base.h: 32 signed 8-bit digits, at most 32 mixed additions, no
+    // doubling), built once per process -- by whoever asks first, normally the helper thread init_public_params()
+    // starts while the GPU comes up.  Read-only afterwards: safe under the OpenMP loops of a MULTICORE build.
+    // LSA_SHIM_FIXED_BASE=0 keeps every product on the generic windowed ladder.
+    static const lsa::FixedBaseTable<F> &generator_table() {
+        static const lsa::FixedBaseTable<F> *tab = [] {
+            auto *t = new lsa::FixedBaseTable<F>();
+            t->build(one().jac());
+            return t;
+        }();
+        return *tab;
+    }
+    static bool fixed_base_on() {
+        static const bool on = !(getenv("LSA_SHIM_FIXED_BASE") && getenv("LSA_SHIM_FIXED_BASE")[0] == '0');
+        return on;
+    }
+    bool is_generator() const {
+        static const G_shim g = one();
+        return memcmp((const void *)this, (const void *)&g, sizeof(G_shim)) == 0;
+    }
     bool is_zero() const { return Z.is_zero(); }
     bool is_special() const { return is_zero() || Z == F::one(); }
     bool operator==(const G_shim &o) const { return lsa::jac_eq(jac(), o.jac()); }
@@ -665,6 +687,8 @@ public:
             }
             return G_shim(res);
         }
+        // the generator (commit.h:43-44,162-163, polytools.h:126-133, poly.h:117: most sites): table look-ups
+        if (fixed_base_on() && p.is_generator()) return G_shim(generator_table().mul(e.data));
         Jac tbl[16];
         tbl[0] = Jac::inf();
         tbl[1] = base;
@@ -841,6 +865,10 @@ public:
             mallopt(M_TOP_PAD, 64 << 20);
 #endif
         }
+        // the generators' fixed-base tables (a few ms of host work) while the GPU comes up
+        static std::future<void> tables;
+        if (alt_bn128_G1::fixed_base_on() && !tables.valid())
+            tables = std::async(std::launch::async, [] { (void)alt_bn128_G1::generator_table(); (void)alt_bn128_G2::generator_table(); });
         const char *d = getenv("LSA_DEVICE");
         lsa_shim::GpuLock lock;
         lsa_require(lsa_init(d ? atoi(d) : 0), "init_public_params");

@@ -5,6 +5,7 @@
 #include "ec.h"
 #include "tower.h"
 #include "fp29x2.h"
+#include "fs29.h"
 using namespace lsa;
 static std::mt19937_64 rng(4242);
 static int fails = 0;
@@ -56,6 +57,18 @@ int main() {
         CHECK(f29x2_to_mont256(sqr<6>(X)) == (a - b).sqr(), "sqr big");
         CHECK(f29x2_to_mont256(condsub4(sub_k<6>(A, B))) == a - b, "condsub4");
         CHECK(sub_k<4>(A, A).is_zero_mod_p() && !X.is_zero_mod_p(), "zero test");
+        // f29x2_inverse (fs29.h; the one inversion of k_prepare_g2 / k_cmp_build_table_g2): a * a^-1 = 1, and the value libff's
+        // Fq2 inverse gives
+        if (t < 200) {
+            const F29x2 I = f29x2_inverse(mul<2>(A, F29x2::one()));      // a tight operand below 2p
+            CHECK(f29x2_to_mont256(I) == a.inverse(), "inverse");
+            CHECK(f29x2_to_mont256(mul<2>(I, A)) == Fq2::one(), "a * a^-1");
+        }
+    }
+    {
+        Fq2 pure_real = {rand_fq(), Fq::zero()}, pure_imag = {Fq::zero(), rand_fq()};
+        CHECK(f29x2_to_mont256(f29x2_inverse(f29x2_from_mont256(pure_real))) == pure_real.inverse(), "inverse (c1 = 0)");
+        CHECK(f29x2_to_mont256(f29x2_inverse(f29x2_from_mont256(pure_imag))) == pure_imag.inverse(), "inverse (c0 = 0)");
     }
     for (int t = 0; t < 12; t++) {
         XYZZ<Fq2> ref = XYZZ<Fq2>::inf();

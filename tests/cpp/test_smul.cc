@@ -1,10 +1,72 @@
 // Host unit test of csrc/smul.h (the per-lane body of k_smul_g1): k*P by GLV + signed 4-bit
 // windows on 29-bit limbs against plain double-and-add with the generic Jacobian formulas of ec.h.
 #include <cstdio>
+#include <array>
 #include <random>
+#include <vector>
 #include "ec.h"
 #include "smul.h"
+#include "tower.h"
+#include "fixed_base.h"
+#include <chrono>
 using namespace lsa;
+
+// csrc/fixed_base.h (the shim's `Fr * generator` on the host: /root/reference/src/prototools/commit.h:43-44,162-163,
+// src/gadgets/poly.h:117): 32 signed 8-bit digits over a table of the base's multiples must give the point
+// double-and-add gives, for G1 and G2, on edge scalars (digit boundaries 127/128/129, carries through whole limbs, r - 1)
+// and random ones; also reports the time per product next to double-and-add.
+template <class F>
+static Jac<F> plain_mul_any(const Jac<F> &P, const uint64_t k[4]) {
+    Jac<F> acc = Jac<F>::inf();
+    for (int i = 255; i >= 0; --i) {
+        acc = jac_dbl(acc);
+        if ((k[i >> 6] >> (i & 63)) & 1) acc = jac_add(acc, P);
+    }
+    return acc;
+}
+template <class F>
+static int fixed_base_check(const Jac<F> &G, const char *name, std::mt19937_64 &rng) {
+    FixedBaseTable<F> tab;
+    auto t0 = std::chrono::steady_clock::now();
+    tab.build(G);
+    const double build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    int fails = 0;
+    std::vector<std::array<uint64_t, 4>> ks;
+    for (uint64_t v : {0ull, 1ull, 2ull, 127ull, 128ull, 129ull, 255ull, 256ull, 257ull, 0x8080ull, 0x7f7full, 0x8181ull, 0xffffull, 0x10000ull,
+                       0xffffffffffffffffull, 0x8080808080808080ull, 0x7f807f807f807f80ull})
+        ks.push_back({v, 0, 0, 0});
+    ks.push_back({0xffffffffffffffffull, 0xffffffffffffffffull, 0xffffffffffffffffull, 0x3fffffffffffffffull});   // 2^254 - 1 (every digit carries)
+    ks.push_back({0x8080808080808080ull, 0x8080808080808080ull, 0x8080808080808080ull, 0x2080808080808080ull});
+    ks.push_back({0, 0, 0, 0x2000000000000000ull});                                                               // 2^253
+    {
+        std::array<uint64_t, 4> rm1;
+        for (int i = 0; i < 4; i++) rm1[i] = (uint64_t)FrParams::MOD[2 * i] | ((uint64_t)FrParams::MOD[2 * i + 1] << 32);
+        rm1[0] -= 1;
+        ks.push_back(rm1);                                                                                         // r - 1: the result is -G
+    }
+    for (int t = 0; t < 300; t++) { std::array<uint64_t, 4> k = {rng(), rng(), rng(), rng() & 0x3fffffffffffffffull}; ks.push_back(k); }
+    for (size_t i = 0; i < ks.size(); i++) {
+        const Jac<F> got = tab.mul(ks[i].data()), want = plain_mul_any(G, ks[i].data());
+        if (!jac_eq(got, want)) { if (fails < 5) printf("%s fixed-base mismatch at scalar %zu\n", name, i); fails++; }
+    }
+    if (!jac_eq(tab.mul(ks[ks.size() - 301].data()), jac_neg(G))) { printf("%s (r - 1) G != -G\n", name); fails++; }
+    // table entries themselves: T[w][j] = (j + 1) 2^(8w) G on the curve's affine form
+    {
+        uint64_t k[4] = {0, 0, 0, 0};
+        k[2] = (uint64_t)77 << 8;                                                                                  // 77 * 2^136 = T[17][76]
+        const Aff<F> e = tab.t[(size_t)17 * FixedBaseTable<F>::HALF + 76];
+        if (!jac_eq(Jac<F>{e.x, e.y, F::one()}, plain_mul_any(G, k))) { printf("%s table entry wrong\n", name); fails++; }
+    }
+    t0 = std::chrono::steady_clock::now();
+    Jac<F> sink = Jac<F>::inf();
+    for (size_t i = 24; i < 224; i++) sink = jac_add(sink, tab.mul(ks[i].data()));
+    const double fb_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 200;
+    t0 = std::chrono::steady_clock::now();
+    for (size_t i = 24; i < 44; i++) sink = jac_add(sink, plain_mul_any(G, ks[i].data()));
+    const double da_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 20;
+    printf("%s fixed base: table %.2f ms, %.1f us per product (double-and-add %.1f us)%s\n", name, build_ms, fb_us, da_us, sink.is_inf() ? "." : "");
+    return fails;
+}
 
 static Jac<Fq> plain_mul(const Jac<Fq> &P, const uint32_t k[8]) {
     Jac<Fq> acc = Jac<Fq>::inf();
@@ -41,6 +103,13 @@ int main() {
         Jac<Fq> want = plain_mul(P, k);
         if (!jac_eq(got, want)) { if (fails < 5) printf("mismatch at t=%d\n", t); fails++; }
         P = jac_add(jac_dbl(P), G);   // next base: 2P + G
+    }
+    {
+        std::mt19937_64 rng2(12);
+        fails += fixed_base_check<Fq>(G, "G1", rng2);
+        const Jac<Fq2> G2 = {fq2_const(LSA_G2_GEN_X), fq2_const(LSA_G2_GEN_Y), Fq2::one()};
+        fails += fixed_base_check<Fq2>(G2, "G2", rng2);
+        fails += fixed_base_check<Fq>(jac_add(jac_dbl(G), G), "G1 (3G, Z != 1)", rng2);
     }
     printf(fails ? "FAILED (%d)\n" : "PASS\n", fails);
     return fails ? 1 : 0;

@@ -27,6 +27,20 @@ def thp():
         return None
 
 
+def host_array(np, shape, dtype, small_pages):
+    """A zeroed host array; small_pages: an anonymous mapping with MADV_NOHUGEPAGE set BEFORE it is touched -- what a
+    std::vector on the glibc heap looks like under transparent_hugepage=madvise / never (numpy asks for huge pages)."""
+    if not small_pages:
+        return np.zeros(shape, dtype=dtype)
+    import ctypes, mmap
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    m = mmap.mmap(-1, nbytes)
+    addr = ctypes.addressof(ctypes.c_char.from_buffer(m))
+    rc = ctypes.CDLL(None, use_errno=True).madvise(ctypes.c_void_p(addr), ctypes.c_size_t(nbytes), 15)   # MADV_NOHUGEPAGE
+    assert rc == 0, "madvise failed"
+    return np.frombuffer(m, dtype=dtype).reshape(shape)
+
+
 def child(args):
     import numpy as np
     t0 = time.perf_counter()
@@ -45,7 +59,11 @@ def child(args):
     G = curve.generator(group)
     width = 12 if group == "g1" else 24
     pts = lsa.batch_exp(group, G, x)
-    P_host = np.zeros((2 * N + 2, width), dtype=np.uint64)
+    P_host = host_array(np, (2 * N + 2, width), np.uint64, args.small_pages)
+    if args.small_pages:
+        w_small = host_array(np, w_vec.shape, np.uint64, True)
+        w_small[...] = w_vec
+        w_vec = w_small
     P_host[:npl] = np.asarray(pts).view(np.uint64).reshape(npl, width)
     one = curve.fq_mont(1)
     if group == "g1":
@@ -67,7 +85,7 @@ def child(args):
         ok = bool(np.array_equal(lsa.normalize(group, r_.reshape(1, width)), want_aff))
         runs.append({"ms": round(dt, 3), "ok": ok, **{k: round(float(st[k]), 3) for k in ("h2d_scalars_ms", "fingerprint_wait_ms", "bases_prepare_ms", "msm_ms")},
                      "cache_hit": int(st["cache_hit"])})
-    print(json.dumps({"cold_child": {"group": group, "log2n": args.log2n, "init_ms": round(init_ms, 1), "thp": thp(), "cold": runs[0], "second": runs[1], "third": runs[2]}}))
+    print(json.dumps({"cold_child": {"group": group, "log2n": args.log2n, "init_ms": round(init_ms, 1), "thp": thp(), "small_pages": bool(args.small_pages), "cold": runs[0], "second": runs[1], "third": runs[2]}}))
 
 
 def main():
@@ -77,6 +95,7 @@ def main():
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--runs", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--small-pages", action="store_true", help="host vectors on 4-KiB pages (MADV_NOHUGEPAGE)")
     ap.add_argument("--env", action="append", default=[], help="KEY=VALUE for the children (one setting); repeatable")
     ap.add_argument("--settings", action="append", default=[], help="a whole setting 'K=V,K=V' (repeatable): one line each")
     args = ap.parse_args()
@@ -87,7 +106,7 @@ def main():
         outs = []
         for r in range(args.runs):
             env = dict(os.environ, **setting)
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--group", args.group, "--log2n", str(args.log2n), "--seed", str(r)],
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", "--group", args.group, "--log2n", str(args.log2n), "--seed", str(r)] + (["--small-pages"] if args.small_pages else []),
                                env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
             line = [l for l in p.stdout.splitlines() if l.startswith('{"cold_child"')]
             if p.returncode != 0 or not line:
@@ -96,7 +115,7 @@ def main():
             outs.append(json.loads(line[-1])["cold_child"])
         good = [o for o in outs if "cold" in o]
         cold = sorted(o["cold"]["ms"] for o in good)
-        summary = {"setting": setting, "group": args.group, "log2n": args.log2n, "runs": len(outs), "thp": good[0]["thp"] if good else None,
+        summary = {"setting": setting, "group": args.group, "log2n": args.log2n, "runs": len(outs), "small_pages": bool(args.small_pages), "thp": good[0]["thp"] if good else None,
                    "cold_ms_runs": [o["cold"]["ms"] for o in good],
                    "cold_ms_median": cold[len(cold) // 2] if cold else None,
                    "cold_ms_p90": cold[min(len(cold) - 1, int(0.9 * len(cold)))] if cold else None,
