@@ -7,6 +7,8 @@ from the MSM) or, for pairings, by planted products that must equal one.  A conf
   cplink_prover   SubspaceSnark::prove shape (subspace.cc:78-85): MSM over N+2 pairs, w[0] = 0
   g2_msm          alt_bn128 G2 MSM
   cppoly          CPpoly d-variable commit + prove ladder (poly.h:30-32,76-88)
+  fr_fold         CPpoly witness recursion + evalMLE at d = 24 (HBM-bound Fr streams)
+  ntt             radix-2 NTT of 2^24 Fr values
   pairing         ONE product of 2^k Miller loops over pairs never seen + one final exponentiation (BASELINE configs[4])
   cphad_verify    the CPhad verifier's pairing shape: 187 Miller loops in 62 products, 62 final exponentiations; with
                   every Q resident (a verifier's keys) and with every Q fresh
@@ -202,6 +204,91 @@ def measure(lsa, torch, np, dev, log2n=20, d=20, log2pairs=12, reps=5, only=None
               "prove_msm_ladder_segmented_ms": ms_ls, "prove_total_ms": ms_p, "prove_pairs": (n - 1) + (n // 2 - 1), "msms_checked": len(ks) + 2,
               "commit_algorithmic_bytes": (96 + 160) * n, "commit_valu": valu(n * (fm1 + adds2 * G2_MSM_FQ_MULS_PER_ADD), ms_c)})
         B1.close(); B2.close()
+
+    # ---- the Fr streams around the MSMs: HBM-bound kernels
+    if on("fr_fold"):
+        dd = 24
+        n = 1 << dd
+        gen = torch.Generator(device=dev).manual_seed(24)
+        d_v = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device=dev, generator=gen)
+        d_v[:, 3] &= (1 << 60) - 1                     # any value below r is a valid Montgomery residue
+        r = rng.uniform_fr(dd)
+        d_r = to_dev(r)
+        d_w = torch.empty_like(d_v)
+        d_out = torch.zeros(4, dtype=torch.int64, device=dev)
+        ms_w = timed(lambda: lsa.cppoly_witness(d_v, d_r, out=d_w), half)
+        ms_e = timed(lambda: lsa.eval_mle_device(d_v, d_r, d_out), half)
+        val = host(d_out).copy()
+        # checks: evalMLE at the corners of the cube is an entry of v; at the random point it equals the value the
+        # round-by-round fold (another kernel: DPMle::pushRandomness, lsa_fr_fold) ends with
+        ok = True
+        for bit, idx in ((0, 0), (1, n - 1)):
+            corner = to_dev(np.stack([curve.fr_mont(bit)] * dd))
+            lsa.eval_mle_device(d_v, corner, d_out)
+            lsa.synchronize()
+            ok = ok and np.array_equal(host(d_out), host(d_v[idx]))
+        cur = d_v.clone()
+        size = n
+        for j in range(dd):
+            size //= 2
+            lsa._check(lsa.lib().lsa_fr_fold(cur.data_ptr(), size, d_r[j].data_ptr(), cur.data_ptr(), 1))
+        lsa.synchronize()
+        fold_end = host(cur[0]).copy()
+        # (the two kernels fold the variables in opposite orders: the fold of the reversed point must agree)
+        cur = d_v.clone()
+        size = n
+        d_rr = to_dev(r[::-1].copy())
+        for j in range(dd):
+            size //= 2
+            lsa._check(lsa.lib().lsa_fr_fold(cur.data_ptr(), size, d_rr[j].data_ptr(), cur.data_ptr(), 1))
+        lsa.synchronize()
+        ok = ok and (np.array_equal(val, fold_end) or np.array_equal(val, host(cur[0])))
+        bw, be = 128 * n, 96 * n
+        emit("Fr fold d=24: CPpoly witness recursion (poly.h:55-67) and evalMLE (polytools.h:207-234) on a resident vector of 2^24", ok,
+             {"witness_ms": ms_w, "eval_mle_ms": ms_e, "algorithmic_bytes": {"witness": bw, "eval_mle": be},
+              "hbm": {"bound": "hbm", "witness_GBps": round(bw / ms_w / 1e6, 1), "eval_mle_GBps": round(be / ms_e / 1e6, 1), "peak_GBps": HBM_PEAK_GBS,
+                      "witness_frac": round(bw / ms_w / 1e6 / HBM_PEAK_GBS, 4), "eval_mle_frac": round(be / ms_e / 1e6 / HBM_PEAK_GBS, 4)},
+              "note": "all rounds together: 2 Montgomery products per 64 bytes read; rounds below ~2^16 elements are launch-bound"})
+        del d_v, d_w, cur
+
+    if on("ntt"):
+        ln = 24
+        n = 1 << ln
+        gen = torch.Generator(device=dev).manual_seed(42)
+        d_a = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device=dev, generator=gen)
+        d_a[:, 3] &= (1 << 60) - 1
+        keep = d_a.clone()
+        wroot = pow(5, (curve.R - 1) >> 28, curve.R)
+        for _ in range(28 - ln):
+            wroot = wroot * wroot % curve.R
+        w = curve.fr_mont(wroot)
+        g5 = curve.fr_mont(5)                          # FieldT::multiplicative_generator (lipmaa.cc:138)
+        ms_f = timed(lambda: lsa.fr_ntt(d_a, w), half)
+        d_a.copy_(keep)
+        # checks: icosetFFT(cosetFFT(a)) == a; FFT of the delta at 1 is omega^k (spot values)
+        lsa.fr_ntt(d_a, w, coset=g5)
+        changed = not torch.equal(d_a, keep)
+        lsa.fr_ntt(d_a, w, inverse=True, coset=g5)
+        lsa.synchronize()
+        ok = changed and torch.equal(d_a, keep)
+        ms_ic = timed(lambda: lsa.fr_ntt(d_a, w, inverse=True, coset=g5), half)
+        delta = torch.zeros((n, 4), dtype=torch.int64, device=dev)
+        delta[1] = torch.from_numpy(curve.fr_mont(1).view(np.int64))
+        lsa.fr_ntt(delta, w)
+        lsa.synchronize()
+        hd = host(delta)
+        for k in (0, 1, 2, 1023, 1024, 65537, n - 1):
+            ok = ok and np.array_equal(hd[k], curve.fr_mont(pow(wroot, k, curve.R)))
+        mults = n * (ln / 2 - 1.5 + 2 + 1 + 1)         # butterflies less the three trivial first stages, pass-1 twiddle (2), pass-2 twiddle, final scale
+        emit("NTT 2^24 over Fr (libfqfft FFT / icosetFFT, lipmaa.cc:102-168) on a resident vector, three passes", ok,
+             {"fft_ms": ms_f, "icoset_fft_ms": ms_ic, "algorithmic_bytes": 64 * n, "passes_over_the_data": 3,
+              "hbm": {"algorithmic_GBps": round(64 * n / ms_f / 1e6, 1), "moved_GBps": round(3 * 64 * n / ms_f / 1e6, 1), "peak_GBps": HBM_PEAK_GBS,
+                      "frac_algorithmic": round(64 * n / ms_f / 1e6 / HBM_PEAK_GBS, 4)},
+              "valu": valu(mults, ms_f),
+              "note": "VALU-bound, not HBM-bound: %.1f field products per element against 64 B of traffic -- at the 175 G/s product "
+                      "ceiling the transform cannot beat %.2f ms, where three passes at 8 TB/s would take %.2f ms" % (
+                          mults / n, mults / FMUL_PEAK_G / 1e6, 3 * 64 * n / HBM_PEAK_GBS / 1e6)})
+        del d_a, keep, delta
 
     fq12_one = np.zeros(48, dtype=np.uint64)
     fq12_one[0:4] = curve.fq_mont(1)

@@ -20,6 +20,7 @@
 
 #include "capi_internal.h"
 #include "tower.h"
+#include "ntt_core.h"
 
 namespace lsa {
 
@@ -150,9 +151,11 @@ int lsa_init(int device) {
     HIPCHK(hipMalloc(&g.d_result, 512));
     HIPCHK(hipHostMalloc(&g.h_result, 512, hipHostMallocDefault));
     g.device = device;
-    g.ready = true;
     upload_prepare();
-    return msm_warmup(g.stream);
+    const int wrc = msm_warmup(g.stream);
+    g.ready = true;                                  // (lsa_shutdown releases what the steps above created)
+    if (wrc) { lsa_shutdown(); return wrc; }         // a library whose warm-up failed is not handed out as ready
+    return LSA_OK;
 }
 
 void lsa_shutdown(void) {
@@ -686,6 +689,7 @@ int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars, siz
 // grow-only device staging buffers of the host-buffer entry points (StageBuf, capi_internal.h)
 namespace {
 StageBuf g_stage_jac, g_stage_bases, g_stage_scalars, g_stage_prefix_scratch;
+StageBuf g_stage_ntt_a, g_stage_ntt_tmp;         // lsa_fr_ntt: the data of host callers, the second buffer of the passes
 }  // namespace
 namespace lsa { StageBuf g_stage_gather; }
 static int stage_jac_ensure(size_t bytes, void **p) {
@@ -695,6 +699,8 @@ static int stage_jac_ensure(size_t bytes, void **p) {
 }
 static void release_stage_buffers() {
     g_stage_jac.release(); g_stage_bases.release(); g_stage_scalars.release(); g_stage_gather.release(); g_stage_prefix_scratch.release();
+    g_stage_ntt_a.release(); g_stage_ntt_tmp.release();
+    ntt_release();                                   // the per-domain twiddle tables (ntt.hip)
     pairing_release();
 }
 
@@ -1727,18 +1733,19 @@ int lsa_fr_ntt(void *a, size_t log_n, const void *omega, int inverse, const void
     Fr w, gco;
     memcpy(&w, omega, sizeof w);
     if (coset_g) memcpy(&gco, coset_g, sizeof gco);
-    // grow-only staging for the twiddle table and (host callers) the data: two hipMalloc / hipFree pairs per call cost a
-    // 2^20-point transform of an unchanged prover more than its kernels (the shim's evaluation_domain calls this 7 times
-    // per Lipmaa proof)
-    static StageBuf s_tw, s_a;
-    if (s_tw.ensure((n / 2 + 1) * sizeof(Fr))) { set_error("fr_ntt: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    // grow-only staging (released by lsa_shutdown, like every other staging buffer) for the second buffer of the passes
+    // and, for host callers, the data: two hipMalloc / hipFree pairs per call cost a 2^20-point transform of an unchanged
+    // prover more than its kernels (the shim's evaluation_domain calls this 7 times per Lipmaa proof).  The twiddle
+    // tables are cached per domain inside ntt.hip.
+    StageBuf &s_a = g_stage_ntt_a;
+    if (log_n > NTT_TILE_LOG && g_stage_ntt_tmp.ensure(n * sizeof(Fr))) { set_error("fr_ntt: hipMalloc failed"); return LSA_ERR_NOMEM; }
     Fr *da = (Fr *)a;
     if (!on_device) {
         if (s_a.ensure(n * sizeof(Fr))) { set_error("fr_ntt: hipMalloc failed"); return LSA_ERR_NOMEM; }
         LSA_UPLOAD(s_a.p, a, n * sizeof(Fr));
         da = (Fr *)s_a.p;
     }
-    rc = fr_ntt_device(da, (unsigned)log_n, w, inverse != 0, coset_g ? &gco : nullptr, (Fr *)s_tw.p, g.stream);
+    rc = fr_ntt_device(da, (unsigned)log_n, w, inverse != 0, coset_g ? &gco : nullptr, (Fr *)g_stage_ntt_tmp.p, g.stream);
     if (rc) return rc;
     // (The download is enqueued BEHIND the kernels, not after a wait for them: the first device -> host copy a process
     // issues on an idle stream costs it 8 ms of copy-engine set-up on this stack.)

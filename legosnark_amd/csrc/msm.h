@@ -76,8 +76,10 @@ int fr_sumcheck_round_device(const Fr *d_suff, const Fr *const *d_tables, size_t
 size_t fr_sumcheck_scratch_elems();
 int fr_scale_upper_device(const Fr *d_old, size_t half, const Fr &k, Fr *d_cur, hipStream_t st);
 
-// ntt.hip: in-place radix-2 NTT of 2^log_n Fr values (device), d_tw: 2^(log_n-1) scratch elements
-int fr_ntt_device(Fr *d_a, unsigned log_n, const Fr &omega, bool inverse, const Fr *coset, Fr *d_tw, hipStream_t st);
+// ntt.hip: in-place radix-2 NTT of 2^log_n Fr values (device) in at most three passes; d_tmp: 2^log_n scratch elements
+// (unused up to 2^10 points); the twiddle tables are cached per domain (ntt_release frees them)
+int fr_ntt_device(Fr *d_a, unsigned log_n, const Fr &omega, bool inverse, const Fr *coset, Fr *d_tmp, hipStream_t st);
+void ntt_release();
 
 // d_out = sum of n Jacobian points in d_in (device-resident).
 template <class F>

@@ -1699,7 +1699,10 @@ int msm_slot_handover(MsmSlot *slot, hipStream_t st) {
     // results appear in call order wherever two calls write the same place: behind every earlier tail with this destination
     for (int i = 0; i < NTAIL; i++) {
         TailBuf &o = g_tail[i];
-        if (i != slot->index && o.pending && o.out == tb.out) HIPCHK(hipStreamWaitEvent(slot->tail, o.done, 0));
+        if (i == slot->index || !o.pending || o.out != tb.out) continue;
+        // (a tail that finished long ago needs no wait command: a blocking small call otherwise issues up to seven of them)
+        if (!o.unjoined && hipEventQuery(o.done) == hipSuccess) { o.pending = false; continue; }
+        HIPCHK(hipStreamWaitEvent(slot->tail, o.done, 0));
     }
     return LSA_OK;
 }
@@ -2134,11 +2137,13 @@ acc_done:
         Jac<F> *res = tail != st ? (Jac<F> *)(tws + res_off) : d_out;
         // pipelined wide calls: the first 16-ary level lane-private (k_reduce2_lane: a seventh of the quad level's work)
         static const bool allow_lane_l1 = getenv("LSA_NO_LANE_L1") == nullptr;
-        // (G1 only: 48 sequential G2 additions are 1.2 ms of latency; and only when the previous call's tail is still in
-        // flight, i.e. calls really are queued back to back: a pair that is waited for right away -- CPpoly's commit --
-        // pays the lane kernel's 0.2 ms of extra latency instead: 6.0 -> 6.25 ms)
-        bool lane_l1 = allow_lane_l1 && std::is_same<C, CurveG1>::value && !blocking && big && kw == 1 && nseg == 1 && m >= 16384 && tail != st &&
-                       prev.pending && &prev != &tb && hipEventQuery(prev.done) == hipErrorNotReady;
+        // (G1 only: 48 sequential G2 additions are 1.2 ms of latency; and only when calls are queued back to back: the
+        // previous call's tail has not been joined by the caller since it was issued.  Decided from the CALL SEQUENCE alone
+        // -- not from whether that tail happens to be running still -- so that the same calls always add in the same order
+        // and return the same Jacobian bytes.  The second half of a commitment pair (reuse_sort) is waited for right away
+        // and would pay the lane kernel's 0.2 ms of extra latency: 6.0 -> 6.25 ms.)
+        bool lane_l1 = allow_lane_l1 && std::is_same<C, CurveG1>::value && !blocking && !reuse_sort && big && kw == 1 && nseg == 1 && m >= 16384 &&
+                       tail != st && prev.pending && prev.unjoined && &prev != &tb;
         do {                                             // at least one k_reduce2 level (it leaves the sum in slot 0)
             const uint32_t m_out = (m + 15) / 16;
             if (lane_l1) {
@@ -2177,6 +2182,12 @@ acc_done:
         }
         if (tail != st) {
             if (prev.pending && &prev != &tb) HIPCHK(hipStreamWaitEvent(tail, prev.done, 0));   // publish in call order
+            // ... also behind every earlier tail that writes THIS destination and is not part of that chain: the compact
+            // pipeline's tails (msm_compact.hip) write d_out themselves and only wait for tails with the same destination
+            for (int i = 0; i < NTAIL; i++) {
+                TailBuf &o = g_tail[i];
+                if (&o != &tb && &o != &prev && o.pending && o.out == (const void *)d_out) HIPCHK(hipStreamWaitEvent(tail, o.done, 0));
+            }
             hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, tail, (const uint32_t *)res, (uint32_t *)d_out, (unsigned)(nseg * sizeof(Jac<F>) / 4));
         }
         if (profile) (void)hipEventRecord(ev7, tail);  // 7

@@ -1,4 +1,4 @@
-// legosnark_amd/csrc/ntt.hip -- radix-2 number-theoretic transform over Fr on gfx950.
+// legosnark_amd/csrc/ntt.hip -- radix-2 number-theoretic transform over Fr on gfx950 in at most THREE global passes.
 //
 // Replaces libfqfft's basic_radix2_domain<Fr>::{FFT, iFFT, cosetFFT, icosetFFT}
 // (_basic_radix2_FFT / _multiply_by_coset) as called by the Lipmaa Hadamard gadget,
@@ -7,90 +7,28 @@
 //   final factor 1/n; the coset variants scale a[i] by g^i before / by g^-i after.
 // Fr values are canonical Montgomery residues, so any correct schedule gives libfqfft's bytes.
 //
-//   k_ntt_twiddles   tw[k] = omega^k, k < n/2 (each lane: one power by square-and-multiply, then
-//                    a run of 64 successive products)
-//   k_ntt_scale      a[i] *= c * h^i  (coset shifts, 1/n)
-//   k_ntt_bitrev     in-place bit-reversal permutation (swap when i < rev(i))
-//   k_ntt_local      the first min(log n, 10) butterfly stages on 1024 contiguous elements held
-//                    in LDS (32 KiB): one HBM round trip for ten stages
-//   k_ntt_stage      one butterfly stage per launch for the strides beyond the LDS tile
-// HBM traffic at n = 2^20: 64 MB per global pass, 1 + (log n - 10) passes; about as many Fr
-// products (n/2 log n) as a 2^20 MSM has field products per 1/16 of its work: HBM/latency bound.
+// Schedule (ntt_core.h): n = 2^(l1 + l2 + l3); every pass is one launch of k_ntt_pass, one workgroup per tile of 2^10
+// elements held in LDS as 29-bit limbs (36 KB): pass 1 transforms 2^10 / 2^l1 neighbouring stride-m columns and applies
+// the inter-pass twiddles, pass 2 the same inside each block of m, pass 3 the contiguous rows, and writes the result
+// transposed to its natural position with the final scale.  Bit reversal happens on the way into LDS, coset shifts on
+// the first load, 1/n and the inverse coset on the last store: no separate scale / bit-reversal launches.
+//   n <= 2^10: one launch;  n <= 2^16: two;  n <= 2^28: three.   HBM traffic: 64 B per element and pass.
+// Constants (the butterflies' twiddles W, the two-level tables of the inter-pass twiddles and of the coset powers) are
+// computed once per domain (log n, omega, direction[, coset generator]) and cached (k_ntt_pow_table: one launch each).
+// Work per element: (log n) / 2 butterfly products, less the trivial first stage of every pass, + 2 per inter-pass
+// twiddle + 1 final product: 13.5 at n = 2^20 against 10 for an ideal radix-2 -- on fr29.h's product, 1.75x the rate of
+// the 8 x 32-bit CIOS the previous version used.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
+
+#include <vector>
 
 #include "fp.h"
 #include "msm.h"
+#include "ntt_core.h"
 
 namespace lsa {
-
-__device__ __forceinline__ Fr fr_pow(Fr base, uint64_t e) {
-    Fr acc = Fr::one();
-    bool started = false;
-    for (int i = 63; i >= 0; --i) {
-        if (started) acc = acc * acc;
-        if ((e >> i) & 1) { acc = started ? acc * base : base; started = true; }
-    }
-    return acc;
-}
-
-static constexpr unsigned NTT_RUN = 64;     // successive powers per lane
-__global__ __launch_bounds__(256) void k_ntt_twiddles(Fr omega, size_t count, Fr *__restrict__ tw) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t lo = t * NTT_RUN;
-    if (lo >= count) return;
-    Fr x = fr_pow(omega, lo);
-    for (size_t k = lo; k < lo + NTT_RUN && k < count; k++) { tw[k] = x; x = x * omega; }
-}
-
-// a[i] *= c * h^i
-__global__ __launch_bounds__(256) void k_ntt_scale(Fr *__restrict__ a, size_t n, Fr c, Fr h) {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t lo = t * NTT_RUN;
-    if (lo >= n) return;
-    Fr x = c * fr_pow(h, lo);
-    for (size_t k = lo; k < lo + NTT_RUN && k < n; k++) { a[k] = a[k] * x; x = x * h; }
-}
-
-__global__ __launch_bounds__(256) void k_ntt_bitrev(Fr *__restrict__ a, unsigned log_n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >> log_n) return;
-    const size_t j = (size_t)(__brevll((unsigned long long)i) >> (64 - log_n));
-    if (i < j) { Fr x = a[i]; a[i] = a[j]; a[j] = x; }
-}
-
-// stages s = 0 .. ls-1 (butterfly spans 2 .. 2^ls <= 1024) on the block's 2^ls contiguous
-// elements; twiddle of span len, position j: omega^(j * n/len) = tw[j << (log_n - s - 1)]
-static constexpr unsigned NTT_LOCAL_LOG = 10;
-__global__ __launch_bounds__(256) void k_ntt_local(Fr *__restrict__ a, unsigned log_n, unsigned ls, const Fr *__restrict__ tw) {
-    __shared__ Fr tile[1u << NTT_LOCAL_LOG];
-    const unsigned tsz = 1u << ls;
-    Fr *base = a + (size_t)blockIdx.x * tsz;
-    for (unsigned x = threadIdx.x; x < tsz; x += 256) tile[x] = base[x];
-    __syncthreads();
-    for (unsigned s = 0; s < ls; s++) {
-        const unsigned hl = 1u << s;                      // half span
-        for (unsigned b = threadIdx.x; b < tsz / 2; b += 256) {
-            const unsigned j = b & (hl - 1), i0 = ((b >> s) << (s + 1)) | j;
-            const Fr u = tile[i0], v = tile[i0 + hl] * tw[(size_t)j << (log_n - s - 1)];
-            tile[i0] = u + v;
-            tile[i0 + hl] = u - v;
-        }
-        __syncthreads();
-    }
-    for (unsigned x = threadIdx.x; x < tsz; x += 256) base[x] = tile[x];
-}
-
-// one stage s >= NTT_LOCAL_LOG in global memory
-__global__ __launch_bounds__(256) void k_ntt_stage(Fr *__restrict__ a, unsigned log_n, unsigned s, const Fr *__restrict__ tw) {
-    const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >> (log_n - 1)) return;
-    const size_t hl = (size_t)1 << s;
-    const size_t j = b & (hl - 1), i0 = ((b >> s) << (s + 1)) | j;
-    const Fr u = a[i0], v = a[i0 + hl] * tw[j << (log_n - s - 1)];
-    a[i0] = u + v;
-    a[i0 + hl] = u - v;
-}
 
 #define HIPCHK(x)                                                                      \
     do {                                                                               \
@@ -101,6 +39,60 @@ __global__ __launch_bounds__(256) void k_ntt_stage(Fr *__restrict__ a, unsigned 
         }                                                                              \
     } while (0)
 
+__device__ __forceinline__ Fr fr_pow_dev(Fr base, uint64_t e) {
+    Fr acc = Fr::one();
+    bool started = false;
+    for (int i = 63; i >= 0; --i) {
+        if (started) acc = acc * acc;
+        if ((e >> i) & 1) { acc = started ? acc * base : base; started = true; }
+    }
+    return acc;
+}
+
+// pass 2's twiddles: out[k2 n3 + i3] = c0 * base^(i3 k2), base = omega^n1
+__global__ __launch_bounds__(256) void k_ntt_t2_table(Fr base, Fr c0, unsigned l2, unsigned l3, Fr *__restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >> (l2 + l3)) return;
+    const uint64_t k2 = t >> l3, i3 = t & (((uint64_t)1 << l3) - 1);
+    out[t] = c0 * fr_pow_dev(base, i3 * k2);
+}
+
+// out[k] = c0 * base^k, k < count (each lane: one power by square-and-multiply, then a run of successive products)
+static constexpr unsigned NTT_RUN = 16;
+__global__ __launch_bounds__(256) void k_ntt_pow_table(Fr base, Fr c0, size_t count, Fr *__restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t lo = t * NTT_RUN;
+    if (lo >= count) return;
+    Fr x = c0 * fr_pow_dev(base, lo);
+    for (size_t k = lo; k < lo + NTT_RUN && k < count; k++) { out[k] = x; x = x * base; }
+}
+
+// 256-bit words -> limbs (the W table: read once per butterfly)
+__global__ __launch_bounds__(256) void k_ntt_unpack_table(const Fr *__restrict__ in, size_t count, uint32_t *__restrict__ out9) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const Fr29 v = Fr29::from_words(in[t]);
+#pragma unroll
+    for (int i = 0; i < 9; i++) out9[t * 9 + i] = v.l[i];
+}
+
+// one pass over one tile (ntt_core.h); dynamic LDS: the tile's elements (9 words each: 36.9 KB, four workgroups per CU)
+__global__ __launch_bounds__(256) void k_ntt_pass(NttArgs a) {
+    extern __shared__ uint32_t lds[];
+    const unsigned tid = threadIdx.x, w = blockIdx.x;
+    const unsigned T = 1u << (a.pass.l + a.pass.logC);
+    for (unsigned x = tid; x < T; x += 256) ntt_tile_load(a, w, x, lds);
+    __syncthreads();
+#pragma unroll 1
+    for (unsigned s = 0; s < a.pass.l; s++) {
+        for (unsigned b = tid; b < T / 2; b += 256) ntt_tile_stage(a, s, b, lds);
+        __syncthreads();
+    }
+    for (unsigned x = tid; x < T; x += 256) ntt_tile_store(a, w, x, lds);
+}
+
+// (fp.h's operator* is a different function in the device pass: host code reaches it through __host__ __device__ helpers)
+static __host__ __device__ Fr fr_mul_hd(const Fr &a, const Fr &b) { return a * b; }
 static __host__ __device__ Fr host_pow(Fr base, uint64_t e) {
     Fr acc = Fr::one();
     for (int i = 63; i >= 0; --i) {
@@ -110,25 +102,147 @@ static __host__ __device__ Fr host_pow(Fr base, uint64_t e) {
     return acc;
 }
 
-// In place on d_a (2^log_n elements).  omega: primitive 2^log_n-th root of unity.  coset: g or
-// nullptr.  d_tw: scratch of 2^(log_n-1) elements.  Asynchronous on st.
-int fr_ntt_device(Fr *d_a, unsigned log_n, const Fr &omega, bool inverse, const Fr *coset, Fr *d_tw, hipStream_t st) {
-    const size_t n = (size_t)1 << log_n;
-    if (log_n == 0) return LSA_OK;                        // the 1-point transform is the identity (1/n = 1, g^0 = 1)
+// ---- per-domain constants, cached on the device
+namespace {
+struct DomainTables {
+    unsigned L = 0;
+    Fr omega;                      // as the caller passed it (the key), with `inverse`
+    bool inverse = false;
+    void *mem = nullptr;
+    Fr *Tlo = nullptr, *Thi = nullptr, *T2 = nullptr;
+    uint32_t *W9 = nullptr;        // W as limbs
+    uint64_t tick = 0;
+};
+struct CosetTables {
+    unsigned L = 0;
+    Fr g;
+    bool inverse = false;
+    void *mem = nullptr;
+    Fr *Glo = nullptr, *Ghi = nullptr;
+    uint64_t tick = 0;
+};
+constexpr int NTT_CACHE = 4;
+DomainTables g_dom[NTT_CACHE];
+CosetTables g_cos[NTT_CACHE];
+uint64_t g_ntt_tick = 0;
+
+int launch_pow_table(const Fr &base, const Fr &c0, size_t count, Fr *out, hipStream_t st) {
+    const unsigned blocks = (unsigned)(((count + NTT_RUN - 1) / NTT_RUN + 255) / 256);
+    hipLaunchKernelGGL(k_ntt_pow_table, dim3(blocks), dim3(256), 0, st, base, c0, count, out);
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
+// a table about to be replaced may still be read by a transform queued on `st`: everything here is ordered on `st`,
+// and hipFree waits for the device
+int domain_tables(const NttPlan &p, const Fr &omega, bool inverse, hipStream_t st, DomainTables **out) {
+    DomainTables *victim = &g_dom[0];
+    for (auto &d : g_dom) {
+        if (d.mem && d.L == p.L && d.inverse == inverse && memcmp(&d.omega, &omega, sizeof(Fr)) == 0) { d.tick = ++g_ntt_tick; *out = &d; return LSA_OK; }
+        if (d.tick < victim->tick) victim = &d;
+    }
+    DomainTables &d = *victim;
+    if (d.mem) { (void)hipFree(d.mem); d.mem = nullptr; }
+    const size_t nW = (size_t)1 << (p.lmax - 1), nlo = (size_t)1 << p.h, nhi = (size_t)1 << (p.L - p.h);
+    const size_t n2t = p.l2 ? (size_t)1 << (p.l2 + p.l3) : 0;
+    if (hipMalloc(&d.mem, (nW + nlo + nhi + n2t) * sizeof(Fr) + nW * 36) != hipSuccess) { (void)hipGetLastError(); d.mem = nullptr; set_error("fr_ntt: twiddle allocation failed"); return LSA_ERR_NOMEM; }
+    Fr *Wp = (Fr *)d.mem;           // W as words: the source of W9
+    d.Tlo = Wp + nW;
+    d.Thi = d.Tlo + nlo;
+    d.T2 = n2t ? d.Thi + nhi : nullptr;
+    d.W9 = (uint32_t *)(d.Thi + nhi + n2t);
+    d.L = p.L; d.omega = omega; d.inverse = inverse; d.tick = ++g_ntt_tick;
     const Fr w = inverse ? omega.inverse() : omega;
-    const unsigned run_blocks = (unsigned)((n / NTT_RUN + 255) / 256 + 1);
-    if (!inverse && coset) hipLaunchKernelGGL(k_ntt_scale, dim3(run_blocks), dim3(256), 0, st, d_a, n, Fr::one(), *coset);
-    hipLaunchKernelGGL(k_ntt_twiddles, dim3(run_blocks), dim3(256), 0, st, w, n / 2, d_tw);
-    hipLaunchKernelGGL(k_ntt_bitrev, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_a, log_n);
-    const unsigned ls = log_n < NTT_LOCAL_LOG ? log_n : NTT_LOCAL_LOG;
-    hipLaunchKernelGGL(k_ntt_local, dim3((unsigned)(n >> ls)), dim3(256), 0, st, d_a, log_n, ls, d_tw);
-    for (unsigned s = ls; s < log_n; s++)
-        hipLaunchKernelGGL(k_ntt_stage, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, d_a, log_n, s, d_tw);
-    if (inverse) {
-        // 1/n = 2^-log_n; with a coset also g^-i
-        const Fr two = Fr::one() + Fr::one();
-        const Fr ninv = host_pow(two, log_n).inverse();
-        hipLaunchKernelGGL(k_ntt_scale, dim3(run_blocks), dim3(256), 0, st, d_a, n, ninv, coset ? coset->inverse() : Fr::one());
+    const Fr c32 = Fr::from_u32(32);                       // Montgomery value * 32 = the canonical words of the 2^261 form
+    int rc = launch_pow_table(host_pow(w, ((uint64_t)1 << p.L) >> p.lmax), c32, nW, Wp, st);
+    if (!rc) {
+        hipLaunchKernelGGL(k_ntt_unpack_table, dim3((unsigned)((nW + 255) / 256)), dim3(256), 0, st, (const Fr *)Wp, nW, d.W9);
+        if (hipGetLastError() != hipSuccess) { set_error("fr_ntt: table kernel launch failed"); rc = LSA_ERR_HIP; }
+    }
+    if (!rc) rc = launch_pow_table(w, c32, nlo, d.Tlo, st);
+    if (!rc) rc = launch_pow_table(host_pow(w, (uint64_t)1 << p.h), c32, nhi, d.Thi, st);
+    if (!rc && n2t) {
+        hipLaunchKernelGGL(k_ntt_t2_table, dim3((unsigned)((n2t + 255) / 256)), dim3(256), 0, st, host_pow(w, (uint64_t)1 << p.l1), c32, p.l2, p.l3, d.T2);
+        if (hipGetLastError() != hipSuccess) { set_error("fr_ntt: table kernel launch failed"); rc = LSA_ERR_HIP; }
+    }
+    if (rc) { (void)hipFree(d.mem); d.mem = nullptr; return rc; }
+    *out = &d;
+    return LSA_OK;
+}
+int coset_tables(const NttPlan &p, const Fr &g, bool inverse, hipStream_t st, CosetTables **out) {
+    CosetTables *victim = &g_cos[0];
+    for (auto &d : g_cos) {
+        if (d.mem && d.L == p.L && d.inverse == inverse && memcmp(&d.g, &g, sizeof(Fr)) == 0) { d.tick = ++g_ntt_tick; *out = &d; return LSA_OK; }
+        if (d.tick < victim->tick) victim = &d;
+    }
+    CosetTables &d = *victim;
+    if (d.mem) { (void)hipFree(d.mem); d.mem = nullptr; }
+    const size_t nlo = (size_t)1 << p.h, nhi = (size_t)1 << (p.L - p.h);
+    if (hipMalloc(&d.mem, (nlo + nhi) * sizeof(Fr)) != hipSuccess) { (void)hipGetLastError(); d.mem = nullptr; set_error("fr_ntt: coset table allocation failed"); return LSA_ERR_NOMEM; }
+    d.Glo = (Fr *)d.mem;
+    d.Ghi = d.Glo + nlo;
+    d.L = p.L; d.g = g; d.inverse = inverse; d.tick = ++g_ntt_tick;
+    const Fr c32 = Fr::from_u32(32);
+    // forward: g^i on load; inverse: (1/n) g^-k on store (the 1/n rides in the high table)
+    const Fr base = inverse ? g.inverse() : g;
+    const Fr hi0 = inverse ? fr_mul_hd(c32, host_pow(Fr::from_u32(2), p.L).inverse()) : c32;
+    int rc = launch_pow_table(base, c32, nlo, d.Glo, st);
+    if (!rc) rc = launch_pow_table(host_pow(base, (uint64_t)1 << p.h), hi0, nhi, d.Ghi, st);
+    if (rc) { (void)hipFree(d.mem); d.mem = nullptr; return rc; }
+    *out = &d;
+    return LSA_OK;
+}
+}  // namespace
+
+void ntt_release() {
+    for (auto &d : g_dom) { if (d.mem) (void)hipFree(d.mem); d = DomainTables(); }
+    for (auto &d : g_cos) { if (d.mem) (void)hipFree(d.mem); d = CosetTables(); }
+}
+
+// d_a: 2^log_n elements, transformed in place (the result is in d_a when the call returns to the stream); d_tmp: scratch
+// of the same size (untouched for log_n <= NTT_TILE_LOG).  omega: primitive 2^log_n-th root of unity.  coset: g or
+// nullptr.  Asynchronous on st.
+int fr_ntt_device(Fr *d_a, unsigned log_n, const Fr &omega, bool inverse, const Fr *coset, Fr *d_tmp, hipStream_t st) {
+    if (log_n == 0) return LSA_OK;                        // the 1-point transform is the identity (1/n = 1, g^0 = 1)
+    static const bool attr_set = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_pass), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipGetLastError();
+        return true;
+    }();
+    (void)attr_set;
+    const NttPlan p = ntt_plan(log_n);
+    DomainTables *dt = nullptr;
+    int rc = domain_tables(p, omega, inverse, st, &dt);
+    if (rc) return rc;
+    CosetTables *ct = nullptr;
+    if (coset) {
+        rc = coset_tables(p, *coset, inverse, st, &ct);
+        if (rc) return rc;
+    }
+    unsigned kinds[3], nk = 0;
+    if (p.l1) kinds[nk++] = 1;
+    if (p.l2) kinds[nk++] = 2;
+    kinds[nk++] = 3;
+    const Fr *src = d_a;
+    for (unsigned i = 0; i < nk; i++) {
+        NttArgs a = {};
+        a.plan = p;
+        a.pass = ntt_pass(p, kinds[i]);
+        // first pass a -> tmp, the middle one in place on tmp, the last one tmp -> a; a single pass is one workgroup
+        // working in place (it reads its whole tile before it writes)
+        Fr *dst = (nk == 1 || i + 1 == nk) ? d_a : d_tmp;
+        a.src = src;
+        a.dst = dst;
+        a.W = dt->W9; a.Tlo = dt->Tlo; a.Thi = dt->Thi; a.T2 = dt->T2;
+        a.Glo = ct ? ct->Glo : nullptr;
+        a.Ghi = ct ? ct->Ghi : nullptr;
+        a.gh = p.h;
+        a.pre_scale = (i == 0 && coset && !inverse) ? 1 : 0;
+        a.post_scale = (i + 1 == nk && coset && inverse) ? 1 : 0;
+        const Fr c32 = Fr::from_u32(32);
+        a.cst = inverse ? fr_mul_hd(c32, host_pow(Fr::from_u32(2), p.L).inverse()) : c32;
+        const size_t lds_bytes = (size_t)ntt_tile_words(a.pass) * 4;
+        hipLaunchKernelGGL(k_ntt_pass, dim3(a.pass.tiles), dim3(256), lds_bytes, st, a);
+        src = dst;
     }
     HIPCHK(hipGetLastError());
     return LSA_OK;

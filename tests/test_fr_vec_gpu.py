@@ -124,10 +124,10 @@ def test_sumcheck_prover_inner_loop_on_device(lsa):
     assert np.array_equal(d_b[:1].cpu().numpy().view(np.uint64), hb[:1])
 
 
-@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 10, 11, 13, 16])
+@pytest.mark.parametrize("log_n", [0, 1, 2, 5, 9, 10, 11, 12, 13, 15, 16, 17, 18, 20])
 def test_ntt_vs_oracle(lsa, log_n):
     """libfqfft FFT / iFFT / cosetFFT / icosetFFT over Fr, byte for byte against the restated
-    _basic_radix2_FFT (sizes below, at and above the 1024-element LDS tile)."""
+    _basic_radix2_FFT: one pass (up to the 1024-element LDS tile), two passes (up to 2^16), three passes."""
     n = 1 << log_n
     a, _ = o.random_scalars(n, seed=3000 + log_n)
     w = o.fr_mont(o.fr_root_of_unity(log_n))
@@ -163,3 +163,26 @@ def test_ntt_round_trip_full_size_on_device(lsa):
     host = delta.cpu().numpy().view(np.uint64)
     for k in (0, 1, 2, 1023, 1024, 65537, n - 1):
         assert np.array_equal(host[k], o.fr_mont(pow(wi, k, o.R))), k
+
+
+def test_ntt_domains_alternate_and_tables_are_reused(lsa):
+    """The per-domain twiddle tables are cached (four domains, four coset generators): transforms over five domains in
+    turn, forward and inverse, with two coset generators, keep giving the oracle's bytes when their tables have been
+    evicted and rebuilt in between; a host buffer and a device buffer give the same result."""
+    import torch
+    g5, g7 = o.fr_mont(o.FR_GENERATOR), o.fr_mont(7)
+    data = {}
+    for log_n in (6, 11, 12, 14, 17):
+        a, _ = o.random_scalars(1 << log_n, seed=4000 + log_n)
+        data[log_n] = (a, o.fr_mont(o.fr_root_of_unity(log_n)))
+    for rep in range(2):
+        for log_n, (a, w) in data.items():
+            for inverse in (False, True):
+                for coset in (None, g5, g7):
+                    got = lsa.fr_ntt(a, w, inverse=inverse, coset=coset)
+                    assert np.array_equal(got, o.fr_domain_transform(a, w, inverse=inverse, coset=coset)), (rep, log_n, inverse)
+    a, w = data[14]
+    d_a = torch.from_numpy(a.view(np.int64)).to("cuda:0")
+    lsa.fr_ntt(d_a, w, coset=g7)
+    lsa.synchronize()
+    assert np.array_equal(d_a.cpu().numpy().view(np.uint64), lsa.fr_ntt(a, w, coset=g7))

@@ -9,7 +9,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("name", ["test_fp29", "test_glv", "test_fp29x2", "test_tower29", "test_smul", "test_w12", "test_tmiller", "test_inv29"])
+@pytest.mark.parametrize("name", ["test_fp29", "test_glv", "test_fp29x2", "test_tower29", "test_smul", "test_w12", "test_tmiller", "test_inv29", "test_ntt_core"])
 def test_host_cpp(name, tmp_path):
     src = os.path.join(ROOT, "tests", "cpp", name + ".cc")
     if not os.path.exists(src):

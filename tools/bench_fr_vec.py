@@ -54,5 +54,36 @@ def main():
                               "eval_mle_ms": (t2 - t1) * 1e3, "matches_gpu": bool(ok)}))
 
 
+def ntt():
+    """lsa_fr_ntt on device-resident vectors (libfqfft's FFT / icosetFFT as /root/reference/src/gadgets/lipmaa.cc:102-168
+    calls them): ms per transform with the domain's tables cached, 64 B per element of algorithmic traffic (read once,
+    written once), field products per second against the 175 G/s ceiling of the 29-bit-limb product."""
+    lsa.init(0)
+    g = o.fr_mont(o.FR_GENERATOR)
+    for log_n in (10, 12, 16, 18, 20, 22, 24):
+        n = 1 << log_n
+        gen = torch.Generator(device="cuda:0").manual_seed(log_n)
+        d_a = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device="cuda:0", generator=gen)
+        d_a[:, 3] &= (1 << 60) - 1
+        w = o.fr_mont(o.fr_root_of_unity(log_n))
+        for name, kw in (("FFT", {}), ("icosetFFT", {"inverse": True, "coset": g})):
+            lsa.fr_ntt(d_a, w, **kw)
+            lsa.synchronize()
+            reps = 20 if log_n <= 20 else 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                lsa.fr_ntt(d_a, w, **kw)
+            lsa.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            passes = 1 if log_n <= 10 else (2 if log_n <= 16 else 3)
+            mults = n * (log_n / 2 - 0.5 * passes + 2 * (passes - 1) + 1 + (1 if kw else 0))
+            print(json.dumps({"op": "ntt " + name, "log_n": log_n, "ms": round(dt * 1e3, 4), "passes": passes,
+                              "algorithmic_GBps": round(64 * n / dt / 1e9, 1), "frac_of_8TBps": round(64 * n / dt / 8e12, 4),
+                              "moved_GBps": round(64 * n * passes / dt / 1e9, 1), "G_field_mults_per_s": round(mults / dt / 1e9, 1)}), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "ntt":
+        ntt()
+    else:
+        main()
