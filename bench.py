@@ -116,20 +116,38 @@ def reference_binary_run(d=20):
     accounting of the time spent inside the library (LSA_SHIM_STATS=1).  What a LegoSNARK user sees end to end."""
     import re
     import subprocess
-    exe = os.path.join(ROOT, "build", "reference", "hadamard")
+    # the binary the reference's OWN CMakeLists.txt builds (its flags: OPT_FLAGS "-O3 -ggdb", -Wall -Wextra -Wfatal-errors,
+    # /root/reference/CMakeLists.txt:27-33,54-64) against the drop-in packages; the Makefile build (-O3 -w) if that is absent
+    rel = os.path.join("build", "reference_cmake", "src", "examples", "hadamard")
+    how = "the reference's CMakeLists.txt, default configuration (-O3 -ggdb, MULTICORE=OFF)"
+    if not os.path.exists(os.path.join(ROOT, rel)):
+        rel, how = os.path.join("build", "reference", "hadamard"), "legosnark_amd/shim/Makefile (-O3)"
+    exe = os.path.join(ROOT, rel)
     if not os.path.exists(exe):
-        return {"program": "build/reference/hadamard", "status": "absent (built only where the reference's sources are)"}
+        return {"program": rel, "status": "absent (built only where the reference's sources are)"}
     env = dict(os.environ, LSA_SHIM_STATS="1")
     t0 = time.perf_counter()
     try:
         r = subprocess.run([exe, str(d)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     except subprocess.TimeoutExpired:
-        return {"program": "build/reference/hadamard %d" % d, "status": "timeout"}
+        return {"program": "%s %d" % (rel, d), "status": "timeout"}
     wall = time.perf_counter() - t0
-    res = {"program": "build/reference/hadamard %d (unchanged source, libff-compatible shim)" % d, "status": "rc=%d" % r.returncode, "wall_s": round(wall, 3),
+    res = {"program": "%s %d (unchanged source, libff-compatible shim)" % (rel, d), "built_by": how, "status": "rc=%d" % r.returncode, "wall_s": round(wall, 3),
            "timers_ms": {}}
     for m in re.finditer(r"^##(\S+) (.*?): ([0-9.e+]+) micros", r.stdout, re.M):
         res["timers_ms"]["%s %s" % (m.group(1), m.group(2))] = round(float(m.group(3)) / 1e3, 3)
+    # the reference's -DMULTICORE=ON configuration (-fopenmp -DMULTICORE=1: chunks = threads, lipmaa.cc's OpenMP loops)
+    mc = os.path.join(ROOT, "build", "reference_cmake_mc", "src", "examples", "hadamard")
+    if os.path.exists(mc):
+        try:
+            nthr = str(min(8, len(os.sched_getaffinity(0))))
+            m_ = subprocess.run([mc, str(d)], env=dict(os.environ, OMP_NUM_THREADS=nthr), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+            tm = {"%s %s" % (x.group(1), x.group(2)): round(float(x.group(3)) / 1e3, 3) for x in re.finditer(r"^##(\S+) (.*?): ([0-9.e+]+) micros", m_.stdout, re.M)}
+            res["multicore_build"] = {"program": "build/reference_cmake_mc/src/examples/hadamard %d (-DMULTICORE=ON)" % d, "rc": m_.returncode, "omp_threads": int(nthr),
+                                      "nchunks_printed": sorted(set(re.findall(r"NCHUNKS : (\d+)", m_.stdout))),
+                                      "timers_ms": {k: v for k, v in tm.items() if "TOTAL" in k or "lipmaa" in k}}
+        except Exception as e:
+            res["multicore_build"] = {"error": str(e)[:200]}
     # rc 0 says little (the reference's verifiers print nothing when a check fails, SURVEY.md 3.3): the verifier side of
     # the same build is checked beside it -- legosnark_amd/shim/checks/pairing_check.cc runs the reference's own
     # simple_pairing_check on true and false statements and its unchanged CPPoly::verify, deferred and call by call
@@ -486,6 +504,31 @@ def main():
             }
             lsa.crs_cache_clear()
             del P_host
+            # ... and the FIRST call of a process, which is all the reference ever makes per key (one prove per process,
+            # src/gadgets/subspace.cc:78-85): five fresh child processes (tools/cold_msm.py), each its own lsa_init, the
+            # same P and w shapes on pageable host memory, every result checked by the identity
+            try:
+                import subprocess
+                cm = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cold_msm.py"), "--runs", "5", "--log2n", str(args.log2n)],
+                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+                cl = [json.loads(l)["cold_msm"] for l in cm.stdout.splitlines() if l.startswith('{"cold_msm"')]
+                if cl:
+                    c0 = cl[0]
+                    host_path["cold_ms_runs"] = c0["cold_ms_runs"]
+                    host_path["cold_ms_median"] = c0["cold_ms_median"]
+                    host_path["cold_ms_p90"] = c0["cold_ms_p90"]
+                    host_path["cold_runs_all_checked"] = c0["all_ok"]
+                    host_path["cold_split_of_the_median_run"] = sorted(c0["cold_split"], key=lambda t: t["ms"])[len(c0["cold_split"]) // 2] if c0["cold_split"] else None
+                    host_path["cold_second_call_ms"] = c0["second_ms"]
+                    host_path["transparent_hugepage"] = c0["thp"]
+                    host_path["cold_note"] = ("cold_ms_runs: the first lsa_g1_msm of five fresh processes; cold_ms above: the same call inside this "
+                                              "long-lived process right after the cache was cleared (1.8 GB of copies freed)")
+                else:
+                    host_path["cold_ms_runs"] = None
+                    host_path["cold_error"] = (cm.stderr or cm.stdout)[-300:]
+            except Exception as e:                               # reported, not hidden
+                host_path["cold_ms_runs"] = None
+                host_path["cold_error"] = str(e)[:300]
 
     # BASELINE.json configs[3] shape whenever there is more than one rank: one 2^24+2 CPlink MSM
     cplink_sharded = None
@@ -560,7 +603,7 @@ def main():
             # the other BASELINE.json configs, each result-checked (a failed check carries "error" and no time)
             from legosnark_amd import benchcfg
             out["configs"] = benchcfg.measure(lsa, torch, np, dev, log2n=20, d=20, log2pairs=12, reps=5,
-                                              only={"g2_msm", "cppoly", "pairing", "cphad_verify"})
+                                              only={"g2_msm", "cppoly", "pairing", "cphad_verify", "fr_fold", "ntt"})
             for c in out["configs"]:
                 if c["config"].startswith("pairing product") and "error" not in c:
                     # 192 B in per pair; 384 B out per workgroup of five pairs (the partial products the tree continues from)

@@ -1355,7 +1355,7 @@ static int msm_host_local(const void *bases_jac, const void *scalars, size_t n, 
 
 template <class F>
 static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *out_jac, int group, bool sharded = false) {
-    LSA_TRACE_CALL("msm", n);
+    LSA_TRACE_CALL(group == 1 ? "msm_g1" : "msm_g2", n);
     int rc = require_ready();
     if (rc) return rc;
     if (sharded && lsa_comm_world() <= 1) sharded = false;
@@ -1386,6 +1386,9 @@ static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *
     st.msm_ms = ms_since(t0);
     st.total_ms = ms_since(t_all);
     g_host_stats = st;
+    if (trace_on())
+        fprintf(stderr, "[lsa]   msm_split                  h2d_scalars=%.3f fingerprint_wait=%.3f bases_prepare=%.3f kernels=%.3f hit=%d table=%d\n",
+                st.h2d_scalars_ms, st.fingerprint_wait_ms, st.bases_prepare_ms, st.msm_ms, st.cache_hit, st.table);
     return LSA_OK;
 }
 

@@ -216,7 +216,7 @@ struct Terms {
 
 unsigned g_force_m = 0;                    // lsa_pairing_set_chunk: pairs per accumulator, 0 = by batch size
 inline int force_kernel() {
-    static const int f = getenv("LSA_MILLER_KERNEL") ? atoi(getenv("LSA_MILLER_KERNEL")) : 0;   // 1-4: the fused kernels of miller.h, 5: tables
+    static const int f = getenv("LSA_MILLER_KERNEL") ? atoi(getenv("LSA_MILLER_KERNEL")) : 0;   // 3: one lane per pairing (miller.h), 5: tables, 6: fused
     return f;
 }
 
@@ -268,9 +268,9 @@ int run_miller(const Terms &t, void **d_res) {
     // arithmetic and Fq12 chain side by side, no table through memory.  (LSA_MILLER_KERNEL = 6 forces it, 5 the tables.)
     const bool no_cache = t.on_device || t.n > 1024 || g_tabs.max_tables == 0;
     if (!t.qpre && t.n && g_force_m == 0 && ((force_kernel() == 0 && no_cache) || force_kernel() == 6)) return run_fused(t, {}, d_res);
-    // ---- the round-1/2 kernels of miller.h (one to twelve lanes per pairing, everything fused per lane group): only when forced
+    // ---- the one-lane-per-pairing kernel of miller.h (the family's fallback): only when forced
     const bool plain = !t.qpre && !t.flags;
-    if (plain && force_kernel() >= 1 && force_kernel() <= 4) {
+    if (plain && force_kernel() == 3) {
         const void *d_p = t.g1, *d_q = t.g2;
         if (!t.on_device) {
             if (g_pair_p.ensure(n * sizeof(Jac<Fq>)) || g_pair_q.ensure(n * sizeof(Jac<Fq2>))) { set_error("pairing: hipMalloc failed"); return LSA_ERR_NOMEM; }

@@ -355,49 +355,10 @@ struct WMiller {
 };
 
 // ------------------------------------------------------------------------------------
-// SIX LANES per pairing, ten pairings per wavefront (G6).  The wavefront engine above keeps one
-// product per lane and so leaves most issue slots of a batch idle (42 of 64 lanes in a product
-// phase, 12 in a reduction, 1 in a combine phase, one pairing per wavefront).  Here lane k of a
-// group owns coefficient k of f: it computes c_k of f*f (six Fq2 products, lazily accumulated and
-// reduced once per component) or of f*line (three), the G2 point's products ride as one extra
-// product per lane, and the bounded-lazy combine steps of all ten groups run side by side.  The
-// ate loop count is a curve constant, so every group of every wavefront executes the same
-// instruction stream.  ~9 x 10^3 instructions per doubling step for TEN pairings instead of
-// ~7 x 10^3 for one.  Same formulas, same bounds contract (a < 4p, b < 20p), same values.
+// (Rounds 1-2 had two more engines here: six lanes per pairing, ten pairings per wavefront (G6Miller) and twelve lanes per
+// pairing (G12Miller).  Every shape they served went to the fused kernel (tmiller.h: G2Pre + TabMillerP) in round 3;
+// removed in round 5.  What remains below are the component products the table kernels still use.)
 // ------------------------------------------------------------------------------------
-static constexpr int G6_GROUPS = 10;
-static constexpr int G6_F = 0, G6_T = 6, G6_L = 12, G6_V = 15, G6_G = G6_V + WM_NVARS, G6_STRIDE = G6_G + WM_SIDE;   // Fq2S per group
-static constexpr int G6_LDS_FQ2 = G6_GROUPS * G6_STRIDE;
-
-// lo + xi*hi for lazily summed lo (<= 6 terms < 2p) and hi (<= 5 terms), both components  [< 2; tight]
-LSA_HD Fq2S g6_finish(const F29x2 &lo_, const F29x2 &hi_) {
-    const F29 lo0 = w12_norm_u(lo_.c0), lo1 = w12_norm_u(lo_.c1), h0 = w12_norm_u(hi_.c0), h1 = w12_norm_u(hi_.c1);
-    F29 a8, b8;
-#pragma unroll
-    for (int i = 0; i < 9; i++) { a8.l[i] = h0.l[i] << 3; b8.l[i] = h1.l[i] << 3; }
-    a8 = w12_norm_u(a8);
-    b8 = w12_norm_u(b8);
-    // c0 = lo0 + 9 h0 + (10p - h1) < 12 + 90 + 10;   c1 = lo1 + 9 h1 + h0 < 12 + 90 + 10
-    const F29 s0 = w12_norm_u(add_lazy(add_lazy(add_lazy(a8, h0), lo0), sub_k<10>(F29::zero(), h1)));
-    const F29 s1 = w12_norm_u(add_lazy(add_lazy(add_lazy(b8, h1), lo1), h0));
-    return {Fs{mul(s0, F29::one())}, Fs{mul(s1, F29::one())}};
-}
-// coefficient k of a*b (all six coefficients of b)
-LSA_HD Fq2S g6_coeff_full(int k, const Fq2S *A, const Fq2S *B) {
-    F29x2 lo = F29x2::zero(), hi = F29x2::zero();
-    for (int i = 0; i < 6; i++) {
-        int j = k - i;
-        const uint32_t wrap = w12_mask(0u - (uint32_t)(j < 0));
-        if (j < 0) j += 6;
-        const Fq2S p = w12_fq2_mul(A[i], B[j]);
-#pragma unroll
-        for (int l = 0; l < 9; l++) {
-            lo.c0.l[l] += p.c0.v.l[l] & ~wrap; lo.c1.l[l] += p.c1.v.l[l] & ~wrap;
-            hi.c0.l[l] += p.c0.v.l[l] & wrap;  hi.c1.l[l] += p.c1.v.l[l] & wrap;
-        }
-    }
-    return g6_finish(lo, hi);
-}
 // The unordered index pairs {t, u} behind coefficient k of a SQUARE: t + u = k (plain) or k + 6
 // (wrapped, times xi).  k even: 4 pairs (two of them squares), k odd: 3 -- instead of the 6
 // ordered pairs of a general product.  j-th pair of coefficient k:
@@ -407,186 +368,6 @@ LSA_HD void sqr_pair(int k, int j, int &t, int &u, bool &wrap) {
     else { t = k + j - hk; u = k + 6 - t; wrap = true; }
 }
 LSA_HD int sqr_pair_count(int k) { return 4 - (k & 1); }
-// coefficient k of a*a: 4 or 3 Fq2 products instead of 6 (the same canonical value)
-LSA_HD Fq2S g6_coeff_square(int k, const Fq2S *A) {
-    F29x2 lo = F29x2::zero(), hi = F29x2::zero();
-    const int cnt = sqr_pair_count(k);
-    for (int j = 0; j < 4; j++) {
-        if (j >= cnt) break;
-        int t, u;
-        bool wr;
-        sqr_pair(k, j, t, u, wr);
-        const uint32_t wrap = w12_mask(0u - (uint32_t)wr);
-        const uint32_t sh = t == u ? 0u : 1u;                    // off-diagonal pairs count twice
-        const Fq2S p = w12_fq2_mul(A[t], A[u]);
-#pragma unroll
-        for (int l = 0; l < 9; l++) {
-            lo.c0.l[l] += (p.c0.v.l[l] << sh) & ~wrap; lo.c1.l[l] += (p.c1.v.l[l] << sh) & ~wrap;
-            hi.c0.l[l] += (p.c0.v.l[l] << sh) & wrap;  hi.c1.l[l] += (p.c1.v.l[l] << sh) & wrap;
-        }
-    }
-    return g6_finish(lo, hi);
-}
-// coefficient k of a * (l0 + l3 w^3 + l4 w^4): L = {l0, l3, l4}
-LSA_HD Fq2S g6_coeff_sparse(int k, const Fq2S *A, const Fq2S *L) {
-    F29x2 lo = F29x2::zero(), hi = F29x2::zero();
-    for (int t = 0; t < 3; t++) {
-        int i = k - (t == 0 ? 0 : t + 2);                       // b index 0, 3, 4
-        const uint32_t wrap = w12_mask(0u - (uint32_t)(i < 0));
-        if (i < 0) i += 6;
-        const Fq2S p = w12_fq2_mul(A[i], L[t]);
-#pragma unroll
-        for (int l = 0; l < 9; l++) {
-            lo.c0.l[l] += p.c0.v.l[l] & ~wrap; lo.c1.l[l] += p.c1.v.l[l] & ~wrap;
-            hi.c0.l[l] += p.c0.v.l[l] & wrap;  hi.c1.l[l] += p.c1.v.l[l] & wrap;
-        }
-    }
-    return g6_finish(lo, hi);
-}
-
-template <class X>
-struct G6Miller {
-    X &x;
-    Fq2S *mem;          // G6_LDS_FQ2 elements
-    using WM = WMiller<X>;
-    struct Side { int8_t a[WM_SIDE], b[WM_SIDE]; int n; };
-
-    // product phase: lane (g, k): T[k] = coefficient k of F*F (mode 1) / F*line (mode 2) / nothing (0);
-    // then side product k of the group
-    LSA_HD void products(int mode, const Side sd) {
-        Fq2S *m = mem;
-        x.par([=](unsigned lane) {
-            const unsigned g = lane / 6, k = lane % 6;
-            if (g >= (unsigned)G6_GROUPS) return;
-            Fq2S *base = m + g * G6_STRIDE;
-            if (mode == 1) base[G6_T + k] = g6_coeff_square((int)k, base + G6_F);
-            else if (mode == 2) base[G6_T + k] = g6_coeff_sparse((int)k, base + G6_F, base + G6_L);
-            if ((int)k < sd.n) base[G6_G + k] = w12_fq2_mul(base[G6_V + sd.a[k]], base[G6_V + sd.b[k]]);
-        });
-    }
-    // combine phase: lanes k < 6 publish T -> F (when fcopy), lane k == 0 runs `body(V, G, L)`
-    template <class Body>
-    LSA_HD void combine(bool fcopy, Body body) {
-        Fq2S *m = mem;
-        x.par([=](unsigned lane) {
-            const unsigned g = lane / 6, k = lane % 6;
-            if (g >= (unsigned)G6_GROUPS) return;
-            Fq2S *base = m + g * G6_STRIDE;
-            if (fcopy) base[G6_F + k] = base[G6_T + k];
-            if (k == 0) body(base + G6_V, base + G6_G, base + G6_L);
-        });
-    }
-
-    LSA_HD void doubling_round() {
-        products(1, Side{{WM_RX, WM_RY, WM_RZ, WM_S, WM_RX, 0}, {WM_RY, WM_RY, WM_RZ, WM_S, WM_RX, 0}, 5});
-        combine(true, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
-            const F29x2 B = WM::ld(Gg[1]), C = WM::ld(Gg[2]);
-            const F29x2 H = sub_k<4>(WM::ld(Gg[3]), add_lazy(B, C));
-            Vv[WM_A] = WM::st(WM::halve2(WM::ld(Gg[0])));
-            Vv[WM_B] = Gg[1];
-            Vv[WM_D] = WM::st(WM::triple(C));
-            Vv[WM_H] = WM::st(H);
-            Vv[WM_NH] = WM::st(sub_k<6>(F29x2::zero(), H));
-            Vv[WM_J3] = WM::st(WM::triple(WM::ld(Gg[4])));
-        });
-        products(0, Side{{WM_TWB, WM_B, WM_PY, WM_PX, 0, 0}, {WM_D, WM_H, WM_NH, WM_J3, 0, 0}, 4});
-        combine(false, [](Fq2S *Vv, Fq2S *Gg, Fq2S *L) {
-            const F29x2 E = WM::ld(Gg[0]), B = WM::ld(Vv[WM_B]);
-            const F29x2 F = WM::triple(E);
-            Vv[WM_E] = Gg[0];
-            Vv[WM_G] = WM::st(condsub4(WM::halve2(add_lazy(B, F).norm())));
-            Vv[WM_BMF] = WM::st(sub_k<6>(B, F));
-            Vv[WM_RZ] = Gg[1];
-            L[0] = WM::st(WM::xi_times(WM::csub2(sub_k<2>(E, B))));
-            L[1] = Gg[2];
-            L[2] = Gg[3];
-        });
-        products(2, Side{{WM_E, WM_A, WM_G, 0, 0, 0}, {WM_E, WM_BMF, WM_G, 0, 0, 0}, 3});
-        combine(true, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
-            const F29x2 Y3 = WM::csub2(condsub4(sub_k<6>(WM::ld(Gg[2]), WM::triple(WM::ld(Gg[0])))));
-            Vv[WM_RX] = Gg[1];
-            Vv[WM_RY] = WM::st(Y3);
-            Vv[WM_S] = WM::st(add_lazy(Y3, WM::ld(Vv[WM_RZ])).norm());
-        });
-    }
-
-    LSA_HD void addition_round(int x2, int y2) {
-        products(0, Side{{(int8_t)x2, (int8_t)y2, 0, 0, 0, 0}, {WM_RZ, WM_RZ, 0, 0, 0, 0}, 2});
-        combine(false, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
-            const F29x2 E = sub_k<2>(WM::ld(Vv[WM_RY]), WM::ld(Gg[1]));
-            Vv[WM_DD] = WM::st(sub_k<2>(WM::ld(Vv[WM_RX]), WM::ld(Gg[0])));
-            Vv[WM_EE] = WM::st(E);
-            Vv[WM_NE] = WM::st(sub_k<4>(F29x2::zero(), E));
-        });
-        products(0, Side{{WM_DD, WM_EE, WM_EE, WM_DD, WM_DD, WM_PX}, {WM_DD, WM_EE, (int8_t)x2, (int8_t)y2, WM_PY, WM_NE}, 6});
-        combine(false, [](Fq2S *Vv, Fq2S *Gg, Fq2S *L) {
-            Vv[WM_F] = Gg[0];
-            Vv[WM_GG] = Gg[1];
-            L[0] = WM::st(WM::xi_times(WM::csub2(sub_k<2>(WM::ld(Gg[2]), WM::ld(Gg[3])))));
-            L[1] = Gg[4];
-            L[2] = Gg[5];
-        });
-        products(2, Side{{WM_DD, WM_RX, WM_RZ, 0, 0, 0}, {WM_F, WM_F, WM_GG, 0, 0, 0}, 3});
-        combine(true, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
-            const F29x2 H = WM::ld(Gg[0]), I = WM::ld(Gg[1]);
-            const F29x2 J = sub_k<4>(add_lazy(H, WM::ld(Gg[2])), add_lazy(I, I));
-            Vv[WM_HH] = Gg[0];
-            Vv[WM_JJ] = WM::st(J);
-            Vv[WM_IMJ] = WM::st(sub_k<8>(I, J));
-        });
-        products(0, Side{{WM_DD, WM_EE, WM_HH, WM_RZ, 0, 0}, {WM_JJ, WM_IMJ, WM_RY, WM_HH, 0, 0}, 4});
-        combine(false, [](Fq2S *Vv, Fq2S *Gg, Fq2S *) {
-            const F29x2 Y3 = WM::csub2(sub_k<2>(WM::ld(Gg[1]), WM::ld(Gg[2])));
-            Vv[WM_RX] = Gg[0];
-            Vv[WM_RY] = WM::st(Y3);
-            Vv[WM_RZ] = Gg[3];
-            Vv[WM_S] = WM::st(add_lazy(Y3, WM::ld(Gg[3])).norm());
-        });
-    }
-
-    // group g < count: F <- miller_loop(P[g], Q[g]); the other groups idle on zeros
-    LSA_HD void run(const Jac<Fq> *P, const Jac<Fq2> *Q, unsigned count) {
-        Fq2S *m = mem;
-        x.par([=](unsigned lane) {
-            const unsigned g = lane / 6, k = lane % 6;
-            if (g >= (unsigned)G6_GROUPS) return;
-            Fq2S *base = m + g * G6_STRIDE;
-            Fq2S *Vv = base + G6_V;
-            base[G6_F + k] = k == 0 ? P2::one() : P2::zero();
-            if (k < 2) {
-                wm_setup(k, g < count, P + g, Q + g, Vv);
-            }
-        });
-        for (int i = 63; i >= 0; --i) {
-            doubling_round();
-            if (ate_bit(i)) addition_round(WM_QX, WM_QY);
-        }
-        addition_round(WM_Q1X, WM_Q1Y);
-        addition_round(WM_Q2X, WM_Q2Y);
-    }
-    // coefficient k of group g's f in the tower order
-    LSA_HD Fq12S result(unsigned g) const {
-        Fq12S t;
-        for (int k = 0; k < 6; k++) w12_tower_ref(t, k) = mem[g * G6_STRIDE + G6_F + k];
-        return t;
-    }
-};
-
-// ------------------------------------------------------------------------------------
-// TWELVE lanes per pairing, five pairings per wavefront (G12): the same round structure with
-// one Fq COMPONENT per lane.  A lone wavefront already saturates its SIMD's 64-bit
-// multiply-add pipe, so a batch that leaves SIMDs idle (fewer than ~10^4 pairings with G6) gets
-// faster only by doing less per lane on more SIMDs.  Lane (k, part) computes component `part`
-// of coefficient k: each Fq2 product costs it ONE fused two-product reduction (dot2), and the
-// wrapped terms (i + j >= 6) take their a-operand from XF = xi * F, kept next to F, so that a
-// coefficient is a plain sum of six (three) dot2 results and one reduction -- no cross-lane xi
-// step.  Operand contract of these products: a < 20p (F or xi*F), b < 2p (F or the line, whose
-// first coefficient is reduced here for that reason).
-// ------------------------------------------------------------------------------------
-static constexpr int G12_GROUPS = 5;
-static constexpr int G12_F = 0, G12_XF = 6, G12_T = 12, G12_L = 18, G12_V = 21, G12_G = G12_V + WM_NVARS, G12_STRIDE = G12_G + WM_SIDE;
-static constexpr int G12_LDS_FQ2 = G12_GROUPS * G12_STRIDE;
-
 // component `part` of a*b: part 0: a0*b0 + a1*(KB p - b1), part 1: a0*b1 + a1*b0.  b's components < KB p.
 template <int KB>
 LSA_HD F29 g12_comp_mul(unsigned part, const Fq2S &a, const Fq2S &b) {
@@ -602,180 +383,5 @@ LSA_HD F29 g12_comp_mul(unsigned part, const Fq2S &a, const Fq2S &b) {
 }
 LSA_HD Fs &g12_part(Fq2S &v, unsigned part) { return part ? v.c1 : v.c0; }
 
-template <class X>
-struct G12Miller {
-    X &x;
-    Fq2S *mem;          // G12_LDS_FQ2 elements
-    using WM = WMiller<X>;
-    struct Side { int8_t a[WM_SIDE], b[WM_SIDE]; int n; };
-
-    LSA_HD void products(int mode, const Side sd) {
-        Fq2S *m = mem;
-        x.par([=](unsigned lane) {
-            const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
-            if (g >= (unsigned)G12_GROUPS) return;
-            Fq2S *base = m + g * G12_STRIDE;
-            if (mode == 1) {
-                // F*F is a square: the 4 (k even) or 3 (k odd) unordered pairs of sqr_pair()
-                // instead of 6 ordered ones; off-diagonal pairs count twice (same total weight 6)
-                const int cnt = sqr_pair_count((int)k);
-                F29 sum = F29::zero();
-                for (int j = 0; j < 4; j++) {
-                    if (j >= cnt) break;
-                    int t, u;
-                    bool wrap;
-                    sqr_pair((int)k, j, t, u, wrap);
-                    const F29 x1 = g12_comp_mul<2>(part, base[(wrap ? G12_XF : G12_F) + t], base[G12_F + u]);
-                    sum = add_lazy(sum, t == u ? x1 : add_lazy(x1, x1));
-                }
-                g12_part(base[G12_T + k], part) = Fs{mul(w12_norm_u(sum), F29::one())};     // < 12p -> < 2p
-            } else if (mode) {
-                F29 sum = F29::zero();
-                for (int t = 0; t < 3; t++) {
-                    // b = L[t] (w^0, w^3, w^4), a index k - {0,3,4}
-                    int ai = (int)k - (t == 0 ? 0 : t + 2);
-                    const bool wrap = ai < 0;
-                    if (wrap) ai += 6;
-                    sum = add_lazy(sum, g12_comp_mul<2>(part, base[(wrap ? G12_XF : G12_F) + ai], base[G12_L + t]));
-                }
-                g12_part(base[G12_T + k], part) = Fs{mul(w12_norm_u(sum), F29::one())};     // < 6p -> < 2p
-            }
-            if ((int)k < sd.n) g12_part(base[G12_G + k], part) = Fs{g12_comp_mul<20>(part, base[G12_V + sd.a[k]], base[G12_V + sd.b[k]])};
-        });
-    }
-    template <class Body>
-    LSA_HD void combine(bool fcopy, Body body) {
-        Fq2S *m = mem;
-        x.par([=](unsigned lane) {
-            const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
-            if (g >= (unsigned)G12_GROUPS || part) return;
-            Fq2S *base = m + g * G12_STRIDE;
-            if (fcopy) {
-                const Fq2S t = base[G12_T + k];
-                base[G12_F + k] = t;
-                base[G12_XF + k] = WM::st(WM::xi_times(WM::ld(t)));                        // [< 20]
-            }
-            if (k == 0) body(base + G12_V, base + G12_G, base + G12_L);
-        });
-    }
-    // xi * t brought back under 2p (the line's first coefficient is a b-operand here)
-    static LSA_HD Fq2S xi_reduced(const F29x2 &t) {
-        const F29x2 v = WM::xi_times(t);
-        return {Fs{mul(v.c0, F29::one())}, Fs{mul(v.c1, F29::one())}};
-    }
-
-    // The Miller loop as a table-driven sequence of steps through ONE call site, so that the
-    // kernel holds one copy of the product phase and one of the combine phase (~25 KB of code
-    // that stays in the instruction cache) instead of seven inlined copies of each.
-    // ops 0-2: the three rounds of a doubling step, 3-6: the four rounds of an addition step.
-    struct Step { int mode; bool fcopy; Side sd; };
-    static LSA_HD Step step_of(int op, int x2, int y2) {
-        const int8_t X2 = (int8_t)x2, Y2 = (int8_t)y2;
-        switch (op) {
-        case 0: return {1, true, Side{{WM_RX, WM_RY, WM_RZ, WM_S, WM_RX, 0}, {WM_RY, WM_RY, WM_RZ, WM_S, WM_RX, 0}, 5}};
-        case 1: return {0, false, Side{{WM_TWB, WM_B, WM_PY, WM_PX, 0, 0}, {WM_D, WM_H, WM_NH, WM_J3, 0, 0}, 4}};
-        case 2: return {2, true, Side{{WM_E, WM_A, WM_G, 0, 0, 0}, {WM_E, WM_BMF, WM_G, 0, 0, 0}, 3}};
-        case 3: return {0, false, Side{{X2, Y2, 0, 0, 0, 0}, {WM_RZ, WM_RZ, 0, 0, 0, 0}, 2}};
-        case 4: return {0, false, Side{{WM_DD, WM_EE, WM_EE, WM_DD, WM_DD, WM_PX}, {WM_DD, WM_EE, X2, Y2, WM_PY, WM_NE}, 6}};
-        case 5: return {2, true, Side{{WM_DD, WM_RX, WM_RZ, 0, 0, 0}, {WM_F, WM_F, WM_GG, 0, 0, 0}, 3}};
-        default: return {0, false, Side{{WM_DD, WM_EE, WM_HH, WM_RZ, 0, 0}, {WM_JJ, WM_IMJ, WM_RY, WM_HH, 0, 0}, 4}};
-        }
-    }
-    // the point / line arithmetic after the products of round `op` (lane 0 of the group)
-    static LSA_HD void combine_op(int op, Fq2S *Vv, Fq2S *Gg, Fq2S *L) {
-        switch (op) {
-        case 0: {
-            const F29x2 B = WM::ld(Gg[1]), C = WM::ld(Gg[2]);
-            const F29x2 H = sub_k<4>(WM::ld(Gg[3]), add_lazy(B, C));
-            Vv[WM_A] = WM::st(WM::halve2(WM::ld(Gg[0])));
-            Vv[WM_B] = Gg[1];
-            Vv[WM_D] = WM::st(WM::triple(C));
-            Vv[WM_H] = WM::st(H);
-            Vv[WM_NH] = WM::st(sub_k<6>(F29x2::zero(), H));
-            Vv[WM_J3] = WM::st(WM::triple(WM::ld(Gg[4])));
-        } break;
-        case 1: {
-            const F29x2 E = WM::ld(Gg[0]), B = WM::ld(Vv[WM_B]);
-            const F29x2 F = WM::triple(E);
-            Vv[WM_E] = Gg[0];
-            Vv[WM_G] = WM::st(condsub4(WM::halve2(add_lazy(B, F).norm())));
-            Vv[WM_BMF] = WM::st(sub_k<6>(B, F));
-            Vv[WM_RZ] = Gg[1];
-            L[0] = xi_reduced(WM::csub2(sub_k<2>(E, B)));
-            L[1] = Gg[2];
-            L[2] = Gg[3];
-        } break;
-        case 2: {
-            const F29x2 Y3 = WM::csub2(condsub4(sub_k<6>(WM::ld(Gg[2]), WM::triple(WM::ld(Gg[0])))));
-            Vv[WM_RX] = Gg[1];
-            Vv[WM_RY] = WM::st(Y3);
-            Vv[WM_S] = WM::st(add_lazy(Y3, WM::ld(Vv[WM_RZ])).norm());
-        } break;
-        case 3: {
-            const F29x2 E = sub_k<2>(WM::ld(Vv[WM_RY]), WM::ld(Gg[1]));
-            Vv[WM_DD] = WM::st(sub_k<2>(WM::ld(Vv[WM_RX]), WM::ld(Gg[0])));
-            Vv[WM_EE] = WM::st(E);
-            Vv[WM_NE] = WM::st(sub_k<4>(F29x2::zero(), E));
-        } break;
-        case 4: {
-            Vv[WM_F] = Gg[0];
-            Vv[WM_GG] = Gg[1];
-            L[0] = xi_reduced(WM::csub2(sub_k<2>(WM::ld(Gg[2]), WM::ld(Gg[3]))));
-            L[1] = Gg[4];
-            L[2] = Gg[5];
-        } break;
-        case 5: {
-            const F29x2 H = WM::ld(Gg[0]), I = WM::ld(Gg[1]);
-            const F29x2 J = sub_k<4>(add_lazy(H, WM::ld(Gg[2])), add_lazy(I, I));
-            Vv[WM_HH] = Gg[0];
-            Vv[WM_JJ] = WM::st(J);
-            Vv[WM_IMJ] = WM::st(sub_k<8>(I, J));
-        } break;
-        default: {
-            const F29x2 Y3 = WM::csub2(sub_k<2>(WM::ld(Gg[1]), WM::ld(Gg[2])));
-            Vv[WM_RX] = Gg[0];
-            Vv[WM_RY] = WM::st(Y3);
-            Vv[WM_RZ] = Gg[3];
-            Vv[WM_S] = WM::st(add_lazy(Y3, WM::ld(Gg[3])).norm());
-        } break;
-        }
-    }
-
-    LSA_HD void run(const Jac<Fq> *P, const Jac<Fq2> *Q, unsigned count) {
-        Fq2S *m = mem;
-        x.par([=](unsigned lane) {
-            const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
-            if (g >= (unsigned)G12_GROUPS || part) return;
-            Fq2S *base = m + g * G12_STRIDE;
-            Fq2S *Vv = base + G12_V;
-            const Fq2S f0 = k == 0 ? P2::one() : P2::zero();
-            base[G12_F + k] = f0;
-            base[G12_XF + k] = WM::st(WM::xi_times(WM::ld(f0)));
-            if (k < 2) {
-                wm_setup(k, g < count, P + g, Q + g, Vv);
-            }
-        });
-        // phases 0..63: doubling step (+ addition of Q when the bit of 6u+2 is set); 64, 65: the
-        // additions of pi(Q) and -pi^2(Q)
-#pragma unroll 1
-        for (int ph = 0; ph < 66; ph++) {
-            const bool dbl = ph < 64;
-            const bool add = dbl ? ate_bit(63 - ph) != 0 : true;
-            const int x2 = ph == 64 ? WM_Q1X : (ph == 65 ? WM_Q2X : WM_QX), y2 = x2 + 1;
-            const int first = dbl ? 0 : 3, last = add ? 7 : 3;
-#pragma unroll 1
-            for (int op = first; op < last; op++) {
-                const Step st = step_of(op, x2, y2);
-                products(st.mode, st.sd);
-                combine(st.fcopy, [=](Fq2S *Vv, Fq2S *Gg, Fq2S *L) { combine_op(op, Vv, Gg, L); });
-            }
-        }
-    }
-    LSA_HD Fq12S result(unsigned g) const {
-        Fq12S t;
-        for (int k = 0; k < 6; k++) w12_tower_ref(t, k) = mem[g * G12_STRIDE + G12_F + k];
-        return t;
-    }
-};
 
 }  // namespace lsa

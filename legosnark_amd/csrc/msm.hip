@@ -1711,7 +1711,7 @@ int msm_slot_end(MsmSlot *slot, hipStream_t st) {
     HIPCHK(hipEventRecord(tb.done, slot->tail));
     tb.pending = true;
     tb.unjoined = slot->tail != st;
-    g_slot = (g_slot + 1) % tail_slots();
+    if (slot->tail != st || g_overlap == false) g_slot = (g_slot + 1) % tail_slots();      // (an inline tail = a blocking call: the slot is free again when it returns)
     return LSA_OK;
 }
 
@@ -1993,12 +1993,13 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     size_t o_wave = tcarve((size_t)kw * wpw * 2 * sizeof(A));
     size_t o_win = tcarve((size_t)kw * ((wpw + 15) / 16) * 2 * sizeof(A));   // reduction levels ping-pong between the two
     size_t o_res = tcarve((size_t)nseg * sizeof(Jac<F>));                      // this call's result(s) before they are published
-    // all slots grow together, so that a new problem size pays its allocations in one call
-    // instead of once per slot
-    for (auto &t : g_tail) {
-        if (toff <= t.ws.cap) continue;
-        if (t.pending) HIPCHK(hipEventSynchronize(t.done));            // about to reallocate: the old tail must be finished
-        if (t.ws.ensure(toff) != 0) { set_error("msm: tail workspace allocation of %zu bytes failed", toff); return LSA_ERR_NOMEM; }
+    // Only the slot this call uses grows (round 5; before, all eight grew together: the first G2 MSM of a process --
+    // the reference's provers issue a handful, each blocking -- paid nine hipFree + hipMalloc pairs, 4 ms on a good box
+    // and tens of ms on a slow one).  Blocking calls keep re-using one slot (below), so a prover that only ever blocks
+    // grows one slot per problem size; queued callers grow a slot the first time it sees the size.
+    if (toff > tb.ws.cap) {
+        if (tb.pending) HIPCHK(hipEventSynchronize(tb.done));          // about to reallocate: the old tail must be finished
+        if (tb.ws.ensure(toff) != 0) { set_error("msm: tail workspace allocation of %zu bytes failed", toff); return LSA_ERR_NOMEM; }
     }
     if (tb.pending) HIPCHK(hipStreamWaitEvent(st, tb.done, 0));        // the front may not overwrite buckets a tail still reads
     tb.out = d_out;
@@ -2091,7 +2092,6 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
         hipLaunchKernelGGL((k_size_scatter<C>), dim3(sb), dim3(256), 0, st, hist, nb, heavy_threshold, bin_start, bin_cursor, perm, heavy_list, heavy_count, buckets, gsz, bin_shift, split);
     }
     mark(st);  // 4
-    static const bool g2_occ2 = getenv("LSA_G2_OCC1") == nullptr;
     // (measured equal: 3.18 ms for the pair kernel -- 160 VGPRs, no scratch, three wavefronts per SIMD, ~18 % more
     // instructions per addition -- against 3.09 ms for the one-lane kernel at 2^20 pairs: both are instruction-issue
     // bound, the 316 B of scratch were never the cost.  LSA_G2_PAIR=1 selects the pair kernel.)
@@ -2101,7 +2101,7 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
             hipLaunchKernelGGL(k_accumulate_g2_pair, dim3((nb * 2 + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
             goto acc_done;
         }
-        if (split == 1 && g2_occ2) {
+        if (split == 1) {       // (the generic one-lane kernel at full occupancy -- LSA_G2_OCC1 -- lost to this one in rounds 2-4; removed)
             hipLaunchKernelGGL(k_accumulate_g2_occ2, dim3((nb + 255) / 256), dim3(256), 0, st, d_bases, entries, offs, hist, perm, bin_start, buckets);
             goto acc_done;
         }
@@ -2195,7 +2195,8 @@ acc_done:
     }
     tb.pending = true;
     tb.unjoined = (tail != st);
-    g_slot = (g_slot + 1) % tail_slots();
+    // a blocking caller waits for this tail before it calls again: its next call can take the same slot (and its workspace)
+    if (!blocking) g_slot = (g_slot + 1) % tail_slots();
     HIPCHK(hipGetLastError());
     if (g_profile) g_ev_calls++;
     return LSA_OK;

@@ -98,60 +98,6 @@ __global__ __launch_bounds__(LANES) void k_final_exp_wave(const Fq12 *__restrict
     if (lane < 12) reinterpret_cast<Fq *>(&out[e])[lane] = w12_fq_ref(w.slot(0), lane)->to_mont256();
 }
 
-// One wavefront per pairing (miller.h, WMiller).
-__global__ __launch_bounds__(64) void k_miller_wave(const Jac<Fq> *__restrict__ g1, const Jac<Fq2> *__restrict__ g2, size_t n,
-                                                    Fq12 *__restrict__ out) {
-    __shared__ Fq2S lds[WM_LDS_FQ2];
-    const size_t e = blockIdx.x;
-    if (e >= n) return;
-    const unsigned lane = threadIdx.x;
-    WaveExec ex;
-    W12<WaveExec> w{ex, lds, lds + 6 * W12_SLOTS};
-    WMiller<WaveExec> m{w, lds + W12_LDS_FQ2, lds + W12_LDS_FQ2 + WM_NVARS};
-    m.run(g1[e], g2[e]);
-    if (lane < 12) reinterpret_cast<Fq *>(&out[e])[lane] = w12_fq_ref(w.slot(0), lane)->to_mont256();
-}
-
-// Six lanes per pairing, ten pairings per wavefront (miller.h, G6Miller): the batch shape.
-__global__ __launch_bounds__(64) void k_miller_g6(const Jac<Fq> *__restrict__ g1, const Jac<Fq2> *__restrict__ g2, size_t n,
-                                                  Fq12 *__restrict__ out) {
-    __shared__ Fq2S lds[G6_LDS_FQ2];
-    const size_t lo = (size_t)blockIdx.x * G6_GROUPS;
-    if (lo >= n) return;
-    const unsigned count = (unsigned)(n - lo < (size_t)G6_GROUPS ? n - lo : (size_t)G6_GROUPS);
-    const unsigned lane = threadIdx.x, g = lane / 6, k = lane % 6;
-    WaveExec ex;
-    G6Miller<WaveExec> m{ex, lds};
-    m.run(g1 + lo, g2 + lo, count);
-    if (g < count) {
-        // coefficient k of w^k sits at tower position t = (k & 1) * 3 + (k >> 1): Fq numbers 2t, 2t+1
-        const unsigned t = (k & 1) * 3 + (k >> 1);
-        const Fq2S c = lds[g * G6_STRIDE + G6_F + k];
-        Fq *o = reinterpret_cast<Fq *>(&out[lo + g]);
-        o[2 * t] = c.c0.to_mont256();
-        o[2 * t + 1] = c.c1.to_mont256();
-    }
-}
-
-// Twelve lanes per pairing, five pairings per wavefront (miller.h, G12Miller): batches that would
-// leave SIMDs idle with ten pairings per wavefront.
-__global__ __launch_bounds__(64) void k_miller_g12(const Jac<Fq> *__restrict__ g1, const Jac<Fq2> *__restrict__ g2, size_t n,
-                                                   Fq12 *__restrict__ out) {
-    __shared__ Fq2S lds[G12_LDS_FQ2];
-    const size_t lo = (size_t)blockIdx.x * G12_GROUPS;
-    if (lo >= n) return;
-    const unsigned count = (unsigned)(n - lo < (size_t)G12_GROUPS ? n - lo : (size_t)G12_GROUPS);
-    const unsigned lane = threadIdx.x, g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
-    WaveExec ex;
-    G12Miller<WaveExec> m{ex, lds};
-    m.run(g1 + lo, g2 + lo, count);
-    if (g < count) {
-        const unsigned t = (k & 1) * 3 + (k >> 1);                  // tower position of w^k
-        const Fq2S c = lds[g * G12_STRIDE + G12_F + k];
-        reinterpret_cast<Fq *>(&out[lo + g])[2 * t + part] = (part ? c.c1 : c.c0).to_mont256();
-    }
-}
-
 // out[b] = prod in[8b .. 8b+7], one wavefront per group of 8 (W12 products)
 __global__ __launch_bounds__(192) void k_fq12_prod8_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
     __shared__ Fq2S lds[W12_LDS_FQ2];
@@ -445,28 +391,14 @@ __global__ __launch_bounds__(192) void k_miller_rtab(const Jac<Fq> *__restrict__
         }                                                                              \
     } while (0)
 
+// One lane per pairing (miller.h: miller_one): the least total work and no cooperation between lanes -- the fallback of
+// the family (LSA_MILLER_KERNEL=3) beside the fused kernel (k_miller_fused), which every fresh pair takes by default.
+// (Rounds 1-2 also had one pairing per wavefront, six and twelve lanes per pairing -- k_miller_wave / _g6 / _g12; they
+// lost every shape to the fused kernel in rounds 3 and 4 and were removed in round 5.)
 int miller_device(const void *d_g1, const void *d_g2, size_t n, void *d_out, hipStream_t st) {
     if (n == 0) return LSA_OK;
-    // Measured inside lsa_pairing_product calls (tools/pairing_sweep.py: every Miller kernel starts
-    // on a chip that idled through the previous final exponentiation): up to one wavefront per
-    // SIMD (1024 pairings) the one-pairing-per-wavefront kernel is as fast as any (2.9-3.1 ms per
-    // call); five pairings per wavefront (twelve lanes each) hold 3.2 ms up to 3072 pairings but
-    // jump to 4.4 ms once their wavefronts cover more than ~3/4 of the SIMDs -- the same kernel
-    // takes 1.8 ms at 4096 pairings in a back-to-back loop (tools/miller_sweep.py), so this is the
-    // chip ramping up, not work; ten pairings per wavefront (six lanes each, 4 or 3 products per
-    // coefficient of f^2 since the squaring uses unordered pairs) stay at 3.6-3.9 ms from 3073 to
-    // 8192 pairings and win from there on; from 2^16 on one lane per pairing does the least work.
-    static const int force = getenv("LSA_MILLER_KERNEL") ? atoi(getenv("LSA_MILLER_KERNEL")) : 0;   // 1: wave, 2: g6, 3: lane, 4: g12
-    const int pick = force ? force : (n <= 1024 ? 1 : (n <= 3072 ? 4 : (n < 65536 ? 2 : 3)));
-    if (pick == 1)
-        hipLaunchKernelGGL(k_miller_wave, dim3((unsigned)n), dim3(64), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, n, (Fq12 *)d_out);
-    else if (pick == 4)
-        hipLaunchKernelGGL(k_miller_g12, dim3((unsigned)((n + G12_GROUPS - 1) / G12_GROUPS)), dim3(64), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, n, (Fq12 *)d_out);
-    else if (pick == 2)
-        hipLaunchKernelGGL(k_miller_g6, dim3((unsigned)((n + G6_GROUPS - 1) / G6_GROUPS)), dim3(64), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, n, (Fq12 *)d_out);
-    else
-        hipLaunchKernelGGL(k_miller, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, n,
-                           (Fq12 *)d_out);
+    hipLaunchKernelGGL(k_miller, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, n,
+                       (Fq12 *)d_out);
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }
@@ -475,10 +407,9 @@ int final_exp_device(const void *d_in, size_t n, void *d_out, hipStream_t st) {
     if (n == 0) return LSA_OK;
     if (n < 16384)   // fewer elements than lanes to fill the chip: one wavefront per element
     {
-        // three wavefronts per element: the one-phase row product of w12.h (LSA_FINAL_EXP_LANES=128: the two-phase product)
-        static const unsigned lanes = getenv("LSA_FINAL_EXP_LANES") ? (unsigned)atoi(getenv("LSA_FINAL_EXP_LANES")) : 192u;
-        if (lanes == 128) hipLaunchKernelGGL(k_final_exp_wave<128>, dim3((unsigned)n), dim3(128), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);
-        else hipLaunchKernelGGL(k_final_exp_wave<192>, dim3((unsigned)n), dim3(192), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);
+        // three wavefronts per element: the one-phase row product of w12.h (the two-wavefront, two-phase engine it
+        // replaced in round 4 -- LSA_FINAL_EXP_LANES=128 -- was removed in round 5); the one-lane kernel below is the fallback
+        hipLaunchKernelGGL(k_final_exp_wave<192>, dim3((unsigned)n), dim3(192), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);
     }
     else
         hipLaunchKernelGGL(k_final_exp, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const Fq12 *)d_in, n, (Fq12 *)d_out);

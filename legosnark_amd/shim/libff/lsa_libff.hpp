@@ -38,7 +38,9 @@
 #include "../../csrc/tower.h"
 #include "../../csrc/fixed_base.h"
 #include <future>
+#include <algorithm>
 #include <atomic>
+#include <functional>
 #include <chrono>
 #include <cstdlib>
 // The reference's -DMULTICORE=ON build (/root/reference/CMakeLists.txt:35-39,57-59,78-80: -fopenmp -DMULTICORE=1) calls
@@ -61,6 +63,7 @@ enum StatKind { ST_MSM_G1, ST_MSM_G2, ST_PAIRING, ST_G2_PRECOMP, ST_BATCH_EXP, S
 struct Stats {
     std::atomic<uint64_t> calls[ST_KINDS], ns[ST_KINDS], items[ST_KINDS];
     std::atomic<uint64_t> msm_us[4], msm_hits, msm_tables;     // lsa_msm_host_stats summed: h2d, fingerprint wait, bases, kernels
+    std::atomic<uint64_t> smul_fixed{0}, smul_small{0};         // host scalar multiplications served by a fixed-base table / below 2^16
     bool on = false;
     std::chrono::steady_clock::time_point born = std::chrono::steady_clock::now();
     static const char *name(int k) {
@@ -82,6 +85,8 @@ struct Stats {
                         "\"cache_hits\": %llu, \"on_pre_shifted_copies\": %llu}, ",
                 (double)s.msm_us[0].load() * 1e-3, (double)s.msm_us[1].load() * 1e-3, (double)s.msm_us[2].load() * 1e-3, (double)s.msm_us[3].load() * 1e-3,
                 (unsigned long long)s.msm_hits.load(), (unsigned long long)s.msm_tables.load());
+        fprintf(stderr, "\"scalar_mul_host_split\": {\"fixed_base_table\": %llu, \"scalar_below_2^16\": %llu}, ",
+                (unsigned long long)s.smul_fixed.load(), (unsigned long long)s.smul_small.load());
         fprintf(stderr, "\"inside_ms\": %.3f, \"process_ms\": %.3f}}\n", inside, wall);
     }
     static Stats &get() {
@@ -681,6 +686,7 @@ public:
         long top = 255;
         while (top >= 0 && !e.test_bit(top)) --top;
         if (top < 16) {
+            lsa_shim::Stats::get().smul_small.fetch_add(1, std::memory_order_relaxed);
             for (long i = top; i >= 0; --i) {
                 res = lsa::jac_dbl(res);
                 if (e.test_bit(i)) res = lsa::jac_add(res, base);
@@ -688,7 +694,28 @@ public:
             return G_shim(res);
         }
         // the generator (commit.h:43-44,162-163, polytools.h:126-133, poly.h:117: most sites): table look-ups
-        if (fixed_base_on() && p.is_generator()) return G_shim(generator_table().mul(e.data));
+        if (fixed_base_on() && p.is_generator()) {
+            lsa_shim::Stats::get().smul_fixed.fetch_add(1, std::memory_order_relaxed);
+            return G_shim(generator_table().mul(e.data));
+        }
+        if (getenv("LSA_SHIM_BASE_HISTOGRAM")) {                      // diagnostic: which bases the generic ladder multiplies, how often
+            static std::mutex hm;
+            static std::vector<std::pair<std::string, unsigned>> hist;
+            std::lock_guard<std::mutex> lk(hm);
+            const std::string key((const char *)&p, 16);
+            bool found = false;
+            for (auto &h : hist) if (h.first == key) { h.second++; found = true; }
+            if (!found) hist.emplace_back(key, 1u);
+            static const int reg = atexit([] {
+                std::vector<unsigned> c;
+                for (auto &h : hist) c.push_back(h.second);
+                std::sort(c.begin(), c.end(), std::greater<unsigned>());
+                fprintf(stderr, "{\"lsa_shim_base_histogram\": {\"group\": %d, \"distinct\": %zu, \"top\": [", GROUP, c.size());
+                for (size_t i = 0; i < c.size() && i < 12; i++) fprintf(stderr, "%s%u", i ? ", " : "", c[i]);
+                fprintf(stderr, "]}}\n");
+            });
+            (void)reg;
+        }
         Jac tbl[16];
         tbl[0] = Jac::inf();
         tbl[1] = base;

@@ -101,36 +101,6 @@ int main() {
             CHECK(w2.load_tower(0) == miller_one(Pp, Qq), "wave miller loop");
         }
     }
-    // six lanes per pairing, ten pairings per (emulated) wavefront
-    {
-        std::vector<Fq2S> lds3(G6_LDS_FQ2);
-        Jac<Fq> Ps[G6_GROUPS];
-        Jac<Fq2> Qs[G6_GROUPS];
-        const unsigned count = 7;                                   // three idle groups
-        for (unsigned g = 0; g < count; g++) {
-            Ps[g] = {rand_fq(), rand_fq(), g % 2 ? Fq::one() : rand_fq()};
-            Qs[g] = {{rand_fq(), rand_fq()}, {rand_fq(), rand_fq()}, g % 3 ? Fq2::one() : Fq2{rand_fq(), rand_fq()}};
-        }
-        Ps[2].Z = Fq::zero();
-        G6Miller<LoopExec> m6{ex, lds3.data()};
-        m6.run(Ps, Qs, count);
-        for (unsigned g = 0; g < count; g++) CHECK(m6.result(g) == miller_one(Ps[g], Qs[g]), "six-lane miller loop");
-    }
-    // twelve lanes per pairing, five pairings per (emulated) wavefront
-    {
-        std::vector<Fq2S> lds4(G12_LDS_FQ2);
-        Jac<Fq> Ps[G12_GROUPS];
-        Jac<Fq2> Qs[G12_GROUPS];
-        const unsigned count = 4;                                   // one idle group
-        for (unsigned g = 0; g < count; g++) {
-            Ps[g] = {rand_fq(), rand_fq(), g % 2 ? Fq::one() : rand_fq()};
-            Qs[g] = {{rand_fq(), rand_fq()}, {rand_fq(), rand_fq()}, g % 3 ? Fq2::one() : Fq2{rand_fq(), rand_fq()}};
-        }
-        Qs[1].Z = Fq2::zero();
-        G12Miller<LoopExec> m12{ex, lds4.data()};
-        m12.run(Ps, Qs, count);
-        for (unsigned g = 0; g < count; g++) CHECK(m12.result(g) == miller_one(Ps[g], Qs[g]), "twelve-lane miller loop");
-    }
     printf(fails ? "FAILED (%d)\n" : "PASS\n", fails);
     return fails ? 1 : 0;
 }

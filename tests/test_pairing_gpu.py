@@ -124,12 +124,12 @@ def test_sharded_pairing_product_two_ranks_on_one_gpu(lsa):
         assert np.array_equal(job.run(ps, qs), o.pairing_product(ps, qs))
 
 
-@pytest.mark.parametrize("kernel", [1, 2, 3, 4])
+@pytest.mark.parametrize("kernel", [3, 5, 6])
 def test_every_miller_kernel_vs_oracle(kernel):
-    """The library picks the Miller-loop kernel by batch size (one pairing per wavefront / ten
-    per wavefront with six lanes each / one per lane / five per wavefront with twelve lanes each); LSA_MILLER_KERNEL forces one.  Each is run
-    in its own process on 25 pairs (two full groups of ten and a partial one) with
-    un-normalised inputs and an infinity, byte for byte against the oracle."""
+    """LSA_MILLER_KERNEL forces one Miller-loop path: 3 = one pairing per lane (miller.h, the family's fallback),
+    5 = line tables (k_g2_precomp + the table kernels), 6 = the fused kernel (what fresh pairs take by default).  Each is
+    run in its own process on 25 pairs (five full workgroups of five) with un-normalised inputs and an infinity, byte for
+    byte against the oracle.  (The wavefront / six-lane / twelve-lane engines of rounds 1-2 were removed in round 5.)"""
     import os
     import subprocess
     import sys

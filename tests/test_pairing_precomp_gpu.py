@@ -213,7 +213,7 @@ def test_a_failed_call_leaves_no_half_built_table_behind(lsa):
         lsa.g2_table_cache(4096)
 
 
-@pytest.mark.parametrize("switch", ["LSA_MILLER_ROWS=0", "LSA_MILLER_SPLIT=1", "LSA_FINAL_EXP_LANES=128"])
+@pytest.mark.parametrize("switch", ["LSA_MILLER_ROWS=0", "LSA_MILLER_SPLIT=1"])
 def test_the_older_kernels_behind_their_switches_give_the_same_bytes(lsa, switch):
     """k_miller_wtab (two-phase rounds), the row-engine Miller loop on ONE workgroup instead of eight, and the
     two-wavefront final exponentiation stay in the library behind A/B

@@ -133,7 +133,7 @@ def test_shim_stats_and_call_trace_account_for_a_run():
     assert len(lines) == 1, r.stderr[-2000:]
     st = json.loads(lines[0])["lsa_shim_stats"]
     traced = [l.split() for l in r.stderr.splitlines() if l.startswith("[lsa] ")]
-    n_msm = sum(1 for t in traced if t[1] == "msm")
+    n_msm = sum(1 for t in traced if t[1] in ("msm_g1", "msm_g2"))
     assert n_msm == st["msm_g1"]["calls"] + st["msm_g2"]["calls"] > 0
     assert sum(1 for t in traced if t[1] == "pairing_terms") == st["pairing"]["calls"] > 0
     assert 0 < st["inside_ms"] < st["process_ms"]
