@@ -107,6 +107,7 @@ int require_ready() {
 using namespace lsa;
 
 static void release_stage_buffers();
+static void warm_stage_buffers();
 static void crs_cache_clear();
 
 extern "C" {
@@ -121,7 +122,7 @@ const char *lsa_last_error(void) { return g_err; }
 }  // extern "C"
 namespace lsa {
 bool trace_on() {
-    static const bool on = getenv("LSA_TRACE") && getenv("LSA_TRACE")[0] == '1';
+    static const bool on = getenv("LSA_TRACE") && (getenv("LSA_TRACE")[0] == '1' || getenv("LSA_TRACE")[0] == '2');
     return on;
 }
 double CallTrace::now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -153,6 +154,7 @@ int lsa_init(int device) {
     g.device = device;
     upload_prepare();
     const int wrc = msm_warmup(g.stream);
+    warm_stage_buffers();
     g.ready = true;                                  // (lsa_shutdown releases what the steps above created)
     if (wrc) { lsa_shutdown(); return wrc; }         // a library whose warm-up failed is not handed out as ready
     return LSA_OK;
@@ -481,7 +483,11 @@ int upload_host(void *d_dst, const void *h_src, size_t bytes) {
 }
 int download_host(void *h_dst, const void *d_src, size_t bytes) {
     if (bytes == 0) return LSA_OK;
-    if (staged(bytes)) {
+    // (large destinations the library has not seen before go through the slots as well: the runtime would pin the caller's
+    // pages and keep them registered, and a caller that frees such a buffer afterwards -- a Python array, a temporary
+    // std::vector outside the shim's allocator settings -- stalls its next GPU submission by 12-25 ms when the pages are
+    // unmapped: measured as a 15.5 ms bubble in front of the first MSM after a 96-MiB download, 26 ms after 192 MiB)
+    if (staged(bytes) || (bytes >= STAGE_BELOW && large_copy_staged(h_dst, bytes))) {
         const int rc = g_copier.run(const_cast<void *>(d_src), h_dst, bytes, true);
         if (rc <= 0) return rc;
     }
@@ -696,6 +702,15 @@ static int stage_jac_ensure(size_t bytes, void **p) {
     if (g_stage_jac.ensure(bytes)) return -1;
     *p = g_stage_jac.p;
     return 0;
+}
+// lsa_init: the staging buffers of the host-vector entry points at the BASELINE scale (2^20 scalars, 2^20 G2 points in
+// Jacobian form), beside msm_warmup's workspaces: no allocation inside a prover's first multiExpMA (LSA_WARM=0: lazy)
+static void warm_stage_buffers() {
+    const char *w = getenv("LSA_WARM");
+    if (w && w[0] == '0') return;
+    (void)g_stage_scalars.ensure((size_t)34 << 20);
+    (void)g_stage_jac.ensure((size_t)202 << 20);
+    (void)hipGetLastError();
 }
 static void release_stage_buffers() {
     g_stage_jac.release(); g_stage_bases.release(); g_stage_scalars.release(); g_stage_gather.release(); g_stage_prefix_scratch.release();

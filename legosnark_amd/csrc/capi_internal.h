@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "msm.h"
 
 namespace lsa {
@@ -54,6 +55,8 @@ struct StageBuf {
     size_t cap = 0;
     int ensure(size_t bytes) {
         if (bytes <= cap) return 0;
+        static const bool noisy = getenv("LSA_TRACE") && getenv("LSA_TRACE")[0] == '2';
+        if (noisy) fprintf(stderr, "[lsa]   stage_grow                  %zu -> %zu bytes\n", cap, bytes < 4096 ? (size_t)4096 : bytes + bytes / 4);
         if (p) { (void)hipStreamSynchronize(g.stream); (void)hipFree(p); }
         p = nullptr; cap = 0;
         size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;

@@ -1497,6 +1497,9 @@ struct Workspace {
     size_t cap = 0;
     int ensure(size_t bytes) {
         if (bytes <= cap) return 0;
+        // LSA_TRACE=2: every growth of a workspace (a hipFree + hipMalloc pair inside somebody's call: 0.5 ms on one box, 10+ on another)
+        static const bool noisy = getenv("LSA_TRACE") && getenv("LSA_TRACE")[0] == '2';
+        if (noisy) fprintf(stderr, "[lsa]   workspace_grow              %zu -> %zu bytes\n", cap, bytes + bytes / 8);
         if (ptr) (void)hipFree(ptr);
         ptr = nullptr; cap = 0;
         size_t want = bytes + bytes / 8;
@@ -1661,11 +1664,17 @@ int msm_warmup(hipStream_t st) {
     if (rc) return rc;
     rc = msm_func_attrs();
     if (rc) return rc;
+    // Workspaces for the first calls of a process at the BASELINE scale (2^20 pairs, G1 and G2, plain layout and copies):
+    // the front workspace and tail slot 0 as large as those calls need (377 MB / 343 MB, LSA_TRACE=2 prints every growth),
+    // so that a prover's first multiExpMA does not start with hipFree + hipMalloc pairs -- 0.5 ms each on one box, 10 ms and
+    // more on another (the first G2 MSM of a process: 11.6 ms on a good box with them, 26 ms of them on a slow one).
+    // One tail slot: a caller that only ever blocks -- the reference's provers and verifiers -- never leaves slot 0; queued
+    // callers grow the other slots on first use.  LSA_WARM_MB=m: front = m MB, tail = 0.9 m (0: nothing).
     const char *mb = getenv("LSA_WARM_MB");
-    const size_t front = (mb ? (size_t)atoll(mb) : 192) << 20, tailb = front / 2;
+    const size_t front = (mb ? (size_t)atoll(mb) : 400) << 20, tailb = front / 10 * 9;
     if (front) {
         if (g_ws.ensure(front) != 0) (void)hipGetLastError();          // (no memory: the first call will say so)
-        for (auto &t : g_tail) if (t.ws.ensure(tailb) != 0) (void)hipGetLastError();
+        if (g_tail[0].ws.ensure(tailb) != 0) (void)hipGetLastError();
     }
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u);      // loads the code object
     for (auto &t : g_tail) if (t.stream) hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, t.stream, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
