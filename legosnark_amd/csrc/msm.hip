@@ -2002,13 +2002,16 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     size_t o_wave = tcarve((size_t)kw * wpw * 2 * sizeof(A));
     size_t o_win = tcarve((size_t)kw * ((wpw + 15) / 16) * 2 * sizeof(A));   // reduction levels ping-pong between the two
     size_t o_res = tcarve((size_t)nseg * sizeof(Jac<F>));                      // this call's result(s) before they are published
-    // Only the slot this call uses grows (round 5; before, all eight grew together: the first G2 MSM of a process --
+    // A BLOCKING call grows only the slot it uses (round 5; before, all eight grew together: the first G2 MSM of a process --
     // the reference's provers issue a handful, each blocking -- paid nine hipFree + hipMalloc pairs, 4 ms on a good box
     // and tens of ms on a slow one).  Blocking calls keep re-using one slot (below), so a prover that only ever blocks
     // grows one slot per problem size; queued callers grow a slot the first time it sees the size.
-    if (toff > tb.ws.cap) {
-        if (tb.pending) HIPCHK(hipEventSynchronize(tb.done));          // about to reallocate: the old tail must be finished
-        if (tb.ws.ensure(toff) != 0) { set_error("msm: tail workspace allocation of %zu bytes failed", toff); return LSA_ERR_NOMEM; }
+    // A QUEUED call (the integrator's pipelined form) still grows every slot at once: its successors take the other slots
+    // within microseconds, and a new problem size then pays its allocations in one call instead of in eight.
+    for (auto &t : g_tail) {
+        if (toff <= t.ws.cap || (blocking && &t != &tb)) continue;
+        if (t.pending) HIPCHK(hipEventSynchronize(t.done));            // about to reallocate: the old tail must be finished
+        if (t.ws.ensure(toff) != 0) { set_error("msm: tail workspace allocation of %zu bytes failed", toff); return LSA_ERR_NOMEM; }
     }
     if (tb.pending) HIPCHK(hipStreamWaitEvent(st, tb.done, 0));        // the front may not overwrite buckets a tail still reads
     tb.out = d_out;
