@@ -255,6 +255,38 @@ def main():
             # the same two counter passes for the dominant kernel of BASELINE configs[4] (2^12 fresh pairs: k_miller_fused)
             pairing_traffic = pmc_traffic(kernel_substr="k_miller_fused", exclude="\x00", extra_args=("--only-configs", "pairing"))
 
+    # The FIRST multiExpMA of a process -- all the reference ever makes per key (one prove per process,
+    # src/gadgets/subspace.cc:78-85): five fresh child processes (tools/cold_msm.py), each its own lsa_init, the CPlink
+    # prover's P and w on pageable host memory, every result checked by the identity.  Run BEFORE this process creates
+    # its GPU context: a prover has the device to itself (beside a second live context every submission of the child
+    # waits for the hardware scheduler: +1.5 ms, measured).
+    cold_runs = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_host_path and not args.total_log2n and not being_profiled():
+        try:
+            import subprocess
+            cm = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cold_msm.py"), "--runs", "5", "--log2n", str(args.log2n)],
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
+            cl = [json.loads(l)["cold_msm"] for l in cm.stdout.splitlines() if l.startswith('{"cold_msm"')]
+            if cl:
+                c0 = cl[0]
+                cold_runs = {
+                    "cold_ms_runs": c0["cold_ms_runs"], "cold_ms_median": c0["cold_ms_median"], "cold_ms_p90": c0["cold_ms_p90"],
+                    "cold_runs_all_checked": c0["all_ok"],
+                    "cold_split_of_the_median_run": sorted(c0["cold_split"], key=lambda t: t["ms"])[len(c0["cold_split"]) // 2] if c0["cold_split"] else None,
+                    "cold_second_call_ms": c0["second_ms"], "import_and_lsa_init_ms": c0["import_and_lsa_init_ms"], "transparent_hugepage": c0["thp"],
+                    "cold_note": "cold_ms_runs: the first lsa_g1_msm of five fresh processes that have the GPU to themselves (tools/cold_msm.py); cold_ms: "
+                                 "the same call inside this long-lived process right after its cache was cleared (1.8 GB of copies freed)",
+                }
+            else:
+                cold_runs = {"cold_ms_runs": None, "cold_error": (cm.stderr or cm.stdout)[-300:]}
+        except Exception as e:                               # reported, not hidden
+            cold_runs = {"cold_ms_runs": None, "cold_error": str(e)[:300]}
+
+    # ... and the reference's unchanged example binaries, for the same reason before this process has a GPU context
+    ref_run = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_configs and not args.total_log2n and args.log2n == 20 and not being_profiled():
+        ref_run = reference_binary_run()
+
     import numpy as np
     import torch
     import legosnark_amd as lsa
@@ -504,31 +536,8 @@ def main():
             }
             lsa.crs_cache_clear()
             del P_host
-            # ... and the FIRST call of a process, which is all the reference ever makes per key (one prove per process,
-            # src/gadgets/subspace.cc:78-85): five fresh child processes (tools/cold_msm.py), each its own lsa_init, the
-            # same P and w shapes on pageable host memory, every result checked by the identity
-            try:
-                import subprocess
-                cm = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cold_msm.py"), "--runs", "5", "--log2n", str(args.log2n)],
-                                    stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=400)
-                cl = [json.loads(l)["cold_msm"] for l in cm.stdout.splitlines() if l.startswith('{"cold_msm"')]
-                if cl:
-                    c0 = cl[0]
-                    host_path["cold_ms_runs"] = c0["cold_ms_runs"]
-                    host_path["cold_ms_median"] = c0["cold_ms_median"]
-                    host_path["cold_ms_p90"] = c0["cold_ms_p90"]
-                    host_path["cold_runs_all_checked"] = c0["all_ok"]
-                    host_path["cold_split_of_the_median_run"] = sorted(c0["cold_split"], key=lambda t: t["ms"])[len(c0["cold_split"]) // 2] if c0["cold_split"] else None
-                    host_path["cold_second_call_ms"] = c0["second_ms"]
-                    host_path["transparent_hugepage"] = c0["thp"]
-                    host_path["cold_note"] = ("cold_ms_runs: the first lsa_g1_msm of five fresh processes; cold_ms above: the same call inside this "
-                                              "long-lived process right after the cache was cleared (1.8 GB of copies freed)")
-                else:
-                    host_path["cold_ms_runs"] = None
-                    host_path["cold_error"] = (cm.stderr or cm.stdout)[-300:]
-            except Exception as e:                               # reported, not hidden
-                host_path["cold_ms_runs"] = None
-                host_path["cold_error"] = str(e)[:300]
+            if cold_runs is not None:
+                host_path.update(cold_runs)
 
     # BASELINE.json configs[3] shape whenever there is more than one rank: one 2^24+2 CPlink MSM
     cplink_sharded = None
@@ -611,8 +620,8 @@ def main():
                     c["traffic_detail"] = pairing_traffic
             if any("error" in c for c in out["configs"]):
                 raise SystemExit("bench.py: a config's result check failed: %s" % [c for c in out["configs"] if "error" in c])
-        if not args.no_configs and world == 1 and not strong and args.log2n == 20 and not being_profiled():
-            out["unchanged_reference_binary"] = reference_binary_run()
+        if ref_run is not None:
+            out["unchanged_reference_binary"] = ref_run
             vc = out["unchanged_reference_binary"].get("verifier_check")
             if vc and (vc.get("rc") != 0 or vc.get("failures") != 0 or "error" in vc):
                 raise SystemExit("bench.py: the verifier check beside the unchanged reference binary failed: %s" % vc)

@@ -14,35 +14,137 @@
 //                  table of eq-monomials and takes a dot product; folding the top variable d
 //                  times gives the same element of Fr, and Fr values are canonical Montgomery
 //                  residues, so the 32 output bytes are identical.
-// Both are HBM streams with two Montgomery products per 64 B read (32-bit CIOS, fp.h): about
-// as many VALU cycles as HBM cycles at the chip's ratios, so large rounds are bound by
-// whichever is slower and the small rounds by launch latency.  Algorithmic bytes per round
+// Both are HBM streams.  Round 5: ONE product per output element instead of two -- v' = v0 + r (v1 - v0) is the same
+// field element as -v0 (r - 1) + v1 r, and Fr values are canonical, so the bytes are the reference's -- on the 29-bit
+// limbs of fr29.h (the round's r is put into 2^261 form once per thread, so data words go in and out without
+// conversion: a fifth of the instructions of two 32-bit CIOS products), and the rounds of at most FOLD_TAIL output
+// elements run inside ONE workgroup (a barrier between rounds instead of a launch each).  Algorithmic bytes per round
 // over m output elements: pairs 64 B in + 64 B out, halves 64 B in + 32 B out.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fp.h"
+#include "fr29.h"
 #include "msm.h"
 
 namespace lsa {
 
+static constexpr size_t FOLD_TAIL = 2048;          // rounds of at most this many output elements: one workgroup, no launches
+
+// the round's scalar in 2^261 form (Montgomery value * 32: the canonical words of r * 2^261), as limbs
+__device__ __forceinline__ Fr29 fr_to_261(const Fr &r) { return Fr29::from_words(r * Fr::from_u32(32)); }
+// x * r as libff words: x's words are read as the 2^261 form of x / 32, the product with r in 2^261 form is x r 2^256
+__device__ __forceinline__ Fr fr_mul_261(const Fr &x, const Fr29 &r261) { return mul(Fr29::from_words(x), r261).canonical2().to_words(); }
+
 __global__ __launch_bounds__(256) void k_fold_pairs(const Fr *__restrict__ v, size_t m, const Fr *__restrict__ r_ptr,
                                                     Fr *__restrict__ w, Fr *__restrict__ vout) {
-    const Fr r = *r_ptr;
-    const Fr r1 = r - Fr::one();
+    const Fr29 r261 = fr_to_261(*r_ptr);
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < m; p += (size_t)gridDim.x * blockDim.x) {
         const Fr a = v[2 * p], b = v[2 * p + 1];
-        w[p] = b - a;
-        vout[p] = b * r - a * r1;
+        const Fr d = b - a;
+        w[p] = d;
+        vout[p] = a + fr_mul_261(d, r261);               // = -a (r - 1) + b r
+    }
+}
+// R consecutive rounds in ONE pass: round j + 1 pairs up neighbouring outputs of round j, so a lane that owns 2^R
+// neighbouring inputs runs all R rounds in registers -- the intermediate vectors never reach memory (3 rounds: 16
+// elements moved per 8 inputs instead of 28) and R rounds cost one launch.  m: outputs of the LAST of the R rounds;
+// w0: where the first round's witness coefficients go, the later rounds' follow (2^(R-1) m, 2^(R-2) m, ... entries).
+template <int R>
+__global__ __launch_bounds__(256) void k_fold_pairs_multi(const Fr *__restrict__ v, size_t m, const Fr *__restrict__ r_ptr, Fr *__restrict__ w0,
+                                                          Fr *__restrict__ vout) {
+    constexpr int IN = 1 << R;
+    Fr29 r261[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) r261[j] = fr_to_261(r_ptr[j]);
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < m; t += (size_t)gridDim.x * blockDim.x) {
+        Fr x[IN];
+#pragma unroll
+        for (int i = 0; i < IN; i++) x[i] = v[(size_t)IN * t + i];
+        Fr *w = w0;
+        size_t outs = m << (R - 1);                      // outputs of the current round
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const int cnt = IN >> (j + 1);               // this lane's outputs in round j
+#pragma unroll
+            for (int i = 0; i < cnt; i++) {
+                const Fr d = x[2 * i + 1] - x[2 * i];
+                w[(size_t)cnt * t + i] = d;
+                x[i] = x[2 * i] + fr_mul_261(d, r261[j]);
+            }
+            w += outs;
+            outs >>= 1;
+        }
+        vout[t] = x[0];
+    }
+}
+// the remaining rounds (m_first, m_first / 2, ... 1 output elements) by one workgroup; round j reads what round j - 1
+// wrote (ping-pong between bufA and bufB, continuing the caller's parity), r_ptr / w advance per round
+__global__ __launch_bounds__(256) void k_fold_pairs_tail(const Fr *src, size_t m_first, const Fr *__restrict__ r_ptr, Fr *w, Fr *bufA, Fr *bufB,
+                                                         unsigned parity) {
+    for (size_t m = m_first; m >= 1; m >>= 1) {
+        const Fr29 r261 = fr_to_261(*r_ptr);
+        Fr *dst = (parity & 1u) ? bufB : bufA;
+        for (size_t p = threadIdx.x; p < m; p += 256) {
+            const Fr a = src[2 * p], b = src[2 * p + 1];
+            const Fr d = b - a;
+            w[p] = d;
+            dst[p] = a + fr_mul_261(d, r261);
+        }
+        __syncthreads();                                 // the block's global writes are visible to the block
+        src = dst;
+        w += m;
+        r_ptr++;
+        parity++;
     }
 }
 
 // cur may alias old: lane p reads old[p], old[p+half] and writes cur[p] only
 __global__ __launch_bounds__(256) void k_fold_halves(const Fr *old, size_t half, const Fr *__restrict__ r_ptr, Fr *cur) {
-    const Fr r = *r_ptr;
-    const Fr r0 = Fr::one() - r;
+    const Fr29 r261 = fr_to_261(*r_ptr);
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < half; p += (size_t)gridDim.x * blockDim.x) {
-        cur[p] = old[p] * r0 + old[p + half] * r;
+        const Fr a = old[p];
+        cur[p] = a + fr_mul_261(old[p + half] - a, r261);   // = a (1 - r) + old[p + half] r
+    }
+}
+// R consecutive rounds of the top-variable fold in ONE pass: with q outputs after the R rounds, lane p < q owns the 2^R
+// inputs old[p + j q]; round 1 pairs (j, j + 2^(R-1)) with r_hi[0], round 2 (j, j + 2^(R-2)) with r_hi[-1], ... -- the
+// intermediate vectors never reach memory (evalMLE reads its table ONCE).  cur must not alias old (lanes read q apart).
+template <int R>
+__global__ __launch_bounds__(256) void k_fold_halves_multi(const Fr *__restrict__ old, size_t q, const Fr *__restrict__ r_hi, Fr *__restrict__ cur) {
+    constexpr int IN = 1 << R;
+    Fr29 r261[R];
+#pragma unroll
+    for (int j = 0; j < R; j++) r261[j] = fr_to_261(*(r_hi - j));
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < q; p += (size_t)gridDim.x * blockDim.x) {
+        Fr x[IN];
+#pragma unroll
+        for (int i = 0; i < IN; i++) x[i] = old[p + (size_t)i * q];
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            const int cnt = IN >> (j + 1);
+#pragma unroll
+            for (int i = 0; i < cnt; i++) x[i] = x[i] + fr_mul_261(x[i + cnt] - x[i], r261[j]);
+        }
+        cur[p] = x[0];
+    }
+}
+// evalMLE's last rounds (half = half_first, half_first / 2, ... 1; the scalar of the round with half = 2^i is r[i]) by one
+// workgroup, in place on buf; the last round writes *out
+__global__ __launch_bounds__(256) void k_fold_halves_tail(const Fr *src, size_t half_first, const Fr *__restrict__ r, Fr *buf, Fr *out) {
+    unsigned i = 0;
+    while (((size_t)1 << i) < half_first) i++;
+    for (size_t half = half_first; half >= 1; half >>= 1, i--) {
+        const Fr29 r261 = fr_to_261(r[i]);
+        Fr *dst = half == 1 ? out : buf;
+        for (size_t p = threadIdx.x; p < half; p += 256) {
+            const Fr a = src[p];
+            dst[p] = a + fr_mul_261(src[p + half] - a, r261);
+        }
+        __syncthreads();
+        src = buf;
+        if (half == 1) break;
     }
 }
 
@@ -117,8 +219,9 @@ __global__ __launch_bounds__(64) void k_sumcheck_finish(const Fr *__restrict__ p
 // DPBeta::pushRandomness suffix update (/root/reference/src/prototools/mle.h:46-53):
 //   cur[p] = old[half + p] * k,  p < half   (cur may alias old)
 __global__ __launch_bounds__(256) void k_scale_upper(const Fr *old, size_t half, Fr k, Fr *cur) {
+    const Fr29 k261 = fr_to_261(k);
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < half; p += (size_t)gridDim.x * blockDim.x)
-        cur[p] = old[p + half] * k;
+        cur[p] = fr_mul_261(old[p + half], k261);
 }
 
 #define HIPCHK(x)                                                                      \
@@ -144,12 +247,27 @@ int fr_cppoly_fold_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_w, Fr *d
     const Fr *src = d_v;
     Fr *bufA = d_tmp, *bufB = d_tmp + (N >> 1);
     size_t start = 0;
-    for (size_t i = 0; i < d; i++) {
-        const size_t m = (size_t)1 << (d - i - 1);
-        Fr *dst = (i & 1) ? bufB : bufA;
-        hipLaunchKernelGGL(k_fold_pairs, dim3(stream_blocks(m)), dim3(256), 0, st, src, m, d_r + i, d_w + start, dst);
+    size_t i = 0;
+    unsigned which = 0;                                  // the next launch writes bufA (0) or bufB (1); it never reads the one it writes
+    while (i < d) {
+        const size_t m = (size_t)1 << (d - i - 1);       // outputs of round i
+        if (m <= FOLD_TAIL) {                            // this round and every later one: one workgroup
+            hipLaunchKernelGGL(k_fold_pairs_tail, dim3(1), dim3(256), 0, st, src, m, d_r + i, d_w + start, bufA, bufB, which);
+            break;
+        }
+        // up to three rounds per launch while their last round still has more than FOLD_TAIL outputs
+        static const unsigned rmax = getenv("LSA_FOLD_ROUNDS") ? (unsigned)atoi(getenv("LSA_FOLD_ROUNDS")) : 3u;
+        unsigned R = 1;
+        while (R < rmax && R < 3 && (m >> R) > FOLD_TAIL) R++;
+        const size_t mo = m >> (R - 1);                  // outputs of the last of the R rounds
+        Fr *dst = which ? bufB : bufA;                   // (every launch's output is at most half the previous one's: both halves of d_tmp are large enough)
+        if (R == 3) hipLaunchKernelGGL((k_fold_pairs_multi<3>), dim3(stream_blocks(mo)), dim3(256), 0, st, src, mo, d_r + i, d_w + start, dst);
+        else if (R == 2) hipLaunchKernelGGL((k_fold_pairs_multi<2>), dim3(stream_blocks(mo)), dim3(256), 0, st, src, mo, d_r + i, d_w + start, dst);
+        else hipLaunchKernelGGL(k_fold_pairs, dim3(stream_blocks(mo)), dim3(256), 0, st, src, mo, d_r + i, d_w + start, dst);
         src = dst;
-        start += m;
+        which ^= 1u;
+        for (unsigned j = 0; j < R; j++) start += m >> j;
+        i += R;
     }
     HIPCHK(hipGetLastError());
     return LSA_OK;
@@ -172,11 +290,28 @@ int fr_eval_mle_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_tmp, Fr *d_
         return LSA_OK;
     }
     const Fr *src = d_v;
-    for (size_t i = d; i-- > 0;) {
-        const size_t half = (size_t)1 << i;
-        Fr *dst = i == 0 ? d_out : d_tmp;
-        hipLaunchKernelGGL(k_fold_halves, dim3(stream_blocks(half)), dim3(256), 0, st, src, half, d_r + i, dst);
+    // d_tmp holds 2^(d-1) elements: a multi-round launch writes its (shorter) output behind what the next launch reads --
+    // ping-pong between the two halves of d_tmp (the first launch reads d_v)
+    Fr *pp[2] = {d_tmp, d_tmp + ((size_t)1 << (d - 1)) / 2};
+    unsigned which = 0;
+    size_t i = d;                                        // rounds left: the next one has half = 2^(i-1) and uses r[i-1]
+    while (i > 0) {
+        const size_t half = (size_t)1 << (i - 1);
+        if (half <= FOLD_TAIL) {                         // this round and every later one: one workgroup, in place behind a copy
+            hipLaunchKernelGGL(k_fold_halves_tail, dim3(1), dim3(256), 0, st, src, half, d_r, pp[which], d_out);
+            break;
+        }
+        static const unsigned rmax = getenv("LSA_FOLD_ROUNDS_HALVES") ? (unsigned)atoi(getenv("LSA_FOLD_ROUNDS_HALVES")) : 3u;
+        unsigned R = 1;
+        while (R < rmax && R < 3 && (half >> R) > FOLD_TAIL) R++;
+        const size_t q = half >> (R - 1);                // outputs after the R rounds
+        Fr *dst = pp[which];
+        if (R == 3) hipLaunchKernelGGL((k_fold_halves_multi<3>), dim3(stream_blocks(q)), dim3(256), 0, st, src, q, d_r + (i - 1), dst);
+        else if (R == 2) hipLaunchKernelGGL((k_fold_halves_multi<2>), dim3(stream_blocks(q)), dim3(256), 0, st, src, q, d_r + (i - 1), dst);
+        else hipLaunchKernelGGL((k_fold_halves_multi<1>), dim3(stream_blocks(q)), dim3(256), 0, st, src, q, d_r + (i - 1), dst);
         src = dst;
+        which ^= 1u;
+        i -= R;
     }
     HIPCHK(hipGetLastError());
     return LSA_OK;
