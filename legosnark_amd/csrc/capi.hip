@@ -696,6 +696,10 @@ int lsa_msm_run(const lsa_bases *bases, size_t first, const void *d_scalars, siz
 namespace {
 StageBuf g_stage_jac, g_stage_bases, g_stage_scalars, g_stage_prefix_scratch;
 StageBuf g_stage_ntt_a, g_stage_ntt_tmp;         // lsa_fr_ntt: the data of host callers, the second buffer of the passes
+// the Fr recursions (lsa_fr_cppoly_witness, lsa_fr_eval_mle): scratch, and for host callers v / r / w -- grow-only like the
+// others (round 5; before, every call paid a hipMalloc + hipFree pair per buffer, and the recursions' cached hipGraphs
+// (fr_vec.hip) are keyed by these pointers)
+StageBuf g_stage_fr_tmp, g_stage_fr_v, g_stage_fr_r, g_stage_fr_w;
 }  // namespace
 namespace lsa { StageBuf g_stage_gather; }
 static int stage_jac_ensure(size_t bytes, void **p) {
@@ -715,7 +719,9 @@ static void warm_stage_buffers() {
 static void release_stage_buffers() {
     g_stage_jac.release(); g_stage_bases.release(); g_stage_scalars.release(); g_stage_gather.release(); g_stage_prefix_scratch.release();
     g_stage_ntt_a.release(); g_stage_ntt_tmp.release();
+    g_stage_fr_tmp.release(); g_stage_fr_v.release(); g_stage_fr_r.release(); g_stage_fr_w.release();
     ntt_release();                                   // the per-domain twiddle tables (ntt.hip)
+    fr_vec_release();                                // the cached hipGraphs of the Fr recursions (fr_vec.hip)
     pairing_release();
 }
 
@@ -1645,15 +1651,15 @@ int lsa_fr_cppoly_witness(const void *v, size_t d, const void *r, void *w, int o
     if (d > 40) { set_error("cppoly_witness: d = %zu too large", d); return LSA_ERR_INVALID; }
     if (!v || !w || (d && !r)) { set_error("cppoly_witness: null argument"); return LSA_ERR_INVALID; }
     const size_t N = (size_t)1 << d;
-    DevBuf d_tmp, d_v, d_r, d_w;
-    if (d_tmp.alloc((N / 2 + N / 4 + 1) * sizeof(Fr))) { set_error("cppoly_witness: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    StageBuf &d_tmp = g_stage_fr_tmp, &d_v = g_stage_fr_v, &d_r = g_stage_fr_r, &d_w = g_stage_fr_w;
+    if (d_tmp.ensure((N / 2 + N / 4 + 1) * sizeof(Fr))) { set_error("cppoly_witness: hipMalloc failed"); return LSA_ERR_NOMEM; }
     if (on_device) {
         rc = fr_cppoly_fold_device((const Fr *)v, d, (const Fr *)r, (Fr *)w, (Fr *)d_tmp.p, g.stream);
         if (rc) return rc;
-        HIPCHK(hipStreamSynchronize(g.stream));   // scratch is freed on return
+        HIPCHK(hipStreamSynchronize(g.stream));   // (callers read w from their own streams)
         return LSA_OK;
     }
-    if (d_v.alloc(N * sizeof(Fr)) || d_r.alloc((d + 1) * sizeof(Fr)) || d_w.alloc(N * sizeof(Fr))) { set_error("cppoly_witness: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    if (d_v.ensure(N * sizeof(Fr)) || d_r.ensure((d + 1) * sizeof(Fr)) || d_w.ensure(N * sizeof(Fr))) { set_error("cppoly_witness: hipMalloc failed"); return LSA_ERR_NOMEM; }
     LSA_UPLOAD(d_v.p, v, N * sizeof(Fr));
     if (d) LSA_UPLOAD(d_r.p, r, d * sizeof(Fr));
     rc = fr_cppoly_fold_device((const Fr *)d_v.p, d, (const Fr *)d_r.p, (Fr *)d_w.p, (Fr *)d_tmp.p, g.stream);
@@ -1670,15 +1676,15 @@ int lsa_fr_eval_mle(const void *v, size_t d, const void *r, void *out, int on_de
     if (d > 40) { set_error("eval_mle: d = %zu too large", d); return LSA_ERR_INVALID; }
     if (!v || !out || (d && !r)) { set_error("eval_mle: null argument"); return LSA_ERR_INVALID; }
     const size_t N = (size_t)1 << d;
-    DevBuf d_tmp, d_v, d_r, d_o;
-    if (d_tmp.alloc((N / 2 + 1) * sizeof(Fr))) { set_error("eval_mle: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    StageBuf &d_tmp = g_stage_fr_tmp, &d_v = g_stage_fr_v, &d_r = g_stage_fr_r, &d_o = g_stage_fr_w;
+    if (d_tmp.ensure((N / 2 + N / 4 + 1) * sizeof(Fr))) { set_error("eval_mle: hipMalloc failed"); return LSA_ERR_NOMEM; }
     if (on_device) {
         rc = fr_eval_mle_device((const Fr *)v, d, (const Fr *)r, (Fr *)d_tmp.p, (Fr *)out, g.stream);
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(g.stream));
         return LSA_OK;
     }
-    if (d_v.alloc(N * sizeof(Fr)) || d_r.alloc((d + 1) * sizeof(Fr)) || d_o.alloc(sizeof(Fr))) { set_error("eval_mle: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    if (d_v.ensure(N * sizeof(Fr)) || d_r.ensure((d + 1) * sizeof(Fr)) || d_o.ensure(sizeof(Fr))) { set_error("eval_mle: hipMalloc failed"); return LSA_ERR_NOMEM; }
     LSA_UPLOAD(d_v.p, v, N * sizeof(Fr));
     if (d) LSA_UPLOAD(d_r.p, r, d * sizeof(Fr));
     rc = fr_eval_mle_device((const Fr *)d_v.p, d, (const Fr *)d_r.p, (Fr *)d_tmp.p, (Fr *)d_o.p, g.stream);

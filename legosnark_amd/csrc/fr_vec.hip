@@ -238,10 +238,79 @@ static unsigned stream_blocks(size_t m) {
     return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
+// ---- the launch sequences of the two recursions as hipGraphs.  A witness recursion at d = 24 is a memset and ~8 kernels of
+// 5-400 us: issued one by one the host needs ~0.1 ms for them and the short ones wait for it.  The sequence only depends on
+// (d, the four pointers), and callers pass the same buffers again and again (the library's staging buffers behind the
+// host entry points, a prover's resident vectors), so the instantiated graph of the last few argument sets is kept and
+// relaunched with ONE call.  LSA_FR_GRAPHS=0: plain launches.
+namespace {
+struct FoldGraph {
+    int kind = 0;                       // 1: witness recursion, 2: evalMLE
+    size_t d = 0;
+    const void *a0 = nullptr, *a1 = nullptr, *a2 = nullptr, *a3 = nullptr, *a4 = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t tick = 0;
+};
+constexpr int FOLD_GRAPHS = 6;
+FoldGraph g_fold_graphs[FOLD_GRAPHS];
+uint64_t g_fold_tick = 0;
+bool g_fold_graphs_broken = false;
+bool fold_graphs_on() {
+    static const bool on = !(getenv("LSA_FR_GRAPHS") && getenv("LSA_FR_GRAPHS")[0] == '0');
+    return on && !g_fold_graphs_broken;
+}
+// issue(st) queues the sequence on st; returns an LSA code.  The first call with a new argument set captures it.
+template <class Issue>
+int fold_run(int kind, size_t d, const void *a0, const void *a1, const void *a2, const void *a3, const void *a4, hipStream_t st, Issue issue) {
+    if (!fold_graphs_on() || d < 8) return issue(st);
+    FoldGraph *victim = &g_fold_graphs[0];
+    for (auto &g : g_fold_graphs) {
+        if (g.exec && g.kind == kind && g.d == d && g.a0 == a0 && g.a1 == a1 && g.a2 == a2 && g.a3 == a3 && g.a4 == a4) {
+            g.tick = ++g_fold_tick;
+            if (hipGraphLaunch(g.exec, st) == hipSuccess) return LSA_OK;
+            (void)hipGetLastError();
+            g_fold_graphs_broken = true;
+            return issue(st);
+        }
+        if (g.tick < victim->tick) victim = &g;
+    }
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); g_fold_graphs_broken = true; return issue(st); }
+    const int rc = issue(st);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &graph);
+    if (rc != LSA_OK || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        g_fold_graphs_broken = true;                     // (nothing was executed during the capture: run it plainly)
+        return rc != LSA_OK ? rc : issue(st);
+    }
+    hipGraphExec_t exec = nullptr;
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
+        (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        g_fold_graphs_broken = true;
+        return issue(st);
+    }
+    (void)hipGraphDestroy(graph);
+    if (victim->exec) (void)hipGraphExecDestroy(victim->exec);
+    *victim = FoldGraph{kind, d, a0, a1, a2, a3, a4, exec, ++g_fold_tick};
+    if (hipGraphLaunch(exec, st) != hipSuccess) { (void)hipGetLastError(); g_fold_graphs_broken = true; return issue(st); }
+    return LSA_OK;
+}
+}  // namespace
+void fr_vec_release() {
+    for (auto &g : g_fold_graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); g = FoldGraph(); }
+    g_fold_graphs_broken = false;
+}
+
 // CPPoly::prove witness coefficients: d_v (2^d, untouched), d_r (d), d_w (2^d; the first
 // 2^d - 1 entries are written, the last is zeroed like the reference's value-initialised
 // vector), d_tmp: scratch of 2^(d-1) + 2^(d-2) elements (ping-pong).  Asynchronous on st.
+static int fr_cppoly_fold_issue(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_w, Fr *d_tmp, hipStream_t st);
 int fr_cppoly_fold_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_w, Fr *d_tmp, hipStream_t st) {
+    return fold_run(1, d, d_v, d_r, d_w, d_tmp, nullptr, st, [=](hipStream_t s) { return fr_cppoly_fold_issue(d_v, d, d_r, d_w, d_tmp, s); });
+}
+static int fr_cppoly_fold_issue(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_w, Fr *d_tmp, hipStream_t st) {
     const size_t N = (size_t)1 << d;
     HIPCHK(hipMemsetAsync(d_w + (N - 1), 0, sizeof(Fr), st));
     const Fr *src = d_v;
@@ -256,7 +325,7 @@ int fr_cppoly_fold_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_w, Fr *d
             break;
         }
         // up to three rounds per launch while their last round still has more than FOLD_TAIL outputs
-        static const unsigned rmax = getenv("LSA_FOLD_ROUNDS") ? (unsigned)atoi(getenv("LSA_FOLD_ROUNDS")) : 3u;
+        static const unsigned rmax = getenv("LSA_FOLD_ROUNDS") ? (unsigned)atoi(getenv("LSA_FOLD_ROUNDS")) : 2u;        // (measured at d = 24: 1 round 0.83, 2 rounds 0.74, 3 rounds 0.80 ms: eight 32-byte pieces per lane coalesce worse than four)
         unsigned R = 1;
         while (R < rmax && R < 3 && (m >> R) > FOLD_TAIL) R++;
         const size_t mo = m >> (R - 1);                  // outputs of the last of the R rounds
@@ -284,7 +353,11 @@ int fr_fold_halves_device(const Fr *d_old, size_t half, const Fr *d_r, Fr *d_cur
 // evalMLE(v, r): d_v (2^d, untouched), d_r (d), d_tmp scratch of 2^(d-1) elements; the value
 // ends up in d_out (one Fr).  Bit i of the index pairs with r[i] (polytools.h:219-226), so the
 // top variable is r[d-1].
+static int fr_eval_mle_issue(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_tmp, Fr *d_out, hipStream_t st);
 int fr_eval_mle_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_tmp, Fr *d_out, hipStream_t st) {
+    return fold_run(2, d, d_v, d_r, d_tmp, d_out, nullptr, st, [=](hipStream_t s) { return fr_eval_mle_issue(d_v, d, d_r, d_tmp, d_out, s); });
+}
+static int fr_eval_mle_issue(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_tmp, Fr *d_out, hipStream_t st) {
     if (d == 0) {
         HIPCHK(hipMemcpyAsync(d_out, d_v, sizeof(Fr), hipMemcpyDeviceToDevice, st));
         return LSA_OK;
@@ -301,7 +374,7 @@ int fr_eval_mle_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_tmp, Fr *d_
             hipLaunchKernelGGL(k_fold_halves_tail, dim3(1), dim3(256), 0, st, src, half, d_r, pp[which], d_out);
             break;
         }
-        static const unsigned rmax = getenv("LSA_FOLD_ROUNDS_HALVES") ? (unsigned)atoi(getenv("LSA_FOLD_ROUNDS_HALVES")) : 3u;
+        static const unsigned rmax = getenv("LSA_FOLD_ROUNDS_HALVES") ? (unsigned)atoi(getenv("LSA_FOLD_ROUNDS_HALVES")) : 2u; // (0.75 / 0.66 / 0.81 ms: eight read streams 2^21 elements apart are one too many)
         unsigned R = 1;
         while (R < rmax && R < 3 && (half >> R) > FOLD_TAIL) R++;
         const size_t q = half >> (R - 1);                // outputs after the R rounds

@@ -74,6 +74,7 @@ int fr_eval_mle_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_tmp, Fr *d_
 int fr_sumcheck_round_device(const Fr *d_suff, const Fr *const *d_tables, size_t m, size_t half, const Fr *pre, const Fr *rho,
                              Fr *d_partial, Fr *d_out, hipStream_t st);
 size_t fr_sumcheck_scratch_elems();
+void fr_vec_release();            // the cached hipGraphs of the recursions (lsa_shutdown)
 int fr_scale_upper_device(const Fr *d_old, size_t half, const Fr &k, Fr *d_cur, hipStream_t st);
 
 // ntt.hip: in-place radix-2 NTT of 2^log_n Fr values (device) in at most three passes; d_tmp: 2^log_n scratch elements
