@@ -700,6 +700,7 @@ StageBuf g_stage_ntt_a, g_stage_ntt_tmp;         // lsa_fr_ntt: the data of host
 // others (round 5; before, every call paid a hipMalloc + hipFree pair per buffer, and the recursions' cached hipGraphs
 // (fr_vec.hip) are keyed by these pointers)
 StageBuf g_stage_fr_tmp, g_stage_fr_v, g_stage_fr_r, g_stage_fr_w;
+StageBuf g_stage_sc_partial, g_stage_sc_out;     // lsa_fr_sumcheck_round: block partials and the coefficients (one call per round of a prover)
 }  // namespace
 namespace lsa { StageBuf g_stage_gather; }
 static int stage_jac_ensure(size_t bytes, void **p) {
@@ -720,6 +721,7 @@ static void release_stage_buffers() {
     g_stage_jac.release(); g_stage_bases.release(); g_stage_scalars.release(); g_stage_gather.release(); g_stage_prefix_scratch.release();
     g_stage_ntt_a.release(); g_stage_ntt_tmp.release();
     g_stage_fr_tmp.release(); g_stage_fr_v.release(); g_stage_fr_r.release(); g_stage_fr_w.release();
+    g_stage_sc_partial.release(); g_stage_sc_out.release();
     ntt_release();                                   // the per-domain twiddle tables (ntt.hip)
     fr_vec_release();                                // the cached hipGraphs of the Fr recursions (fr_vec.hip)
     pairing_release();
@@ -1702,8 +1704,9 @@ int lsa_fr_sumcheck_round(const void *suff, const void *const *tables, size_t m,
     if (rho_j && !pre) { set_error("sumcheck_round: rho_j without pre"); return LSA_ERR_INVALID; }
     for (size_t t = 0; t < m; t++) if (!tables[t]) { set_error("sumcheck_round: null table"); return LSA_ERR_INVALID; }
     const size_t ncoef = m + (rho_j ? 2 : 1);
-    DevBuf d_partial, d_out, d_suff, d_tab[4];
-    if (d_partial.alloc(fr_sumcheck_scratch_elems() * sizeof(Fr)) || d_out.alloc(8 * sizeof(Fr))) { set_error("sumcheck_round: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    StageBuf &d_partial = g_stage_sc_partial, &d_out = g_stage_sc_out;
+    DevBuf d_suff, d_tab[4];
+    if (d_partial.ensure(fr_sumcheck_scratch_elems() * sizeof(Fr)) || d_out.ensure(8 * sizeof(Fr))) { set_error("sumcheck_round: hipMalloc failed"); return LSA_ERR_NOMEM; }
     const Fr *tabs[4] = {nullptr, nullptr, nullptr, nullptr};
     const Fr *sf = (const Fr *)suff;
     if (on_device) {
