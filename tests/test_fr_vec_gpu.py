@@ -9,8 +9,10 @@ import oracle_lib as o
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("d", [0, 1, 2, 3, 9, 13])
+@pytest.mark.parametrize("d", [0, 1, 2, 3, 9, 11, 12, 13, 14, 15, 16, 17])
 def test_cppoly_witness_vs_oracle(lsa, d):
+    """d <= 11: every round in the one-workgroup tail kernel; 12-13: one single-round launch first; from 14 on launches of
+    two rounds in registers (k_fold_pairs_multi), an odd number of leading rounds at 15 and 17."""
     v, _ = o.random_scalars(1 << d, seed=300 + d)
     r, _ = o.random_scalars(max(d, 1), seed=400 + d)
     r = r[:d]
@@ -20,12 +22,39 @@ def test_cppoly_witness_vs_oracle(lsa, d):
     assert not got[-1].any()                       # value-initialised tail entry (poly.h:52)
 
 
-@pytest.mark.parametrize("d", [0, 1, 2, 7, 12])
+@pytest.mark.parametrize("d", [0, 1, 2, 7, 12, 13, 14, 15, 16, 18])
 def test_eval_mle_vs_oracle(lsa, d):
     v, _ = o.random_scalars(1 << d, seed=500 + d)
     r, _ = o.random_scalars(max(d, 1), seed=600 + d)
     r = r[:d]
     assert np.array_equal(lsa.eval_mle(v, r), o.fr_eval_mle(v, r))
+
+
+@pytest.mark.parametrize("switch", ["LSA_FR_GRAPHS=0", "LSA_FOLD_ROUNDS=1", "LSA_FOLD_ROUNDS=3", "LSA_FOLD_ROUNDS_HALVES=1", "LSA_FOLD_ROUNDS_HALVES=3"])
+def test_fold_schedules_behind_their_switches_give_the_oracles_bytes(switch):
+    """One, two (default) or three rounds per launch, with or without the cached hipGraph: the same witness coefficients and
+    the same evalMLE value as the oracle at d = 16 and 17, called twice (the second call replays the graph), from a child
+    process (the switches are read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import legosnark_amd as lsa, oracle_lib as o\n"
+        "lsa.init(0)\n"
+        "for d in (16, 17):\n"
+        "    v, _ = o.random_scalars(1 << d, seed=900 + d); r, _ = o.random_scalars(d, seed=950 + d)\n"
+        "    ww, we = o.fr_cppoly_witness(v, r), o.fr_eval_mle(v, r)\n"
+        "    for rep in range(2):\n"
+        "        assert np.array_equal(lsa.cppoly_witness(v, r), ww), (d, rep)\n"
+        "        assert np.array_equal(lsa.eval_mle(v, r), we), (d, rep)\n"
+        "print('OK')\n"
+    ) % (root, os.path.join(root, "tests"))
+    k, val = switch.split("=")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{k: val}), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:]
 
 
 def test_eval_mle_special_points(lsa):

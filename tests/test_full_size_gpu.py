@@ -264,3 +264,43 @@ def test_cplink_prover_shape_2pow24_and_two_rank_split(lsa):
             got_s = B0.msm(d_w[first:first + m], n=m, first=first)
             assert canon("g1", got_s) == k_times_gen("g1", o.fr_dot(w[first:first + m], x[first:first + m])), (first, m)
     B0.close()
+
+
+@pytest.mark.parametrize("log_n", [22, 25])
+def test_ntt_beyond_2pow20_round_trip_and_delta(lsa, log_n):
+    """The three-pass NTT at sizes the oracle is too slow for (2^22: passes of 8 + 7 + 7 stages; 2^25: 9 + 8 + 8, tiles of
+    two columns): icosetFFT(cosetFFT(a)) == a, iFFT(FFT(a)) == a, the transform of the delta at position 1 is omega^k at
+    sampled positions, and linearity FFT(a) + FFT(delta) == FFT(a + delta) at those positions."""
+    import torch
+    n = 1 << log_n
+    gen = torch.Generator(device="cuda:0").manual_seed(100 + log_n)
+    d_a = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device="cuda:0", generator=gen)
+    d_a[:, 3] &= (1 << 60) - 1
+    keep = d_a.clone()
+    wi = o.fr_root_of_unity(log_n)
+    w, g = o.fr_mont(wi), o.fr_mont(o.FR_GENERATOR)
+    lsa.fr_ntt(d_a, w, coset=g)
+    assert not torch.equal(d_a, keep)
+    lsa.fr_ntt(d_a, w, inverse=True, coset=g)
+    lsa.synchronize()
+    assert torch.equal(d_a, keep)
+    lsa.fr_ntt(d_a, w)
+    lsa.synchronize()
+    fa = d_a.clone()
+    lsa.fr_ntt(d_a, w, inverse=True)
+    lsa.synchronize()
+    assert torch.equal(d_a, keep)
+    delta = torch.zeros((n, 4), dtype=torch.int64, device="cuda:0")
+    delta[1] = torch.from_numpy(o.fr_mont(1).view(np.int64))
+    both = keep.clone()
+    a1 = o.limbs_to_int(keep[1].cpu().numpy().view(np.uint64)) * pow(o.MONT, -1, o.R) % o.R
+    both[1] = torch.from_numpy(o.fr_mont((a1 + 1) % o.R).view(np.int64))
+    lsa.fr_ntt(delta, w)
+    lsa.fr_ntt(both, w)
+    lsa.synchronize()
+    hd, hf, hb = (t.cpu().numpy().view(np.uint64) for t in (delta, fa, both))
+    minv = pow(o.MONT, -1, o.R)
+    for k in (0, 1, 2, 1023, 1024, 65537, (1 << 21) + 5, n - 1):
+        assert np.array_equal(hd[k], o.fr_mont(pow(wi, k, o.R))), k
+        s = (o.limbs_to_int(hf[k]) + o.limbs_to_int(hd[k])) * minv % o.R
+        assert o.limbs_to_int(hb[k]) * minv % o.R == s, k
