@@ -83,9 +83,16 @@ __global__ __launch_bounds__(256) void k_ntt_pass(NttArgs a) {
     const unsigned T = 1u << (a.pass.l + a.pass.logC);
     for (unsigned x = tid; x < T; x += 256) ntt_tile_load(a, w, x, lds);
     __syncthreads();
+    // two stages per LDS round trip (ntt_tile_stage2); an odd number of stages starts with a single one
+    unsigned s = 0;
+    if (a.pass.l & 1u) {
+        for (unsigned b = tid; b < T / 2; b += 256) ntt_tile_stage(a, 0, b, lds);
+        __syncthreads();
+        s = 1;
+    }
 #pragma unroll 1
-    for (unsigned s = 0; s < a.pass.l; s++) {
-        for (unsigned b = tid; b < T / 2; b += 256) ntt_tile_stage(a, s, b, lds);
+    for (; s < a.pass.l; s += 2) {
+        for (unsigned g = tid; g < T / 4; g += 256) ntt_tile_stage2(a, s, g, lds);
         __syncthreads();
     }
     for (unsigned x = tid; x < T; x += 256) ntt_tile_store(a, w, x, lds);

@@ -159,6 +159,32 @@ LSA_HD void ntt_tile_stage(const NttArgs &a, unsigned s, unsigned b, uint32_t *l
     ntt_lds_put(lds, i0, add(u, t));
     ntt_lds_put(lds, i1, sub2r(u, t));
 }
+// stages s and s + 1 together on the four elements j0, j0 + 2^s, j0 + 2^(s+1), j0 + 2^(s+1) + 2^s of group gidx (< tile / 4):
+// the same four products and the same values as two calls of ntt_tile_stage per pair, with one LDS round trip and one
+// barrier instead of two (a radix-4 step written as two radix-2 steps in registers)
+LSA_HD void ntt_tile_stage2(const NttArgs &a, unsigned s, unsigned gidx, uint32_t *lds) {
+    const unsigned l = a.pass.l, logC = a.pass.logC, len = 1u << l;
+    unsigned c, jg;
+    if (a.pass.kind != 3) { c = gidx & ((1u << logC) - 1); jg = gidx >> logC; }
+    else { jg = gidx & ((len >> 2) - 1); c = gidx >> (l - 2); }
+    const unsigned h = 1u << s, pos = jg & (h - 1), j0 = ((jg >> s) << (s + 2)) | pos;
+    const unsigned base = a.pass.kind != 3 ? c : c * (len + 1), sh = a.pass.kind != 3 ? logC : 0u;
+    const unsigned i0 = base + (j0 << sh), i1 = base + ((j0 + h) << sh), i2 = base + ((j0 + 2 * h) << sh), i3 = base + ((j0 + 3 * h) << sh);
+    Fr29 x0 = ntt_lds_get(lds, i0), x1 = ntt_lds_get(lds, i1), x2 = ntt_lds_get(lds, i2), x3 = ntt_lds_get(lds, i3);
+    if (s != 0) {                                                                  // stage s: both pairs share the twiddle of position pos
+        const Fr29 w = ntt_lds_get(a.W, pos << (a.plan.lmax - 1 - s));
+        x1 = mul(x1, w);
+        x3 = mul(x3, w);
+    }
+    const Fr29 y0 = add(x0, x1), y1 = sub2r(x0, x1), y2 = add(x2, x3), y3 = sub2r(x2, x3);
+    // stage s + 1: (y0, y2) at position pos, (y1, y3) at position pos + 2^s of a 2^(s+2)-point butterfly
+    const unsigned shw = a.plan.lmax - 2 - s;
+    const Fr29 t2 = mul(y2, ntt_lds_get(a.W, pos << shw)), t3 = mul(y3, ntt_lds_get(a.W, (pos + h) << shw));
+    ntt_lds_put(lds, i0, add(y0, t2));
+    ntt_lds_put(lds, i2, sub2r(y0, t2));
+    ntt_lds_put(lds, i1, add(y1, t3));
+    ntt_lds_put(lds, i3, sub2r(y1, t3));
+}
 LSA_HD void ntt_tile_store(const NttArgs &a, unsigned w, unsigned x, const uint32_t *lds) {
     const NttPlan &p = a.plan;
     const unsigned l = a.pass.l, logC = a.pass.logC, C = 1u << logC, len = 1u << l;

@@ -131,8 +131,20 @@ static void run_three_pass(std::vector<Fr> &a, unsigned L, Fr omega, bool invers
         std::vector<uint32_t> lds(ntt_tile_words(args.pass));
         for (unsigned w_ = 0; w_ < args.pass.tiles; w_++) {
             for (unsigned x = 0; x < T; x++) ntt_tile_load(args, w_, x, lds.data());
-            for (unsigned s = 0; s < args.pass.l; s++)
-                for (unsigned b = 0; b < T / 2; b++) ntt_tile_stage(args, s, b, lds.data());
+            // the kernel's schedule: an odd number of stages starts with a single one, then two stages per LDS round trip;
+            // tiles of even size also run the plain one-stage-at-a-time schedule (the two must agree: checked through the result)
+            if (tile_log & 1) {
+                unsigned s = 0;
+                if (args.pass.l & 1u) { for (unsigned b = 0; b < T / 2; b++) ntt_tile_stage(args, 0, b, lds.data()); s = 1; }
+                for (; s < args.pass.l; s += 2)
+                    for (unsigned g4 = 0; g4 < T / 4; g4++) ntt_tile_stage2(args, s, g4, lds.data());
+            } else if (args.pass.l >= 2 && !(args.pass.l & 1u)) {
+                for (unsigned s = 0; s < args.pass.l; s += 2)
+                    for (unsigned g4 = 0; g4 < T / 4; g4++) ntt_tile_stage2(args, s, g4, lds.data());
+            } else {
+                for (unsigned s = 0; s < args.pass.l; s++)
+                    for (unsigned b = 0; b < T / 2; b++) ntt_tile_stage(args, s, b, lds.data());
+            }
             for (unsigned x = 0; x < T; x++) ntt_tile_store(args, w_, x, lds.data());
         }
         src = dst;

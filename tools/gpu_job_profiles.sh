@@ -2,7 +2,7 @@
 # the round's profile set (GPU box): rocprofv3 kernel traces of the bench command, of the other configs, of the
 # unchanged hadamard 20, time vs n, one isolated compact call; everything under gpurun_out/<tag>_*
 cd "$(dirname "$0")/.." || exit 1
-TAG=${TAG:-r05_v2}
+TAG=${TAG:-r05_v3}
 export TMPDIR=/tmp
 OUT=$(pwd)/gpurun_out
 mkdir -p "$OUT"
