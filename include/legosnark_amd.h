@@ -41,7 +41,11 @@ typedef enum {
 
 /* ---- lifecycle -------------------------------------------------------------------- */
 /* Replaces default_ec_pp::init_public_params() as the one-time setup call
- * (src/examples/cplink.cc:81).  Selects `device`, creates the library's HIP stream. */
+ * (src/examples/cplink.cc:81).  Selects `device`, creates the library's HIP stream, and pays here what the first calls
+ * of a prover would otherwise pay inside themselves: the code object, the internal streams and their copy-engine queues,
+ * the pinned slots of the host-copy path, and workspaces / staging buffers sized for 2^20 pairs of G1 or G2 (about 1 GB
+ * of device memory; LSA_WARM=0: everything lazily, LSA_WARM_MB=m: another size) -- a hipFree + hipMalloc pair inside a
+ * call costs 0.5 to 10+ ms depending on the box.  A failed warm-up is reported and leaves the library shut down. */
 int lsa_init(int device);
 void lsa_shutdown(void);
 int lsa_device_count(void);
@@ -66,9 +70,13 @@ int lsa_stream_join_to(void *stream);
  * Replaces libff::multi_exp_with_mixed_addition<G1<pp>,Fr<pp>,multi_exp_method_BDLO12>
  * (src/utils/globl.h:74-77, multiExpMA) and libff::multi_exp<..BDLO12>
  * (src/utils/sparsemexp.h:58,89).  `chunks` is libff's CPU work split
- * (src/utils/globl.h:67-71); it does not change the result and is accepted for
- * signature compatibility only.  bases: n x 96 B (G1) / 192 B (G2); scalars: n x 32 B;
- * out: one Jacobian point. */
+ * (src/utils/globl.h:67-71; omp_get_max_threads() in the reference's -DMULTICORE=ON build); it does not change the
+ * result and is accepted for signature compatibility only.  bases: n x 96 B (G1) / 192 B (G2); scalars: n x 32 B;
+ * out: one Jacobian point.
+ * Host buffers the library has not been handed before travel through its own pinned slots (a range is copied directly
+ * by the runtime only from its third sighting on): the first call on a 2^20-point G1 vector is ~7 ms whatever pages
+ * the caller's allocator uses.  Callers should not free large buffers right before a call: unmapping memory the HIP
+ * runtime has touched stalls the next submission by 15-25 ms (the libff-compatible shim keeps vectors on the heap). */
 int lsa_g1_msm(const void *bases_jac, const void *scalars_mont, size_t n, size_t chunks, void *out_jac);
 int lsa_g2_msm(const void *bases_jac, const void *scalars_mont, size_t n, size_t chunks, void *out_jac);
 
@@ -275,7 +283,9 @@ int lsa_fr_scale_upper(const void *old_mont, size_t half, const void *k_mont, vo
  * Fr; libff::get_root_of_unity).  inverse == 0: a[k] <- sum_i a[i] omega^(ik), after a[i] *= g^i
  * when coset_g != NULL (cosetFFT).  inverse != 0: the same with omega^-1, then a[k] *= 1/n and,
  * with coset_g, *= g^-k (iFFT / icosetFFT).  coset_g: HOST, one Fr, or NULL.
- * on_device != 0: a is a device pointer; else a host pointer.  log_n <= 28. */
+ * on_device != 0: a is a device pointer; else a host pointer.  log_n <= 28.
+ * At most three passes over the data (csrc/ntt.hip); the twiddle tables of the last four domains (log_n, omega,
+ * direction) and coset generators stay on the device; a second vector of the same size is kept as scratch. */
 int lsa_fr_ntt(void *a_mont, size_t log_n, const void *omega_mont, int inverse, const void *coset_g_mont, int on_device);
 
 /* ---- pairing ---------------------------------------------------------------------------- */
