@@ -170,16 +170,25 @@ struct TableCache {
 } g_tabs;
 
 // Tables lsa_g2_tables_prefetch has promised (their slots are taken, their keys resolve) but not yet built: built
-// five at a time (one wavefront of k_g2_precomp holds five points and takes as long for five as for one) or when a
-// Miller call arrives, whichever is first -- always before anything on lsa_stream() can read them.  A verifier that
-// derives twenty G2 points one after the other (CPPoly::verify, src/gadgets/poly.h:115-118) pays four launches, not
-// twenty dependent ones.
+// when a Miller call arrives or when `batch()` of them are waiting, whichever is first -- always before anything on
+// lsa_stream() can read them.  One wavefront of k_g2_precomp holds five points and takes as long (0.65 ms) for five as
+// for one; further wavefronts run beside it.  A verifier that derives twenty G2 points one after the other
+// (CPPoly::verify, src/gadgets/poly.h:115-118) spends 0.45 ms of host time on them since the fixed-base tables of round 5,
+// so ONE launch of four workgroups when its Miller call arrives (0.65 ms) beats four launches of one queued behind each
+// other (2.6 ms: the round-4 setting, LSA_G2_PREFETCH_BATCH=5, which paid when a product took 0.27 ms of host time).
 struct PendingTables {
     std::vector<Jac<Fq2>> pts;
     std::vector<uint64_t> dst;
     std::vector<Key128> keys;
     StageBuf dev;
-    static constexpr size_t BATCH = 5;
+    static size_t batch() {
+        static const size_t b = [] {
+            const char *e = getenv("LSA_G2_PREFETCH_BATCH");
+            const long v = e ? atol(e) : 60;
+            return (size_t)(v < 1 ? 1 : v > 1024 ? 1024 : v);
+        }();
+        return b;
+    }
     int build(const std::vector<char> &h, size_t m) {
         if (dev.ensure(h.size())) { set_error("g2_tables_prefetch: staging allocation failed"); return LSA_ERR_NOMEM; }
         LSA_UPLOAD(dev.p, h.data(), h.size());
@@ -601,7 +610,7 @@ int lsa_g2_tables_prefetch(const void *g2_jac, size_t n) {
         g_pending.keys.push_back(key);
     }
     // (a cache smaller than a batch could hand a promised slot to somebody else before it is built)
-    if (g_pending.pts.size() >= PendingTables::BATCH || g_tabs.max_tables < 4 * PendingTables::BATCH) return g_pending.flush();
+    if (g_pending.pts.size() >= PendingTables::batch() || g_tabs.max_tables < 4 * PendingTables::batch()) return g_pending.flush();
     return LSA_OK;
 }
 

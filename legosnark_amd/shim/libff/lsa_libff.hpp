@@ -37,6 +37,7 @@
 #include "../../csrc/ec.h"
 #include "../../csrc/tower.h"
 #include "../../csrc/fixed_base.h"
+#include "../../csrc/smul_host.h"
 #include <future>
 #include <algorithm>
 #include <atomic>
@@ -63,8 +64,9 @@ enum StatKind { ST_MSM_G1, ST_MSM_G2, ST_PAIRING, ST_G2_PRECOMP, ST_BATCH_EXP, S
 struct Stats {
     std::atomic<uint64_t> calls[ST_KINDS], ns[ST_KINDS], items[ST_KINDS];
     std::atomic<uint64_t> msm_us[4], msm_hits, msm_tables;     // lsa_msm_host_stats summed: h2d, fingerprint wait, bases, kernels
-    std::atomic<uint64_t> smul_fixed{0}, smul_small{0};         // host scalar multiplications served by a fixed-base table / below 2^16
-    bool on = false;
+    // host scalar multiplications by group (G1, G2) and route: fixed-base table / scalar below 2^16 / any other (GLV ladder)
+    std::atomic<uint64_t> smul_n[2][3] = {}, smul_ns[2][3] = {};
+    bool on = false, each = false;                              // LSA_SHIM_STATS=1: totals at exit; =2: also one line per forwarded call
     std::chrono::steady_clock::time_point born = std::chrono::steady_clock::now();
     static const char *name(int k) {
         static const char *const n[ST_KINDS] = {"msm_g1", "msm_g2", "pairing", "g2_precompute", "batch_exp", "normalize", "scalar_mul_host", "sparse_msm"};
@@ -85,8 +87,14 @@ struct Stats {
                         "\"cache_hits\": %llu, \"on_pre_shifted_copies\": %llu}, ",
                 (double)s.msm_us[0].load() * 1e-3, (double)s.msm_us[1].load() * 1e-3, (double)s.msm_us[2].load() * 1e-3, (double)s.msm_us[3].load() * 1e-3,
                 (unsigned long long)s.msm_hits.load(), (unsigned long long)s.msm_tables.load());
-        fprintf(stderr, "\"scalar_mul_host_split\": {\"fixed_base_table\": %llu, \"scalar_below_2^16\": %llu}, ",
-                (unsigned long long)s.smul_fixed.load(), (unsigned long long)s.smul_small.load());
+        fprintf(stderr, "\"scalar_mul_host_split\": {");
+        for (int g = 0; g < 2; g++) {
+            static const char *const route[3] = {"fixed_base_table", "scalar_below_2^16", "other_base"};
+            for (int r = 0; r < 3; r++)
+                fprintf(stderr, "%s\"g%d_%s\": {\"calls\": %llu, \"ms\": %.3f}", g + r ? ", " : "", g + 1, route[r],
+                        (unsigned long long)s.smul_n[g][r].load(), (double)s.smul_ns[g][r].load() * 1e-6);
+        }
+        fprintf(stderr, "}, ");
         fprintf(stderr, "\"inside_ms\": %.3f, \"process_ms\": %.3f}}\n", inside, wall);
     }
     static Stats &get() {
@@ -97,7 +105,7 @@ struct Stats {
             t->msm_hits = 0;
             t->msm_tables = 0;
             const char *e = getenv("LSA_SHIM_STATS");
-            if (e && e[0] == '1') { t->on = true; atexit(report); }
+            if (e && (e[0] == '1' || e[0] == '2')) { t->on = true; t->each = e[0] == '2'; atexit(report); }
             return t;
         }();
         return *s;
@@ -112,8 +120,24 @@ struct StatScope {
         s.items[k].fetch_add(items, std::memory_order_relaxed);
     }
     ~StatScope() {
-        Stats::get().ns[kind].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
-                                        std::memory_order_relaxed);
+        Stats &s = Stats::get();
+        const auto t1 = std::chrono::steady_clock::now();
+        s.ns[kind].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count(), std::memory_order_relaxed);
+        if (s.each)
+            fprintf(stderr, "lsa_shim_call %s at_ms %.3f took_ms %.3f\n", Stats::name(kind), std::chrono::duration<double, std::milli>(t0 - s.born).count(),
+                    std::chrono::duration<double, std::milli>(t1 - t0).count());
+    }
+};
+struct SmulScope {                                                  // one host scalar multiplication: its route is set before it returns
+    const int group;
+    int route = 2;
+    const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit SmulScope(int g) : group(g - 1) {}
+    ~SmulScope() {
+        Stats &s = Stats::get();
+        s.smul_n[group][route].fetch_add(1, std::memory_order_relaxed);
+        s.smul_ns[group][route].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
+                                          std::memory_order_relaxed);
     }
 };
 }  // namespace lsa_shim
@@ -680,13 +704,14 @@ public:
     // for scalars below 2^16.
     friend G_shim operator*(const alt_bn128_Fr &k, const G_shim &p) {
         lsa_shim::StatScope scope(lsa_shim::ST_SCALAR_MUL_HOST, 1);
+        lsa_shim::SmulScope route(GROUP);
         const bigint<4> e = k.as_bigint();
         const Jac base = p.jac();
         Jac res = Jac::inf();
         long top = 255;
         while (top >= 0 && !e.test_bit(top)) --top;
         if (top < 16) {
-            lsa_shim::Stats::get().smul_small.fetch_add(1, std::memory_order_relaxed);
+            route.route = 1;
             for (long i = top; i >= 0; --i) {
                 res = lsa::jac_dbl(res);
                 if (e.test_bit(i)) res = lsa::jac_add(res, base);
@@ -695,7 +720,7 @@ public:
         }
         // the generator (commit.h:43-44,162-163, polytools.h:126-133, poly.h:117: most sites): table look-ups
         if (fixed_base_on() && p.is_generator()) {
-            lsa_shim::Stats::get().smul_fixed.fetch_add(1, std::memory_order_relaxed);
+            route.route = 0;
             return G_shim(generator_table().mul(e.data));
         }
         if (getenv("LSA_SHIM_BASE_HISTOGRAM")) {                      // diagnostic: which bases the generic ladder multiplies, how often
@@ -716,6 +741,10 @@ public:
             });
             (void)reg;
         }
+        // any other base (each is met once or twice: no table pays): GLV halves in width-5 NAF over one chain of 127
+        // doublings (csrc/smul_host.h); LSA_SHIM_GLV=0 keeps the 4-bit window ladder below for an A/B
+        static const bool glv_on = !(getenv("LSA_SHIM_GLV") && getenv("LSA_SHIM_GLV")[0] == '0');
+        if (glv_on) return G_shim(lsa::glv_mul_host(base, e.data));
         Jac tbl[16];
         tbl[0] = Jac::inf();
         tbl[1] = base;

@@ -8,6 +8,7 @@
 #include "smul.h"
 #include "tower.h"
 #include "fixed_base.h"
+#include "smul_host.h"
 #include <chrono>
 using namespace lsa;
 
@@ -68,6 +69,56 @@ static int fixed_base_check(const Jac<F> &G, const char *name, std::mt19937_64 &
     return fails;
 }
 
+// csrc/smul_host.h (the shim's `Fr * P` on a base that is not a generator): GLV halves in width-5 NAF against
+// double-and-add, on a walk of bases with Z != 1, edge scalars (0, 1, small, r - 1, lambda, lambda + 1, 2^127 +- 1) and
+// random ones; infinity as a base; reports the time per product.
+template <class F>
+static int glv_host_check(const char *name, std::mt19937_64 &rng) {
+    const Jac<F> G = GlvGenerator<F>::get();
+    int fails = 0;
+    std::vector<std::array<uint64_t, 4>> ks;
+    for (uint64_t v : {0ull, 1ull, 2ull, 3ull, 15ull, 16ull, 17ull, 31ull, 32ull, 33ull, 0xffffull, 0x10000ull, 0xffffffffffffffffull}) ks.push_back({v, 0, 0, 0});
+    ks.push_back({0xffffffffffffffffull, 0x7fffffffffffffffull, 0, 0});                                            // 2^127 - 1
+    ks.push_back({0, 0x8000000000000000ull, 0, 0});                                                                // 2^127
+    ks.push_back({1, 0x8000000000000000ull, 0, 0});
+    {
+        std::array<uint64_t, 4> rm1, lam;
+        constexpr uint32_t L[8] = LSA_GLV_LAMBDA;
+        for (int i = 0; i < 4; i++) {
+            rm1[i] = (uint64_t)FrParams::MOD[2 * i] | ((uint64_t)FrParams::MOD[2 * i + 1] << 32);
+            lam[i] = (uint64_t)L[2 * i] | ((uint64_t)L[2 * i + 1] << 32);
+        }
+        rm1[0] -= 1;
+        ks.push_back(rm1);
+        ks.push_back(lam);
+        lam[0] += 1;
+        ks.push_back(lam);
+        lam[0] -= 2;
+        ks.push_back(lam);
+    }
+    const size_t edge = ks.size();
+    for (int t = 0; t < 400; t++) {
+        std::array<uint64_t, 4> k = {rng(), rng(), rng(), rng() & 0x1fffffffffffffffull};                          // below 2^253 < r
+        if (t % 7 == 3) { k[2] = k[3] = 0; }                                                                       // 128-bit scalars
+        if (t % 7 == 5) { k[1] = k[2] = k[3] = 0; }
+        ks.push_back(k);
+    }
+    Jac<F> P = G;
+    for (size_t i = 0; i < ks.size(); i++) {
+        const Jac<F> want = plain_mul_any(P, ks[i].data());
+        if (!jac_eq(glv_mul_host(P, ks[i].data()), want)) { if (fails < 5) printf("%s GLV mismatch at scalar %zu\n", name, i); fails++; }
+        if (i % 4 == 0 && !jac_eq(glv_mul_host(P, ks[i].data(), false), want)) { if (fails < 5) printf("%s GLV (Jacobian table) mismatch at scalar %zu\n", name, i); fails++; }
+        P = jac_add(jac_dbl(P), G);                                                                                // next base: 2P + G (Z != 1)
+    }
+    if (!glv_mul_host(Jac<F>::inf(), ks[edge].data()).is_inf()) { printf("%s k * O != O\n", name); fails++; }
+    auto t0 = std::chrono::steady_clock::now();
+    Jac<F> sink = Jac<F>::inf();
+    for (size_t i = edge; i < edge + 100; i++) sink = jac_add(sink, glv_mul_host(P, ks[i].data()));
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 100;
+    printf("%s any base: %.1f us per product (GLV, width-5 NAF)%s\n", name, us, sink.is_inf() ? "." : "");
+    return fails;
+}
+
 static Jac<Fq> plain_mul(const Jac<Fq> &P, const uint32_t k[8]) {
     Jac<Fq> acc = Jac<Fq>::inf();
     for (int i = 255; i >= 0; --i) {
@@ -110,6 +161,8 @@ int main() {
         const Jac<Fq2> G2 = {fq2_const(LSA_G2_GEN_X), fq2_const(LSA_G2_GEN_Y), Fq2::one()};
         fails += fixed_base_check<Fq2>(G2, "G2", rng2);
         fails += fixed_base_check<Fq>(jac_add(jac_dbl(G), G), "G1 (3G, Z != 1)", rng2);
+        fails += glv_host_check<Fq>("G1", rng2);
+        fails += glv_host_check<Fq2>("G2", rng2);
     }
     printf(fails ? "FAILED (%d)\n" : "PASS\n", fails);
     return fails ? 1 : 0;
