@@ -288,6 +288,15 @@ int lsa_fr_scale_upper(const void *old_mont, size_t half, const void *k_mont, vo
  * direction) and coset generators stay on the device; a second vector of the same size is kept as scratch. */
 int lsa_fr_ntt(void *a_mont, size_t log_n, const void *omega_mont, int inverse, const void *coset_g_mont, int on_device);
 
+/* The same four transforms on libfqfft's step_radix2_domain<Fr> of m = 2^big_log + 2^small_log points, small_log <
+ * big_log <= 27: the domain libfqfft's get_evaluation_domain selects for every size that is not a power of two
+ * (src/prototools/interp.h:62, src/gadgets/lipmaa.cc:102 with such an n) [upstream, recalled:
+ * libfqfft/evaluation_domain/domains/step_radix2_domain.tcc].  Evaluation points: omega^(2k) for k < 2^big_log, then
+ * omega sigma^j for j < 2^small_log, sigma = omega^(2^(big_log + 1 - small_log)).  a: m Fr values, in place, coefficients
+ * <-> values in that order.  omega: a primitive 2^(big_log + 1)-th root of unity (HOST, one Fr: the domain's `omega`,
+ * libff::get_root_of_unity(2^(big_log + 1))).  inverse / coset_g / on_device as for lsa_fr_ntt. */
+int lsa_fr_ntt_step(void *a_mont, size_t big_log, size_t small_log, const void *omega_mont, int inverse, const void *coset_g_mont, int on_device);
+
 /* ---- pairing ---------------------------------------------------------------------------- */
 /* out[i] = miller_loop(precompute_G1(P_i), precompute_G2(Q_i)), i < n: replaces libff
  * alt_bn128_pp::precompute_G1 / precompute_G2 / miller_loop (src/utils/globl.h:96-102,

@@ -99,6 +99,7 @@ def lib():
         L.lsa_fr_eval_mle.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.lsa_fr_fold.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.lsa_fr_ntt.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.lsa_fr_ntt_step.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.lsa_fr_sumcheck_round.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.lsa_fr_scale_upper.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.lsa_miller_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
@@ -619,6 +620,26 @@ def fr_ntt(a, omega, inverse=False, coset=None):
     log_n = _log2_exact(a.numel() * a.element_size() // 32)
     _after_torch(a)
     _check(lib().lsa_fr_ntt(_ptr(a), log_n, _host_ptr(omega), 1 if inverse else 0, _host_ptr(cg) if cg is not None else None, 1))
+    return a
+
+
+def fr_ntt_step(a, big_log, small_log, omega, inverse=False, coset=None):
+    """libfqfft step_radix2_domain FFT / iFFT / cosetFFT / icosetFFT over Fr on 2^big_log + 2^small_log values (omega: a
+    primitive 2^(big_log + 1)-th root of unity).  numpy (host, returns a new array) or torch CUDA tensor (device, in place)."""
+    omega = np.ascontiguousarray(omega, dtype=np.uint64).reshape(4)
+    cg = np.ascontiguousarray(coset, dtype=np.uint64).reshape(4) if coset is not None else None
+    m = (1 << big_log) + (1 << small_log)
+    if isinstance(a, np.ndarray):
+        out = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4).copy()
+        if len(out) != m:
+            raise ValueError("fr_ntt_step: expected %d values" % m)
+        _check(lib().lsa_fr_ntt_step(_host_ptr(out), big_log, small_log, _host_ptr(omega), 1 if inverse else 0,
+                                     _host_ptr(cg) if cg is not None else None, 0))
+        return out
+    if a.numel() * a.element_size() != 32 * m:
+        raise ValueError("fr_ntt_step: expected %d values" % m)
+    _after_torch(a)
+    _check(lib().lsa_fr_ntt_step(_ptr(a), big_log, small_log, _host_ptr(omega), 1 if inverse else 0, _host_ptr(cg) if cg is not None else None, 1))
     return a
 
 

@@ -1781,6 +1781,33 @@ int lsa_fr_ntt(void *a, size_t log_n, const void *omega, int inverse, const void
     return LSA_OK;
 }
 
+int lsa_fr_ntt_step(void *a, size_t big_log, size_t small_log, const void *omega, int inverse, const void *coset_g, int on_device) {
+    LSA_TRACE_CALL("fr_ntt_step", ((size_t)1 << (big_log & 31)) + ((size_t)1 << (small_log & 31)));
+    int rc = require_ready();
+    if (rc) return rc;
+    if (big_log > 27 || small_log >= big_log) {
+        set_error("fr_ntt_step: need small_log < big_log <= 27 (got %zu, %zu): omega is a 2^(big_log + 1)-th root of unity of a field of 2-adicity 28", small_log, big_log);
+        return LSA_ERR_INVALID;
+    }
+    if (!a || !omega) { set_error("fr_ntt_step: null argument"); return LSA_ERR_INVALID; }
+    const size_t big = (size_t)1 << big_log, m = big + ((size_t)1 << small_log);
+    Fr w, gco;
+    memcpy(&w, omega, sizeof w);
+    if (coset_g) memcpy(&gco, coset_g, sizeof gco);
+    if (g_stage_ntt_tmp.ensure(big * sizeof(Fr))) { set_error("fr_ntt_step: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    Fr *da = (Fr *)a;
+    if (!on_device) {
+        if (g_stage_ntt_a.ensure(m * sizeof(Fr))) { set_error("fr_ntt_step: hipMalloc failed"); return LSA_ERR_NOMEM; }
+        LSA_UPLOAD(g_stage_ntt_a.p, a, m * sizeof(Fr));
+        da = (Fr *)g_stage_ntt_a.p;
+    }
+    rc = fr_ntt_step_device(da, (unsigned)big_log, (unsigned)small_log, w, inverse != 0, coset_g ? &gco : nullptr, (Fr *)g_stage_ntt_tmp.p, g.stream);
+    if (rc) return rc;
+    if (!on_device) LSA_DOWNLOAD(a, g_stage_ntt_a.p, m * sizeof(Fr));
+    else HIPCHK(hipStreamSynchronize(g.stream));
+    return LSA_OK;
+}
+
 int lsa_fr_fold(const void *old, size_t half, const void *r, void *cur, int on_device) {
     LSA_TRACE_CALL("fr_fold", half);
     int rc = require_ready();

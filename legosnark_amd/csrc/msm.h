@@ -81,6 +81,9 @@ int fr_scale_upper_device(const Fr *d_old, size_t half, const Fr &k, Fr *d_cur, 
 // (unused up to 2^10 points); the twiddle tables are cached per domain (ntt_release frees them)
 int fr_ntt_device(Fr *d_a, unsigned log_n, const Fr &omega, bool inverse, const Fr *coset, Fr *d_tmp, hipStream_t st);
 void ntt_release();
+// libfqfft step_radix2_domain (m = 2^big_log + 2^small_log) in place on d_a; d_scratch: 2^big_log elements; omega: primitive
+// 2^(big_log + 1)-th root of unity
+int fr_ntt_step_device(Fr *d_a, unsigned big_log, unsigned small_log, const Fr &omega, bool inverse, const Fr *coset, Fr *d_scratch, hipStream_t st);
 
 // d_out = sum of n Jacobian points in d_in (device-resident).
 template <class F>

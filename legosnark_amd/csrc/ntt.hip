@@ -128,7 +128,7 @@ struct CosetTables {
     Fr *Glo = nullptr, *Ghi = nullptr;
     uint64_t tick = 0;
 };
-constexpr int NTT_CACHE = 4;
+constexpr int NTT_CACHE = 8;          // a step domain keeps two sub-domains, each in both directions
 DomainTables g_dom[NTT_CACHE];
 CosetTables g_cos[NTT_CACHE];
 uint64_t g_ntt_tick = 0;
@@ -251,6 +251,135 @@ int fr_ntt_device(Fr *d_a, unsigned log_n, const Fr &omega, bool inverse, const 
         hipLaunchKernelGGL(k_ntt_pass, dim3(a.pass.tiles), dim3(256), lds_bytes, st, a);
         src = dst;
     }
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
+
+// ---------------------------------------------------------------- libfqfft's step radix-2 domain
+// step_radix2_domain<Fr> (m = 2^b + 2^s, s < b: the domain get_evaluation_domain picks for every size that is not a
+// power of two, /root/reference/src/prototools/interp.h:62, src/gadgets/lipmaa.cc:102): the evaluation points are
+//   x_k = omega^(2k), k < 2^b   and   x_(2^b + j) = omega sigma^j, j < 2^s,
+// omega a primitive 2^(b+1)-th root of unity, sigma = omega^(2^(b+1-s)).  FFT: a polynomial of degree < m reduced modulo
+// x^big - 1 (c_i = a_i + a_(i+big)) goes through the big radix-2 transform with omega^2; reduced modulo x^big + 1
+// (d_i = a_i - a_(i+big)), scaled by omega^i and wrapped modulo y^small - 1 (e_i = sum_j d_(i + j small)) through the small
+// one with sigma.  iFFT undoes the two transforms and solves the 2 x 2 system for the two halves of the prefix.  The
+// elementwise steps below run on fp.h's Fr (a handful of products per element against the transforms' 13);
+// the two transforms are fr_ntt_device.  Grid-stride loops: lane t meets i = t, t + T, ... and steps its powers by base^T.
+constexpr unsigned STEP_BLOCK = 256;
+struct StepPow { Fr base, stride; };                      // base, base^T (T: the launch's lane count)
+
+// forward, before the transforms: a[0 .. big) <- c, D[0 .. big) <- omega^i d_i (with the coset shift g^i folded in)
+__global__ __launch_bounds__(256) void k_step_fwd_pre(Fr *__restrict__ a, Fr *__restrict__ D, size_t big, size_t small, StepPow w, StepPow g,
+                                                      Fr g_big, int coset) {
+    const size_t T = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= big) return;
+    Fr wi = fr_pow_dev(w.base, t), gi = coset ? fr_pow_dev(g.base, t) : Fr::one();
+    for (size_t i = t; i < big; i += T) {
+        Fr x0 = a[i];
+        if (coset) x0 = x0 * gi;
+        Fr c = x0, d = x0;
+        if (i < small) {
+            Fr x1 = a[i + big];
+            if (coset) x1 = x1 * (gi * g_big);
+            c = x0 + x1;
+            d = x0 - x1;
+        }
+        a[i] = c;
+        D[i] = d * wi;
+        wi = wi * w.stride;
+        if (coset) gi = gi * g.stride;
+    }
+}
+// D[k] <- sum_(j < R) D[k + j q], k < q: R-fold wrap of a vector of R q elements
+__global__ __launch_bounds__(256) void k_step_wrap(Fr *__restrict__ D, size_t q, unsigned R) {
+    const size_t T = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < q; k += T) {
+        Fr s = D[k];
+        for (unsigned j = 1; j < R; j++) s = s + D[k + (size_t)j * q];
+        D[k] = s;
+    }
+}
+// inverse, after the transforms: D[i] <- omega^i U0[i] for small <= i < big, 0 below (the j = 0 term is not part of the sum)
+__global__ __launch_bounds__(256) void k_step_inv_mid(const Fr *__restrict__ a, Fr *__restrict__ D, size_t big, size_t small, StepPow w) {
+    const size_t T = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= big) return;
+    Fr wi = fr_pow_dev(w.base, t);
+    for (size_t i = t; i < big; i += T) {
+        D[i] = i < small ? Fr::zero() : a[i] * wi;
+        wi = wi * w.stride;
+    }
+}
+// a[i], a[big + i] <- (U0[i] +- omega^-i (U1[i] - S[i])) / 2 for i < small; the inverse coset shift on every entry
+__global__ __launch_bounds__(256) void k_step_inv_post(Fr *__restrict__ a, const Fr *__restrict__ S, size_t big, size_t small, StepPow wi_, StepPow gi_,
+                                                       Fr gi_big, Fr half, int coset) {
+    const size_t T = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= big) return;
+    Fr wi = fr_pow_dev(wi_.base, t), gi = coset ? fr_pow_dev(gi_.base, t) : Fr::one();
+    for (size_t i = t; i < big; i += T) {
+        if (i < small) {
+            const Fr u0 = a[i], u1 = (a[big + i] - S[i]) * wi;
+            Fr lo = (u0 + u1) * half, hi = (u0 - u1) * half;
+            if (coset) { lo = lo * gi; hi = hi * (gi * gi_big); }
+            a[i] = lo;
+            a[big + i] = hi;
+        } else if (coset) {
+            a[i] = a[i] * gi;
+        }
+        wi = wi * wi_.stride;
+        if (coset) gi = gi * gi_.stride;
+    }
+}
+
+namespace {
+unsigned step_blocks(size_t n) {
+    const size_t b = (n + STEP_BLOCK - 1) / STEP_BLOCK;
+    return (unsigned)(b < 1 ? 1 : b > 2048 ? 2048 : b);          // 2048 workgroups of 256: eight per CU
+}
+StepPow step_pow(const Fr &base, unsigned blocks) { return {base, host_pow(base, (uint64_t)blocks * STEP_BLOCK)}; }
+int step_wrap(Fr *D, size_t from, size_t to, hipStream_t st) {
+    while (from > to) {
+        const unsigned R = (unsigned)((from / to) < 8 ? (from / to) : 8);
+        const size_t q = from / R;
+        hipLaunchKernelGGL(k_step_wrap, dim3(step_blocks(q)), dim3(STEP_BLOCK), 0, st, D, q, R);
+        from = q;
+    }
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
+}  // namespace
+
+// d_a: 2^big_log + 2^small_log elements, transformed in place; d_scratch: 2^big_log elements.  omega: primitive
+// 2^(big_log + 1)-th root of unity (step_radix2_domain::omega).  Asynchronous on st.
+int fr_ntt_step_device(Fr *d_a, unsigned big_log, unsigned small_log, const Fr &omega, bool inverse, const Fr *coset, Fr *d_scratch, hipStream_t st) {
+    const size_t big = (size_t)1 << big_log, small = (size_t)1 << small_log;
+    const Fr big_omega = fr_mul_hd(omega, omega), small_omega = host_pow(omega, (uint64_t)1 << (big_log + 1 - small_log));
+    const unsigned blocks = step_blocks(big);
+    Fr *D = d_scratch;
+    int rc;
+    if (!inverse) {
+        const Fr g = coset ? *coset : Fr::one();
+        hipLaunchKernelGGL(k_step_fwd_pre, dim3(blocks), dim3(STEP_BLOCK), 0, st, d_a, D, big, small, step_pow(omega, blocks), step_pow(g, blocks),
+                           host_pow(g, big), coset ? 1 : 0);
+        HIPCHK(hipGetLastError());
+        rc = step_wrap(D, big, small, st);
+        if (rc) return rc;
+        // e lives in D[0 .. small), its transform's scratch right behind it (2 small <= big); then D is free for the big one
+        rc = fr_ntt_device(D, small_log, small_omega, false, nullptr, D + small, st);
+        if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(d_a + big, D, small * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        return fr_ntt_device(d_a, big_log, big_omega, false, nullptr, D, st);
+    }
+    rc = fr_ntt_device(d_a, big_log, big_omega, true, nullptr, D, st);
+    if (rc) return rc;
+    rc = fr_ntt_device(d_a + big, small_log, small_omega, true, nullptr, D, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_step_inv_mid, dim3(blocks), dim3(STEP_BLOCK), 0, st, (const Fr *)d_a, D, big, small, step_pow(omega, blocks));
+    HIPCHK(hipGetLastError());
+    rc = step_wrap(D, big, small, st);
+    if (rc) return rc;
+    const Fr omega_inv = omega.inverse(), g_inv = coset ? coset->inverse() : Fr::one();
+    hipLaunchKernelGGL(k_step_inv_post, dim3(blocks), dim3(STEP_BLOCK), 0, st, d_a, (const Fr *)D, big, small, step_pow(omega_inv, blocks),
+                       step_pow(g_inv, blocks), host_pow(g_inv, big), Fr::from_u32(2).inverse(), coset ? 1 : 0);
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }

@@ -646,3 +646,88 @@ void oracle_fr_domain_transform(ofp_t *a, size_t log_n, const ofp_t *omega, int 
         for (size_t i = 1; i < n; i++) { fr_mul_(&a[i], &a[i], &u); fr_mul_(&u, &u, &gi); }
     }
 }
+
+/* libfqfft step_radix2_domain<FieldT>::{FFT, iFFT, cosetFFT, icosetFFT} (m = big_m + small_m, big_m = 2^big_log, small_m =
+ * 2^small_log < big_m; omega a primitive 2 big_m-th root of unity, big_omega = omega^2, small_omega =
+ * get_root_of_unity(small_m) = omega^(2 big_m / small_m)) [upstream, recalled:
+ * libfqfft/evaluation_domain/domains/step_radix2_domain.tcc -- the c / d / e vectors of FFT, the U0 / U1 / tmp vectors
+ * of iFFT, in upstream's order of operations].  Checked against the definition (values of the polynomial at
+ * omega^(2k), then at omega small_omega^j) in tests/test_oracle_golden.py. */
+static void fr_from_size(ofp_t *out, size_t n) {
+    ofp_t one, acc, bit;
+    fr_one(&one);
+    fr_zero(&acc);
+    bit = one;
+    for (size_t v = n; v; v >>= 1) {
+        if (v & 1) fr_add_(&acc, &acc, &bit);
+        fr_add_(&bit, &bit, &bit);
+    }
+    *out = acc;
+}
+static void fr_scale_by_powers(ofp_t *a, size_t n, const ofp_t *g) {   /* _multiply_by_coset */
+    ofp_t u = *g;
+    for (size_t i = 1; i < n; i++) { fr_mul_(&a[i], &a[i], &u); fr_mul_(&u, &u, g); }
+}
+void oracle_fr_step_domain_transform(ofp_t *a, size_t big_log, size_t small_log, const ofp_t *omega, int inverse, const ofp_t *coset_g) {
+    const size_t big_m = (size_t)1 << big_log, small_m = (size_t)1 << small_log, m = big_m + small_m, compr = big_m / small_m;
+    ofp_t big_omega, small_omega, one;
+    fr_one(&one);
+    fr_mul_(&big_omega, omega, omega);
+    small_omega = *omega;
+    for (size_t e = small_m; e < 2 * big_m; e <<= 1) fr_mul_(&small_omega, &small_omega, &small_omega);
+    ofp_t *c = (ofp_t *)calloc(big_m, sizeof(ofp_t)), *d = (ofp_t *)calloc(big_m, sizeof(ofp_t)), *e = (ofp_t *)calloc(small_m, sizeof(ofp_t));
+    if (!inverse) {
+        if (coset_g) fr_scale_by_powers(a, m, coset_g);
+        ofp_t omega_i = one;
+        for (size_t i = 0; i < big_m; i++) {
+            if (i < small_m) { fr_add_(&c[i], &a[i], &a[i + big_m]); fr_sub_(&d[i], &a[i], &a[i + big_m]); }
+            else { c[i] = a[i]; d[i] = a[i]; }
+            fr_mul_(&d[i], &omega_i, &d[i]);
+            fr_mul_(&omega_i, &omega_i, omega);
+        }
+        for (size_t i = 0; i < small_m; i++) {
+            fr_zero(&e[i]);
+            for (size_t j = 0; j < compr; j++) fr_add_(&e[i], &e[i], &d[i + j * small_m]);
+        }
+        oracle_fr_radix2_fft(c, big_log, &big_omega);
+        oracle_fr_radix2_fft(e, small_log, &small_omega);
+        for (size_t i = 0; i < big_m; i++) a[i] = c[i];
+        for (size_t i = 0; i < small_m; i++) a[i + big_m] = e[i];
+    } else {
+        ofp_t *U0 = c, *U1 = e, *tmp = d, inv, sz, omega_i, over_two, two;
+        for (size_t i = 0; i < big_m; i++) U0[i] = a[i];
+        for (size_t i = 0; i < small_m; i++) U1[i] = a[big_m + i];
+        ofp_inv(&inv, &big_omega, 1);
+        oracle_fr_radix2_fft(U0, big_log, &inv);
+        ofp_inv(&inv, &small_omega, 1);
+        oracle_fr_radix2_fft(U1, small_log, &inv);
+        fr_from_size(&sz, big_m);
+        ofp_inv(&inv, &sz, 1);
+        for (size_t i = 0; i < big_m; i++) fr_mul_(&U0[i], &U0[i], &inv);
+        fr_from_size(&sz, small_m);
+        ofp_inv(&inv, &sz, 1);
+        for (size_t i = 0; i < small_m; i++) fr_mul_(&U1[i], &U1[i], &inv);
+        omega_i = one;
+        for (size_t i = 0; i < big_m; i++) { fr_mul_(&tmp[i], &U0[i], &omega_i); fr_mul_(&omega_i, &omega_i, omega); }
+        for (size_t i = small_m; i < big_m; i++) a[i] = U0[i];                       /* A_suffix */
+        for (size_t i = 0; i < small_m; i++)
+            for (size_t j = 1; j < compr; j++) fr_sub_(&U1[i], &U1[i], &tmp[i + j * small_m]);
+        ofp_inv(&inv, omega, 1);
+        omega_i = one;
+        for (size_t i = 0; i < small_m; i++) { fr_mul_(&U1[i], &U1[i], &omega_i); fr_mul_(&omega_i, &omega_i, &inv); }
+        fr_add_(&two, &one, &one);
+        ofp_inv(&over_two, &two, 1);
+        for (size_t i = 0; i < small_m; i++) {                                       /* A_prefix */
+            ofp_t s, t;
+            fr_add_(&s, &U0[i], &U1[i]);
+            fr_sub_(&t, &U0[i], &U1[i]);
+            fr_mul_(&a[i], &s, &over_two);
+            fr_mul_(&a[big_m + i], &t, &over_two);
+        }
+        if (coset_g) {
+            ofp_inv(&inv, coset_g, 1);
+            fr_scale_by_powers(a, m, &inv);
+        }
+    }
+    free(c); free(d); free(e);
+}

@@ -136,6 +136,8 @@ void oracle_fr_scale_upper(ofp_t *cur, const ofp_t *old, const ofp_t *k, size_t 
  * reference call sites /root/reference/src/gadgets/lipmaa.cc:68-81,102-175 */
 void oracle_fr_radix2_fft(ofp_t *a, size_t log_n, const ofp_t *omega);
 void oracle_fr_domain_transform(ofp_t *a, size_t log_n, const ofp_t *omega, int inverse, const ofp_t *coset_g);
+/* libfqfft step_radix2_domain (2^big_log + 2^small_log points); omega: primitive 2^(big_log + 1)-th root of unity */
+void oracle_fr_step_domain_transform(ofp_t *a, size_t big_log, size_t small_log, const ofp_t *omega, int inverse, const ofp_t *coset_g);
 
 /* ---- test-input helper: out = sum_i a[i]*b[i] in Fr ---- */
 void oracle_fr_dot(ofp_t *out, const ofp_t *a, const ofp_t *b, size_t n);

@@ -284,6 +284,16 @@ def fr_domain_transform(a, omega, inverse=False, coset=None):
     return a
 
 
+def fr_step_domain_transform(a, big_log, small_log, omega, inverse=False, coset=None):
+    """libfqfft step_radix2_domain FFT / iFFT / cosetFFT / icosetFFT on 2^big_log + 2^small_log values."""
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4).copy()
+    assert len(a) == (1 << big_log) + (1 << small_log)
+    cg = _p(np.ascontiguousarray(coset, dtype=np.uint64)) if coset is not None else None
+    lib().oracle_fr_step_domain_transform(_p(a), C.c_size_t(big_log), C.c_size_t(small_log), _p(np.ascontiguousarray(omega, dtype=np.uint64)),
+                                          C.c_int(1 if inverse else 0), cg)
+    return a
+
+
 def reduced_pairing(p, q):
     p = np.ascontiguousarray(p, dtype=np.uint64)
     q = np.ascontiguousarray(q, dtype=np.uint64)

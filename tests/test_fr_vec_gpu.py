@@ -215,3 +215,57 @@ def test_ntt_domains_alternate_and_tables_are_reused(lsa):
     lsa.fr_ntt(d_a, w, coset=g7)
     lsa.synchronize()
     assert np.array_equal(d_a.cpu().numpy().view(np.uint64), lsa.fr_ntt(a, w, coset=g7))
+
+
+@pytest.mark.parametrize("big_log,small_log", [(1, 0), (2, 1), (3, 0), (5, 2), (9, 8), (10, 0), (10, 9), (11, 3), (12, 10), (14, 13), (16, 5), (17, 16), (18, 12)])
+def test_step_domain_vs_oracle(lsa, big_log, small_log):
+    """libfqfft step_radix2_domain (the domain of every size that is not a power of two) FFT / iFFT / cosetFFT / icosetFFT,
+    byte for byte against its restatement in the oracle: sub-transforms of one, two and three passes, small_m = 1, and
+    small_m = big_m / 2."""
+    m = (1 << big_log) + (1 << small_log)
+    a, _ = o.random_scalars(m, seed=5000 + 32 * big_log + small_log)
+    w = o.fr_mont(o.fr_root_of_unity(big_log + 1))
+    g = o.fr_mont(o.FR_GENERATOR)
+    for inverse in (False, True):
+        for coset in (None, g):
+            got = lsa.fr_ntt_step(a, big_log, small_log, w, inverse=inverse, coset=coset)
+            want = o.fr_step_domain_transform(a, big_log, small_log, w, inverse=inverse, coset=coset)
+            assert np.array_equal(got, want), (inverse, coset is not None)
+
+
+def test_step_domain_round_trip_and_spot_values_at_full_size_on_device(lsa):
+    """m = 2^22 + 2^21 (three quarters of 2^23) on the device: icosetFFT(cosetFFT(a)) = a, and FFT's values at sampled domain
+    points equal Horner's at omega^(2k) / omega sigma^j for a sparse polynomial."""
+    import torch
+    big_log, small_log = 22, 21
+    big, small = 1 << big_log, 1 << small_log
+    m = big + small
+    a, _ = o.random_scalars(m, seed=77)
+    w_int = o.fr_root_of_unity(big_log + 1)
+    w, g = o.fr_mont(w_int), o.fr_mont(o.FR_GENERATOR)
+    d_a = torch.from_numpy(a.view(np.int64).copy()).to("cuda:0")
+    lsa.fr_ntt_step(d_a, big_log, small_log, w, coset=g)
+    assert not np.array_equal(d_a.cpu().numpy().view(np.uint64), a)
+    lsa.fr_ntt_step(d_a, big_log, small_log, w, inverse=True, coset=g)
+    assert np.array_equal(d_a.cpu().numpy().view(np.uint64), a)
+    # a(x) = 3 + 5 x^7 + 11 x^(big + 12345) + x^(m - 1)
+    R = o.R
+    terms = {0: 3, 7: 5, big + 12345: 11, m - 1: 1}
+    sp = np.zeros((m, 4), dtype=np.uint64)
+    for i, c in terms.items():
+        sp[i] = o.fr_mont(c)
+    got = lsa.fr_ntt_step(sp, big_log, small_log, w)
+    sigma = pow(w_int, 2 * big // small, R)
+    for idx in (0, 1, 2, big // 2 + 3, big - 1, big, big + 1, big + small // 3, m - 1):
+        x = pow(w_int, 2 * idx, R) if idx < big else w_int * pow(sigma, idx - big, R) % R
+        want = sum(c * pow(x, i, R) for i, c in terms.items()) % R
+        assert np.array_equal(got[idx], o.fr_mont(want).reshape(4)), idx
+
+
+def test_step_domain_arguments_are_checked(lsa):
+    a, _ = o.random_scalars(3, seed=1)
+    w = o.fr_mont(o.fr_root_of_unity(2))
+    with pytest.raises(Exception, match="big_log"):
+        lsa._check(lsa.lib().lsa_fr_ntt_step(lsa._host_ptr(a), 28, 0, lsa._host_ptr(w), 0, None, 0))  # omega would be a 2^29-th root of unity
+    with pytest.raises(Exception, match="big_log"):
+        lsa._check(lsa.lib().lsa_fr_ntt_step(lsa._host_ptr(a), 1, 1, lsa._host_ptr(w), 0, None, 0))   # small_m = big_m: a power of two

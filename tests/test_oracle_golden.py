@@ -310,3 +310,30 @@ def test_oracle_radix2_fft_is_the_dft():
         assert cos == [sum(a[i] * pow(g, i, R) * pow(w, i * k, R) for i in range(n)) % R for k in range(n)]
         back = _fr_ints(o.fr_domain_transform(o.fr_domain_transform(a_m, w_m, coset=o.fr_mont(g)), w_m, inverse=True, coset=o.fr_mont(g)))
         assert back == a
+
+
+def test_oracle_step_domain_is_evaluation_at_its_points():
+    """The restated step_radix2_domain (m = 2^b + 2^s) against its definition in Python integers: FFT gives the values of
+    the polynomial at omega^(2k), k < 2^b, then at omega sigma^j, j < 2^s (libfqfft's get_domain_element order); iFFT and
+    the coset variants by their defining identities."""
+    R = o.R
+    for big_log, small_log in ((1, 0), (2, 0), (2, 1), (3, 1), (4, 3), (5, 0), (5, 2)):
+        big, small = 1 << big_log, 1 << small_log
+        m = big + small
+        w = o.fr_root_of_unity(big_log + 1)
+        sigma = pow(w, 2 * big // small, R)
+        assert sigma == o.fr_root_of_unity(small_log)                       # get_root_of_unity(small_m)
+        pts = [pow(w, 2 * k, R) for k in range(big)] + [w * pow(sigma, j, R) % R for j in range(small)]
+        assert len(set(pts)) == m
+        a_m, a = o.random_scalars(m, seed=900 + 10 * big_log + small_log)
+        a = [int(x) for x in a]
+        w_m, g = o.fr_mont(w), 5
+        ev = lambda cs, x: sum(c * pow(x, i, R) for i, c in enumerate(cs)) % R
+        got = _fr_ints(o.fr_step_domain_transform(a_m, big_log, small_log, w_m))
+        assert got == [ev(a, x) for x in pts], (big_log, small_log)
+        back = o.fr_step_domain_transform(o.fr_step_domain_transform(a_m, big_log, small_log, w_m), big_log, small_log, w_m, inverse=True)
+        assert _fr_ints(back) == a
+        cos = o.fr_step_domain_transform(a_m, big_log, small_log, w_m, coset=o.fr_mont(g))
+        assert _fr_ints(cos) == [ev(a, g * x % R) for x in pts]
+        back = o.fr_step_domain_transform(cos, big_log, small_log, w_m, inverse=True, coset=o.fr_mont(g))
+        assert _fr_ints(back) == a
