@@ -66,3 +66,19 @@ def test_binary_output_round_trips(tmp_path):
 
 def test_reproducible_randomness_only_under_the_test_macro(tmp_path):
     build_and_run(tmp_path, ["-DLSA_SHIM_TEST_SEED"])
+
+
+def test_evaluation_domains_select_and_behave_as_libfqfft(tmp_path):
+    """tests/cpp/test_shim_domains.cc: which domain get_evaluation_domain returns for a size (basic radix-2 for powers of
+    two, the step domain for 2^b + 2^s, the rounded size otherwise) and the step domain's host helpers -- points,
+    vanishing polynomial, Lagrange coefficients, add_poly_Z, divide_by_Z_on_coset -- against their definitions."""
+    import legosnark_amd
+    if not os.path.exists(legosnark_amd.LIB_PATH):
+        legosnark_amd.build()
+    exe = str(tmp_path / "shim_domains")
+    libdir = os.path.join(ROOT, "legosnark_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-w", "-I", os.path.join(ROOT, "legosnark_amd", "shim"),
+                           os.path.join(ROOT, "tests", "cpp", "test_shim_domains.cc"), "-o", exe,
+                           "-L" + libdir, "-llegosnark_amd", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-3000:]
