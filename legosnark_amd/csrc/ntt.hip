@@ -332,8 +332,10 @@ __global__ __launch_bounds__(256) void k_step_inv_post(Fr *__restrict__ a, const
 
 namespace {
 unsigned step_blocks(size_t n) {
-    const size_t b = (n + STEP_BLOCK - 1) / STEP_BLOCK;
-    return (unsigned)(b < 1 ? 1 : b > 2048 ? 2048 : b);          // 2048 workgroups of 256: eight per CU
+    // eight elements per lane where there are enough: a lane's first power costs ~30 products (square-and-multiply), the
+    // later ones one each
+    const size_t b = (n + 8 * STEP_BLOCK - 1) / (8 * STEP_BLOCK);
+    return (unsigned)(b < 1 ? 1 : b > 2048 ? 2048 : b);          // at most 2048 workgroups of 256: eight per CU
 }
 StepPow step_pow(const Fr &base, unsigned blocks) { return {base, host_pow(base, (uint64_t)blocks * STEP_BLOCK)}; }
 int step_wrap(Fr *D, size_t from, size_t to, hipStream_t st) {
