@@ -82,6 +82,24 @@ def ntt():
             print(json.dumps({"op": "ntt " + name, "log_n": log_n, "ms": round(dt * 1e3, 4), "passes": passes,
                               "algorithmic_GBps": round(64 * n / dt / 1e9, 1), "frac_of_8TBps": round(64 * n / dt / 8e12, 4),
                               "moved_GBps": round(64 * n * passes / dt / 1e9, 1), "G_field_mults_per_s": round(mults / dt / 1e9, 1)}), flush=True)
+    # libfqfft's step radix-2 domain (sizes that are not powers of two): m = 2^b + 2^s
+    for big_log, small_log in ((10, 9), (16, 12), (20, 19), (20, 10), (22, 21), (23, 22)):
+        m = (1 << big_log) + (1 << small_log)
+        gen = torch.Generator(device="cuda:0").manual_seed(100 + big_log)
+        d_a = torch.randint(0, 1 << 62, (m, 4), dtype=torch.int64, device="cuda:0", generator=gen)
+        d_a[:, 3] &= (1 << 60) - 1
+        w = o.fr_mont(o.fr_root_of_unity(big_log + 1))
+        for name, kw in (("FFT", {}), ("icosetFFT", {"inverse": True, "coset": g})):
+            lsa.fr_ntt_step(d_a, big_log, small_log, w, **kw)
+            lsa.synchronize()
+            reps = 20 if big_log <= 20 else 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                lsa.fr_ntt_step(d_a, big_log, small_log, w, **kw)
+            lsa.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            print(json.dumps({"op": "step domain " + name, "m": "2^%d + 2^%d" % (big_log, small_log), "ms": round(dt * 1e3, 4),
+                              "algorithmic_GBps": round(64 * m / dt / 1e9, 1), "frac_of_8TBps": round(64 * m / dt / 8e12, 4)}), flush=True)
 
 
 if __name__ == "__main__":
