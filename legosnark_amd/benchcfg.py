@@ -244,10 +244,10 @@ def measure(lsa, torch, np, dev, log2n=20, d=20, log2pairs=12, reps=5, only=None
         lsa.synchronize()
         ok = ok and (np.array_equal(val, fold_end) or np.array_equal(val, host(cur[0])))
         # algorithmic bytes: v read once, w written once (witness); the table read once (evalMLE).  Bytes moved: what the
-        # launches read and write -- two rounds per launch in registers (fr_vec.hip), so a launch over n_in inputs moves
-        # 64 n_in (witness) / 40 n_in (evalMLE) bytes and the launches' inputs are N, N/4, N/16, ...
+        # launches read and write -- twelve rounds per pass (fr_vec.hip: k_fold_pairs_fused), so a pass over n_in inputs
+        # moves 64 n_in (witness) / 32 n_in (evalMLE) bytes + n_in / 4096 outputs, and the passes' inputs are N, N / 4096
         bw_alg, be_alg = 64 * n, 32 * n
-        bw, be = 64 * n * 4 // 3, 40 * n * 4 // 3
+        bw, be = 64 * n + (64 + 32) * (n >> 12), 32 * n + (32 + 32) * (n >> 12)
         emit("Fr fold d=24: CPpoly witness recursion (poly.h:55-67) and evalMLE (polytools.h:207-234) on a resident vector of 2^24", ok,
              {"witness_ms": ms_w, "eval_mle_ms": ms_e, "algorithmic_bytes": {"witness": bw_alg, "eval_mle": be_alg}, "bytes_moved": {"witness": bw, "eval_mle": be},
               "hbm": {"bound": "hbm", "peak_GBps": HBM_PEAK_GBS,
@@ -255,9 +255,10 @@ def measure(lsa, torch, np, dev, log2n=20, d=20, log2pairs=12, reps=5, only=None
                       "witness_frac_algorithmic": round(bw_alg / ms_w / 1e6 / HBM_PEAK_GBS, 4),
                       "eval_mle_moved_GBps": round(be / ms_e / 1e6, 1), "eval_mle_frac_moved": round(be / ms_e / 1e6 / HBM_PEAK_GBS, 4),
                       "eval_mle_frac_algorithmic": round(be_alg / ms_e / 1e6 / HBM_PEAK_GBS, 4)},
-              "note": "all d rounds of each recursion: one product per output element on 29-bit limbs, two rounds per launch in registers, the "
-                      "last eleven rounds in one workgroup, the launch sequence replayed as a hipGraph; with every round through memory "
-                      "(round 4) the same recursions moved 128 N / 96 N bytes"})
+              "note": "all d rounds of each recursion: one product per output element on 29-bit limbs, twelve rounds per pass (two in "
+                      "registers, ten as a tree in LDS), the last rounds in one workgroup, the launch sequence replayed as a hipGraph; "
+                      "with two rounds per launch (start of round 5) the same recursions moved 85 N / 53 N bytes, with every round "
+                      "through memory (round 4) 128 N / 96 N"})
         del d_v, d_w, cur
 
     if on("ntt"):

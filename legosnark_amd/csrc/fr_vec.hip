@@ -9,17 +9,17 @@
 //   k_fold_halves  one round of DPMle::pushRandomness
 //                  (/root/reference/src/prototools/mle.h:199-210):
 //                      cur[p] = old[p]*(1-r) + old[p+half]*r
-//                  also the whole of MultiVPolyT::evalMLE
-//                  (/root/reference/src/prototools/polytools.h:207-234): the reference builds the
-//                  table of eq-monomials and takes a dot product; folding the top variable d
-//                  times gives the same element of Fr, and Fr values are canonical Montgomery
-//                  residues, so the 32 output bytes are identical.
+//   evalMLE        MultiVPolyT::evalMLE (/root/reference/src/prototools/polytools.h:207-234): the reference builds
+//                  the table of eq-monomials and takes a dot product; folding one variable after the other (here:
+//                  from the bottom, the pairs recursion without its coefficients) gives the same element of Fr, and
+//                  Fr values are canonical Montgomery residues, so the 32 output bytes are identical.
 // Both are HBM streams.  Round 5: ONE product per output element instead of two -- v' = v0 + r (v1 - v0) is the same
 // field element as -v0 (r - 1) + v1 r, and Fr values are canonical, so the bytes are the reference's -- on the 29-bit
-// limbs of fr29.h (the round's r is put into 2^261 form once per thread, so data words go in and out without
-// conversion: a fifth of the instructions of two 32-bit CIOS products), and the rounds of at most FOLD_TAIL output
-// elements run inside ONE workgroup (a barrier between rounds instead of a launch each).  Algorithmic bytes per round
-// over m output elements: pairs 64 B in + 64 B out, halves 64 B in + 32 B out.
+// limbs of fr29.h (the round's r is put into 2^261 form once per workgroup, so data words go in and out without
+// conversion: a fifth of the instructions of two 32-bit CIOS products).  The recursions run up to TWELVE rounds per pass
+// over the data (k_fold_pairs_fused: two rounds in registers, the others as a tree in LDS) and their last rounds inside
+// ONE workgroup (k_fold_pairs_tail: a barrier between rounds instead of a launch each): the witness recursion at d = 24
+// reads v once and writes every coefficient once (1.07 GB), evalMLE reads its table once (0.54 GB).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -30,71 +30,104 @@
 
 namespace lsa {
 
-static constexpr size_t FOLD_TAIL = 2048;          // rounds of at most this many output elements: one workgroup, no launches
 
 // the round's scalar in 2^261 form (Montgomery value * 32: the canonical words of r * 2^261), as limbs
 __device__ __forceinline__ Fr29 fr_to_261(const Fr &r) { return Fr29::from_words(r * Fr::from_u32(32)); }
 // x * r as libff words: x's words are read as the 2^261 form of x / 32, the product with r in 2^261 form is x r 2^256
 __device__ __forceinline__ Fr fr_mul_261(const Fr &x, const Fr29 &r261) { return mul(Fr29::from_words(x), r261).canonical2().to_words(); }
 
-__global__ __launch_bounds__(256) void k_fold_pairs(const Fr *__restrict__ v, size_t m, const Fr *__restrict__ r_ptr,
-                                                    Fr *__restrict__ w, Fr *__restrict__ vout) {
-    const Fr29 r261 = fr_to_261(*r_ptr);
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < m; p += (size_t)gridDim.x * blockDim.x) {
-        const Fr a = v[2 * p], b = v[2 * p + 1];
-        const Fr d = b - a;
-        w[p] = d;
-        vout[p] = a + fr_mul_261(d, r261);               // = -a (r - 1) + b r
+// Up to FUSE_ROUNDS consecutive rounds in ONE pass over the data: round j + 1 pairs up neighbouring outputs of round j,
+// so a workgroup that owns a tile of 2^tr neighbouring inputs runs tr rounds on its own -- two in registers (a lane takes
+// four neighbouring inputs to one value), the others as a tree over the tile's values in LDS --
+// and the intermediate vectors never reach memory: the witness recursion at d = 24 is a pass of 12 rounds (v read
+// once, every w written once) and the one-workgroup tail; evalMLE (WRITE_W = false) reads its table once and writes 2^12
+// values.  The tree's upper levels keep few lanes busy (a tile of 4096 inputs spends 3072 of its 4095 products at full
+// width); the other workgroups of the CU stream meanwhile.  The rounds' scalars are put into 2^261 form once per workgroup.
+//   m0: outputs of this launch's first round over ALL tiles (tiles << (tr - 1)); round j's witness coefficients go to
+//   w0 + m0 + m0 / 2 + ... (j terms), a tile's share of them contiguous; vout[tile] = the tile's value after tr rounds.
+static constexpr unsigned FUSE_ROUNDS = 12;
+template <bool WRITE_W>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fold_pairs_fused(const Fr *__restrict__ v, size_t tiles, unsigned tr, const Fr *__restrict__ r_ptr,
+                                                          Fr *__restrict__ w0, size_t m0, Fr *__restrict__ vout) {
+    __shared__ uint32_t s_r[FUSE_ROUNDS][9];
+    __shared__ Fr s_x[(size_t)1 << (FUSE_ROUNDS - 2)];
+    if (threadIdx.x < tr) {
+        const Fr29 c = fr_to_261(r_ptr[threadIdx.x]);
+#pragma unroll
+        for (int k = 0; k < 9; k++) s_r[threadIdx.x][k] = c.l[k];
     }
-}
-// R consecutive rounds in ONE pass: round j + 1 pairs up neighbouring outputs of round j, so a lane that owns 2^R
-// neighbouring inputs runs all R rounds in registers -- the intermediate vectors never reach memory (3 rounds: 16
-// elements moved per 8 inputs instead of 28) and R rounds cost one launch.  m: outputs of the LAST of the R rounds;
-// w0: where the first round's witness coefficients go, the later rounds' follow (2^(R-1) m, 2^(R-2) m, ... entries).
-template <int R>
-__global__ __launch_bounds__(256) void k_fold_pairs_multi(const Fr *__restrict__ v, size_t m, const Fr *__restrict__ r_ptr, Fr *__restrict__ w0,
-                                                          Fr *__restrict__ vout) {
-    constexpr int IN = 1 << R;
-    Fr29 r261[R];
+    __syncthreads();
+    auto scalar = [&](unsigned j) {
+        Fr29 c;                                                // the same value in every lane: kept in scalar registers
 #pragma unroll
-    for (int j = 0; j < R; j++) r261[j] = fr_to_261(r_ptr[j]);
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < m; t += (size_t)gridDim.x * blockDim.x) {
-        Fr x[IN];
-#pragma unroll
-        for (int i = 0; i < IN; i++) x[i] = v[(size_t)IN * t + i];
-        Fr *w = w0;
-        size_t outs = m << (R - 1);                      // outputs of the current round
-#pragma unroll
-        for (int j = 0; j < R; j++) {
-            const int cnt = IN >> (j + 1);               // this lane's outputs in round j
-#pragma unroll
-            for (int i = 0; i < cnt; i++) {
-                const Fr d = x[2 * i + 1] - x[2 * i];
-                w[(size_t)cnt * t + i] = d;
-                x[i] = x[2 * i] + fr_mul_261(d, r261[j]);
+        for (int k = 0; k < 9; k++) c.l[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_r[j][k]);
+        return c;
+    };
+    const size_t vals = (size_t)1 << (tr - 2);               // values a tile leaves in LDS after its first two rounds
+    for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        {
+            const Fr29 r0 = scalar(0), r1 = scalar(1);
+            const Fr *in = v + (tile << tr);
+            Fr *wa = w0 + (tile << (tr - 1)), *wb = w0 + m0 + (tile << (tr - 2));
+#pragma unroll 1
+            for (size_t u = threadIdx.x; u < vals; u += 256) {
+                const Fr x0 = in[4 * u], x1 = in[4 * u + 1], x2 = in[4 * u + 2], x3 = in[4 * u + 3];
+                const Fr d0 = x1 - x0, d1 = x3 - x2;
+                if (WRITE_W) { wa[2 * u] = d0; wa[2 * u + 1] = d1; }
+                const Fr y0 = x0 + fr_mul_261(d0, r0), y1 = x2 + fr_mul_261(d1, r0);
+                const Fr d = y1 - y0;
+                if (WRITE_W) wb[u] = d;
+                s_x[u] = y0 + fr_mul_261(d, r1);
             }
-            w += outs;
-            outs >>= 1;
         }
-        vout[t] = x[0];
+        __syncthreads();
+        size_t woff = m0 + (m0 >> 1);                        // where round 2's coefficients start
+        for (unsigned j = 2; j < tr; j++) {
+            const size_t cnt = (size_t)1 << (tr - 1 - j);    // this tile's outputs in round j: at most 512
+            const Fr29 rj = scalar(j);
+            Fr *wj = w0 + woff + (tile << (tr - 1 - j));
+            Fr y[2];
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const size_t u = threadIdx.x + (size_t)it * 256;
+                if (u < cnt) {
+                    const Fr a = s_x[2 * u], b = s_x[2 * u + 1];
+                    const Fr d = b - a;
+                    if (WRITE_W) wj[u] = d;
+                    y[it] = a + fr_mul_261(d, rj);
+                }
+            }
+            __syncthreads();                                 // every pair has been read
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const size_t u = threadIdx.x + (size_t)it * 256;
+                if (u < cnt) s_x[u] = y[it];
+            }
+            __syncthreads();
+            woff += m0 >> j;
+        }
+        if (threadIdx.x == 0) vout[tile] = s_x[0];
+        __syncthreads();                                     // s_x is free for the next tile
     }
 }
+
 // the remaining rounds (m_first, m_first / 2, ... 1 output elements) by one workgroup; round j reads what round j - 1
-// wrote (ping-pong between bufA and bufB, continuing the caller's parity), r_ptr / w advance per round
+// wrote (ping-pong between bufA and bufB, continuing the caller's parity), r_ptr / w advance per round.
+// w == nullptr: evalMLE's last rounds -- no coefficients kept; out != nullptr: the last round's value goes there
 __global__ __launch_bounds__(256) void k_fold_pairs_tail(const Fr *src, size_t m_first, const Fr *__restrict__ r_ptr, Fr *w, Fr *bufA, Fr *bufB,
-                                                         unsigned parity) {
+                                                         unsigned parity, Fr *out) {
     for (size_t m = m_first; m >= 1; m >>= 1) {
         const Fr29 r261 = fr_to_261(*r_ptr);
-        Fr *dst = (parity & 1u) ? bufB : bufA;
+        Fr *dst = (m == 1 && out) ? out : ((parity & 1u) ? bufB : bufA);
         for (size_t p = threadIdx.x; p < m; p += 256) {
             const Fr a = src[2 * p], b = src[2 * p + 1];
             const Fr d = b - a;
-            w[p] = d;
+            if (w) w[p] = d;
             dst[p] = a + fr_mul_261(d, r261);
         }
         __syncthreads();                                 // the block's global writes are visible to the block
         src = dst;
-        w += m;
+        if (w) w += m;
         r_ptr++;
         parity++;
     }
@@ -108,46 +141,6 @@ __global__ __launch_bounds__(256) void k_fold_halves(const Fr *old, size_t half,
         cur[p] = a + fr_mul_261(old[p + half] - a, r261);   // = a (1 - r) + old[p + half] r
     }
 }
-// R consecutive rounds of the top-variable fold in ONE pass: with q outputs after the R rounds, lane p < q owns the 2^R
-// inputs old[p + j q]; round 1 pairs (j, j + 2^(R-1)) with r_hi[0], round 2 (j, j + 2^(R-2)) with r_hi[-1], ... -- the
-// intermediate vectors never reach memory (evalMLE reads its table ONCE).  cur must not alias old (lanes read q apart).
-template <int R>
-__global__ __launch_bounds__(256) void k_fold_halves_multi(const Fr *__restrict__ old, size_t q, const Fr *__restrict__ r_hi, Fr *__restrict__ cur) {
-    constexpr int IN = 1 << R;
-    Fr29 r261[R];
-#pragma unroll
-    for (int j = 0; j < R; j++) r261[j] = fr_to_261(*(r_hi - j));
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < q; p += (size_t)gridDim.x * blockDim.x) {
-        Fr x[IN];
-#pragma unroll
-        for (int i = 0; i < IN; i++) x[i] = old[p + (size_t)i * q];
-#pragma unroll
-        for (int j = 0; j < R; j++) {
-            const int cnt = IN >> (j + 1);
-#pragma unroll
-            for (int i = 0; i < cnt; i++) x[i] = x[i] + fr_mul_261(x[i + cnt] - x[i], r261[j]);
-        }
-        cur[p] = x[0];
-    }
-}
-// evalMLE's last rounds (half = half_first, half_first / 2, ... 1; the scalar of the round with half = 2^i is r[i]) by one
-// workgroup, in place on buf; the last round writes *out
-__global__ __launch_bounds__(256) void k_fold_halves_tail(const Fr *src, size_t half_first, const Fr *__restrict__ r, Fr *buf, Fr *out) {
-    unsigned i = 0;
-    while (((size_t)1 << i) < half_first) i++;
-    for (size_t half = half_first; half >= 1; half >>= 1, i--) {
-        const Fr29 r261 = fr_to_261(r[i]);
-        Fr *dst = half == 1 ? out : buf;
-        for (size_t p = threadIdx.x; p < half; p += 256) {
-            const Fr a = src[p];
-            dst[p] = a + fr_mul_261(src[p + half] - a, r261);
-        }
-        __syncthreads();
-        src = buf;
-        if (half == 1) break;
-    }
-}
-
 // ------------------------------------------------------------------------------------
 // Sumcheck round polynomial (CPSumcheck::make_new_h_poly, /root/reference/src/gadgets/sumcheck.h:85-106):
 //   h_j(X) = sum_{p < half} betaPoly(j,p)(X) * prod_t mlePoly_t(j,p)(X)
@@ -306,6 +299,12 @@ void fr_vec_release() {
 // CPPoly::prove witness coefficients: d_v (2^d, untouched), d_r (d), d_w (2^d; the first
 // 2^d - 1 entries are written, the last is zeroed like the reference's value-initialised
 // vector), d_tmp: scratch of 2^(d-1) + 2^(d-2) elements (ping-pong).  Asynchronous on st.
+// Rounds per pass of k_fold_pairs_fused for a vector with `avail` rounds left: twelve while the vector is long; a short
+// vector is cut into at least 256 tiles (one per CU) so that its last eight rounds are all the one-workgroup tail gets.
+static unsigned fused_rounds(size_t avail) {
+    const size_t t = avail - 8;
+    return (unsigned)(t > FUSE_ROUNDS ? FUSE_ROUNDS : t);
+}
 static int fr_cppoly_fold_issue(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_w, Fr *d_tmp, hipStream_t st);
 int fr_cppoly_fold_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_w, Fr *d_tmp, hipStream_t st) {
     return fold_run(1, d, d_v, d_r, d_w, d_tmp, nullptr, st, [=](hipStream_t s) { return fr_cppoly_fold_issue(d_v, d, d_r, d_w, d_tmp, s); });
@@ -313,31 +312,24 @@ int fr_cppoly_fold_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_w, Fr *d
 static int fr_cppoly_fold_issue(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_w, Fr *d_tmp, hipStream_t st) {
     const size_t N = (size_t)1 << d;
     HIPCHK(hipMemsetAsync(d_w + (N - 1), 0, sizeof(Fr), st));
+    if (d == 0) return LSA_OK;
     const Fr *src = d_v;
     Fr *bufA = d_tmp, *bufB = d_tmp + (N >> 1);
-    size_t start = 0;
-    size_t i = 0;
+    size_t start = 0, i = 0;
     unsigned which = 0;                                  // the next launch writes bufA (0) or bufB (1); it never reads the one it writes
-    while (i < d) {
-        const size_t m = (size_t)1 << (d - i - 1);       // outputs of round i
-        if (m <= FOLD_TAIL) {                            // this round and every later one: one workgroup
-            hipLaunchKernelGGL(k_fold_pairs_tail, dim3(1), dim3(256), 0, st, src, m, d_r + i, d_w + start, bufA, bufB, which);
-            break;
-        }
-        // up to three rounds per launch while their last round still has more than FOLD_TAIL outputs
-        static const unsigned rmax = getenv("LSA_FOLD_ROUNDS") ? (unsigned)atoi(getenv("LSA_FOLD_ROUNDS")) : 2u;        // (measured at d = 24: 1 round 0.83, 2 rounds 0.74, 3 rounds 0.80 ms: eight 32-byte pieces per lane coalesce worse than four)
-        unsigned R = 1;
-        while (R < rmax && R < 3 && (m >> R) > FOLD_TAIL) R++;
-        const size_t mo = m >> (R - 1);                  // outputs of the last of the R rounds
-        Fr *dst = which ? bufB : bufA;                   // (every launch's output is at most half the previous one's: both halves of d_tmp are large enough)
-        if (R == 3) hipLaunchKernelGGL((k_fold_pairs_multi<3>), dim3(stream_blocks(mo)), dim3(256), 0, st, src, mo, d_r + i, d_w + start, dst);
-        else if (R == 2) hipLaunchKernelGGL((k_fold_pairs_multi<2>), dim3(stream_blocks(mo)), dim3(256), 0, st, src, mo, d_r + i, d_w + start, dst);
-        else hipLaunchKernelGGL(k_fold_pairs, dim3(stream_blocks(mo)), dim3(256), 0, st, src, mo, d_r + i, d_w + start, dst);
+    while (d - i >= 10) {                                // passes of up to twelve rounds (k_fold_pairs_fused)
+        const unsigned tr = fused_rounds(d - i);
+        const size_t m = (size_t)1 << (d - i - 1), tiles = (size_t)1 << (d - i - tr);
+        Fr *dst = which ? bufB : bufA;                   // (a pass's output is at most a quarter of its input: both parts of d_tmp are large enough)
+        hipLaunchKernelGGL((k_fold_pairs_fused<true>), dim3((unsigned)(tiles < 65536 ? tiles : 65536)), dim3(256), 0, st, src, tiles, tr, d_r + i,
+                           d_w + start, m, dst);
         src = dst;
         which ^= 1u;
-        for (unsigned j = 0; j < R; j++) start += m >> j;
-        i += R;
+        for (unsigned j = 0; j < tr; j++) start += m >> j;
+        i += tr;
     }
+    // the remaining rounds (at most nine, at most 256 outputs in the first): one workgroup
+    hipLaunchKernelGGL(k_fold_pairs_tail, dim3(1), dim3(256), 0, st, src, (size_t)1 << (d - i - 1), d_r + i, d_w + start, bufA, bufB, which, (Fr *)nullptr);
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }
@@ -350,7 +342,7 @@ int fr_fold_halves_device(const Fr *d_old, size_t half, const Fr *d_r, Fr *d_cur
     return LSA_OK;
 }
 
-// evalMLE(v, r): d_v (2^d, untouched), d_r (d), d_tmp scratch of 2^(d-1) elements; the value
+// evalMLE(v, r): d_v (2^d, untouched), d_r (d), d_tmp scratch of 2^(d-1) + 2^(d-2) elements; the value
 // ends up in d_out (one Fr).  Bit i of the index pairs with r[i] (polytools.h:219-226), so the
 // top variable is r[d-1].
 static int fr_eval_mle_issue(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_tmp, Fr *d_out, hipStream_t st);
@@ -362,30 +354,23 @@ static int fr_eval_mle_issue(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_tmp, 
         HIPCHK(hipMemcpyAsync(d_out, d_v, sizeof(Fr), hipMemcpyDeviceToDevice, st));
         return LSA_OK;
     }
-    const Fr *src = d_v;
-    // d_tmp holds 2^(d-1) elements: a multi-round launch writes its (shorter) output behind what the next launch reads --
-    // ping-pong between the two halves of d_tmp (the first launch reads d_v)
-    Fr *pp[2] = {d_tmp, d_tmp + ((size_t)1 << (d - 1)) / 2};
+    // The variables from the BOTTOM: round j pairs neighbours with r[j] -- the same multilinear value as folding the top
+    // variable first, and a canonical residue either way -- so the passes are the witness recursion's without its
+    // coefficients: the table is read ONCE, then the one-workgroup tail.
+    const Fr *in = d_v;
+    Fr *pp[2] = {d_tmp, d_tmp + ((size_t)1 << (d - 1))};
     unsigned which = 0;
-    size_t i = d;                                        // rounds left: the next one has half = 2^(i-1) and uses r[i-1]
-    while (i > 0) {
-        const size_t half = (size_t)1 << (i - 1);
-        if (half <= FOLD_TAIL) {                         // this round and every later one: one workgroup, in place behind a copy
-            hipLaunchKernelGGL(k_fold_halves_tail, dim3(1), dim3(256), 0, st, src, half, d_r, pp[which], d_out);
-            break;
-        }
-        static const unsigned rmax = getenv("LSA_FOLD_ROUNDS_HALVES") ? (unsigned)atoi(getenv("LSA_FOLD_ROUNDS_HALVES")) : 2u; // (0.75 / 0.66 / 0.81 ms: eight read streams 2^21 elements apart are one too many)
-        unsigned R = 1;
-        while (R < rmax && R < 3 && (half >> R) > FOLD_TAIL) R++;
-        const size_t q = half >> (R - 1);                // outputs after the R rounds
-        Fr *dst = pp[which];
-        if (R == 3) hipLaunchKernelGGL((k_fold_halves_multi<3>), dim3(stream_blocks(q)), dim3(256), 0, st, src, q, d_r + (i - 1), dst);
-        else if (R == 2) hipLaunchKernelGGL((k_fold_halves_multi<2>), dim3(stream_blocks(q)), dim3(256), 0, st, src, q, d_r + (i - 1), dst);
-        else hipLaunchKernelGGL((k_fold_halves_multi<1>), dim3(stream_blocks(q)), dim3(256), 0, st, src, q, d_r + (i - 1), dst);
-        src = dst;
+    size_t j = 0;
+    while (d - j >= 10) {
+        const unsigned tr = fused_rounds(d - j);
+        const size_t tiles = (size_t)1 << (d - j - tr);
+        hipLaunchKernelGGL((k_fold_pairs_fused<false>), dim3((unsigned)(tiles < 65536 ? tiles : 65536)), dim3(256), 0, st, in, tiles, tr, d_r + j,
+                           (Fr *)nullptr, (size_t)1 << (d - j - 1), pp[which]);
+        in = pp[which];
         which ^= 1u;
-        i -= R;
+        j += tr;
     }
+    hipLaunchKernelGGL(k_fold_pairs_tail, dim3(1), dim3(256), 0, st, in, (size_t)1 << (d - j - 1), d_r + j, (Fr *)nullptr, pp[0], pp[1], which, d_out);
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }

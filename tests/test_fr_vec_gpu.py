@@ -9,10 +9,11 @@ import oracle_lib as o
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("d", [0, 1, 2, 3, 9, 11, 12, 13, 14, 15, 16, 17])
+@pytest.mark.parametrize("d", [0, 1, 2, 3, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 20, 21, 22])
 def test_cppoly_witness_vs_oracle(lsa, d):
-    """d <= 11: every round in the one-workgroup tail kernel; 12-13: one single-round launch first; from 14 on launches of
-    two rounds in registers (k_fold_pairs_multi), an odd number of leading rounds at 15 and 17."""
+    """d <= 9: every round in the one-workgroup tail kernel; from 10 on passes of k_fold_pairs_fused: tiles of 4 inputs
+    (d = 10: two rounds in registers, no tree), of 16 ... 2048 (the tree in LDS, one and two values per lane), of 4096 from
+    d = 20 on; two passes at 21 and 22 (the second with tiles of 4 and 16)."""
     v, _ = o.random_scalars(1 << d, seed=300 + d)
     r, _ = o.random_scalars(max(d, 1), seed=400 + d)
     r = r[:d]
@@ -22,7 +23,7 @@ def test_cppoly_witness_vs_oracle(lsa, d):
     assert not got[-1].any()                       # value-initialised tail entry (poly.h:52)
 
 
-@pytest.mark.parametrize("d", [0, 1, 2, 7, 12, 13, 14, 15, 16, 18])
+@pytest.mark.parametrize("d", [0, 1, 2, 7, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 21, 22])
 def test_eval_mle_vs_oracle(lsa, d):
     v, _ = o.random_scalars(1 << d, seed=500 + d)
     r, _ = o.random_scalars(max(d, 1), seed=600 + d)
@@ -30,11 +31,10 @@ def test_eval_mle_vs_oracle(lsa, d):
     assert np.array_equal(lsa.eval_mle(v, r), o.fr_eval_mle(v, r))
 
 
-@pytest.mark.parametrize("switch", ["LSA_FR_GRAPHS=0", "LSA_FOLD_ROUNDS=1", "LSA_FOLD_ROUNDS=3", "LSA_FOLD_ROUNDS_HALVES=1", "LSA_FOLD_ROUNDS_HALVES=3"])
+@pytest.mark.parametrize("switch", ["LSA_FR_GRAPHS=0"])
 def test_fold_schedules_behind_their_switches_give_the_oracles_bytes(switch):
-    """One, two (default) or three rounds per launch, with or without the cached hipGraph: the same witness coefficients and
-    the same evalMLE value as the oracle at d = 16 and 17, called twice (the second call replays the graph), from a child
-    process (the switches are read once)."""
+    """Without the cached hipGraph (plain launches): the same witness coefficients and the same evalMLE value as the oracle
+    at d = 16 and 17, called twice, from a child process (the switch is read once)."""
     import os
     import subprocess
     import sys

@@ -38,10 +38,10 @@ def main():
                 fn()
             lsa.synchronize()
             dt = (time.perf_counter() - t0) / reps
-            # algorithmic: v read once + w written once (64 N) / the table read once (32 N); moved: two rounds per launch,
-            # launches over N, N/4, ... inputs of 64 (40) bytes each (round 4: every round through memory, 128 N / 96 N)
+            # algorithmic: v read once + w written once (64 N) / the table read once (32 N); moved: the same + 1 / 4096 of it
+            # (twelve rounds per pass; two rounds per launch moved 85 N / 53 N, every round through memory 128 N / 96 N)
             alg = (64 if name == "cppoly_witness" else 32) * N
-            moved = (64 if name == "cppoly_witness" else 40) * N * 4 // 3
+            moved = alg + alg // 4096 * 2
             print(json.dumps({"op": name, "d": d, "ms": round(dt * 1e3, 4), "moved_GBps": round(moved / dt / 1e9, 1), "frac_of_8TBps_moved": round(moved / dt / 8e12, 4),
                               "frac_of_8TBps_algorithmic": round(alg / dt / 8e12, 4)}))
         if d == 20:
