@@ -36,21 +36,19 @@ __device__ __forceinline__ Fr29 fr_to_261(const Fr &r) { return Fr29::from_words
 // x * r as libff words: x's words are read as the 2^261 form of x / 32, the product with r in 2^261 form is x r 2^256
 __device__ __forceinline__ Fr fr_mul_261(const Fr &x, const Fr29 &r261) { return mul(Fr29::from_words(x), r261).canonical2().to_words(); }
 
-// Up to FUSE_ROUNDS consecutive rounds in ONE pass over the data: round j + 1 pairs up neighbouring outputs of round j,
-// so a workgroup that owns a tile of 2^tr neighbouring inputs runs tr rounds on its own -- two in registers (a lane takes
-// four neighbouring inputs to one value), the others as a tree over the tile's values in LDS --
-// and the intermediate vectors never reach memory: the witness recursion at d = 24 is a pass of 12 rounds (v read
-// once, every w written once) and the one-workgroup tail; evalMLE (WRITE_W = false) reads its table once and writes 2^12
-// values.  The tree's upper levels keep few lanes busy (a tile of 4096 inputs spends 3072 of its 4095 products at full
-// width); the other workgroups of the CU stream meanwhile.  The rounds' scalars are put into 2^261 form once per workgroup.
-//   m0: outputs of this launch's first round over ALL tiles (tiles << (tr - 1)); round j's witness coefficients go to
-//   w0 + m0 + m0 / 2 + ... (j terms), a tile's share of them contiguous; vout[tile] = the tile's value after tr rounds.
-static constexpr unsigned FUSE_ROUNDS = 12;
-template <bool WRITE_W>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fold_pairs_fused(const Fr *__restrict__ v, size_t tiles, unsigned tr, const Fr *__restrict__ r_ptr,
-                                                          Fr *__restrict__ w0, size_t m0, Fr *__restrict__ vout) {
-    __shared__ uint32_t s_r[FUSE_ROUNDS][9];
-    __shared__ Fr s_x[(size_t)1 << (FUSE_ROUNDS - 2)];
+// Several consecutive rounds in ONE pass over the data: round j + 1 pairs up neighbouring outputs of round j, so a
+// workgroup that owns a block of 2^bl neighbouring inputs (bl <= 12) runs tr <= bl rounds on its own -- two in registers (a
+// lane takes four neighbouring inputs to one value), the others as a tree over the block's values in LDS -- and the
+// intermediate vectors never reach memory; the block's 2^(bl - tr) results go to vout.  The rounds' scalars are put into
+// 2^261 form once per workgroup and held in scalar registers.
+//   m0: outputs of this launch's first round over ALL blocks (blocks << (bl - 1)); round j's witness coefficients go to
+//   w0 + m0 + m0 / 2 + ... (j terms), a block's share of them contiguous.
+static constexpr unsigned FUSE_BLOCK_LOG = 12;
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_fold_pairs_fused(const Fr *__restrict__ v, size_t blocks, unsigned bl, unsigned tr,
+                                                                                                const Fr *__restrict__ r_ptr, Fr *__restrict__ w0, size_t m0,
+                                                                                                Fr *__restrict__ vout) {
+    __shared__ uint32_t s_r[FUSE_BLOCK_LOG][9];
+    __shared__ Fr s_x[(size_t)1 << (FUSE_BLOCK_LOG - 2)];
     if (threadIdx.x < tr) {
         const Fr29 c = fr_to_261(r_ptr[threadIdx.x]);
 #pragma unroll
@@ -63,29 +61,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int k = 0; k < 9; k++) c.l[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_r[j][k]);
         return c;
     };
-    const size_t vals = (size_t)1 << (tr - 2);               // values a tile leaves in LDS after its first two rounds
-    for (size_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const size_t vals = (size_t)1 << (bl - 2);               // values a block leaves in LDS after its first two rounds
+    for (size_t blk = blockIdx.x; blk < blocks; blk += gridDim.x) {
         {
             const Fr29 r0 = scalar(0), r1 = scalar(1);
-            const Fr *in = v + (tile << tr);
-            Fr *wa = w0 + (tile << (tr - 1)), *wb = w0 + m0 + (tile << (tr - 2));
+            const Fr *in = v + (blk << bl);
+            Fr *wa = w0 + (blk << (bl - 1)), *wb = w0 + m0 + (blk << (bl - 2));
 #pragma unroll 1
             for (size_t u = threadIdx.x; u < vals; u += 256) {
                 const Fr x0 = in[4 * u], x1 = in[4 * u + 1], x2 = in[4 * u + 2], x3 = in[4 * u + 3];
                 const Fr d0 = x1 - x0, d1 = x3 - x2;
-                if (WRITE_W) { wa[2 * u] = d0; wa[2 * u + 1] = d1; }
+                wa[2 * u] = d0;
+                wa[2 * u + 1] = d1;
                 const Fr y0 = x0 + fr_mul_261(d0, r0), y1 = x2 + fr_mul_261(d1, r0);
                 const Fr d = y1 - y0;
-                if (WRITE_W) wb[u] = d;
+                wb[u] = d;
                 s_x[u] = y0 + fr_mul_261(d, r1);
             }
         }
         __syncthreads();
         size_t woff = m0 + (m0 >> 1);                        // where round 2's coefficients start
         for (unsigned j = 2; j < tr; j++) {
-            const size_t cnt = (size_t)1 << (tr - 1 - j);    // this tile's outputs in round j: at most 512
+            const size_t cnt = (size_t)1 << (bl - 1 - j);    // this block's outputs in round j: at most 512
             const Fr29 rj = scalar(j);
-            Fr *wj = w0 + woff + (tile << (tr - 1 - j));
+            Fr *wj = w0 + woff + (blk << (bl - 1 - j));
             Fr y[2];
 #pragma unroll
             for (int it = 0; it < 2; it++) {
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 if (u < cnt) {
                     const Fr a = s_x[2 * u], b = s_x[2 * u + 1];
                     const Fr d = b - a;
-                    if (WRITE_W) wj[u] = d;
+                    wj[u] = d;
                     y[it] = a + fr_mul_261(d, rj);
                 }
             }
@@ -106,8 +105,100 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             __syncthreads();
             woff += m0 >> j;
         }
-        if (threadIdx.x == 0) vout[tile] = s_x[0];
-        __syncthreads();                                     // s_x is free for the next tile
+        const size_t outs = (size_t)1 << (bl - tr);
+        for (size_t u = threadIdx.x; u < outs; u += 256) vout[(blk << (bl - tr)) + u] = s_x[u];
+        __syncthreads();                                     // s_x is free for the next block
+    }
+}
+
+// evalMLE's passes: the same blocks and rounds, on LAZY 29-bit-limb values -- no coefficient leaves the kernel, so
+// nothing between a block's inputs and its results has to be canonical: a round is
+//   d = b - a + K_j r   (K_j = 2 (j + 1) >= the bound of a: non-negative),   y = a + d r_j / 2^261   (the product is < 2r)
+// and a value that enters round j below (1 + 2j) r leaves it below (3 + 2j) r: twelve rounds stay far below the 121 r the
+// product accepts.  Per product: a limb subtraction, the product, a limb addition -- no unpacking, canonical form or
+// packing.  A block's results are brought back to canonical words by one more product (with 2^261: the shifted form's one).
+// (Measured and not kept: taking variables 6 and 7 of a block in the register rounds, so that a wavefront's loads are 2 KB
+// runs instead of 64 pieces of 128 B -- 211-232 us per pass either way -- and requesting the next slice's inputs before
+// the current ones are used -- 262 us.  The pass is bound by the product: 16.8 M of them in 0.21 ms.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_eval_mle_fused(const Fr *__restrict__ v, size_t blocks, unsigned bl, unsigned tr,
+                                                                                              const Fr *__restrict__ r_ptr, Fr *__restrict__ vout) {
+    __shared__ uint32_t s_r[FUSE_BLOCK_LOG][9], s_off[FUSE_BLOCK_LOG][9];
+    __shared__ uint32_t s_x[((size_t)1 << (FUSE_BLOCK_LOG - 2)) * 9];      // lazy values, 9 words apart: conflict-free
+    if (threadIdx.x < tr) {
+        const unsigned j = threadIdx.x;
+        const Fr29 c = fr_to_261(r_ptr[j]);
+        uint64_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            s_r[j][k] = c.l[k];
+            carry += (uint64_t)Fr29::r(k) * (2u * (j + 1u));               // K_j r as tight limbs (the top limb takes the rest)
+            s_off[j][k] = k < 8 ? (uint32_t)carry & Fr29::MASK : (uint32_t)carry;
+            carry >>= 29;
+        }
+    }
+    __syncthreads();
+    auto uniform = [&](const uint32_t (*tab)[9], unsigned j) {
+        Fr29 c;
+#pragma unroll
+        for (int k = 0; k < 9; k++) c.l[k] = (uint32_t)__builtin_amdgcn_readfirstlane((int)tab[j][k]);
+        return c;
+    };
+    // y = a + (b - a + off) * rj
+    auto round = [](const Fr29 &a, const Fr29 &b, const Fr29 &off, const Fr29 &rj) {
+        Fr29 d;
+        int32_t c = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int32_t t = (int32_t)b.l[k] - (int32_t)a.l[k] + (int32_t)off.l[k] + c;
+            if (k < 8) { d.l[k] = (uint32_t)t & Fr29::MASK; c = t >> 29; }
+            else d.l[k] = (uint32_t)t;
+        }
+        return add(a, mul(d, rj));
+    };
+    auto lds_get = [&](size_t u) {
+        Fr29 x;
+#pragma unroll
+        for (int k = 0; k < 9; k++) x.l[k] = s_x[u * 9 + k];
+        return x;
+    };
+    auto lds_put = [&](size_t u, const Fr29 &x) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) s_x[u * 9 + k] = x.l[k];
+    };
+    const size_t vals = (size_t)1 << (bl - 2);
+    for (size_t blk = blockIdx.x; blk < blocks; blk += gridDim.x) {
+        {
+            const Fr29 r0 = uniform(s_r, 0), r1 = uniform(s_r, 1), o0 = uniform(s_off, 0), o1 = uniform(s_off, 1);
+            const Fr *in = v + (blk << bl);
+#pragma unroll 1
+            for (size_t u = threadIdx.x; u < vals; u += 256) {
+                const Fr x0 = in[4 * u], x1 = in[4 * u + 1], x2 = in[4 * u + 2], x3 = in[4 * u + 3];
+                const Fr29 y0 = round(Fr29::from_words(x0), Fr29::from_words(x1), o0, r0);
+                const Fr29 y1 = round(Fr29::from_words(x2), Fr29::from_words(x3), o0, r0);
+                lds_put(u, round(y0, y1, o1, r1));
+            }
+        }
+        __syncthreads();
+        for (unsigned j = 2; j < tr; j++) {
+            const size_t cnt = (size_t)1 << (bl - 1 - j);
+            const Fr29 rj = uniform(s_r, j), oj = uniform(s_off, j);
+            Fr29 y[2];
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const size_t u = threadIdx.x + (size_t)it * 256;
+                if (u < cnt) y[it] = round(lds_get(2 * u), lds_get(2 * u + 1), oj, rj);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const size_t u = threadIdx.x + (size_t)it * 256;
+                if (u < cnt) lds_put(u, y[it]);
+            }
+            __syncthreads();
+        }
+        const size_t outs = (size_t)1 << (bl - tr);
+        for (size_t u = threadIdx.x; u < outs; u += 256) vout[(blk << (bl - tr)) + u] = mul(lds_get(u), Fr29::one()).canonical2().to_words();
+        __syncthreads();
     }
 }
 
@@ -299,11 +390,17 @@ void fr_vec_release() {
 // CPPoly::prove witness coefficients: d_v (2^d, untouched), d_r (d), d_w (2^d; the first
 // 2^d - 1 entries are written, the last is zeroed like the reference's value-initialised
 // vector), d_tmp: scratch of 2^(d-1) + 2^(d-2) elements (ping-pong).  Asynchronous on st.
-// Rounds per pass of k_fold_pairs_fused for a vector with `avail` rounds left: twelve while the vector is long; a short
-// vector is cut into at least 256 tiles (one per CU) so that its last eight rounds are all the one-workgroup tail gets.
-static unsigned fused_rounds(size_t avail) {
-    const size_t t = avail - 8;
-    return (unsigned)(t > FUSE_ROUNDS ? FUSE_ROUNDS : t);
+// A pass over a vector with `avail` rounds left (avail >= 10): blocks of 2^12 inputs (the whole vector when it is
+// shorter), `want` rounds, but never so many that fewer than eight rounds are left for the one-workgroup tail.
+struct FusedPass { unsigned bl, tr; size_t blocks; };
+static FusedPass fused_pass(size_t avail, unsigned want) {
+    FusedPass p;
+    p.bl = (unsigned)(avail < FUSE_BLOCK_LOG ? avail : FUSE_BLOCK_LOG);
+    const size_t room = avail - 8;
+    p.tr = (unsigned)(room < want ? room : want);
+    if (p.tr > p.bl) p.tr = p.bl;
+    p.blocks = (size_t)1 << (avail - p.bl);
+    return p;
 }
 static int fr_cppoly_fold_issue(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_w, Fr *d_tmp, hipStream_t st);
 int fr_cppoly_fold_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_w, Fr *d_tmp, hipStream_t st) {
@@ -317,16 +414,16 @@ static int fr_cppoly_fold_issue(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_w,
     Fr *bufA = d_tmp, *bufB = d_tmp + (N >> 1);
     size_t start = 0, i = 0;
     unsigned which = 0;                                  // the next launch writes bufA (0) or bufB (1); it never reads the one it writes
-    while (d - i >= 10) {                                // passes of up to twelve rounds (k_fold_pairs_fused)
-        const unsigned tr = fused_rounds(d - i);
-        const size_t m = (size_t)1 << (d - i - 1), tiles = (size_t)1 << (d - i - tr);
+    while (d - i >= 10) {                                // passes of up to twelve rounds each (k_fold_pairs_fused)
+        const FusedPass p = fused_pass(d - i, FUSE_BLOCK_LOG);
+        const size_t m = (size_t)1 << (d - i - 1);
         Fr *dst = which ? bufB : bufA;                   // (a pass's output is at most a quarter of its input: both parts of d_tmp are large enough)
-        hipLaunchKernelGGL((k_fold_pairs_fused<true>), dim3((unsigned)(tiles < 65536 ? tiles : 65536)), dim3(256), 0, st, src, tiles, tr, d_r + i,
-                           d_w + start, m, dst);
+        hipLaunchKernelGGL(k_fold_pairs_fused, dim3((unsigned)(p.blocks < 65536 ? p.blocks : 65536)), dim3(256), 0, st, src, p.blocks, p.bl, p.tr,
+                           d_r + i, d_w + start, m, dst);
         src = dst;
         which ^= 1u;
-        for (unsigned j = 0; j < tr; j++) start += m >> j;
-        i += tr;
+        for (unsigned j = 0; j < p.tr; j++) start += m >> j;
+        i += p.tr;
     }
     // the remaining rounds (at most nine, at most 256 outputs in the first): one workgroup
     hipLaunchKernelGGL(k_fold_pairs_tail, dim3(1), dim3(256), 0, st, src, (size_t)1 << (d - i - 1), d_r + i, d_w + start, bufA, bufB, which, (Fr *)nullptr);
@@ -362,13 +459,11 @@ static int fr_eval_mle_issue(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_tmp, 
     unsigned which = 0;
     size_t j = 0;
     while (d - j >= 10) {
-        const unsigned tr = fused_rounds(d - j);
-        const size_t tiles = (size_t)1 << (d - j - tr);
-        hipLaunchKernelGGL((k_fold_pairs_fused<false>), dim3((unsigned)(tiles < 65536 ? tiles : 65536)), dim3(256), 0, st, in, tiles, tr, d_r + j,
-                           (Fr *)nullptr, (size_t)1 << (d - j - 1), pp[which]);
+        const FusedPass p = fused_pass(d - j, FUSE_BLOCK_LOG);
+        hipLaunchKernelGGL(k_eval_mle_fused, dim3((unsigned)(p.blocks < 65536 ? p.blocks : 65536)), dim3(256), 0, st, in, p.blocks, p.bl, p.tr, d_r + j, pp[which]);
         in = pp[which];
         which ^= 1u;
-        j += tr;
+        j += p.tr;
     }
     hipLaunchKernelGGL(k_fold_pairs_tail, dim3(1), dim3(256), 0, st, in, (size_t)1 << (d - j - 1), d_r + j, (Fr *)nullptr, pp[0], pp[1], which, d_out);
     HIPCHK(hipGetLastError());
