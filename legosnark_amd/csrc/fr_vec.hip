@@ -246,26 +246,43 @@ __global__ __launch_bounds__(256) void k_fold_halves(const Fr *old, size_t half,
 static constexpr int SC_MAX_M = 4;
 struct ScTables { const Fr *t[SC_MAX_M]; };
 
-__global__ __launch_bounds__(256) void k_sumcheck_partial(const Fr *__restrict__ suff, ScTables tabs, unsigned m, size_t half,
-                                                         Fr *__restrict__ partial) {
+// The products run on fr29.h's limbs with LAZY sums (a coefficient of q is a sum of two products: < 4r; the lane's running
+// sums are brought back below 2r every sixteen indices).  Both operands of a product are data here, read in the shifted form
+// (fr29.h: libff's words of x are the 2^261 form of x / 32), so every product loses a factor 32 -- the same number of times
+// in every term of every coefficient (each term is suff times one factor per table: M products, M - 1 without suff, whose
+// place the 2^261 form of 1 takes) -- and the factor comes back with the constant that makes the lane's sums canonical.
+template <int M>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sumcheck_partial(const Fr *__restrict__ suff, ScTables tabs, size_t half, Fr *__restrict__ partial) {
     __shared__ Fr lds[256];
-    Fr c[SC_MAX_M + 1];
-    for (unsigned i = 0; i <= m; i++) c[i] = Fr::zero();
+    Fr29 c[M + 1];
+#pragma unroll
+    for (int i = 0; i <= M; i++) c[i] = Fr29::zero();
+    const Fr29 one = Fr29::one();
+    unsigned since = 0;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < half; p += (size_t)gridDim.x * blockDim.x) {
-        Fr q[SC_MAX_M + 1];
-        q[0] = suff ? suff[p] : Fr::one();
-        unsigned deg = 0;
-        for (unsigned t = 0; t < m; t++) {
-            const Fr v0 = tabs.t[t][p], dv = tabs.t[t][p + half] - v0;
-            q[deg + 1] = q[deg] * dv;                    // q <- q * (v0 + dv X)
-            for (unsigned i = deg; i >= 1; i--) q[i] = q[i] * v0 + q[i - 1] * dv;
-            q[0] = q[0] * v0;
-            deg++;
+        Fr29 q[M + 1];
+        q[0] = suff ? Fr29::from_words(suff[p]) : one;
+#pragma unroll
+        for (int t = 0; t < M; t++) {
+            const Fr29 v0 = Fr29::from_words(tabs.t[t][p]);
+            const Fr29 dv = sub2r(Fr29::from_words(tabs.t[t][p + half]), v0);       // < 3r
+            q[t + 1] = mul(q[t], dv);                                               // q <- q * (v0 + dv X)
+#pragma unroll
+            for (int i = t; i >= 1; i--) q[i] = add(mul(q[i], v0), mul(q[i - 1], dv));
+            q[0] = mul(q[0], v0);
         }
-        for (unsigned i = 0; i <= m; i++) c[i] = c[i] + q[i];
+#pragma unroll
+        for (int i = 0; i <= M; i++) c[i] = add(c[i], q[i]);
+        if (++since == 16) {                                                        // 16 * 4r + 2r < 121 r
+#pragma unroll
+            for (int i = 0; i <= M; i++) c[i] = mul(c[i], one);
+            since = 0;
+        }
     }
-    for (unsigned i = 0; i <= m; i++) {
-        lds[threadIdx.x] = c[i];
+    const Fr29 fix = fr_to_261(Fr::from_u32(1u << (5 * (suff ? M : M - 1))));       // 32^(products per term), in 2^261 form
+#pragma unroll
+    for (int i = 0; i <= M; i++) {
+        lds[threadIdx.x] = mul(c[i], fix).canonical2().to_words();
         __syncthreads();
         for (unsigned s = 128; s >= 1; s >>= 1) {
             if (threadIdx.x < s) lds[threadIdx.x] = lds[threadIdx.x] + lds[threadIdx.x + s];
@@ -276,17 +293,25 @@ __global__ __launch_bounds__(256) void k_sumcheck_partial(const Fr *__restrict__
     }
 }
 
-// out[0..m(+1)] = (have_beta ? ((1-rho) + (2rho-1) X) * pre : 1) * sum of the block partials
-__global__ __launch_bounds__(64) void k_sumcheck_finish(const Fr *__restrict__ partial, unsigned nblocks, unsigned m, int have_beta,
-                                                        Fr pre, Fr rho, Fr *__restrict__ out) {
+// out[0..m(+1)] = (have_beta ? ((1-rho) + (2rho-1) X) * pre : 1) * sum of the block partials (one workgroup: the partials of a
+// coefficient are summed by all its lanes, then a tree -- a lone lane walking 1024 partials took 0.4 ms)
+__global__ __launch_bounds__(256) void k_sumcheck_finish(const Fr *__restrict__ partial, unsigned nblocks, unsigned m, int have_beta,
+                                                         Fr pre, Fr rho, Fr *__restrict__ out) {
     __shared__ Fr S[SC_MAX_M + 1];
-    const unsigned i = threadIdx.x;
-    if (i <= m) {
+    __shared__ Fr lds[256];
+    for (unsigned i = 0; i <= m; i++) {
         Fr acc = Fr::zero();
-        for (unsigned b = 0; b < nblocks; b++) acc = acc + partial[(size_t)b * (SC_MAX_M + 1) + i];
-        S[i] = acc;
+        for (unsigned b = threadIdx.x; b < nblocks; b += 256) acc = acc + partial[(size_t)b * (SC_MAX_M + 1) + i];
+        lds[threadIdx.x] = acc;
+        __syncthreads();
+        for (unsigned s = 128; s >= 1; s >>= 1) {
+            if (threadIdx.x < s) lds[threadIdx.x] = lds[threadIdx.x] + lds[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) S[i] = lds[0];
+        __syncthreads();
     }
-    __syncthreads();
+    const unsigned i = threadIdx.x;
     if (!have_beta) {
         if (i <= m) out[i] = S[i];
         return;
@@ -479,8 +504,11 @@ int fr_sumcheck_round_device(const Fr *d_suff, const Fr *const *d_tables, size_t
     for (int t = 0; t < SC_MAX_M; t++) tabs.t[t] = t < (int)m ? d_tables[t] : nullptr;
     size_t b = (half + 255) / 256;
     const unsigned blocks = (unsigned)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
-    hipLaunchKernelGGL(k_sumcheck_partial, dim3(blocks), dim3(256), 0, st, d_suff, tabs, (unsigned)m, half, d_partial);
-    hipLaunchKernelGGL(k_sumcheck_finish, dim3(1), dim3(64), 0, st, d_partial, blocks, (unsigned)m, rho ? 1 : 0,
+    if (m == 1) hipLaunchKernelGGL((k_sumcheck_partial<1>), dim3(blocks), dim3(256), 0, st, d_suff, tabs, half, d_partial);
+    else if (m == 2) hipLaunchKernelGGL((k_sumcheck_partial<2>), dim3(blocks), dim3(256), 0, st, d_suff, tabs, half, d_partial);
+    else if (m == 3) hipLaunchKernelGGL((k_sumcheck_partial<3>), dim3(blocks), dim3(256), 0, st, d_suff, tabs, half, d_partial);
+    else hipLaunchKernelGGL((k_sumcheck_partial<4>), dim3(blocks), dim3(256), 0, st, d_suff, tabs, half, d_partial);
+    hipLaunchKernelGGL(k_sumcheck_finish, dim3(1), dim3(256), 0, st, d_partial, blocks, (unsigned)m, rho ? 1 : 0,
                        pre ? *pre : Fr::one(), rho ? *rho : Fr::zero(), d_out);
     HIPCHK(hipGetLastError());
     return LSA_OK;

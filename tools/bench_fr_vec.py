@@ -102,8 +102,38 @@ def ntt():
                               "algorithmic_GBps": round(64 * m / dt / 1e9, 1), "frac_of_8TBps": round(64 * m / dt / 8e12, 4)}), flush=True)
 
 
+def sumcheck():
+    """lsa_fr_sumcheck_round on device-resident tables (CPSumcheck::make_new_h_poly, /root/reference/src/gadgets/sumcheck.h:85-106):
+    ms per round polynomial at half = 2^23 (round 0 of a prover at d = 24) and 2^19, two and three MLE tables with the beta
+    factor; 32 (2 m + 1) bytes per index of algorithmic traffic."""
+    lsa.init(0)
+    pre, rho = o.fr_mont(12345), o.fr_mont(67890)
+    for log_half in (19, 23):
+        half = 1 << log_half
+        gen = torch.Generator(device="cuda:0").manual_seed(log_half)
+        def table(n):
+            t = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device="cuda:0", generator=gen)
+            t[:, 3] &= (1 << 60) - 1
+            return t
+        for m in (2, 3):
+            tabs = [table(2 * half) for _ in range(m)]
+            suff = table(half)
+            lsa.sumcheck_round(tabs, suff=suff, pre=pre, rho_j=rho)
+            reps = 10
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                lsa.sumcheck_round(tabs, suff=suff, pre=pre, rho_j=rho)
+            dt = (time.perf_counter() - t0) / reps
+            byt = 32 * (2 * m + 1) * half
+            print(json.dumps({"op": "sumcheck_round", "m": m, "log_half": log_half, "ms": round(dt * 1e3, 4), "algorithmic_GBps": round(byt / dt / 1e9, 1),
+                              "frac_of_8TBps": round(byt / dt / 8e12, 4)}), flush=True)
+            del tabs, suff
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "ntt":
+    if len(sys.argv) > 1 and sys.argv[1] == "sumcheck":
+        sumcheck()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ntt":
         ntt()
     else:
         main()
