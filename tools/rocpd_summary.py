@@ -75,6 +75,22 @@ def pmc_means(db_path):
     return db.execute(q).fetchall()
 
 
+def pmc_largest(db_path):
+    """per kernel and counter: the launches whose counter value is within 2 % of the largest (a tool that runs several sizes:
+    the figures of the largest one), count, mean value, mean duration"""
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select kernel_name, counter_name, value, duration from counters_collection").fetchall()
+    groups = {}
+    for name, ctr, val, dur in rows:
+        groups.setdefault((name, ctr), []).append((val, dur))
+    out = []
+    for (name, ctr), lst in sorted(groups.items()):
+        top = max(v for v, _ in lst)
+        sel = [(v, d) for v, d in lst if v >= 0.98 * top]
+        out.append((name, ctr, len(sel), sum(v for v, _ in sel) / len(sel), sum(d for _, d in sel) / len(sel)))
+    return out
+
+
 def pmc(paths):
     print("%-60s %-18s %6s %16s %12s %5s %5s %7s %7s" % ("kernel", "counter", "calls", "mean_value", "avg_us", "vgpr", "sgpr", "lds", "scratch"))
     for p in paths:
@@ -82,6 +98,13 @@ def pmc(paths):
             if "lsa::" not in name:
                 continue
             print("%-60s %-18s %6d %16.3f %12.3f %5d %5d %7d %7d" % (short(name)[:60], ctr, cnt, val, dur / 1e3, vg, sg, lds, scr))
+    print("# the largest launches of each kernel (value within 2 % of its maximum)")
+    print("%-60s %-18s %6s %16s %12s" % ("kernel", "counter", "calls", "mean_value", "avg_us"))
+    for p in paths:
+        for name, ctr, cnt, val, dur in pmc_largest(p):
+            if "lsa::" not in name:
+                continue
+            print("%-60s %-18s %6d %16.3f %12.3f" % (short(name)[:60], ctr, cnt, val, dur / 1e3))
 
 
 def hbm(fetch_db, write_db, needle, out):
