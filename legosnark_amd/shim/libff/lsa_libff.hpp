@@ -744,6 +744,13 @@ public:
         // any other base (each is met once or twice: no table pays): GLV halves in width-5 NAF over one chain of 127
         // doublings (csrc/smul_host.h); LSA_SHIM_GLV=0 keeps the 4-bit window ladder below for an A/B
         static const bool glv_on = !(getenv("LSA_SHIM_GLV") && getenv("LSA_SHIM_GLV")[0] == '0');
+        if constexpr (GROUP == 2) {
+            // G2: the four-dimensional split over psi (66 doublings instead of 127); LSA_SHIM_GLS4=0: the two-dimensional one.
+            // (Both use endomorphisms that act as scalars on the prime-order subgroup G2 only -- where every point libff
+            // hands out lies; a point of the twist outside G2 must go through LSA_SHIM_GLV=0.)
+            static const bool gls_on = !(getenv("LSA_SHIM_GLS4") && getenv("LSA_SHIM_GLS4")[0] == '0');
+            if (glv_on && gls_on) return G_shim(lsa::gls4_mul_host(base, e.data));
+        }
         if (glv_on) return G_shim(lsa::glv_mul_host(base, e.data));
         Jac tbl[16];
         tbl[0] = Jac::inf();

@@ -119,6 +119,63 @@ static int glv_host_check(const char *name, std::mt19937_64 &rng) {
     return fails;
 }
 
+// csrc/smul_host.h, G2's four-dimensional split: (1) the decomposition k = sum k_i mu^i (mod r) in the scalar field, with
+// |k_i| < 2^66, on edge and random scalars; (2) gls4_mul_host against double-and-add on a walk of bases with Z != 1.
+static Fr fr_from_i128(__int128 v) {
+    const bool neg = v < 0;
+    unsigned __int128 m = (unsigned __int128)(neg ? -v : v);
+    uint32_t w[8] = {(uint32_t)m, (uint32_t)(m >> 32), (uint32_t)(m >> 64), (uint32_t)(m >> 96), 0, 0, 0, 0};
+    const Fr x = Fr::from_canonical(w);
+    return neg ? x.neg() : x;
+}
+static int gls4_check(std::mt19937_64 &rng) {
+    int fails = 0;
+    if (!gls4_ok()) { printf("psi(G) != mu G on the generator of G2\n"); return 1; }
+    const uint64_t U = 4965661367192848881ull;
+    const unsigned __int128 mu128 = (unsigned __int128)6 * U * U;
+    const Fr mu = fr_from_i128((__int128)mu128);
+    std::vector<std::array<uint64_t, 4>> ks;
+    for (uint64_t v : {0ull, 1ull, 2ull, 31ull, 32ull, 0xffffffffffffffffull}) ks.push_back({v, 0, 0, 0});
+    ks.push_back({(uint64_t)mu128, (uint64_t)(mu128 >> 64), 0, 0});
+    ks.push_back({(uint64_t)mu128 + 1, (uint64_t)(mu128 >> 64), 0, 0});
+    ks.push_back({0, 0, 0, 0x2000000000000000ull});
+    {
+        std::array<uint64_t, 4> rm1;
+        for (int i = 0; i < 4; i++) rm1[i] = (uint64_t)FrParams::MOD[2 * i] | ((uint64_t)FrParams::MOD[2 * i + 1] << 32);
+        rm1[0] -= 1;
+        ks.push_back(rm1);
+    }
+    for (int t = 0; t < 3000; t++) ks.push_back({rng(), rng(), rng(), rng() & 0x1fffffffffffffffull});
+    __int128 worst = 0;
+    for (size_t i = 0; i < ks.size(); i++) {
+        const Gls4 d = gls4_decompose(ks[i].data());
+        Fr acc = Fr::zero(), pw = Fr::one();
+        for (int t = 0; t < 4; t++) {
+            acc = acc + fr_from_i128(d.k[t]) * pw;
+            pw = pw * mu;
+            const __int128 a = d.k[t] < 0 ? -d.k[t] : d.k[t];
+            if (a > worst) worst = a;
+        }
+        uint32_t w[8];
+        for (int j = 0; j < 4; j++) { w[2 * j] = (uint32_t)ks[i][j]; w[2 * j + 1] = (uint32_t)(ks[i][j] >> 32); }
+        if (acc != Fr::from_canonical(w)) { if (fails < 5) printf("GLS decomposition wrong at scalar %zu\n", i); fails++; }
+    }
+    if (worst >> 66) { printf("GLS sub-scalar of more than 66 bits\n"); fails++; }
+    const Jac<Fq2> G = GlvGenerator<Fq2>::get();
+    Jac<Fq2> P = G;
+    for (size_t i = 0; i < 400; i++) {
+        if (!jac_eq(gls4_mul_host(P, ks[i].data()), plain_mul_any(P, ks[i].data()))) { if (fails < 5) printf("GLS product mismatch at scalar %zu\n", i); fails++; }
+        P = jac_add(jac_dbl(P), G);
+    }
+    if (!gls4_mul_host(Jac<Fq2>::inf(), ks[20].data()).is_inf()) { printf("GLS k * O != O\n"); fails++; }
+    auto t0 = std::chrono::steady_clock::now();
+    Jac<Fq2> sink = Jac<Fq2>::inf();
+    for (size_t i = 20; i < 120; i++) sink = jac_add(sink, gls4_mul_host(P, ks[i].data()));
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 100;
+    printf("G2 any base, four-dimensional: %.1f us per product%s\n", us, sink.is_inf() ? "." : "");
+    return fails;
+}
+
 static Jac<Fq> plain_mul(const Jac<Fq> &P, const uint32_t k[8]) {
     Jac<Fq> acc = Jac<Fq>::inf();
     for (int i = 255; i >= 0; --i) {
@@ -163,6 +220,7 @@ int main() {
         fails += fixed_base_check<Fq>(jac_add(jac_dbl(G), G), "G1 (3G, Z != 1)", rng2);
         fails += glv_host_check<Fq>("G1", rng2);
         fails += glv_host_check<Fq2>("G2", rng2);
+        fails += gls4_check(rng2);
     }
     printf(fails ? "FAILED (%d)\n" : "PASS\n", fails);
     return fails ? 1 : 0;
