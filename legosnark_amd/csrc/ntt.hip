@@ -268,26 +268,41 @@ int fr_ntt_device(Fr *d_a, unsigned log_n, const Fr &omega, bool inverse, const 
 constexpr unsigned STEP_BLOCK = 256;
 struct StepPow { Fr base, stride; };                      // base, base^T (T: the launch's lane count)
 
+// The products of these kernels are data x constant: the constant in 2^261 form on fr29.h's limbs, the data word read as
+// the shifted form (fr29.h), so the result's words are libff's -- a third of the instructions of the 8 x 32-bit product.
+__device__ __forceinline__ Fr29 step_to261(const Fr &x) { return Fr29::from_words(x * Fr::from_u32(32)); }
+__device__ __forceinline__ Fr step_mul(const Fr &x, const Fr29 &c) { return mul(Fr29::from_words(x), c).canonical2().to_words(); }
+__device__ __forceinline__ Fr29 step_pow261(const Fr29 &base, uint64_t e) {          // base^e in 2^261 form (tight, < 2r)
+    Fr29 acc = Fr29::one();
+    bool started = false;
+    for (int i = 63; i >= 0; --i) {
+        if (started) acc = mul(acc, acc);
+        if ((e >> i) & 1) { acc = started ? mul(acc, base) : base; started = true; }
+    }
+    return acc;
+}
+
 // forward, before the transforms: a[0 .. big) <- c, D[0 .. big) <- omega^i d_i (with the coset shift g^i folded in)
 __global__ __launch_bounds__(256) void k_step_fwd_pre(Fr *__restrict__ a, Fr *__restrict__ D, size_t big, size_t small, StepPow w, StepPow g,
                                                       Fr g_big, int coset) {
     const size_t T = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= big) return;
-    Fr wi = fr_pow_dev(w.base, t), gi = coset ? fr_pow_dev(g.base, t) : Fr::one();
+    const Fr29 ws = step_to261(w.stride), gs = step_to261(g.stride), gb = step_to261(g_big);
+    Fr29 wi = step_pow261(step_to261(w.base), t), gi = coset ? step_pow261(step_to261(g.base), t) : Fr29::one();
     for (size_t i = t; i < big; i += T) {
         Fr x0 = a[i];
-        if (coset) x0 = x0 * gi;
+        if (coset) x0 = step_mul(x0, gi);
         Fr c = x0, d = x0;
         if (i < small) {
             Fr x1 = a[i + big];
-            if (coset) x1 = x1 * (gi * g_big);
+            if (coset) x1 = step_mul(x1, mul(gi, gb));
             c = x0 + x1;
             d = x0 - x1;
         }
         a[i] = c;
-        D[i] = d * wi;
-        wi = wi * w.stride;
-        if (coset) gi = gi * g.stride;
+        D[i] = step_mul(d, wi);
+        wi = mul(wi, ws);
+        if (coset) gi = mul(gi, gs);
     }
 }
 // D[k] <- sum_(j < R) D[k + j q], k < q: R-fold wrap of a vector of R q elements
@@ -303,10 +318,11 @@ __global__ __launch_bounds__(256) void k_step_wrap(Fr *__restrict__ D, size_t q,
 __global__ __launch_bounds__(256) void k_step_inv_mid(const Fr *__restrict__ a, Fr *__restrict__ D, size_t big, size_t small, StepPow w) {
     const size_t T = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= big) return;
-    Fr wi = fr_pow_dev(w.base, t);
+    const Fr29 ws = step_to261(w.stride);
+    Fr29 wi = step_pow261(step_to261(w.base), t);
     for (size_t i = t; i < big; i += T) {
-        D[i] = i < small ? Fr::zero() : a[i] * wi;
-        wi = wi * w.stride;
+        D[i] = i < small ? Fr::zero() : step_mul(a[i], wi);
+        wi = mul(wi, ws);
     }
 }
 // a[i], a[big + i] <- (U0[i] +- omega^-i (U1[i] - S[i])) / 2 for i < small; the inverse coset shift on every entry
@@ -314,19 +330,19 @@ __global__ __launch_bounds__(256) void k_step_inv_post(Fr *__restrict__ a, const
                                                        Fr gi_big, Fr half, int coset) {
     const size_t T = (size_t)gridDim.x * blockDim.x, t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= big) return;
-    Fr wi = fr_pow_dev(wi_.base, t), gi = coset ? fr_pow_dev(gi_.base, t) : Fr::one();
+    const Fr29 ws = step_to261(wi_.stride), gs = step_to261(gi_.stride), gb = step_to261(gi_big), h = step_to261(half);
+    Fr29 wi = step_pow261(step_to261(wi_.base), t), gi = coset ? step_pow261(step_to261(gi_.base), t) : Fr29::one();
     for (size_t i = t; i < big; i += T) {
         if (i < small) {
-            const Fr u0 = a[i], u1 = (a[big + i] - S[i]) * wi;
-            Fr lo = (u0 + u1) * half, hi = (u0 - u1) * half;
-            if (coset) { lo = lo * gi; hi = hi * (gi * gi_big); }
-            a[i] = lo;
-            a[big + i] = hi;
+            const Fr u0 = a[i], u1 = step_mul(a[big + i] - S[i], wi);
+            // with the coset shift the halving and the shift are one constant each
+            a[i] = step_mul(u0 + u1, coset ? mul(h, gi) : h);
+            a[big + i] = step_mul(u0 - u1, coset ? mul(h, mul(gi, gb)) : h);
         } else if (coset) {
-            a[i] = a[i] * gi;
+            a[i] = step_mul(a[i], gi);
         }
-        wi = wi * wi_.stride;
-        if (coset) gi = gi * gi_.stride;
+        wi = mul(wi, ws);
+        if (coset) gi = mul(gi, gs);
     }
 }
 
