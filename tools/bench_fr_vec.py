@@ -130,8 +130,37 @@ def sumcheck():
             del tabs, suff
 
 
+def single_rounds():
+    """One round of DPMle::pushRandomness (lsa_fr_fold: 64 B in + 32 B out per output element) and of the DPBeta suffix
+    update (lsa_fr_scale_upper: 32 B in + 32 B out) on device-resident tables: the per-round work of a resident sumcheck
+    prover beside lsa_fr_sumcheck_round -- plain HBM streams, one product per output element."""
+    lsa.init(0)
+    L = lsa.lib()
+    for d in (20, 24):
+        n, half = 1 << d, 1 << (d - 1)
+        gen = torch.Generator(device="cuda:0").manual_seed(d)
+        t = torch.randint(0, 1 << 62, (n, 4), dtype=torch.int64, device="cuda:0", generator=gen)
+        t[:, 3] &= (1 << 60) - 1
+        r = torch.from_numpy(o.fr_mont(12345).view(np.int64).copy()).to("cuda:0")
+        k = o.fr_mont(777)
+        cur = torch.empty((half, 4), dtype=torch.int64, device="cuda:0")
+        for name, byt, fn in (("fr_fold (pushRandomness)", 96 * half, lambda: lsa._check(L.lsa_fr_fold(t.data_ptr(), half, r.data_ptr(), cur.data_ptr(), 1))),
+                              ("fr_scale_upper (DPBeta suffix)", 64 * half, lambda: lsa._check(L.lsa_fr_scale_upper(t.data_ptr(), half, lsa._host_ptr(k), cur.data_ptr(), 1)))):
+            fn()
+            lsa.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                fn()
+            lsa.synchronize()
+            dt = (time.perf_counter() - t0) / 10
+            print(json.dumps({"op": name, "log_half": d - 1, "ms": round(dt * 1e3, 4), "algorithmic_GBps": round(byt / dt / 1e9, 1),
+                              "frac_of_8TBps": round(byt / dt / 8e12, 4)}), flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "sumcheck":
+    if len(sys.argv) > 1 and sys.argv[1] == "single":
+        single_rounds()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sumcheck":
         sumcheck()
     elif len(sys.argv) > 1 and sys.argv[1] == "ntt":
         ntt()
