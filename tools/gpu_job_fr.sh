@@ -1,5 +1,5 @@
 #!/bin/bash
-cd /root/repo || exit 1
+cd "$(dirname "$0")/.." || exit 1
 python3 tools/bench_fr_vec.py ntt > gpurun_out/r05_v4_ntt.txt 2>&1
 sh tools/profile_cmd_timeline.sh r05_v4_ntt 12 tools/bench_fr_vec.py ntt > /dev/null 2>&1
 python3 tools/bench_fr_vec.py > gpurun_out/r05_v4_fr_vec.txt 2>&1
