@@ -243,6 +243,15 @@ def measure(lsa, torch, np, dev, log2n=20, d=20, log2pairs=12, reps=5, only=None
             lsa._check(lsa.lib().lsa_fr_fold(cur.data_ptr(), size, d_rr[j].data_ptr(), cur.data_ptr(), 1))
         lsa.synchronize()
         ok = ok and (np.array_equal(val, fold_end) or np.array_equal(val, host(cur[0])))
+        # a resident sumcheck prover's first round at d = 24: the round polynomial over two MLE tables with the beta factor
+        # (make_new_h_poly, sumcheck.h:85-106) and one pushRandomness (mle.h:199-210) -- the second table is d_w's storage
+        hh = n // 2
+        pre_m, rho_m = curve.fr_mont(12345), curve.fr_mont(67890)
+        d_w.copy_(d_v.flip(0))
+        ms_sc = timed(lambda: lsa.sumcheck_round([d_v, d_w], suff=d_w[:hh], pre=pre_m, rho_j=rho_m), half)
+        scr = torch.empty((hh, 4), dtype=torch.int64, device=dev)
+        ms_pr = timed(lambda: lsa._check(lsa.lib().lsa_fr_fold(d_v.data_ptr(), hh, d_r[0].data_ptr(), scr.data_ptr(), 1)), half)
+        del scr
         # algorithmic bytes: v read once, w written once (witness); the table read once (evalMLE).  Bytes moved: what the
         # launches read and write -- twelve rounds per pass (fr_vec.hip: k_fold_pairs_fused), so a pass over n_in inputs
         # moves 64 n_in (witness) / 32 n_in (evalMLE) bytes + n_in / 4096 outputs, and the passes' inputs are N, N / 4096
@@ -255,6 +264,12 @@ def measure(lsa, torch, np, dev, log2n=20, d=20, log2pairs=12, reps=5, only=None
                       "witness_frac_algorithmic": round(bw_alg / ms_w / 1e6 / HBM_PEAK_GBS, 4),
                       "eval_mle_moved_GBps": round(be / ms_e / 1e6, 1), "eval_mle_frac_moved": round(be / ms_e / 1e6 / HBM_PEAK_GBS, 4),
                       "eval_mle_frac_algorithmic": round(be_alg / ms_e / 1e6 / HBM_PEAK_GBS, 4)},
+              "resident_prover_round_0": {"sumcheck_round_ms": ms_sc, "sumcheck_round_algorithmic_bytes": 160 * hh,
+                                          "sumcheck_round_frac_of_hbm": round(160 * hh / ms_sc / 1e6 / HBM_PEAK_GBS, 4),
+                                          "push_randomness_ms": ms_pr, "push_randomness_algorithmic_bytes": 96 * hh,
+                                          "push_randomness_frac_of_hbm": round(96 * hh / ms_pr / 1e6 / HBM_PEAK_GBS, 4),
+                                          "note": "lsa_fr_sumcheck_round over two tables of 2^24 with the beta factor (a blocking call: the coefficients "
+                                                  "come back to the host), lsa_fr_fold of one table: the per-round work of a prover whose tables stay on the device"},
               "note": "all d rounds of each recursion: one product per output element on 29-bit limbs, twelve rounds per pass (two in "
                       "registers, ten as a tree in LDS), the last rounds in one workgroup, the launch sequence replayed as a hipGraph; "
                       "with two rounds per launch (start of round 5) the same recursions moved 85 N / 53 N bytes, with every round "
