@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/fuzz_parity.py [seconds] [seed] -- randomised differential run of the C-ABI against the oracle (GPU box).
+"""tools/fuzz_parity.py [seconds] [seed] [--big] -- randomised differential run of the C-ABI against the oracle (GPU box).
 
 The parametrised tests under tests/ pin chosen shapes; this draws shapes and contents at random for a time budget and
 compares every result with the oracle's restatement of the reference algorithm: MSMs (G1 / G2; bases with random Z,
@@ -51,9 +51,12 @@ def bases(rng, group, n):
     return pts
 
 
+BIG = "--big" in sys.argv            # larger MSMs (the general pipeline beyond the compact one's range, the CRS cache's prefix tables)
+
+
 def case_msm(rng):
     group = rng.choice(["g1", "g1", "g2"])
-    top = 16 if group == "g1" else 13
+    top = (19 if group == "g1" else 16) if BIG else (16 if group == "g1" else 13)
     n = rng.choice([rng.randrange(0, 40), rng.randrange(40, 3000), 1 << rng.randrange(5, top), (1 << rng.randrange(5, top)) + rng.randrange(-3, 4)])
     n = max(n, 0)
     pts, sc = bases(rng, group, n) if n else np.zeros((0, 12 if group == "g1" else 24), dtype=np.uint64), scalars(rng, n) if n else np.zeros((0, 4), dtype=np.uint64)
@@ -158,8 +161,9 @@ CASES = [("msm", case_msm, 5), ("batch_exp", case_batch_exp, 2), ("scalar_mul_ba
 
 
 def main():
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
-    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 20261003
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    budget = float(args[0]) if len(args) > 0 else 300.0
+    seed0 = int(args[1]) if len(args) > 1 else 20261003
     lsa.init(0)
     stats = {name: {"cases": 0, "failures": 0, "failed": []} for name, _, _ in CASES}
     pick = [c for c in CASES for _ in range(c[2])]
