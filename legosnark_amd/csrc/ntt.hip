@@ -20,6 +20,7 @@
 // the 8 x 32-bit CIOS the previous version used.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -55,6 +56,18 @@ __global__ __launch_bounds__(256) void k_ntt_t2_table(Fr base, Fr c0, unsigned l
     if (t >> (l2 + l3)) return;
     const uint64_t k2 = t >> l3, i3 = t & (((uint64_t)1 << l3) - 1);
     out[t] = c0 * fr_pow_dev(base, i3 * k2);
+}
+
+// pass 1's twiddles as one table: out[k1 m + col] = c0 * base^(col k1), m = 2^lm columns (each lane: one power by
+// square-and-multiply, then a run of successive products with base^k1 along its row)
+__global__ __launch_bounds__(256) void k_ntt_t1_table(Fr base, Fr c0, unsigned l1, unsigned lm, Fr *__restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t lo = t * 16;                                                       // 16 consecutive columns of one row (m >= 16: lm >= 4)
+    if (lo >> (l1 + lm)) return;
+    const uint64_t k1 = lo >> lm, col = lo & (((uint64_t)1 << lm) - 1);
+    const Fr step = fr_pow_dev(base, k1);
+    Fr x = c0 * fr_pow_dev(step, col);
+    for (unsigned j = 0; j < 16; j++) { out[lo + j] = x; x = x * step; }
 }
 
 // out[k] = c0 * base^k, k < count (each lane: one power by square-and-multiply, then a run of successive products)
@@ -116,7 +129,7 @@ struct DomainTables {
     Fr omega;                      // as the caller passed it (the key), with `inverse`
     bool inverse = false;
     void *mem = nullptr;
-    Fr *Tlo = nullptr, *Thi = nullptr, *T2 = nullptr;
+    Fr *Tlo = nullptr, *Thi = nullptr, *T2 = nullptr, *T1 = nullptr;
     uint32_t *W9 = nullptr;        // W as limbs
     uint64_t tick = 0;
 };
@@ -151,12 +164,17 @@ int domain_tables(const NttPlan &p, const Fr &omega, bool inverse, hipStream_t s
     if (d.mem) { (void)hipFree(d.mem); d.mem = nullptr; }
     const size_t nW = (size_t)1 << (p.lmax - 1), nlo = (size_t)1 << p.h, nhi = (size_t)1 << (p.L - p.h);
     const size_t n2t = p.l2 ? (size_t)1 << (p.l2 + p.l3) : 0;
-    if (hipMalloc(&d.mem, (nW + nlo + nhi + n2t) * sizeof(Fr) + nW * 36) != hipSuccess) { (void)hipGetLastError(); d.mem = nullptr; set_error("fr_ntt: twiddle allocation failed"); return LSA_ERR_NOMEM; }
+    // pass 1's twiddles as one table of n entries (a product per element less) while n * 32 B stays within LSA_NTT_T1_MB
+    // (default 512: up to 2^24 elements); beyond, and for rows shorter than a lane's run, the two-level look-up
+    static const size_t t1_budget = (size_t)(getenv("LSA_NTT_T1_MB") ? atol(getenv("LSA_NTT_T1_MB")) : 512) << 20;
+    const size_t n1t = (p.l1 && p.L - p.l1 >= 4 && (((size_t)1 << p.L) * sizeof(Fr)) <= t1_budget) ? (size_t)1 << p.L : 0;
+    if (hipMalloc(&d.mem, (nW + nlo + nhi + n2t + n1t) * sizeof(Fr) + nW * 36) != hipSuccess) { (void)hipGetLastError(); d.mem = nullptr; set_error("fr_ntt: twiddle allocation failed"); return LSA_ERR_NOMEM; }
     Fr *Wp = (Fr *)d.mem;           // W as words: the source of W9
     d.Tlo = Wp + nW;
     d.Thi = d.Tlo + nlo;
     d.T2 = n2t ? d.Thi + nhi : nullptr;
-    d.W9 = (uint32_t *)(d.Thi + nhi + n2t);
+    d.T1 = n1t ? d.Thi + nhi + n2t : nullptr;
+    d.W9 = (uint32_t *)(d.Thi + nhi + n2t + n1t);
     d.L = p.L; d.omega = omega; d.inverse = inverse; d.tick = ++g_ntt_tick;
     const Fr w = inverse ? omega.inverse() : omega;
     const Fr c32 = Fr::from_u32(32);                       // Montgomery value * 32 = the canonical words of the 2^261 form
@@ -169,6 +187,10 @@ int domain_tables(const NttPlan &p, const Fr &omega, bool inverse, hipStream_t s
     if (!rc) rc = launch_pow_table(host_pow(w, (uint64_t)1 << p.h), c32, nhi, d.Thi, st);
     if (!rc && n2t) {
         hipLaunchKernelGGL(k_ntt_t2_table, dim3((unsigned)((n2t + 255) / 256)), dim3(256), 0, st, host_pow(w, (uint64_t)1 << p.l1), c32, p.l2, p.l3, d.T2);
+        if (hipGetLastError() != hipSuccess) { set_error("fr_ntt: table kernel launch failed"); rc = LSA_ERR_HIP; }
+    }
+    if (!rc && n1t) {
+        hipLaunchKernelGGL(k_ntt_t1_table, dim3((unsigned)((n1t / 16 + 255) / 256)), dim3(256), 0, st, w, c32, p.l1, p.L - p.l1, d.T1);
         if (hipGetLastError() != hipSuccess) { set_error("fr_ntt: table kernel launch failed"); rc = LSA_ERR_HIP; }
     }
     if (rc) { (void)hipFree(d.mem); d.mem = nullptr; return rc; }
@@ -239,7 +261,7 @@ int fr_ntt_device(Fr *d_a, unsigned log_n, const Fr &omega, bool inverse, const 
         Fr *dst = (nk == 1 || i + 1 == nk) ? d_a : d_tmp;
         a.src = src;
         a.dst = dst;
-        a.W = dt->W9; a.Tlo = dt->Tlo; a.Thi = dt->Thi; a.T2 = dt->T2;
+        a.W = dt->W9; a.Tlo = dt->Tlo; a.Thi = dt->Thi; a.T2 = dt->T2; a.T1 = dt->T1;
         a.Glo = ct ? ct->Glo : nullptr;
         a.Ghi = ct ? ct->Ghi : nullptr;
         a.gh = p.h;

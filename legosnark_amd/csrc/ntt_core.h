@@ -21,6 +21,8 @@
 //   W[j]    = rho^j, rho = omega^(n / 2^lmax), j < 2^(lmax - 1)          the butterflies' twiddles of every pass
 //   Tlo[e], Thi[e]:  omega^e = Thi[e >> h] * Tlo[e & (2^h - 1)]           pass 1's twiddles (two-level: n of them)
 //   T2[k2 n3 + i3] = omega^(n1 i3 k2)                                     pass 2's twiddles (m = n2 n3 of them: one table)
+//   T1[k1 m + i']  = omega^(i' k1)                                        pass 1's twiddles as ONE table of n entries where that is
+//                                                                         affordable (a product per element less than the two-level form)
 //   Glo, Ghi: c * g^i the same way                                        coset powers (forward: on load; inverse: with 1/n on store)
 #pragma once
 #include <stddef.h>
@@ -82,6 +84,7 @@ struct NttArgs {
     const uint32_t *W;            // the butterflies' twiddles as limbs (9 words per entry: no unpacking per butterfly)
     const Fr *Tlo, *Thi;          // 2^261-form words
     const Fr *T2;                 // pass 2's twiddles, or null: two-level look-up (tests)
+    const Fr *T1;                 // pass 1's twiddles omega^(col k) at [k 2^(L - l1) + col] (n of them), or null: two-level look-up
     const Fr *Glo, *Ghi;          // coset / scale tables or null
     unsigned gh;                  // Glo has 2^gh entries
     int pre_scale;                // first pass: a[i] *= G(i) on load
@@ -191,8 +194,9 @@ LSA_HD void ntt_tile_store(const NttArgs &a, unsigned w, unsigned x, const uint3
     const unsigned c = x & (C - 1), k = x >> logC;
     if (a.pass.kind == 1) {
         const uint64_t col = (uint64_t)w * C + c;
-        const Fr29 v = mul(ntt_lds_get(lds, x), ntt_two_level(a.Tlo, a.Thi, p.h, col * k));
-        a.dst[((uint64_t)k << (p.L - p.l1)) + col] = v.to_words();                 // < 2r < 2^256
+        const uint64_t at = ((uint64_t)k << (p.L - p.l1)) + col;
+        const Fr29 tw = a.T1 ? Fr29::from_words(a.T1[at]) : ntt_two_level(a.Tlo, a.Thi, p.h, col * k);
+        a.dst[at] = mul(ntt_lds_get(lds, x), tw).to_words();                         // < 2r < 2^256
     } else if (a.pass.kind == 2) {
         const uint64_t q = (uint64_t)w * C + c;
         const uint64_t k1 = q >> p.l3, i3 = q & ((1ull << p.l3) - 1);

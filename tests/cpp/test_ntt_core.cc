@@ -69,7 +69,7 @@ static void reference_radix2(std::vector<Fr> &a, unsigned L, Fr w) {
 }
 
 struct Tables {
-    std::vector<Fr> W, Tlo, Thi, T2, Glo, Ghi;
+    std::vector<Fr> W, Tlo, Thi, T2, T1, Glo, Ghi;
     Fr cst;
     unsigned gh;
 };
@@ -98,6 +98,12 @@ static void run_three_pass(std::vector<Fr> &a, unsigned L, Fr omega, bool invers
         for (uint64_t k2 = 0; k2 < (1ull << p.l2); k2++)
             for (uint64_t i3 = 0; i3 < (1ull << p.l3); i3++) t.T2[(k2 << p.l3) + i3] = to261(fr_pow(w1, i3 * k2));
     }
+    if (p.l1 && (tile_log % 3) != 0) {                // two of three tile sizes run pass 1 from its full table
+        t.T1.resize(n);
+        const uint64_t m = 1ull << (p.L - p.l1);
+        for (uint64_t k1 = 0; k1 < (1ull << p.l1); k1++)
+            for (uint64_t col = 0; col < m; col++) t.T1[k1 * m + col] = to261(fr_pow(w, col * k1));
+    }
     t.gh = p.h;
     if (coset) {
         const Fr g = inverse ? coset->inverse() : *coset;
@@ -122,6 +128,7 @@ static void run_three_pass(std::vector<Fr> &a, unsigned L, Fr omega, bool invers
         for (size_t j = 0; j < t.W.size(); j++) ntt_lds_put(W9.data(), (unsigned)j, Fr29::from_words(t.W[j]));
         args.W = W9.data(); args.Tlo = t.Tlo.data(); args.Thi = t.Thi.data();
         args.T2 = t.T2.empty() ? nullptr : t.T2.data();
+        args.T1 = t.T1.empty() ? nullptr : t.T1.data();
         args.Glo = coset ? t.Glo.data() : nullptr; args.Ghi = coset ? t.Ghi.data() : nullptr;
         args.gh = t.gh;
         args.pre_scale = (pi == 0 && coset && !inverse) ? 1 : 0;
