@@ -288,7 +288,12 @@ def measure(lsa, torch, np, dev, log2n=20, d=20, log2pairs=12, reps=5, only=None
             wroot = wroot * wroot % curve.R
         w = curve.fr_mont(wroot)
         g5 = curve.fr_mont(5)                          # FieldT::multiplicative_generator (lipmaa.cc:138)
-        ms_f = timed(lambda: lsa.fr_ntt(d_a, w), half)
+        # (a transform is 2.5 ms: a lone warm-up call does not bring an idle chip's clocks up -- 2.9 ms for the two timed calls
+        # that followed it, 2.44 for the same call in a loop -- so a few more go first and at least five are timed)
+        for _ in range(4):
+            lsa.fr_ntt(d_a, w)
+        ntt_reps = max(half, 5)
+        ms_f = timed(lambda: lsa.fr_ntt(d_a, w), ntt_reps)
         d_a.copy_(keep)
         # checks: icosetFFT(cosetFFT(a)) == a; FFT of the delta at 1 is omega^k (spot values)
         lsa.fr_ntt(d_a, w, coset=g5)
@@ -296,7 +301,7 @@ def measure(lsa, torch, np, dev, log2n=20, d=20, log2pairs=12, reps=5, only=None
         lsa.fr_ntt(d_a, w, inverse=True, coset=g5)
         lsa.synchronize()
         ok = changed and torch.equal(d_a, keep)
-        ms_ic = timed(lambda: lsa.fr_ntt(d_a, w, inverse=True, coset=g5), half)
+        ms_ic = timed(lambda: lsa.fr_ntt(d_a, w, inverse=True, coset=g5), ntt_reps)
         delta = torch.zeros((n, 4), dtype=torch.int64, device=dev)
         delta[1] = torch.from_numpy(curve.fr_mont(1).view(np.int64))
         lsa.fr_ntt(delta, w)
