@@ -138,7 +138,7 @@ struct CosetTables {
     Fr g;
     bool inverse = false;
     void *mem = nullptr;
-    Fr *Glo = nullptr, *Ghi = nullptr;
+    Fr *Glo = nullptr, *Ghi = nullptr, *Gfull = nullptr;
     uint64_t tick = 0;
 };
 constexpr int NTT_CACHE = 8;          // a step domain keeps two sub-domains, each in both directions
@@ -206,9 +206,15 @@ int coset_tables(const NttPlan &p, const Fr &g, bool inverse, hipStream_t st, Co
     CosetTables &d = *victim;
     if (d.mem) { (void)hipFree(d.mem); d.mem = nullptr; }
     const size_t nlo = (size_t)1 << p.h, nhi = (size_t)1 << (p.L - p.h);
-    if (hipMalloc(&d.mem, (nlo + nhi) * sizeof(Fr)) != hipSuccess) { (void)hipGetLastError(); d.mem = nullptr; set_error("fr_ntt: coset table allocation failed"); return LSA_ERR_NOMEM; }
+    // the powers as one table of n entries (a product per element less) up to a quarter of the budget of pass 1's twiddles:
+    // 128 MB, 2^22 elements -- at 2^24 the second 512-MB stream costs what the product saved (icosetFFT 2.52 -> 2.54 ms;
+    // 2^20: 0.187 -> 0.172)
+    static const size_t full_budget = ((size_t)(getenv("LSA_NTT_T1_MB") ? atol(getenv("LSA_NTT_T1_MB")) : 512) << 20) / 4;
+    const size_t nfull = (p.L > NTT_TILE_LOG && (((size_t)1 << p.L) * sizeof(Fr)) <= full_budget) ? (size_t)1 << p.L : 0;
+    if (hipMalloc(&d.mem, (nlo + nhi + nfull) * sizeof(Fr)) != hipSuccess) { (void)hipGetLastError(); d.mem = nullptr; set_error("fr_ntt: coset table allocation failed"); return LSA_ERR_NOMEM; }
     d.Glo = (Fr *)d.mem;
     d.Ghi = d.Glo + nlo;
+    d.Gfull = nfull ? d.Ghi + nhi : nullptr;
     d.L = p.L; d.g = g; d.inverse = inverse; d.tick = ++g_ntt_tick;
     const Fr c32 = Fr::from_u32(32);
     // forward: g^i on load; inverse: (1/n) g^-k on store (the 1/n rides in the high table)
@@ -216,6 +222,7 @@ int coset_tables(const NttPlan &p, const Fr &g, bool inverse, hipStream_t st, Co
     const Fr hi0 = inverse ? fr_mul_hd(c32, host_pow(Fr::from_u32(2), p.L).inverse()) : c32;
     int rc = launch_pow_table(base, c32, nlo, d.Glo, st);
     if (!rc) rc = launch_pow_table(host_pow(base, (uint64_t)1 << p.h), hi0, nhi, d.Ghi, st);
+    if (!rc && nfull) rc = launch_pow_table(base, hi0, nfull, d.Gfull, st);
     if (rc) { (void)hipFree(d.mem); d.mem = nullptr; return rc; }
     *out = &d;
     return LSA_OK;
@@ -264,6 +271,7 @@ int fr_ntt_device(Fr *d_a, unsigned log_n, const Fr &omega, bool inverse, const 
         a.W = dt->W9; a.Tlo = dt->Tlo; a.Thi = dt->Thi; a.T2 = dt->T2; a.T1 = dt->T1;
         a.Glo = ct ? ct->Glo : nullptr;
         a.Ghi = ct ? ct->Ghi : nullptr;
+        a.Gfull = ct ? ct->Gfull : nullptr;
         a.gh = p.h;
         a.pre_scale = (i == 0 && coset && !inverse) ? 1 : 0;
         a.post_scale = (i + 1 == nk && coset && inverse) ? 1 : 0;

@@ -86,6 +86,7 @@ struct NttArgs {
     const Fr *T2;                 // pass 2's twiddles, or null: two-level look-up (tests)
     const Fr *T1;                 // pass 1's twiddles omega^(col k) at [k 2^(L - l1) + col] (n of them), or null: two-level look-up
     const Fr *Glo, *Ghi;          // coset / scale tables or null
+    const Fr *Gfull;              // the same powers c g^i as ONE table of n entries, or null: the two-level look-up
     unsigned gh;                  // Glo has 2^gh entries
     int pre_scale;                // first pass: a[i] *= G(i) on load
     int post_scale;               // last pass: X[k] *= G(k) on store (tables), else X[k] *= cst
@@ -143,7 +144,7 @@ LSA_HD NttSlot ntt_load_slot(const NttArgs &a, unsigned w, unsigned x) {
 LSA_HD void ntt_tile_load(const NttArgs &a, unsigned w, unsigned x, uint32_t *lds) {
     const NttSlot s = ntt_load_slot(a, w, x);
     Fr29 v = Fr29::from_words(a.src[s.gaddr]);
-    if (a.pre_scale) v = mul(v, ntt_two_level(a.Glo, a.Ghi, a.gh, s.gaddr));      // [< 2r]
+    if (a.pre_scale) v = mul(v, a.Gfull ? Fr29::from_words(a.Gfull[s.gaddr]) : ntt_two_level(a.Glo, a.Ghi, a.gh, s.gaddr));      // [< 2r]
     ntt_lds_put(lds, s.idx, v);
 }
 // butterfly b (< tile / 2) of stage s; the W table is read from memory (4 KB for 8-stage passes: it lives in the L1 / L2
@@ -207,7 +208,7 @@ LSA_HD void ntt_tile_store(const NttArgs &a, unsigned w, unsigned x, const uint3
         const unsigned per_k2 = 1u << (p.l1 - logC);
         const uint64_t k2 = w / per_k2, k1 = (uint64_t)(w % per_k2) * C + c;
         const uint64_t kout = k1 + (k2 << p.l1) + ((uint64_t)k << (p.l1 + p.l2));
-        const Fr29 g = a.post_scale ? ntt_two_level(a.Glo, a.Ghi, a.gh, kout) : Fr29::from_words(a.cst);
+        const Fr29 g = a.post_scale ? (a.Gfull ? Fr29::from_words(a.Gfull[kout]) : ntt_two_level(a.Glo, a.Ghi, a.gh, kout)) : Fr29::from_words(a.cst);
         a.dst[kout] = mul(ntt_lds_get(lds, c * (len + 1) + k), g).canonical2().to_words();
     }
 }

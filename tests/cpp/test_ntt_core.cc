@@ -69,7 +69,7 @@ static void reference_radix2(std::vector<Fr> &a, unsigned L, Fr w) {
 }
 
 struct Tables {
-    std::vector<Fr> W, Tlo, Thi, T2, T1, Glo, Ghi;
+    std::vector<Fr> W, Tlo, Thi, T2, T1, Glo, Ghi, Gfull;
     Fr cst;
     unsigned gh;
 };
@@ -109,6 +109,7 @@ static void run_three_pass(std::vector<Fr> &a, unsigned L, Fr omega, bool invers
         const Fr g = inverse ? coset->inverse() : *coset;
         t.Glo = pow_table(g, c32, (size_t)1 << t.gh);
         t.Ghi = pow_table(fr_pow(g, (uint64_t)1 << t.gh), c32 * ninv, (size_t)1 << (p.L - t.gh));
+        if ((tile_log % 3) == 1) t.Gfull = pow_table(g, c32 * ninv, n);      // one of three tile sizes takes the coset powers from the full table
     }
     std::vector<Fr> scratch(n);
     std::vector<unsigned> kinds;
@@ -130,6 +131,7 @@ static void run_three_pass(std::vector<Fr> &a, unsigned L, Fr omega, bool invers
         args.T2 = t.T2.empty() ? nullptr : t.T2.data();
         args.T1 = t.T1.empty() ? nullptr : t.T1.data();
         args.Glo = coset ? t.Glo.data() : nullptr; args.Ghi = coset ? t.Ghi.data() : nullptr;
+        args.Gfull = (coset && !t.Gfull.empty()) ? t.Gfull.data() : nullptr;
         args.gh = t.gh;
         args.pre_scale = (pi == 0 && coset && !inverse) ? 1 : 0;
         args.post_scale = (pi + 1 == kinds.size() && coset && inverse) ? 1 : 0;
