@@ -699,9 +699,9 @@ public:
     }
     void print() const { std::cout << *this << "\n"; }
     // libff "scalar * point" on the host (cold path: a verifier's handful of points; vectors of them go through
-    // lsa_mtxmultiexp / lsa_scalar_mul_batch).  The same point as libff's double-and-add; computed MSB-first over
-    // 4-bit digits with the fifteen small multiples of the base (a quarter of the additions), plain double-and-add
-    // for scalars below 2^16.
+    // lsa_mtxmultiexp / lsa_scalar_mul_batch).  The same point as libff's double-and-add, by the cheapest route: plain
+    // double-and-add for scalars below 2^16, the fixed-base table for the generator, a GLV (G1) / Galbraith-Scott (G2)
+    // ladder for any other base (csrc/fixed_base.h, csrc/smul_host.h).
     friend G_shim operator*(const alt_bn128_Fr &k, const G_shim &p) {
         lsa_shim::StatScope scope(lsa_shim::ST_SCALAR_MUL_HOST, 1);
         lsa_shim::SmulScope route(GROUP);
@@ -723,7 +723,8 @@ public:
             route.route = 0;
             return G_shim(generator_table().mul(e.data));
         }
-        if (getenv("LSA_SHIM_BASE_HISTOGRAM")) {                      // diagnostic: which bases the generic ladder multiplies, how often
+        static const bool histogram_on = getenv("LSA_SHIM_BASE_HISTOGRAM") != nullptr;
+        if (histogram_on) {                                           // diagnostic: which bases the generic ladder multiplies, how often
             static std::mutex hm;
             static std::vector<std::pair<std::string, unsigned>> hist;
             std::lock_guard<std::mutex> lk(hm);
