@@ -354,7 +354,8 @@ int lsa_pairing_terms(const void *g1_jac, const void *g2_jac, const void *const 
  * (every call recomputes its tables).  Calls with more than 1024 terms or device-resident points bypass
  * it.  stats: hits, misses, resident tables, evictions. */
 int lsa_g2_table_cache(size_t max_tables);
-/* Starts building the tables of the points the cache does not hold yet and returns without waiting: what
+/* Promises the tables of the points the cache does not hold yet and returns without waiting (they are built in one
+ * launch when the next Miller call arrives, or earlier once LSA_G2_PREFETCH_BATCH = 60 of them are waiting): what
  * libff's precompute_G2 costs the caller when the result is only ever handed back to miller_loop
  * (src/gadgets/poly.h:116-118: precompute_G2(pts[i] * g2) inside a host loop).  Host pointer. */
 int lsa_g2_tables_prefetch(const void *g2_jac, size_t n);

@@ -756,8 +756,8 @@ def pairing_terms(g1, offsets, g2=None, tables=None, index=None, flags=None, fin
 
 
 def g2_tables_prefetch(g2):
-    """Promise the line tables of these G2 points to the device's cache (built asynchronously, five at a time or when the
-    next Miller call arrives): what the shim's precompute_G2 does."""
+    """Promise the line tables of these G2 points to the device's cache (built when the next Miller call arrives,
+    or earlier once LSA_G2_PREFETCH_BATCH = 60 of them are waiting): what the shim's precompute_G2 does."""
     g2 = np.ascontiguousarray(g2, dtype=np.uint64).reshape(-1, 24)
     lib().lsa_g2_tables_prefetch.argtypes = [C.c_void_p, C.c_size_t]
     _check(lib().lsa_g2_tables_prefetch(_host_ptr(g2), len(g2)))
