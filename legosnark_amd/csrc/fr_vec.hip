@@ -262,6 +262,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < half; p += (size_t)gridDim.x * blockDim.x) {
         Fr29 q[M + 1];
         q[0] = suff ? Fr29::from_words(suff[p]) : one;
+        if constexpr (M == 2) {
+            // two tables (the Hadamard prover's shape): five products instead of six -- s (a0 + da X) first, then its
+            // product with (b0 + db X) by Karatsuba: the middle coefficient is (sa0 + sda)(b0 + db) - sa0 b0 - sda db
+            const Fr29 a0 = Fr29::from_words(tabs.t[0][p]), da = sub2r(Fr29::from_words(tabs.t[0][p + half]), a0);
+            const Fr29 b0 = Fr29::from_words(tabs.t[1][p]), db = sub2r(Fr29::from_words(tabs.t[1][p + half]), b0);
+            const Fr29 sa0 = mul(q[0], a0), sda = mul(q[0], da);                      // < 2r each
+            const Fr29 p0 = mul(sa0, b0), p2 = mul(sda, db);
+            const Fr29 pm = mul(add(sa0, sda), add(b0, db));                            // (< 4r)(< 4r)
+            q[0] = p0;
+            q[1] = sub2r(sub2r(pm, p0), p2);                                            // pm - p0 - p2 + 4r < 6r
+            q[2] = p2;
+        } else {
 #pragma unroll
         for (int t = 0; t < M; t++) {
             const Fr29 v0 = Fr29::from_words(tabs.t[t][p]);
@@ -271,9 +283,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int i = t; i >= 1; i--) q[i] = add(mul(q[i], v0), mul(q[i - 1], dv));
             q[0] = mul(q[0], v0);
         }
+        }
 #pragma unroll
         for (int i = 0; i <= M; i++) c[i] = add(c[i], q[i]);
-        if (++since == 16) {                                                        // 16 * 4r + 2r < 121 r
+        if (++since == 16) {                                                        // 16 * 6r + 2r < 121 r
 #pragma unroll
             for (int i = 0; i <= M; i++) c[i] = mul(c[i], one);
             since = 0;
