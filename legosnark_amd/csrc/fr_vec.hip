@@ -202,6 +202,83 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// evalMLE from 2^16 entries on, as the reference states it (MultiVPolyT::evalMLE, polytools.h:207-234: the table of
+// eq-monomials and a dot product) -- with the monomial factored over three groups of index bits,
+//   eq(idx) = E6[idx & 63] * WL[(idx >> 6) & 511] * WH[idx >> 15],
+// so that the n products are data x constant, independent of each other (no tree, no barrier between them), and a
+// wavefront's loads are contiguous 2-KB runs: lane l of a wavefront sums v[(C 512 + j) 64 + l] * WL[j] over its j's (the
+// constant is the same in every lane), multiplies the sum by WH[C] once per 128 elements, and by E6[l] once at the end.
+// The three tables (64 + 512 + 2^(d-15) entries in 2^261 form) cost 2^(d-15) (d - 15) + 5 000 products to build.
+// Sums stay lazy on fr29.h's limbs (32 products of < 2r each between two normalisations).
+static constexpr unsigned MLE_LO = 6, MLE_MID = 9, MLE_MIN_D = 16;
+__global__ __launch_bounds__(256) void k_mle_eq_tables(const Fr *__restrict__ r, unsigned d, Fr *__restrict__ E6, Fr *__restrict__ WL, Fr *__restrict__ WH) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n6 = (size_t)1 << MLE_LO, nl = (size_t)1 << MLE_MID, nh = (size_t)1 << (d - MLE_LO - MLE_MID);
+    unsigned first, bits;
+    size_t idx;
+    Fr *dst;
+    if (t < n6) { first = 0; bits = MLE_LO; idx = t; dst = E6 + t; }
+    else if (t < n6 + nl) { first = MLE_LO; bits = MLE_MID; idx = t - n6; dst = WL + idx; }
+    else if (t < n6 + nl + nh) { first = MLE_LO + MLE_MID; bits = d - MLE_LO - MLE_MID; idx = t - n6 - nl; dst = WH + idx; }
+    else return;
+    Fr acc = Fr::from_u32(32);                                   // (value * 32: the words of the 2^261 form)
+    for (unsigned i = 0; i < bits; i++) {
+        const Fr ri = r[first + i];
+        acc = acc * (((idx >> i) & 1) ? ri : Fr::one() - ri);
+    }
+    *dst = acc;
+}
+__global__ __launch_bounds__(256) void k_mle_dot(const Fr *__restrict__ v, unsigned d, unsigned ju_log, const Fr *__restrict__ E6, const Fr *__restrict__ WL,
+                                                 const Fr *__restrict__ WH, Fr *__restrict__ partial) {
+    __shared__ Fr s_red[256];
+    // a unit: 2^ju_log values of j for one C; wavefront-uniform values are made so explicitly: the constants WL[j], WH[C]
+    // then come through scalar loads into scalar registers
+    const unsigned lane = threadIdx.x & 63, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned ju = 1u << ju_log, per_c = (1u << MLE_MID) >> ju_log;
+    const size_t waves = (size_t)gridDim.x * 4, units = ((size_t)per_c) << (d - MLE_LO - MLE_MID);
+    const Fr29 one = Fr29::one();
+    Fr29 total = Fr29::zero();
+    unsigned since = 0;
+    for (size_t u = (size_t)blockIdx.x * 4 + wave; u < units; u += waves) {
+        const size_t C = u / per_c;
+        const unsigned j0 = (unsigned)(u % per_c) << ju_log;
+        const Fr *in = v + (((C << MLE_MID) + j0) << MLE_LO) + lane;
+        const Fr *wl = WL + j0;
+        Fr29 acc = Fr29::zero();
+#pragma unroll 1
+        for (unsigned jj = 0; jj < ju; jj += 4) {
+            const Fr x0 = in[(size_t)(jj + 0) << MLE_LO], x1 = in[(size_t)(jj + 1) << MLE_LO], x2 = in[(size_t)(jj + 2) << MLE_LO], x3 = in[(size_t)(jj + 3) << MLE_LO];
+            const Fr29 w0 = Fr29::from_words(wl[jj]), w1 = Fr29::from_words(wl[jj + 1]), w2 = Fr29::from_words(wl[jj + 2]), w3 = Fr29::from_words(wl[jj + 3]);
+            acc = add(acc, add(add(mul(Fr29::from_words(x0), w0), mul(Fr29::from_words(x1), w1)),
+                               add(mul(Fr29::from_words(x2), w2), mul(Fr29::from_words(x3), w3))));
+            if ((jj & 28) == 28) acc = mul(acc, one);            // after 32 products: < 64r + 2r, back below 2r
+        }
+        if (ju < 32) acc = mul(acc, one);                        // (short units never met the normalisation above)
+        total = add(total, mul(acc, Fr29::from_words(WH[C])));
+        if (++since == 32) { total = mul(total, one); since = 0; }
+    }
+    s_red[threadIdx.x] = mul(total, Fr29::from_words(E6[lane])).canonical2().to_words();
+    __syncthreads();
+    for (unsigned sft = 128; sft >= 1; sft >>= 1) {
+        if (threadIdx.x < sft) s_red[threadIdx.x] = s_red[threadIdx.x] + s_red[threadIdx.x + sft];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = s_red[0];
+}
+// out = sum of n partials (one workgroup)
+__global__ __launch_bounds__(256) void k_mle_finish(const Fr *__restrict__ partial, unsigned n, Fr *__restrict__ out) {
+    __shared__ Fr lds[256];
+    Fr acc = Fr::zero();
+    for (unsigned b = threadIdx.x; b < n; b += 256) acc = acc + partial[b];
+    lds[threadIdx.x] = acc;
+    __syncthreads();
+    for (unsigned sft = 128; sft >= 1; sft >>= 1) {
+        if (threadIdx.x < sft) lds[threadIdx.x] = lds[threadIdx.x] + lds[threadIdx.x + sft];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = lds[0];
+}
+
 // the remaining rounds (m_first, m_first / 2, ... 1 output elements) by one workgroup; round j reads what round j - 1
 // wrote (ping-pong between bufA and bufB, continuing the caller's parity), r_ptr / w advance per round.
 // w == nullptr: evalMLE's last rounds -- no coefficients kept; out != nullptr: the last round's value goes there
@@ -487,6 +564,23 @@ int fr_eval_mle_device(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_tmp, Fr *d_
 static int fr_eval_mle_issue(const Fr *d_v, size_t d, const Fr *d_r, Fr *d_tmp, Fr *d_out, hipStream_t st) {
     if (d == 0) {
         HIPCHK(hipMemcpyAsync(d_out, d_v, sizeof(Fr), hipMemcpyDeviceToDevice, st));
+        return LSA_OK;
+    }
+    static const bool dot_on = !(getenv("LSA_MLE_DOT") && getenv("LSA_MLE_DOT")[0] == '0');      // 0: the fold passes at every size (A/B)
+    if (dot_on && d >= MLE_MIN_D && d <= 40) {
+        // tables and partials live in the scratch: 64 + 512 + 2^(d-15) + (number of workgroups) elements
+        const size_t nh = (size_t)1 << (d - MLE_LO - MLE_MID);
+        Fr *E6 = d_tmp, *WL = E6 + 64, *WH = WL + 512, *partial = WH + nh;
+        const size_t ntab = 64 + 512 + nh;
+        hipLaunchKernelGGL(k_mle_eq_tables, dim3((unsigned)((ntab + 255) / 256)), dim3(256), 0, st, d_r, (unsigned)d, E6, WL, WH);
+        // units of 2^ju_log values of j: as long as 128 where that still leaves 8192 of them, never shorter than 16
+        unsigned ju_log = 7;
+        while (ju_log > 4 && ((nh << MLE_MID) >> ju_log) < 8192) ju_log--;
+        const size_t units = (nh << MLE_MID) >> ju_log;
+        const unsigned blocks = (unsigned)(units / 4 < 2048 ? units / 4 : 2048);       // four wavefronts per workgroup, a unit each at least
+        hipLaunchKernelGGL(k_mle_dot, dim3(blocks), dim3(256), 0, st, d_v, (unsigned)d, ju_log, (const Fr *)E6, (const Fr *)WL, (const Fr *)WH, partial);
+        hipLaunchKernelGGL(k_mle_finish, dim3(1), dim3(256), 0, st, (const Fr *)partial, blocks, d_out);
+        HIPCHK(hipGetLastError());
         return LSA_OK;
     }
     // The variables from the BOTTOM: round j pairs neighbours with r[j] -- the same multilinear value as folding the top
