@@ -158,8 +158,50 @@ def single_rounds():
                               "frac_of_8TBps": round(byt / dt / 8e12, 4)}), flush=True)
 
 
+def prover_loop():
+    """The Fr work of a whole sumcheck prover over two MLE tables and the beta factor, tables resident on the device
+    (CPSumcheck::prove's loop, /root/reference/src/gadgets/sumcheck.cc:60-92 with sumcheck.h:85-106, mle.h:46-53,199-210):
+    per round j the round polynomial (its coefficients come back to the host: the prover hashes / commits them), then
+    pushRandomness on both tables and the suffix update -- d rounds, the vectors halving.  The reference runs these loops
+    on the host field (`##had_sc (Sumcheck) Prove` of hadamard d also holds its commitments)."""
+    lsa.init(0)
+    L = lsa.lib()
+    for d in (20, 24):
+        n = 1 << d
+        gen = torch.Generator(device="cuda:0").manual_seed(1000 + d)
+        def table(m):
+            t = torch.randint(0, 1 << 62, (m, 4), dtype=torch.int64, device="cuda:0", generator=gen)
+            t[:, 3] &= (1 << 60) - 1
+            return t
+        a0, b0, s0 = table(n), table(n), table(n // 2)
+        rs, _ = o.random_scalars(d, seed=7)
+        ks, _ = o.random_scalars(d, seed=8)
+        pre, rho = o.fr_mont(12345), o.fr_mont(67890)
+        d_r = torch.from_numpy(rs.view(np.int64).copy()).to("cuda:0")
+        ts = []
+        for rep in range(4):
+            a, b, sf = a0.clone(), b0.clone(), s0.clone()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for j in range(d):
+                half = 1 << (d - j - 1)
+                use_suff = j + 1 <= d - 1
+                lsa.sumcheck_round([a[:2 * half], b[:2 * half]], suff=sf[:half] if use_suff else None, pre=pre, rho_j=rho)
+                for tv in (a, b):
+                    lsa._check(L.lsa_fr_fold(tv.data_ptr(), half, d_r[j].data_ptr(), tv.data_ptr(), 1))
+                if half >= 2:
+                    lsa._check(L.lsa_fr_scale_upper(sf.data_ptr(), half // 2, lsa._host_ptr(ks[j]), sf.data_ptr(), 1))
+            lsa.synchronize()
+            ts.append(time.perf_counter() - t0)
+        print(json.dumps({"op": "resident sumcheck prover loop, two tables + beta", "d": d, "rounds": d, "ms": round(sorted(ts)[1] * 1e3, 3),
+                          "ms_runs": [round(x * 1e3, 3) for x in ts]}), flush=True)
+        del a0, b0, s0
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "single":
+    if len(sys.argv) > 1 and sys.argv[1] == "prover":
+        prover_loop()
+    elif len(sys.argv) > 1 and sys.argv[1] == "single":
         single_rounds()
     elif len(sys.argv) > 1 and sys.argv[1] == "sumcheck":
         sumcheck()
