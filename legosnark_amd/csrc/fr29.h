@@ -144,4 +144,50 @@ struct Fr29 {
     }
 };
 
+// Sums of products with ONE reduction: the 17 column sums of up to FOUR schoolbook products a (x) b of tight operands
+// (a column takes at most 9 limb products of 58 bits per product: 36 * 2^58 < 2^64 together with the reduction's own
+// terms), then a single Montgomery reduction -- 4 * 81 + 81 multiply-adds for four products instead of 4 * 162.  For a dot
+// product sum v_j W_j the partial sums are what is wanted anyway.
+struct Fr29Wide {
+    uint64_t c[17];
+};
+LSA_HD Fr29Wide fr29_wide_zero() {
+    Fr29Wide w;
+#pragma unroll
+    for (int k = 0; k < 17; k++) w.c[k] = 0;
+    return w;
+}
+// w += a (x) b; at most four calls between fr29_wide_zero and fr29_wide_reduce
+LSA_HD void fr29_wide_mac(Fr29Wide &w, const Fr29 &a, const Fr29 &b) {
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) w.c[i + j] += (uint64_t)a.l[i] * b.l[j];
+}
+// (the integer w stands for) / 2^261 mod r.  w < 121 r^2 in value.  [< 2r; tight]
+LSA_HD Fr29 fr29_wide_reduce(const Fr29Wide &w) {
+    uint64_t acc = 0;
+    uint32_t m[9];
+    Fr29 o;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        acc += w.c[k];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * Fr29::r(k - i);
+        m[k] = ((uint32_t)acc * Fr29::RINV) & Fr29::MASK;
+        acc += (uint64_t)m[k] * Fr29::r(0);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+        acc += w.c[k];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * Fr29::r(k - i);
+        o.l[k - 9] = (uint32_t)acc & Fr29::MASK;
+        acc >>= 29;
+    }
+    o.l[8] = (uint32_t)acc;
+    return o;
+}
+
 }  // namespace lsa

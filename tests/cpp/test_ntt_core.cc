@@ -177,6 +177,30 @@ int main() {
         for (int i = 0; i < 12; i++) { S = add(S, mul(C, Fr29::one())); ref = ref + c; }
         CHECK(memcmp(mul(S, B).canonical2().to_words().l, (ref * b).l, 32) == 0, "fr29 lazy sums");
     }
+    // sums of up to four products with one reduction (fr29_wide_*): the same residue as four reduced products added up,
+    // also on the largest operands the bounds allow (all limbs at their maximum: 2^29 - 1, the value 2^261 - 1 > r)
+    for (int t = 0; t < 2000; t++) {
+        Fr a[4], b[4];
+        Fr want = Fr::zero();
+        Fr29Wide w = fr29_wide_zero();
+        const int terms = 1 + t % 4;
+        for (int q = 0; q < terms; q++) {
+            a[q] = rand_fr(); b[q] = rand_fr();
+            fr29_wide_mac(w, Fr29::from_words(a[q]), Fr29::from_words(to261(b[q])));
+            want = want + a[q] * b[q];
+        }
+        CHECK(memcmp(fr29_wide_reduce(w).canonical2().to_words().l, want.l, 32) == 0, "fr29 wide sum of products");
+    }
+    {
+        Fr29 top;
+        for (int i = 0; i < 9; i++) top.l[i] = Fr29::MASK;
+        Fr29Wide w = fr29_wide_zero();
+        for (int q = 0; q < 4; q++) fr29_wide_mac(w, top, Fr29::from_words(to261(Fr::one())));       // 4 * (2^261 - 1) * 1
+        const Fr29 got = fr29_wide_reduce(w);
+        const Fr29 one_term = mul(top, Fr29::from_words(to261(Fr::one())));
+        const Fr29 four = add(add(one_term, one_term), add(one_term, one_term));
+        CHECK(memcmp(mul(got, Fr29::one()).canonical2().to_words().l, mul(four, Fr29::one()).canonical2().to_words().l, 32) == 0, "fr29 wide on full limbs");
+    }
     {
         Fr one_w;
         Fr29::one().pack256(one_w.l);
