@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""tools/fuzz_parity.py [seconds] [seed] [--big] -- randomised differential run of the C-ABI against the oracle (GPU box).
+"""tests/fuzz_parity.py [seconds] [seed] [--big] -- randomised differential run of the C-ABI against the oracle (GPU box).
 
 The parametrised tests under tests/ pin chosen shapes; this draws shapes and contents at random for a time budget and
 compares every result with the oracle's restatement of the reference algorithm: MSMs (G1 / G2; bases with random Z,
 points at infinity, repeated bases; scalars of 254 / 128 / 64 / 31 / 16 bits with 0, 1 and r - 1 planted), batch_exp,
 batched scalar multiplication, pairing products with conjugated terms and several segments, the radix-2 and the step
 NTT in all four modes, the witness recursion, evalMLE, pushRandomness and the sumcheck round polynomial.  One JSON line
-per operation kind at the end (cases, failures, the seeds of failures); exit status 1 on any mismatch.  The oracle is the
-checker here, as in tests/: nothing under legosnark_amd/ imports it."""
+per operation kind at the end (cases, failures, the seeds of failures); exit status 1 on any mismatch.  A script, not a
+pytest module (its run time is a budget, not a property): the oracle is the checker here as in the tests beside it."""
 import json
 import os
 import random
@@ -18,7 +18,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import legosnark_amd as lsa  # noqa: E402
 import oracle_lib as o  # noqa: E402
 

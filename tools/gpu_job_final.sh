@@ -25,5 +25,5 @@ python3 tools/bench_fr_vec.py single >> "$OUT/${TAG}_fr_vec.txt" 2>&1
 python3 tools/bench_fr_vec.py prover >> "$OUT/${TAG}_fr_vec.txt" 2>&1
 grep -v oracle "$OUT/${TAG}_fr_vec.txt" | tail -8
 sh tools/profile_cmd_timeline.sh ${TAG}_fr_vec 12 tools/bench_fr_vec.py > /dev/null 2>&1
-python3 tools/fuzz_parity.py ${FUZZ_SECONDS:-300} 5 > "$OUT/${TAG}_fuzz_parity.txt" 2>&1
+python3 tests/fuzz_parity.py ${FUZZ_SECONDS:-300} 5 > "$OUT/${TAG}_fuzz_parity.txt" 2>&1
 tail -2 "$OUT/${TAG}_fuzz_parity.txt"
