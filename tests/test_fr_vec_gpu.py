@@ -107,8 +107,11 @@ def test_cppoly_prove_on_device_end_to_end(lsa):
 
 
 @pytest.mark.parametrize("m,half,beta,suff", [(2, 1, True, True), (2, 7, True, True), (2, 5000, True, True), (2, 300, True, False),
-                                              (1, 64, True, True), (3, 1000, True, True), (4, 33, False, False), (2, 70000, False, False)])
+                                              (1, 64, True, True), (3, 1000, True, True), (4, 33, False, False), (2, 70000, False, False),
+                                              (2, (1 << 18) + 777, True, True), (2, 5 * 262144 + 3, True, True)])
 def test_sumcheck_round_vs_oracle(lsa, m, half, beta, suff):
+    """(The last two shapes give the lanes of the two-table kernel 1 ... 2 and 5 ... 6 indices each: full groups of four
+    indices sharing a reduction and a remainder of one or two.)"""
     tabs = [o.random_scalars(2 * half, seed=2000 + 7 * m + t)[0] for t in range(m)]
     s = o.random_scalars(half, seed=31 + m)[0] if suff else None
     pr = o.random_scalars(2, seed=32 + m)[0]
