@@ -30,6 +30,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden (it is meant to be linked beside libsnark / libff builds and other
+ * C++ code): the entry points declared in this header are its ONLY dynamic symbols (tests/test_capi_symbols.py). */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef enum {
     LSA_OK = 0,
@@ -423,6 +428,9 @@ int lsa_pairing_product_segments(const void *g1_jac, const void *g2_jac, const u
 int lsa_g1_normalize(const void *in_jac, size_t n, void *out_jac);
 int lsa_g2_normalize(const void *in_jac, size_t n, void *out_jac);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -192,7 +192,7 @@ static constexpr int FU_PAIRS = 5;                                     // pairs 
 // tabs (optional): tabs[i] non-null -> the table of g2[i] is also written there (a point seen for the first time: its
 // table goes into the cache while its first Miller loop runs).
 __global__ __launch_bounds__(128) void k_miller_fused(const Jac<Fq> *__restrict__ g1, const Jac<Fq2> *__restrict__ g2, const uint8_t *__restrict__ flags,
-                                                      uint32_t *const *__restrict__ tabs, size_t n, Fq12 *__restrict__ out, int exper) {
+                                                      uint32_t *const *__restrict__ tabs, size_t n, Fq12 *__restrict__ out) {
     using TP = TabMillerP<WaveLocalExec, FU_PAIRS>;
     __shared__ Fq2S g2mem[FU_PAIRS * GP_STRIDE];
     __shared__ Fq2S tpmem[TP::LDS_FQ2];
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(128) void k_miller_fused(const Jac<Fq> *__restrict_
 #pragma unroll 1
     for (int e = -1; e < ATE_NUM_COEFFS; e++) {
         if (wave == 0) {
-            if (e + 1 < ATE_NUM_COEFFS) pre.entry_rounds(kinds[e + 1], e + 1, tout, rows[(e + 1) % 3], true, exper);
-        } else if (e >= 0 && !(exper & 2)) {
+            if (e + 1 < ATE_NUM_COEFFS) pre.entry_rounds(kinds[e + 1], e + 1, tout, rows[(e + 1) % 3], true);
+        } else if (e >= 0) {
             tp.entry(kinds[e], e);
         }
         __syncthreads();
@@ -471,11 +471,8 @@ int g2_table_identity_device(uint32_t *d_tab, hipStream_t st) {
 }
 int miller_fused_device(const void *d_g1, const void *d_g2, const uint8_t *d_flags, uint32_t *const *d_tabs, size_t n, void *d_out, hipStream_t st) {
     if (n == 0) return LSA_OK;
-    // LSA_FUSED_EXPERIMENT (timing only, WRONG values): 1 = no combine phase on the G2 side, 2 = no Fq12 chain, 4 = no
-    // product phase on the G2 side; sums combine ("the fused Miller kernel's ceiling")
-    static const int exper = getenv("LSA_FUSED_EXPERIMENT") ? atoi(getenv("LSA_FUSED_EXPERIMENT")) : 0;
     hipLaunchKernelGGL(k_miller_fused, dim3((unsigned)((n + FU_PAIRS - 1) / FU_PAIRS)), dim3(128), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, d_flags,
-                       d_tabs, n, (Fq12 *)d_out, exper);
+                       d_tabs, n, (Fq12 *)d_out);
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }

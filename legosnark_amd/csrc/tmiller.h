@@ -226,12 +226,9 @@ struct G2Pre {
 
     // one round; after the rounds that complete a line (2: doubling, 5: addition) lanes (k < 3, part) write it out: into the
     // table out[g] (packed, global memory) and / or as three Fq2S at rows[g] (LDS: the consumer's row ring)
-    // exper (k_miller_fused's timing-only experiments, LSA_FUSED_EXPERIMENT): bit 0 skips the combine phase, bit 2 the
-    // product phase -- wrong values, the same control flow: what a restructured round could save at most
-    LSA_HD void round(int op, int x2, uint32_t *const *out, int entry, Fq2S *const *rows = nullptr, bool scaled = false, int exper = 0) {
+    LSA_HD void round(int op, int x2, uint32_t *const *out, int entry, Fq2S *const *rows = nullptr, bool scaled = false) {
         Fq2S *m = mem;
         const Prod pr = products_of(op, x2, scaled);
-        if (!(exper & 4))
         x.par([=](unsigned lane) {
             const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
             if (g >= (unsigned)NG || (int)k >= pr.n) return;
@@ -240,7 +237,6 @@ struct G2Pre {
             const Fs r = {w12_comp_mul<20>(part, w12_load(V + (unsigned)((pr.a >> (8 * k)) & 0xffu)), w12_load(V + (unsigned)((pr.b >> (8 * k)) & 0xffu)))};
             w12_store(&w12_comp(V[GP_P0 + k], part), r);
         });
-        if (!(exper & 1))
         x.par([=](unsigned lane) {
             const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
             if (g >= (unsigned)NG || k) return;
@@ -263,11 +259,11 @@ struct G2Pre {
         }
     }
     // the rounds of table entry `entry` (its kind: tm_entry_kind)
-    LSA_HD void entry_rounds(int kind, int entry, uint32_t *const *out, Fq2S *const *rows, bool scaled = false, int exper = 0) {
+    LSA_HD void entry_rounds(int kind, int entry, uint32_t *const *out, Fq2S *const *rows, bool scaled = false) {
         const int x2 = kind == 2 ? GP_Q1X : (kind == 3 ? GP_Q2X : GP_QX);
         const int first = kind == 0 ? 0 : 3, last = kind == 0 ? 3 : 7;
 #pragma unroll 1
-        for (int op = first; op < last; op++) round(op, x2, out, entry, rows, scaled, exper);
+        for (int op = first; op < last; op++) round(op, x2, out, entry, rows, scaled);
     }
     // scaled mode: the affine G1 point of each pair (libff precompute_G1; neg: -P, the conjugate Miller value)
     LSA_HD void setup_g1(const Jac<Fq> *const *Pp, const uint8_t *neg, unsigned count) {

@@ -35,6 +35,23 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
 
 
+def test_library_exports_nothing_else():
+    """-fvisibility=hidden + csrc/exports.map: the dynamic symbol table is the header, nothing more (the library is
+    linked beside libsnark / libff builds: no stray C++ or kernel-handle symbols may interpose)."""
+    import subprocess
+    import legosnark_amd
+    if not os.path.exists(legosnark_amd.LIB_PATH):
+        legosnark_amd.build()
+    libs = [legosnark_amd.LIB_PATH]
+    lb = legosnark_amd.LIB_PATH.replace(".so", "_loopback.so")
+    if os.path.exists(lb):
+        libs.append(lb)
+    for path in libs:
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+        assert sorted(names) == declared_symbols(), (path, sorted(set(names) ^ set(declared_symbols()))[:10])
+
+
 def test_no_cpu_fallback_without_device():
     """Without a GPU every compute entry point must fail loudly (never fall back)."""
     import legosnark_amd

@@ -2,7 +2,12 @@
 """tools/fused_experiment.py -- k_miller_fused (2^12 fresh pairs, one launch) timed with HIP events under the setting of
 LSA_FUSED_EXPERIMENT in the environment: 0 = the kernel as shipped; 1 / 2 / 4 and their sums leave out the G2 side's
 combine phase / the Fq12 chain / the G2 side's product phase (WRONG values: timing only).  What any restructuring of
-those phases could save at most."""
+those phases could save at most.
+
+The switches were removed from the shipped kernel after round 5 (a nonzero value made every fresh-pair pairing product
+wrong and poisoned the G2 table cache): to repeat the experiment check out commit 6534bcb (csrc/tmiller.h G2Pre::round,
+csrc/pairing.hip miller_fused_device), whose numbers are profiles/r05_v1_fused_miller_experiments.txt.  On the current
+tree this script times the kernel as shipped, whatever LSA_FUSED_EXPERIMENT says."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
