@@ -281,6 +281,16 @@ int lsa_fr_sumcheck_round(const void *suff_mont, const void *const *tables, size
  * p < half (k = rhoInvs[j+1], ONE Fr, HOST pointer); cur may alias old.  on_device != 0: old,
  * cur are device pointers, asynchronous on lsa_stream(); else host pointers. */
 int lsa_fr_scale_upper(const void *old_mont, size_t half, const void *k_mont, void *cur_mont, int on_device);
+/* DPBeta::compute_eq_tbl (src/prototools/mle.h:93-105), the table DPBeta::precomputeAll (mle.h:121-137) starts from;
+ * 2^d entries, 1 <= d <= 30, eqbit(1, x) = x, eqbit(0, x) = 1 - x (mle.cc:12-15).
+ *   variant 0 -- what the reference's loop computes: its doubling step reads dst[p >> 1], so every factor is selected by
+ *                the TOP bit of p:  out[p] = prod_j (1 - r[j]) for p < 2^(d-1),  prod_j r[j] above.  Use this one to
+ *                reproduce the reference's proofs.
+ *   variant 1 -- the table the loop's comment describes:  out[p] = prod_{j < d} eqbit(bit j of p, r[j]).
+ * The prover's first suffix table is then lsa_fr_scale_upper(out, 2^(d-1), rhoInvs[0], suff) (mle.h:132-137).
+ * on_device != 0: r (d entries) and out are device pointers and the call is asynchronous on lsa_stream(); else host
+ * pointers. */
+int lsa_fr_eq_table(const void *r_mont, size_t d, int variant, void *out_mont, int on_device);
 
 /* In-place radix-2 NTT of 2^log_n Fr values, natural order in and out: replaces libfqfft
  * basic_radix2_domain<Fr>::FFT / iFFT / cosetFFT / icosetFFT as used by the Lipmaa gadget

@@ -102,6 +102,7 @@ def lib():
         L.lsa_fr_ntt_step.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.lsa_fr_sumcheck_round.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.lsa_fr_scale_upper.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+        L.lsa_fr_eq_table.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int]
         L.lsa_miller_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
         L.lsa_miller_loop_product.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.lsa_pairing_product.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
@@ -604,6 +605,15 @@ def fr_scale_upper(old, k):
     cur = np.zeros((half, 4), dtype=np.uint64)
     _check(lib().lsa_fr_scale_upper(_host_ptr(old), half, _host_ptr(k), _host_ptr(cur), 0))
     return cur
+
+
+def fr_eq_table(r, variant=0):
+    """DPBeta::compute_eq_tbl (mle.h:93-105) on a host vector r of d Fr: 2^d entries.  variant 0: as the reference's loop
+    computes it (selected by the top index bit only); 1: the eq monomials prod_j eqbit(bit j of p, r[j])."""
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((1 << len(r), 4), dtype=np.uint64)
+    _check(lib().lsa_fr_eq_table(_host_ptr(r), len(r), variant, _host_ptr(out), 0))
+    return out
 
 
 def fr_ntt(a, omega, inverse=False, coset=None):

@@ -1749,6 +1749,26 @@ int lsa_fr_scale_upper(const void *old, size_t half, const void *k, void *cur, i
     return LSA_OK;
 }
 
+int lsa_fr_eq_table(const void *r, size_t d, int variant, void *out, int on_device) {
+    LSA_TRACE_CALL("fr_eq_table", (size_t)1 << (d & 63));
+    int rc = require_ready();
+    if (rc) return rc;
+    if (d == 0 || d > 30) { set_error("fr_eq_table: need 1 <= d <= 30 (got %zu)", d); return LSA_ERR_INVALID; }
+    if (!out || (d && !r)) { set_error("fr_eq_table: null argument"); return LSA_ERR_INVALID; }
+    if (variant != 0 && variant != 1) { set_error("fr_eq_table: variant %d (0: the reference's loop, 1: the eq monomials)", variant); return LSA_ERR_INVALID; }
+    const size_t N = (size_t)1 << d;
+    StageBuf &d_tmp = g_stage_fr_tmp, &d_r = g_stage_fr_r, &d_o = g_stage_fr_w;
+    if (d_tmp.ensure(fr_eq_table_scratch_elems(d) * sizeof(Fr))) { set_error("fr_eq_table: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    if (on_device) return fr_eq_table_device((const Fr *)r, d, variant, (Fr *)d_tmp.p, (Fr *)out, g.stream);
+    if (d_r.ensure((d + 1) * sizeof(Fr)) || d_o.ensure(N * sizeof(Fr))) { set_error("fr_eq_table: hipMalloc failed"); return LSA_ERR_NOMEM; }
+    if (d) LSA_UPLOAD(d_r.p, r, d * sizeof(Fr));
+    rc = fr_eq_table_device((const Fr *)d_r.p, d, variant, (Fr *)d_tmp.p, (Fr *)d_o.p, g.stream);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    LSA_DOWNLOAD(out, d_o.p, N * sizeof(Fr));
+    return LSA_OK;
+}
+
 int lsa_fr_ntt(void *a, size_t log_n, const void *omega, int inverse, const void *coset_g, int on_device) {
     LSA_TRACE_CALL("fr_ntt", (size_t)1 << log_n);
     int rc = require_ready();

@@ -449,6 +449,45 @@ __global__ __launch_bounds__(256) void k_scale_upper(const Fr *old, size_t half,
         cur[p] = fr_mul_261(old[p + half], k261);
 }
 
+// DPBeta::compute_eq_tbl (/root/reference/src/prototools/mle.h:93-105).  Two tables:
+//  * as the reference's loop computes it (variant 0): its doubling step is tmp[p] = eqbit(msb(p), r[j]) * dst[p >> 1] -- the old
+//    index keeps the top bit of p, not the low bits -- so every factor is selected by the TOP bit of p:
+//        dst[p] = prod_j (1 - r[j]) for p < 2^(d-1),   prod_j r[j] above.
+//    That is the table DPBeta::precomputeAll (mle.h:121-137) consumes, hence what a drop-in returns.
+//  * the table the comment above the loop describes (variant 1): dst[p] = prod_{j < d} eqbit(bit j of p, r[j]) -- for a
+//    maintainer who repairs the index upstream.  The monomial is factored over the low and the high half of the index bits:
+//    two small tables (2^lo + 2^(d - lo) entries, <= d / 2 products each), then ONE product per entry of a pure write stream.
+// eqbit(true, r) = r, eqbit(false, r) = 1 - r (mle.cc:12-15).  Fr values are canonical: the association of the products
+// does not matter.
+__global__ __launch_bounds__(256) void k_eq_fill_literal(const Fr *__restrict__ r, unsigned d, size_t n, Fr *__restrict__ out) {
+    Fr lo = Fr::one(), hi = Fr::one();
+    for (unsigned j = 0; j < d; j++) {
+        const Fr rj = r[j];
+        lo = lo * (Fr::one() - rj);
+        hi = hi * rj;
+    }
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x) out[p] = p >= n / 2 ? hi : lo;
+}
+__global__ __launch_bounds__(256) void k_eq_factor_tables(const Fr *__restrict__ r, unsigned d, unsigned lo, Fr *__restrict__ LO, Fr *__restrict__ HI) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t nlo = (size_t)1 << lo, nhi = (size_t)1 << (d - lo);
+    if (t >= nlo + nhi) return;
+    const bool low = t < nlo;
+    const size_t idx = low ? t : t - nlo;
+    const unsigned first = low ? 0u : lo, bits = low ? lo : d - lo;
+    Fr acc = Fr::one();
+    for (unsigned i = 0; i < bits; i++) {
+        const Fr ri = r[first + i];
+        acc = acc * (((idx >> i) & 1) ? ri : Fr::one() - ri);
+    }
+    (low ? LO : HI)[idx] = acc;
+}
+__global__ __launch_bounds__(256) void k_eq_expand(const Fr *__restrict__ LO, const Fr *__restrict__ HI, unsigned lo, size_t n, Fr *__restrict__ out) {
+    const size_t mask = ((size_t)1 << lo) - 1;
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (size_t)gridDim.x * blockDim.x)
+        out[p] = fr_mul_261(LO[p & mask], fr_to_261(HI[p >> lo]));
+}
+
 #define HIPCHK(x)                                                                      \
     do {                                                                               \
         hipError_t e_ = (x);                                                           \
@@ -647,6 +686,22 @@ int fr_sumcheck_round_device(const Fr *d_suff, const Fr *const *d_tables, size_t
     return LSA_OK;
 }
 size_t fr_sumcheck_scratch_elems() { return (size_t)1024 * (SC_MAX_M + 1); }
+
+// d_tmp: 2^(d / 2) + 2^(d - d / 2) elements
+int fr_eq_table_device(const Fr *d_r, size_t d, int variant, Fr *d_tmp, Fr *d_out, hipStream_t st) {
+    const unsigned lo = (unsigned)(d / 2);
+    const size_t nlo = (size_t)1 << lo, nhi = (size_t)1 << (d - lo), n = (size_t)1 << d;
+    if (variant == 0) {
+        hipLaunchKernelGGL(k_eq_fill_literal, dim3(stream_blocks(n)), dim3(256), 0, st, d_r, (unsigned)d, n, d_out);
+        HIPCHK(hipGetLastError());
+        return LSA_OK;
+    }
+    hipLaunchKernelGGL(k_eq_factor_tables, dim3((unsigned)((nlo + nhi + 255) / 256)), dim3(256), 0, st, d_r, (unsigned)d, lo, d_tmp, d_tmp + nlo);
+    hipLaunchKernelGGL(k_eq_expand, dim3(stream_blocks(n)), dim3(256), 0, st, (const Fr *)d_tmp, (const Fr *)(d_tmp + nlo), lo, n, d_out);
+    HIPCHK(hipGetLastError());
+    return LSA_OK;
+}
+size_t fr_eq_table_scratch_elems(size_t d) { return ((size_t)1 << (d / 2)) + ((size_t)1 << (d - d / 2)); }
 
 int fr_scale_upper_device(const Fr *d_old, size_t half, const Fr &k, Fr *d_cur, hipStream_t st) {
     if (half == 0) return LSA_OK;

@@ -76,6 +76,8 @@ int fr_sumcheck_round_device(const Fr *d_suff, const Fr *const *d_tables, size_t
 size_t fr_sumcheck_scratch_elems();
 void fr_vec_release();            // the cached hipGraphs of the recursions (lsa_shutdown)
 int fr_scale_upper_device(const Fr *d_old, size_t half, const Fr &k, Fr *d_cur, hipStream_t st);
+int fr_eq_table_device(const Fr *d_r, size_t d, int variant, Fr *d_tmp, Fr *d_out, hipStream_t st);   // d_tmp: fr_eq_table_scratch_elems(d)
+size_t fr_eq_table_scratch_elems(size_t d);
 
 // ntt.hip: in-place radix-2 NTT of 2^log_n Fr values (device) in at most three passes; d_tmp: 2^log_n scratch elements
 // (unused up to 2^10 points); the twiddle tables are cached per domain (ntt_release frees them)

@@ -202,12 +202,20 @@ struct bigint {
 // bigint::randomize() reads std::random_device for every limb [upstream, recalled].  A
 // reproducible stream exists only under the explicit test-only macro LSA_SHIM_TEST_SEED
 // (then env LSA_SEED seeds a Mersenne twister): never define it in a production build.
-inline void lsa_random_bytes(void *buf, size_t len) {
 #ifdef LSA_SHIM_TEST_SEED
+// (test builds only: checks/resident_prover_check.cc replays one transcript through two provers)
+inline std::mt19937_64 &lsa_test_rng() {
     static std::mt19937_64 g = []() {
         const char *s = getenv("LSA_SEED");
         return std::mt19937_64(s ? strtoull(s, nullptr, 0) : 0x4C45474F534E4152ull);
     }();
+    return g;
+}
+inline void lsa_test_reseed(uint64_t seed) { lsa_test_rng().seed(seed); }
+#endif
+inline void lsa_random_bytes(void *buf, size_t len) {
+#ifdef LSA_SHIM_TEST_SEED
+    std::mt19937_64 &g = lsa_test_rng();
     unsigned char *p = (unsigned char *)buf;
     for (size_t i = 0; i < len; i += 8) { uint64_t r = g(); memcpy(p + i, &r, len - i < 8 ? len - i : 8); }
 #else

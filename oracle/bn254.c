@@ -582,6 +582,28 @@ void oracle_fr_sumcheck_round(ofp_t *out, const ofp_t *suff, const ofp_t *const 
 void oracle_fr_scale_upper(ofp_t *cur, const ofp_t *old, const ofp_t *k, size_t half) {
     for (size_t p = 0; p < half; p++) fr_mul_(&cur[p], &old[half + p], k);
 }
+/* DPBeta::compute_eq_tbl: /root/reference/src/prototools/mle.h:93-105 with eqbit(bool, r) of src/prototools/mle.cc:12-15,
+ * restated literally (the table doubles d - 1 times, the new bit on top).  dst, tmp: 2^d entries; r: d >= 1 entries.
+ * At the end dst[p] = eq(p, r). */
+void oracle_fr_eq_table(ofp_t *dst, const ofp_t *r, size_t d) {
+    size_t N = (size_t)1 << d;
+    ofp_t *a = (ofp_t *)malloc(sizeof(ofp_t) * N), *b = (ofp_t *)malloc(sizeof(ofp_t) * N), one;
+    fr_one(&one);
+    memset(a, 0, sizeof(ofp_t) * N);
+    memset(b, 0, sizeof(ofp_t) * N);
+    fr_sub_(&a[0], &one, &r[0]);                                /* dst[0] = eqbit(false, r[0]) */
+    a[1] = r[0];                                                /* dst[1] = eqbit(true, r[0]) */
+    for (size_t j = 1; j < d; j++) {
+        ofp_t omr; fr_sub_(&omr, &one, &r[j]);
+        for (size_t p = 0; p < ((size_t)1 << (j + 1)); p++) {
+            int msb = p >= ((size_t)1 << j);
+            fr_mul_(&b[p], msb ? &r[j] : &omr, &a[p >> 1]);      /* tmp[p] = eqbit(msb, r[j]) * dst[p >> 1] */
+        }
+        ofp_t *t = a; a = b; b = t;                             /* swap(tmp, dst) */
+    }
+    memcpy(dst, a, sizeof(ofp_t) * N);
+    free(a); free(b);
+}
 /* test-input helper: out = sum_i a[i] * b[i] in Fr (the O(n) check value of the
  * known-discrete-log identity at n = 2^20 .. 2^24) */
 void oracle_fr_dot(ofp_t *out, const ofp_t *a, const ofp_t *b, size_t n) {

@@ -262,6 +262,14 @@ def fr_scale_upper(old, k):
     return cur
 
 
+def fr_eq_table(r):
+    """DPBeta::compute_eq_tbl (mle.h:93-105): 2^len(r) entries."""
+    r = np.ascontiguousarray(r, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((1 << len(r), 4), dtype=np.uint64)
+    lib().oracle_fr_eq_table(_p(out), _p(r), C.c_size_t(len(r)))
+    return out
+
+
 FR_TWO_ADICITY = 28
 FR_GENERATOR = 5          # libff alt_bn128 Fr::multiplicative_generator
 

@@ -121,6 +121,30 @@ def test_sumcheck_round_vs_oracle(lsa, m, half, beta, suff):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("d", [1, 2, 3, 7, 8, 9, 13, 16])
+def test_eq_table_both_variants(lsa, d):
+    """DPBeta::compute_eq_tbl (mle.h:93-105).  Variant 0 = the reference's loop as written (restated literally in the
+    oracle: the doubling step reads dst[p >> 1]); variant 1 = the eq monomials, whose dot product with any v is
+    evalMLE(v, r) (polytools.h:207-234 builds the same table)."""
+    r, _ = o.random_scalars(d, seed=900 + d)
+    assert np.array_equal(lsa.fr_eq_table(r, 0), o.fr_eq_table(r))
+    eq1 = lsa.fr_eq_table(r, 1)
+    v, _ = o.random_scalars(1 << d, seed=950 + d)
+    R = o.R
+    rinv = pow(o.MONT, -1, R)
+    fr_int = lambda x: o.limbs_to_int(x) * rinv % R
+    assert o.fr_dot(v, eq1) == fr_int(o.fr_eval_mle(v, r))
+    if d <= 8:
+        ri = [fr_int(x) for x in r]
+        want = []
+        for p in range(1 << d):
+            acc = 1
+            for j in range(d):
+                acc = acc * (ri[j] if (p >> j) & 1 else 1 - ri[j]) % R
+            want.append(acc)
+        assert [fr_int(x) for x in eq1] == want
+
+
 def test_sumcheck_prover_inner_loop_on_device(lsa):
     """The per-round device work of CPSumcheck::prove at d = 8 (two MLE tables + the beta suffix
     table, all resident): round polynomial, then pushRandomness on every table and the suffix

@@ -288,6 +288,20 @@ def test_oracle_sumcheck_round_matches_bigint_formula():
     old_m, old = o.random_scalars(10, seed=5)
     k_m, k = o.random_scalars(1, seed=6)
     assert _fr_ints(o.fr_scale_upper(old_m, k_m[0])) == [int(old[5 + p]) * int(k[0]) % R for p in range(5)]
+    # DPBeta::compute_eq_tbl (mle.h:93-105), the loop as the reference wrote it, in Python integers.  Its doubling step reads
+    # dst[p >> 1] (not dst[p & (2^j - 1)]), so every factor ends up selected by the TOP bit of p: the table holds
+    # prod (1 - r_j) in its lower half and prod r_j in its upper half.  That is what DPBeta::precomputeAll consumes and what a
+    # drop-in has to return; the closed form is asserted beside the literal loop.
+    for d in (1, 2, 3, 5):
+        r_m, r = o.random_scalars(d, seed=70 + d)
+        dst = [(1 - int(r[0])) % R, int(r[0])]
+        for j in range(1, d):
+            dst = [((int(r[j]) if p >= (1 << j) else (1 - int(r[j]))) * dst[p >> 1]) % R for p in range(1 << (j + 1))]
+        assert _fr_ints(o.fr_eq_table(r_m)) == dst
+        lo = hi = 1
+        for x in r:
+            lo, hi = lo * (1 - int(x)) % R, hi * int(x) % R
+        assert dst == [lo] * (1 << (d - 1)) + [hi] * (1 << (d - 1))
 
 
 def test_oracle_radix2_fft_is_the_dft():

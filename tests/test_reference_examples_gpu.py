@@ -68,6 +68,38 @@ def test_keygen_matrix_batched_call_equals_reference_column_loop():
     assert '"mismatches": 0' in r.stdout
 
 
+@pytest.mark.parametrize("bindir", [BIN, BIN_MC], ids=["single", "multicore"])
+def test_fr_kernels_equal_the_references_own_templates(bindir):
+    """legosnark_amd/shim/checks/fr_check.cc: the reference's unchanged header code -- MultiVPolyT::evalMLE
+    (prototools/polytools.h:207-234), CPPoly::prove's recursion (gadgets/poly.h:55-67, observed through its own multiExpMA
+    over distinct random bases), DPMle::pushRandomness / getMLEPoly and DPBeta::pushRandomness / getBetaPoly
+    (prototools/mle.h), CPSumcheck::make_new_h_poly (gadgets/sumcheck.h:85-106) with one to three tables, with and
+    without the beta factor, d = 1 .. 16 -- against lsa_fr_eval_mle / _cppoly_witness / _fold / _scale_upper /
+    _sumcheck_round on the same random inputs, byte for byte.  This pins the f3 kernels to the reference itself, not
+    only to the oracle's restatement of these loops."""
+    import json
+    r = run("fr_check", "16", "2", bindir=bindir, OMP_NUM_THREADS="4")
+    assert r.returncode == 0, r.stdout[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["mismatching_shapes"] == 0
+    assert line["evalMLE"] == 32 and line["cppoly_witness"] == 12 and line["sumcheck_rounds"] > 500 and line["folds"] > 900 and line["suffix_updates"] > 150 and line["eq_tables"] >= 13
+
+
+@pytest.mark.parametrize("d,inputs", [("8", "random"), ("12", "squares"), ("16", "random")])
+def test_resident_prover_emits_the_references_proof(d, inputs):
+    """legosnark_amd/shim/checks/resident_prover_check.cc: CPHad's prover written against the C-ABI with a, b, c resident
+    on the device (lsa_fr_eval_mle / _cppoly_witness / _eq_table / _sumcheck_round / _fold / _scale_upper,
+    lsa_msm_run_segments_async, lsa_commit_run_async) and the unchanged CPHad::prove (gadgets/hadamardsc.cc:54-98,
+    sumcheck.cc:12-125) on the same inputs and the same seeded random stream: every proof element equal, and the
+    reference's unchanged CPHad::verify accepts the resident proof."""
+    import json
+    r = run("resident_prover_check", d, inputs)
+    assert r.returncode == 0, r.stdout[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])["resident_prover"]
+    assert line["proof_equal"] is True and line["differing_elements"] == 0 and line["reference_verifier_accepts"] is True
+    assert line["d"] == int(d)
+
+
 def test_verifier_side_through_the_shim_deferred_equals_call_by_call():
     """legosnark_amd/shim/checks/pairing_check.cc: libff G2_precomp semantics (coefficients, stream format), deferred
     GT values against explicit C-ABI calls bit for bit, the reference's own simple_pairing_check on true and false
