@@ -160,6 +160,17 @@ def reference_binary_run(d=20):
                                      "cppoly_verify": last.get("cppoly_verify"), "cppoly_verify_ms": last.get("cppoly_verify_ms")}
         except Exception as e:                               # a broken check is reported, not hidden
             res["verifier_check"] = {"program": "build/reference/pairing_check 12", "error": str(e)[:200]}
+    # the same prover with its vectors resident on the device (legosnark_amd/shim/checks/resident_prover_check.cc): CPHad's
+    # prove written against the C-ABI, fed the inputs and the random stream of the unchanged CPHad::prove, every proof
+    # element compared, the resident proof accepted by the reference's verifier
+    rp = os.path.join(ROOT, "build", "reference", "resident_prover_check")
+    if os.path.exists(rp):
+        try:
+            c = subprocess.run([rp, str(d), "squares"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+            js = [l for l in c.stdout.splitlines() if l.startswith('{"resident_prover"')]
+            res["resident_prover"] = dict(json.loads(js[-1])["resident_prover"], rc=c.returncode) if js else {"rc": c.returncode, "error": (c.stderr or c.stdout)[-300:]}
+        except Exception as e:
+            res["resident_prover"] = {"error": str(e)[:200]}
     for line in r.stderr.splitlines():
         if line.startswith('{"lsa_shim_stats"'):
             st = json.loads(line)["lsa_shim_stats"]
@@ -167,6 +178,52 @@ def reference_binary_run(d=20):
             res["process_ms"] = st["process_ms"]
             res["library_calls"] = {k: v for k, v in st.items() if isinstance(v, dict) and v.get("calls")}
     return res
+
+
+def configs_summary(configs, ref_run):
+    """One short entry per BASELINE / SURVEY 8(f) config: [ms, fraction, of what].  valu = field products/s over the measured
+    175 G/s ceiling, hbm = algorithmic bytes/s over 8 TB/s."""
+    def r3(x):
+        return None if x is None else round(float(x), 3)
+    out = {}
+    for c in configs:
+        name = c["config"]
+        if "error" in c:
+            out[name[:24]] = "check failed"
+        elif name.startswith("G2 MSM"):
+            out["g2_msm_2^20"] = [r3(c["ms"]), c["valu"]["frac"], "valu"]
+        elif name.startswith("CPpoly"):
+            out["cppoly_d20_commit"] = [r3(c["commit_ms"]), c["commit_valu"]["frac"], "valu"]
+            out["cppoly_d20_prove"] = [r3(c["prove_total_ms"]), None, "fold %.3f + ladder %.3f ms" % (c["prove_fold_ms"], c["prove_msm_ladder_segmented_ms"] or c["prove_msm_ladder_39_calls_ms"])]
+        elif name.startswith("Fr fold"):
+            out["fr_witness_d24"] = [r3(c["witness_ms"]), c["hbm"]["witness_frac_algorithmic"], "hbm"]
+            out["fr_eval_mle_d24"] = [r3(c["eval_mle_ms"]), c["hbm"]["eval_mle_frac_algorithmic"], "hbm"]
+            rr = c["resident_prover_round_0"]
+            out["fr_sumcheck_round_2^23"] = [r3(rr["sumcheck_round_ms"]), rr["sumcheck_round_frac_of_hbm"], "hbm"]
+            out["fr_push_randomness_2^23"] = [r3(rr["push_randomness_ms"]), rr["push_randomness_frac_of_hbm"], "hbm"]
+        elif name.startswith("NTT"):
+            out["ntt_2^24"] = [r3(c["fft_ms"]), c["valu"]["frac"], "valu"]
+            out["ntt_step_2^23+2^22"] = [r3(c["step_domain_2^23+2^22"]["fft_ms"]), c["step_domain_2^23+2^22"]["frac_of_hbm_algorithmic"], "hbm"]
+        elif name.startswith("pairing product"):
+            out["pairing_2^12_fresh+1_final_exp"] = [r3(c["ms"]), c["valu"]["frac"], "valu"]
+        elif name.startswith("CPhad verifier shape") and "resident" in name:
+            out["cphad_verify_resident_Q"] = [r3(c["ms"]), c["valu"]["frac"], "valu"]
+        elif name.startswith("CPhad verifier shape"):
+            out["cphad_verify_fresh_Q"] = [r3(c["ms"]), c["valu"]["frac"], "valu"]
+        elif name.startswith("one miller_loop"):
+            out["one_miller_loop"] = [r3(c["ms"]), c["valu"]["frac"], "valu"]
+        elif name.startswith("one pairing check"):
+            out["one_pairing_check"] = [r3(c["ms"]), c["valu"]["frac"], "valu"]
+        elif "N=2^24+2" in name:
+            out["cplink_prover_2^24+2_one_gpu"] = [r3(c["ms"]), c["valu"]["frac"], "valu", {"pairs_per_s": round(c["pairs_per_s"]), "table_GB": round(c["table_bytes"] / 1e9, 1)}]
+    if ref_run:
+        tm = ref_run.get("timers_ms", {})
+        out["unchanged_hadamard_20"] = {"prove_ms": tm.get("had_sc TOTAL Prove"), "verify_ms": tm.get("had_sc TOTAL Verify"), "inside_library_ms": ref_run.get("inside_library_ms")}
+        rp = ref_run.get("resident_prover")
+        if rp:
+            out["resident_prover_d20"] = {k: rp.get(k) for k in ("prove_ms", "reference_prove_ms", "proof_equal", "reference_verifier_accepts")}
+    out["format"] = "[ms, fraction, valu = of 175 G field products/s | hbm = algorithmic bytes over 8 TB/s]; every entry result-checked in this run"
+    return out
 
 
 def being_profiled():
@@ -612,7 +669,7 @@ def main():
             # the other BASELINE.json configs, each result-checked (a failed check carries "error" and no time)
             from legosnark_amd import benchcfg
             out["configs"] = benchcfg.measure(lsa, torch, np, dev, log2n=20, d=20, log2pairs=12, reps=5,
-                                              only={"g2_msm", "cppoly", "pairing", "cphad_verify", "fr_fold", "ntt"})
+                                              only={"g2_msm", "cppoly", "pairing", "cphad_verify", "fr_fold", "ntt", "cplink_2pow24"})
             for c in out["configs"]:
                 if c["config"].startswith("pairing product") and "error" not in c:
                     # 192 B in per pair; 384 B out per workgroup of five pairs (the partial products the tree continues from)
@@ -625,6 +682,12 @@ def main():
             vc = out["unchanged_reference_binary"].get("verifier_check")
             if vc and (vc.get("rc") != 0 or vc.get("failures") != 0 or "error" in vc):
                 raise SystemExit("bench.py: the verifier check beside the unchanged reference binary failed: %s" % vc)
+            rp = ref_run.get("resident_prover")
+            if rp and (rp.get("rc") != 0 or rp.get("proof_equal") is not True):
+                raise SystemExit("bench.py: the resident prover's proof differs from the unchanged reference prover's: %s" % rp)
+        # every config once more in a few hundred bytes, close to the END of the line: whoever keeps only the tail of this
+        # process's output still sees one time and one fraction per config (BENCH_r05's tail began inside the pairing entry)
+        out["configs_summary"] = configs_summary(out.get("configs") or [], ref_run)
         if not args.no_cpu_baseline and world == 1 and not strong:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as o   # the checker, timed as the reported CPU baseline
@@ -660,7 +723,7 @@ def main():
                 }
         # One line, the long blocks FIRST: whoever keeps only the tail of this process's stdout still sees the metric, the
         # roofline object, the host-path split and the CPU baseline (round 3's driver record lost those to truncation).
-        tail_keys = ("cplink_prover_host_path_ms", "stage_ms", "cpu_baseline", "roofline", "config", "metric", "value", "unit", "n_gpus", "steps",
+        tail_keys = ("cplink_prover_host_path_ms", "stage_ms", "cpu_baseline", "roofline", "configs_summary", "config", "metric", "value", "unit", "n_gpus", "steps",
                      "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "result_checked_by_identity",
                      "single_call_latency_ms", "cplink_prover_ms")
         ordered = {k: v for k, v in out.items() if k not in tail_keys}

@@ -5,6 +5,8 @@ from the MSM) or, for pairings, by planted products that must equal one.  A conf
 {"config": ..., "error": ...} and no time.
 
   cplink_prover   SubspaceSnark::prove shape (subspace.cc:78-85): MSM over N+2 pairs, w[0] = 0
+  cplink_2pow24   the same at N = 2^24 on ONE GPU (BASELINE configs[3]'s workload without its 8-way split): 1.5 GiB of bases,
+                  24 pre-shifted copies (24 GiB), checked by the known-discrete-log identity
   g2_msm          alt_bn128 G2 MSM
   cppoly          CPpoly d-variable commit + prove ladder (poly.h:30-32,76-88)
   fr_fold         CPpoly witness recursion + evalMLE at d = 24 (HBM-bound Fr streams)
@@ -107,6 +109,61 @@ def measure(lsa, torch, np, dev, log2n=20, d=20, log2pairs=12, reps=5, only=None
         emit("CPlink prover (SubspaceSnark::prove MSM), N=2^%d, resident CRS and witness" % log2n, ok,
              {"pairs": N + 2, "ms": ms, "algorithmic_bytes": 96 * (N + 2), "valu": valu((N + 2) * fm, ms)})
         P.close()
+
+    if on("cplink_2pow24"):
+        # BASELINE configs[3] is this MSM sharded over 8 GPUs; one GPU holds all of it (288 GB): the one-GPU stand-in.
+        # w = (0, rF, u) (cplink.cc:107-108): any value below r is a valid Montgomery residue, drawn on the device.
+        N = 1 << 24
+        n = N + 2
+        a, b = rng.fr_int(), rng.fr_int()
+        x = synth.arith_fr_mont(a, b, n)
+        t0 = time.perf_counter()
+        P = lsa.Bases("g1", lsa.batch_exp("g1", G1, to_dev(x)), on_device=True)
+        lsa.synchronize()
+        setup_s = time.perf_counter() - t0
+        del x
+        gen = torch.Generator(device=dev).manual_seed(2024)
+        d_w = torch.randint(-(1 << 63), (1 << 63) - 1, (n, 4), dtype=torch.int64, device=dev, generator=gen)
+        d_w[:, 3] &= (1 << 60) - 1
+        d_w[0] = 0
+        d_w = d_w.contiguous()
+        res = torch.zeros(12, dtype=torch.int64, device=dev)
+        ms = timed(lambda: P.msm_async(d_w, res), max(3, half))
+        ts = []
+        for _ in range(3):
+            lsa.synchronize()
+            t0 = time.perf_counter()
+            P.msm_async(d_w, res)
+            lsa.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        # sum_i w_i (a + i b) = a T1 + b T2 with T1 = sum w_i, T2 = sum i w_i, exactly, in blocks of 4096 rows of 32-bit words
+        wh = host(d_w)
+        w32 = wh.view(np.uint32).reshape(n, 8)
+        blk = 4096
+        nb = (n + blk - 1) // blk
+        t1 = t2 = 0
+        il = (np.arange(n, dtype=np.uint64) % blk)
+        edges = np.arange(0, n, blk)
+        for k in range(8):
+            col = w32[:, k].astype(np.uint64)
+            sb = np.add.reduceat(col, edges)                       # per block: sum of words (< 2^44)
+            lb = np.add.reduceat(col * il, edges)                  # per block: sum of (row in block) * word (< 2^56)
+            sk = sum(int(v) for v in sb)
+            lk = sum(int(v) for v in lb) + sum(int(j) * blk * int(v) for j, v in enumerate(sb))
+            t1 += sk << (32 * k)
+            t2 += lk << (32 * k)
+        del wh, w32, il
+        dot = (a * t1 + b * t2) * rinv % curve.R
+        ok = np.array_equal(affine("g1", host(res))[0], k_times_gen("g1", [dot])[0])
+        fm = P.field_mults_per_pair(n)
+        emit("CPlink prover (SubspaceSnark::prove MSM) N=2^24+2 on ONE GPU, resident CRS and witness (configs[3]'s workload, unsharded)", ok,
+             {"pairs": n, "ms": ms, "blocking_ms": min(ts), "pairs_per_s": n / ms * 1e3, "algorithmic_bytes": 96 * n,
+              "hbm_frac_algorithmic": round(96 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "valu": valu(n * fm, ms),
+              "table_bytes": int(P.table_windows()) * 64 * n, "pre_shifted_copies": int(P.table_windows()), "handle_setup_s": round(setup_s, 2),
+              "checked_by": "known-discrete-log identity: sum_i w_i (a + i b) * G recomputed by the fixed-base kernel"})
+        P.close()
+        del d_w
+        torch.cuda.empty_cache()
 
     if on("g2_msm"):
         n = 1 << log2n

@@ -304,12 +304,27 @@ __global__ __launch_bounds__(256) void k_fold_pairs_tail(const Fr *src, size_t m
     }
 }
 
+// The one-product-per-element streams (pushRandomness, the suffix update, the eq table): a lane takes STREAM_UNROLL elements
+// a grid stride apart and issues all their loads before the first product -- with one 32-byte load in flight per lane the
+// chip holds too few bytes in flight to cover HBM's latency (the suffix update ran at 0.34 of the peak, the fold -- two loads
+// per element -- at 0.58).
+static constexpr int STREAM_UNROLL = 4;
 // cur may alias old: lane p reads old[p], old[p+half] and writes cur[p] only
 __global__ __launch_bounds__(256) void k_fold_halves(const Fr *old, size_t half, const Fr *__restrict__ r_ptr, Fr *cur) {
     const Fr29 r261 = fr_to_261(*r_ptr);
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < half; p += (size_t)gridDim.x * blockDim.x) {
-        const Fr a = old[p];
-        cur[p] = a + fr_mul_261(old[p + half] - a, r261);   // = a (1 - r) + old[p + half] r
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t p0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < half; p0 += stride * STREAM_UNROLL) {
+        Fr a[STREAM_UNROLL], b[STREAM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < STREAM_UNROLL; u++) {
+            const size_t p = p0 + u * stride;
+            if (p < half) { a[u] = old[p]; b[u] = old[p + half]; }
+        }
+#pragma unroll
+        for (int u = 0; u < STREAM_UNROLL; u++) {
+            const size_t p = p0 + u * stride;
+            if (p < half) cur[p] = a[u] + fr_mul_261(b[u] - a[u], r261);   // = a (1 - r) + old[p + half] r
+        }
     }
 }
 // ------------------------------------------------------------------------------------
@@ -325,6 +340,23 @@ __global__ __launch_bounds__(256) void k_fold_halves(const Fr *old, size_t half,
 // ------------------------------------------------------------------------------------
 static constexpr int SC_MAX_M = 4;
 struct ScTables { const Fr *t[SC_MAX_M]; };
+// x / 2 mod r on a canonical representative (the fixed factor 2^256 of libff's words commutes with the halving)
+__device__ __forceinline__ Fr fr_half(const Fr &x) {
+    const uint32_t odd = 0u - (x.l[0] & 1u);
+    uint32_t t[9];
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c += (uint64_t)x.l[i] + (FrParams::MOD[i] & odd);
+        t[i] = (uint32_t)c;
+        c >>= 32;
+    }
+    t[8] = (uint32_t)c;
+    Fr o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.l[i] = (t[i] >> 1) | (t[i + 1] << 31);
+    return o;
+}
 
 // The products run on fr29.h's limbs with LAZY sums (a coefficient of q is a sum of two products: < 4r; the lane's running
 // sums are brought back below 2r every sixteen indices).  Both operands of a product are data here, read in the shifted form
@@ -339,7 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = 0; i <= M; i++) c[i] = Fr29::zero();
     const Fr29 one = Fr29::one();
     unsigned since = 0, wide_n = 0;
-    Fr29Wide w0 = fr29_wide_zero(), w2 = fr29_wide_zero(), wm = fr29_wide_zero();      // (M == 2 only)
+    Fr29Wide w0 = fr29_wide_zero(), w2 = fr29_wide_zero(), wm = fr29_wide_zero(), wn = fr29_wide_zero();      // (M == 2, 3 only)
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < half; p += (size_t)gridDim.x * blockDim.x) {
         Fr29 q[M + 1];
         q[0] = suff ? Fr29::from_words(suff[p]) : one;
@@ -360,6 +392,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 c[1] = add(c[1], sub2r(sub2r(pm, p0), p2));                            // pm - p0 - p2 + 4r < 6r
                 c[2] = add(c[2], p2);
                 w0 = fr29_wide_zero(); w2 = fr29_wide_zero(); wm = fr29_wide_zero();
+                wide_n = 0;
+                if (++since == 16) {
+#pragma unroll
+                    for (int i = 0; i <= M; i++) c[i] = mul(c[i], one);
+                    since = 0;
+                }
+            }
+            continue;
+        } else if constexpr (M == 3) {
+            // three tables: five reduced products and four shared reductions instead of twelve reduced products.
+            // (s a0 + s da X)(b0 + db X) = e0 + e1 X + e2 X^2 by Karatsuba (e1 = em - e0 - e2, em = (s a1) b1); then
+            // g(X) = E(X) (c0 + dc X) has four coefficients, each only ever summed over p: its values at 0, 1, infinity and
+            // -1 -- e0 c0, em c1 (E(1) = em, C(1) = c1: the upper table entry itself), e2 dc, (2 e0 + 2 e2 - em)(2 c0 - c1) --
+            // go into four wide accumulators (one reduction per four indices each) and are turned into coefficients once,
+            // after the block's tree sum.  Without suff the two products by s fall away (s a0 = a0, s da = da).
+            const Fr29 a0 = Fr29::from_words(tabs.t[0][p]), a1 = Fr29::from_words(tabs.t[0][p + half]);
+            const Fr29 b0 = Fr29::from_words(tabs.t[1][p]), b1 = Fr29::from_words(tabs.t[1][p + half]);
+            const Fr29 c0 = Fr29::from_words(tabs.t[2][p]), c1 = Fr29::from_words(tabs.t[2][p + half]);
+            const Fr29 da = sub2r(a1, a0), db = sub2r(b1, b0), dc = sub2r(c1, c0);          // < 3r
+            Fr29 sa0 = a0, sda = da, sa1 = a1;
+            if (suff) { sa0 = mul(q[0], a0); sda = mul(q[0], da); sa1 = add(sa0, sda); }    // < 2r, < 2r, < 4r
+            const Fr29 e0 = mul(sa0, b0).canonical2(), e2 = mul(sda, db).canonical2(), em = mul(sa1, b1);   // < r, < r, < 2r
+            const Fr29 t = add(e0, e2), em1 = sub2r(add(t, t), em);                         // E(-1) + 2r < 6r
+            const Fr29 cm = sub2r(add(c0, c0), c1);                                         // C(-1) + 2r < 4r
+            fr29_wide_mac(w0, e0, c0);                                                      // 4 * r^2
+            fr29_wide_mac(w2, e2, dc);                                                      // 4 * 3 r^2
+            fr29_wide_mac(wm, em, c1);                                                      // 4 * 2 r^2
+            fr29_wide_mac(wn, em1, cm);                                                     // 4 * 24 r^2 < 121 r^2
+            if (++wide_n == 4) {
+                c[0] = add(c[0], fr29_wide_reduce(w0));
+                c[1] = add(c[1], fr29_wide_reduce(wm));
+                c[2] = add(c[2], fr29_wide_reduce(wn));
+                c[3] = add(c[3], fr29_wide_reduce(w2));
+                w0 = fr29_wide_zero(); w2 = fr29_wide_zero(); wm = fr29_wide_zero(); wn = fr29_wide_zero();
                 wide_n = 0;
                 if (++since == 16) {
 #pragma unroll
@@ -395,7 +461,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             c[2] = add(c[2], p2);
         }
     }
+    if constexpr (M == 3) {
+        if (wide_n) {
+            c[0] = add(c[0], fr29_wide_reduce(w0));
+            c[1] = add(c[1], fr29_wide_reduce(wm));
+            c[2] = add(c[2], fr29_wide_reduce(wn));
+            c[3] = add(c[3], fr29_wide_reduce(w2));
+        }
+    }
     const Fr29 fix = fr_to_261(Fr::from_u32(1u << (5 * (suff ? M : M - 1))));       // 32^(products per term), in 2^261 form
+    Fr tot[M + 1];
 #pragma unroll
     for (int i = 0; i <= M; i++) {
         lds[threadIdx.x] = mul(c[i], fix).canonical2().to_words();
@@ -404,8 +479,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (threadIdx.x < s) lds[threadIdx.x] = lds[threadIdx.x] + lds[threadIdx.x + s];
             __syncthreads();
         }
-        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * (SC_MAX_M + 1) + i] = lds[0];
+        tot[i] = lds[0];
         __syncthreads();
+    }
+    if constexpr (M == 3) {
+        // the block's sums of g(0), g(1), g(-1), g(infinity) (sub2r's offsets are multiples of r: they vanish mod r) ->
+        // coefficients: f0 = g(0), f3 = g(inf), f1 + f2 = g(1) - f0 - f3, f2 - f1 = g(-1) - f0 + f3
+        const Fr s12 = tot[1] - tot[0] - tot[3], d21 = tot[2] - tot[0] + tot[3];
+        const Fr f2 = fr_half(s12 + d21), f1 = fr_half(s12 - d21);
+        tot[1] = f1;
+        tot[2] = f2;
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i <= M; i++) partial[(size_t)blockIdx.x * (SC_MAX_M + 1) + i] = tot[i];
     }
 }
 
@@ -445,8 +532,20 @@ __global__ __launch_bounds__(256) void k_sumcheck_finish(const Fr *__restrict__ 
 //   cur[p] = old[half + p] * k,  p < half   (cur may alias old)
 __global__ __launch_bounds__(256) void k_scale_upper(const Fr *old, size_t half, Fr k, Fr *cur) {
     const Fr29 k261 = fr_to_261(k);
-    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < half; p += (size_t)gridDim.x * blockDim.x)
-        cur[p] = fr_mul_261(old[p + half], k261);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t p0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < half; p0 += stride * STREAM_UNROLL) {
+        Fr x[STREAM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < STREAM_UNROLL; u++) {
+            const size_t p = p0 + u * stride;
+            if (p < half) x[u] = old[p + half];
+        }
+#pragma unroll
+        for (int u = 0; u < STREAM_UNROLL; u++) {
+            const size_t p = p0 + u * stride;
+            if (p < half) cur[p] = fr_mul_261(x[u], k261);
+        }
+    }
 }
 
 // DPBeta::compute_eq_tbl (/root/reference/src/prototools/mle.h:93-105).  Two tables:
