@@ -310,8 +310,23 @@ __global__ __launch_bounds__(256) void k_fold_pairs_tail(const Fr *src, size_t m
 // per element -- at 0.58).
 static constexpr int STREAM_UNROLL = 4;
 // cur may alias old: lane p reads old[p], old[p+half] and writes cur[p] only
+// the round's scalar in 2^261 form: converted by ONE lane of the workgroup (a 32-bit-limb Montgomery product: as many
+// instructions as a whole element of the stream costs, paid by every lane before), handed round through LDS, kept in SGPRs
+__device__ __forceinline__ Fr29 block_scalar_261(const Fr &k, uint32_t (&s_k)[9]) {
+    if (threadIdx.x == 0) {
+        const Fr29 c = fr_to_261(k);
+#pragma unroll
+        for (int i = 0; i < 9; i++) s_k[i] = c.l[i];
+    }
+    __syncthreads();
+    Fr29 c;
+#pragma unroll
+    for (int i = 0; i < 9; i++) c.l[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_k[i]);
+    return c;
+}
 __global__ __launch_bounds__(256) void k_fold_halves(const Fr *old, size_t half, const Fr *__restrict__ r_ptr, Fr *cur) {
-    const Fr29 r261 = fr_to_261(*r_ptr);
+    __shared__ uint32_t s_k[9];
+    const Fr29 r261 = block_scalar_261(*r_ptr, s_k);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t p0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < half; p0 += stride * STREAM_UNROLL) {
         Fr a[STREAM_UNROLL], b[STREAM_UNROLL];
@@ -531,7 +546,8 @@ __global__ __launch_bounds__(256) void k_sumcheck_finish(const Fr *__restrict__ 
 // DPBeta::pushRandomness suffix update (/root/reference/src/prototools/mle.h:46-53):
 //   cur[p] = old[half + p] * k,  p < half   (cur may alias old)
 __global__ __launch_bounds__(256) void k_scale_upper(const Fr *old, size_t half, Fr k, Fr *cur) {
-    const Fr29 k261 = fr_to_261(k);
+    __shared__ uint32_t s_k[9];
+    const Fr29 k261 = block_scalar_261(k, s_k);
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t p0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p0 < half; p0 += stride * STREAM_UNROLL) {
         Fr x[STREAM_UNROLL];
