@@ -105,10 +105,7 @@ int lsa_crs_cache_configure(int mode, size_t max_bytes);
  * against the ~1.2 ms a 2^20-pair MSM saves with them; 0: never; env LSA_CRS_TABLE_AFTER): the call that starts the
  * build and the calls during it run at plain-pipeline speed, the entry switches to the copies when they are complete
  * -- results are the same point either way.  They hold 26 x 64 B per G1 point (128 B per G2 point).  A prover that
- * knows it will re-use a key many times sets 1.  Without an explicit setting the rule is adaptive: a process whose
- * host-path MSMs have kept the device busy for less than a third of the time since the first of them (the unchanged
- * examples: 85 % of their run is host field arithmetic between MSMs) gets the copies at an entry's SECOND hit -- the
- * build then runs in time nobody waits for; back-to-back callers keep the break-even rule. */
+ * knows it will re-use a key many times sets 1. */
 int lsa_crs_cache_table_after(unsigned hits);
 /* Blocks until every background build has finished and its entry has switched (tests, benchmarks). */
 int lsa_crs_cache_wait_tables(void);

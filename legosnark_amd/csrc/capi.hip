@@ -976,16 +976,9 @@ struct CrsCache {
     // GPU time and save ~1.2 ms per MSM: building them at the 23rd hit is the break-even rule (never more than twice the
     // cost of the better choice in hindsight); a key that proves a handful of times never pays for them
     unsigned table_after = CRS_TABLE_AFTER_DEFAULT;
-    // ... unless the caller leaves the GPU idle most of the time (round 6): the unchanged examples spend 85 % of their run in
-    // host field loops between MSMs, a key proves five or six times, and the 27 ms of the build then cost nothing that anyone
-    // waits for -- the copies are built at the SECOND hit when the host-path MSMs have kept the device busy for less than a
-    // third of the time since the first of them (and at least 50 ms have passed).  A caller that issues MSMs back to back
-    // (bench.py's host-path loop) keeps the break-even rule.  An explicit LSA_CRS_TABLE_AFTER / lsa_crs_cache_table_after()
-    // switches the adaptive rule off.
-    bool table_after_adaptive = true;
-    bool duty_started = false;
-    std::chrono::steady_clock::time_point duty_first;
-    double duty_inside_ms = 0;
+    // (Round 6 tried an adaptive rule -- build at the second hit when the caller leaves the GPU idle most of the time, as the
+    // unchanged examples do -- and measured a LOSS on `hadamard 20`: 7 more of its 126 G1 MSMs ran over copies, but the two
+    // background builds ran beside its foreground kernels: msm_g1 76.8-79.6 -> 82.3-86.3 ms.  The break-even rule stays.)
     std::vector<void *> garbage;                    // device buffers to free once the device is idle
 } g_crs;
 
@@ -999,7 +992,7 @@ void crs_configure_from_env() {
         if (e[0] == '0' || !strcmp(e, "off")) g_crs.mode = 0;
         else if (!strcmp(e, "sampled") || e[0] == '1') g_crs.mode = 1;
     }
-    if (const char *ta = getenv("LSA_CRS_TABLE_AFTER")) { g_crs.table_after = (unsigned)atoi(ta); g_crs.table_after_adaptive = false; }
+    if (const char *ta = getenv("LSA_CRS_TABLE_AFTER")) g_crs.table_after = (unsigned)atoi(ta);
     const char *mb = getenv("LSA_CRS_CACHE_MB");
     if (mb && atoll(mb) > 0) g_crs.budget = (size_t)atoll(mb) << 20;
     if (g_crs.budget == 0) {
@@ -1117,11 +1110,7 @@ static int crs_table_progress(CrsEntry &e) {
         e.build.reset();                                               // a failed build (no memory) leaves a plain entry
         return LSA_OK;
     }
-    unsigned after = g_crs.table_after;
-    if (g_crs.table_after_adaptive && g_crs.duty_started && e.hits >= 2 && e.hits < after) {
-        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_crs.duty_first).count();
-        if (wall > 50.0 && g_crs.duty_inside_ms < wall / 3) after = 2;
-    }
+    const unsigned after = g_crs.table_after;
     if (e.hits < after || e.build_attempts >= 2) return LSA_OK;                          // (no endless retries after a failed build)
     e.build_attempts++;
     const size_t tw = msm_table_windows(b->group, b->n);
@@ -1401,7 +1390,6 @@ static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *
     if (sharded && lsa_comm_world() <= 1) sharded = false;
     if (!out_jac || (n && (!bases_jac || !scalars))) { set_error("msm: null argument"); return LSA_ERR_INVALID; }
     const auto t_all = std::chrono::steady_clock::now();
-    if (!g_crs.duty_started) { g_crs.duty_started = true; g_crs.duty_first = t_all; }
     lsa_host_stats st = {};
     st.n = n;
     auto t0 = std::chrono::steady_clock::now();
@@ -1426,7 +1414,6 @@ static int msm_host(const void *bases_jac, const void *scalars, size_t n, void *
     if (!g_crs.garbage.empty()) crs_collect_garbage();     // lsa_stream() has just drained
     st.msm_ms = ms_since(t0);
     st.total_ms = ms_since(t_all);
-    g_crs.duty_inside_ms += st.total_ms;
     g_host_stats = st;
     if (trace_on())
         fprintf(stderr, "[lsa]   msm_split                  h2d_scalars=%.3f fingerprint_wait=%.3f bases_prepare=%.3f kernels=%.3f hit=%d table=%d\n",
@@ -1471,7 +1458,6 @@ int lsa_crs_cache_stats(uint64_t *hits, uint64_t *misses, uint64_t *resident_byt
 int lsa_crs_cache_table_after(unsigned hits) {
     crs_configure_from_env();
     g_crs.table_after = hits;
-    g_crs.table_after_adaptive = false;
     return LSA_OK;
 }
 // blocks until every background table build has finished and its entry has switched (tests, benchmarks)

@@ -2154,10 +2154,9 @@ acc_done:
         // -- not from whether that tail happens to be running still -- so that the same calls always add in the same order
         // and return the same Jacobian bytes.  The second half of a commitment pair (reuse_sort) is waited for right away
         // and would pay the lane kernel's 0.2 ms of extra latency: 6.0 -> 6.25 ms.)
-        // (G2, round 6: the quad level over 65536 pairs is 4096 wavefronts x ~70 000 instructions of Fq2 quad arithmetic -- ~0.45 ms of
-        // the chip's issue slots beside the next call's 3.1-ms accumulate kernel; lane-private it is 64 wavefronts and a seventh of
-        // the work, and its ~1.5 ms of latency still ends before the next front does.  LSA_G2_LANE_L1=0: the quad level.)
-        static const bool g2_lane_l1 = getenv("LSA_G2_LANE_L1") == nullptr || getenv("LSA_G2_LANE_L1")[0] != '0';
+        // (G2, measured in round 6: lane-private, this level is 64 wavefronts at 256 VGPRs + 228 B of scratch and runs longer than
+        // the step it should hide under -- pipelined 2^20-pair G2 MSMs 4.76 -> 5.03 ms.  LSA_G2_LANE_L1=1 selects it all the same.)
+        static const bool g2_lane_l1 = getenv("LSA_G2_LANE_L1") != nullptr && getenv("LSA_G2_LANE_L1")[0] == '1';
         bool lane_l1 = allow_lane_l1 && (std::is_same<C, CurveG1>::value || g2_lane_l1) && !blocking && !reuse_sort && big && kw == 1 && nseg == 1 && m >= 16384 &&
                        tail != st && prev.pending && prev.unjoined && &prev != &tb;
         do {                                             // at least one k_reduce2 level (it leaves the sum in slot 0)
