@@ -32,7 +32,7 @@ unsigned miller_tab_max_pairs();
 void miller_split_release();
 int miller_tab_device(const void *d_g1, const uint32_t *const *d_tabs, const uint8_t *d_flags, const uint32_t *d_acc_off, size_t nacc, unsigned M,
                       const uint32_t *d_ident, void *d_out, hipStream_t st);
-int miller_fused_device(const void *d_g1, const void *d_g2, const uint8_t *d_flags, uint32_t *const *d_tabs, size_t n, void *d_out, hipStream_t st);
+int miller_fused_device(const void *d_g1, const void *d_g2, const uint8_t *d_flags, uint32_t *const *d_tabs, size_t n, void *d_out, hipStream_t st, bool gt_only);
 }  // namespace lsa
 
 using namespace lsa;
@@ -221,6 +221,8 @@ struct Terms {
     const uint64_t *seg = nullptr;         // nseg + 1 offsets; null: every term is its own product
     size_t n = 0, nseg = 0;
     bool on_device = false;                // g1 / g2 are device pointers (no cache: nothing to fingerprint on the host)
+    bool gt_only = false;                  // every value of this job goes through a final exponentiation before it leaves: Miller
+                                           // values may differ from libff's by factors the final exponent kills (signed-digit loop)
 };
 
 unsigned g_force_m = 0;                    // lsa_pairing_set_chunk: pairs per accumulator, 0 = by batch size
@@ -260,7 +262,7 @@ int run_fused(const Terms &t, const std::vector<uint64_t> &emit, void **d_res) {
     rc = mark_uploads();
     if (rc) return rc;
     const char *dm = (const char *)g_pair_meta.p;
-    rc = miller_fused_device(d_p, d_q, (const uint8_t *)(dm + off_flag), emit.empty() ? nullptr : (uint32_t *const *)(dm + off_emit), n, g_pair_f.p, g.stream);
+    rc = miller_fused_device(d_p, d_q, (const uint8_t *)(dm + off_flag), emit.empty() ? nullptr : (uint32_t *const *)(dm + off_emit), n, g_pair_f.p, g.stream, t.gt_only);
     if (rc) return rc;
     if (!t.seg) { *d_res = g_pair_f.p; return LSA_OK; }
     if (nprod == 1 && n > 0) return fq12_product_device(g_pair_f.p, g_pair_s.p, n, d_res, g.stream);
@@ -501,8 +503,10 @@ int run_miller(const Terms &t, void **d_res) {
 }
 
 // the job with host results: out = nseg (or n) Fq12 values
-int run_terms_host(const Terms &t, void *out, bool final_exp) {
-    LSA_TRACE_CALL("pairing_terms", t.n);
+int run_terms_host(const Terms &t_in, void *out, bool final_exp) {
+    LSA_TRACE_CALL("pairing_terms", t_in.n);
+    Terms t = t_in;
+    t.gt_only = final_exp;
     int rc = require_ready();
     if (rc) return rc;
     const size_t nres = t.seg ? t.nseg : t.n;
@@ -678,6 +682,7 @@ static int product_host(const void *g1, const void *g2, size_t n, void *out, boo
     const uint64_t seg[2] = {0, n};
     Terms t;
     t.g1 = g1; t.g2 = g2; t.seg = seg; t.nseg = 1; t.n = n;
+    t.gt_only = final_exp;
     if (!(sharded && lsa_comm_world() > 1)) return run_terms_host(t, out, final_exp);
     // per-rank Miller product (1 for an empty slice), all-gather of the Fq12 partials, product in rank
     // order, one final exponentiation on every rank (SURVEY.md 8e "Pairings").  A rank whose local part

@@ -192,7 +192,7 @@ static constexpr int FU_PAIRS = 5;                                     // pairs 
 // tabs (optional): tabs[i] non-null -> the table of g2[i] is also written there (a point seen for the first time: its
 // table goes into the cache while its first Miller loop runs).
 __global__ __launch_bounds__(128) void k_miller_fused(const Jac<Fq> *__restrict__ g1, const Jac<Fq2> *__restrict__ g2, const uint8_t *__restrict__ flags,
-                                                      uint32_t *const *__restrict__ tabs, size_t n, Fq12 *__restrict__ out) {
+                                                      uint32_t *const *__restrict__ tabs, size_t n, Fq12 *__restrict__ out, int naf) {
     using TP = TabMillerP<WaveLocalExec, FU_PAIRS>;
     __shared__ Fq2S g2mem[FU_PAIRS * GP_STRIDE];
     __shared__ Fq2S tpmem[TP::LDS_FQ2];
@@ -206,7 +206,20 @@ __global__ __launch_bounds__(128) void k_miller_fused(const Jac<Fq> *__restrict_
     if (lo >= n) return;
     const unsigned count = (unsigned)(n - lo < (size_t)FU_PAIRS ? n - lo : (size_t)FU_PAIRS);
     const unsigned tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    if (tid < (unsigned)ATE_NUM_COEFFS) kinds[tid] = (uint8_t)tm_entry_kind((int)tid);
+    // naf: the signed-digit loop (88 entries instead of 102; miller.h: ate_naf_digit) -- values equal to libff's up to factors the
+    // final exponentiation kills; never together with table output (the tables are libff's, row for row).  The identity is the
+    // group law's: a workgroup that holds a G2 point at infinity -- libff feeds its step formulas the non-point (0, 1) then, and
+    // what comes out is defined by those formulas alone -- keeps libff's binary loop.
+    __shared__ int s_naf;
+    if (tid == 0) {
+        int ok = naf;
+        for (unsigned c = 0; c < count; c++) if (g2[lo + c].Z.is_zero()) ok = 0;
+        s_naf = ok;
+    }
+    __syncthreads();
+    const int use_naf = s_naf;
+    const int entries = use_naf ? NAF_NUM_ENTRIES : ATE_NUM_COEFFS;
+    if (tid < (unsigned)entries) kinds[tid] = (uint8_t)(use_naf ? tm_naf_entry_kind((int)tid) : tm_entry_kind((int)tid));
     if (tid < (unsigned)FU_PAIRS) {
         const bool have = tid < count;
         qp[tid] = g2 + lo + (have ? tid : 0);
@@ -229,9 +242,9 @@ __global__ __launch_bounds__(128) void k_miller_fused(const Jac<Fq> *__restrict_
     // step e: the G2 wavefront computes entry e + 1 (scaled by the pair's (px, py)) while the Fq12 wavefront consumes
     // entry e (one call site each)
 #pragma unroll 1
-    for (int e = -1; e < ATE_NUM_COEFFS; e++) {
+    for (int e = -1; e < entries; e++) {
         if (wave == 0) {
-            if (e + 1 < ATE_NUM_COEFFS) pre.entry_rounds(kinds[e + 1], e + 1, tout, rows[(e + 1) % 3], true);
+            if (e + 1 < entries) pre.entry_rounds(kinds[e + 1], e + 1, tout, rows[(e + 1) % 3], true);
         } else if (e >= 0) {
             tp.entry(kinds[e], e);
         }
@@ -469,10 +482,13 @@ int g2_table_identity_device(uint32_t *d_tab, hipStream_t st) {
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }
-int miller_fused_device(const void *d_g1, const void *d_g2, const uint8_t *d_flags, uint32_t *const *d_tabs, size_t n, void *d_out, hipStream_t st) {
+int miller_fused_device(const void *d_g1, const void *d_g2, const uint8_t *d_flags, uint32_t *const *d_tabs, size_t n, void *d_out, hipStream_t st, bool gt_only) {
     if (n == 0) return LSA_OK;
+    // values that only ever leave through a final exponentiation take the signed-digit loop (LSA_MILLER_NAF=0: libff's binary one)
+    static const bool allow_naf = getenv("LSA_MILLER_NAF") == nullptr || getenv("LSA_MILLER_NAF")[0] != '0';
+    const int naf = gt_only && allow_naf && d_tabs == nullptr ? 1 : 0;
     hipLaunchKernelGGL(k_miller_fused, dim3((unsigned)((n + FU_PAIRS - 1) / FU_PAIRS)), dim3(128), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, d_flags,
-                       d_tabs, n, (Fq12 *)d_out);
+                       d_tabs, n, (Fq12 *)d_out, naf);
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }

@@ -80,6 +80,7 @@ enum G2PVar {                                  // Fq2S slots of one point
     GP_L0, GP_L1, GP_L2,                       // the line being assembled
     GP_PX, GP_PY, GP_S1, GP_S2,                // fused kernel: (px, 0), (py, 0) of the pair's G1 point; ell_VW * py, ell_VV * px
     GP_P0, GP_P1, GP_P2, GP_P3, GP_P4, GP_P5,  // the round's products
+    GP_NQX, GP_NQY,                            // -Q (the signed-digit loop's subtractions)
     GP_STRIDE
 };
 static constexpr int GP_GROUPS = 5;
@@ -93,6 +94,23 @@ LSA_HD int tm_entry_kind(int e) {
         idx++;
         if (ate_bit(i)) {
             if (idx == e) return 1;
+            idx++;
+        }
+    }
+    return e == idx ? 2 : 3;
+}
+
+// the signed-digit loop (miller.h: ate_naf_digit): 65 doubling steps, an addition of Q (kind 1) or of -Q (kind 4) at the non-zero
+// digits below the top one, then the two Frobenius steps -- 88 entries.  No table has this shape: fused kernel only.
+static constexpr int NAF_NUM_ENTRIES = 65 + 21 + 2;
+LSA_HD int tm_naf_entry_kind(int e) {
+    int idx = 0;
+    for (int i = 64; i >= 0; --i) {
+        if (idx == e) return 0;
+        idx++;
+        const int d = ate_naf_digit(i);
+        if (d) {
+            if (idx == e) return d > 0 ? 1 : 4;
             idx++;
         }
     }
@@ -260,7 +278,7 @@ struct G2Pre {
     }
     // the rounds of table entry `entry` (its kind: tm_entry_kind)
     LSA_HD void entry_rounds(int kind, int entry, uint32_t *const *out, Fq2S *const *rows, bool scaled = false) {
-        const int x2 = kind == 2 ? GP_Q1X : (kind == 3 ? GP_Q2X : GP_QX);
+        const int x2 = kind == 2 ? GP_Q1X : (kind == 3 ? GP_Q2X : (kind == 4 ? GP_NQX : GP_QX));
         const int first = kind == 0 ? 0 : 3, last = kind == 0 ? 3 : 7;
 #pragma unroll 1
         for (int op = first; op < last; op++) round(op, x2, out, entry, rows, scaled);
@@ -297,6 +315,7 @@ struct G2Pre {
             V[GP_QX] = qx; V[GP_QY] = qy;
             V[GP_Q1X] = q1x; V[GP_Q1Y] = q1y;
             V[GP_Q2X] = gx * q1x.conj(); V[GP_Q2Y] = (gy * q1y.conj()).neg();
+            V[GP_NQX] = qx; V[GP_NQY] = qy.neg();
             V[GP_X] = qx; V[GP_Y] = qy; V[GP_Z] = P2::one();
             V[GP_S] = qy + P2::one();
             V[GP_TWB] = fq2_constT<PB>(LSA_TWIST_B);
@@ -565,6 +584,31 @@ struct TabMiller {
 // ({ell_0, ell_VW * py, ell_VV * px}, by the G2 wavefront of the workgroup) into slot entry % 3 of the accumulator's row
 // ring.  No helper lanes, no scaling rounds, no global loads: five accumulators fill sixty lanes.
 // ------------------------------------------------------------------------------------
+// component c of xi * t for t = (t_c, t_o) < 2p tight: c = 0: 9 t0 - t1 + 2p, c = 1: 9 t1 + t0   [< 20; tight]
+LSA_HD F29 wt_xi_comp(unsigned c, const F29 &tc, const F29 &to) {
+    F29 t8;
+#pragma unroll
+    for (int l = 0; l < 9; l++) t8.l[l] = tc.l[l] << 3;
+    const uint32_t pm = w12_mask(0u - c);
+    const F29 neg = sub_k<2>(F29::zero(), to);
+    F29 sel;
+#pragma unroll
+    for (int l = 0; l < 9; l++) sel.l[l] = (to.l[l] & pm) | (neg.l[l] & ~pm);
+    return w12_norm_u(add_lazy(add_lazy(w12_norm_u(t8), tc), sel));
+}
+// the value of the lane next door (2i <-> 2i + 1): one DPP move per limb
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ F29 wt_swap(const F29 &a) {
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], 0xB1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
+        asm volatile("" : "+v"(r.l[i]));       // opaque: GCNDPPCombine must not fold the move into its consumer (quad29.h)
+    }
+    return r;
+}
+#endif
+
 enum { TP_F = 0, TP_XF = 6, TP_T = 12, TP_RAW = 18, TP_STRIDE = 27 };
 template <class X, int NC>
 struct TabMillerP {
@@ -587,13 +631,17 @@ struct TabMillerP {
         });
     }
     // mode 1: f <- f*f, 2: f <- f * line(entry)
+    // On the device the round is ONE phase: a lane's result is component `part` of coefficient k, its neighbour (DPP
+    // quad_perm) holds the other component, so each lane derives its own component of xi * T and stores both F and XF -- the
+    // wavefront's loads of F / XF all precede these stores in program order (one wavefront, in-order LDS queue).  The host
+    // build (lanes run one after the other) keeps T and a second phase.
     LSA_HD void round(int mode, int entry) {
         Fq2S *m = mem;
         x.par([=](unsigned lane) {
             if (lane >= 12u * NC) return;
             const unsigned part = lane & 1;
             const int base = (int)(lane / 12) * TP_STRIDE, k = (int)((lane % 12) >> 1);
-            Fs *dst = &g12_part(m[base + TP_T + k], part);
+            F29 res;
             if (mode == 2) {
                 // three products, ONE reduction: a < 20p (xi * f) in at most two terms, b < 2p: 4 * 40 + 2 * 4 = 168 < 169 p^2
                 F29 xa[6], yb[6];
@@ -605,7 +653,7 @@ struct TabMillerP {
                     tm_comp_operands<2>(part, w12_load(m + base + (wrap ? TP_XF : TP_F) + ai), w12_load(m + base + TP_RAW + 3 * (entry % 3) + j),
                                         xa[2 * j], yb[2 * j], xa[2 * j + 1], yb[2 * j + 1]);
                 }
-                w12_store(dst, Fs{dotn<6>(xa, yb)});
+                res = dotn<6>(xa, yb);
             } else {
                 // the 4 (k even) or 3 unordered pairs of a square, reduced one by one, summed with their weights (6 in
                 // all) and brought back under 2p by a Montgomery product with 1
@@ -627,9 +675,18 @@ struct TabMillerP {
 #pragma unroll
                     for (int l = 0; l < 9; l++) sum.l[l] += x1.l[l] + (x1.l[l] & w2);
                 }
-                w12_store(dst, Fs{mul(w12_norm_u(sum), F29::one())});
+                res = mul(w12_norm_u(sum), F29::one());
             }
+#if defined(__HIP_DEVICE_COMPILE__)
+            const F29 other = wt_swap(res);
+            const F29 xf = wt_xi_comp(part, res, other);                                      // [< 20]
+            w12_store(&g12_part(m[base + TP_F + k], part), Fs{res});
+            w12_store(&g12_part(m[base + TP_XF + k], part), Fs{xf});
+#else
+            w12_store(&g12_part(m[base + TP_T + k], part), Fs{res});
+#endif
         });
+#if !defined(__HIP_DEVICE_COMPILE__)
         x.par([=](unsigned lane) {
             if (lane >= 12u * NC || (lane & 1)) return;
             const unsigned c = lane / 12, k = (lane % 12) >> 1;
@@ -638,6 +695,7 @@ struct TabMillerP {
             base[TP_F + k] = tv;
             base[TP_XF + k] = WM::st(WM::xi_times(WM::ld(tv)));                              // [< 20]
         });
+#endif
     }
     // one table entry (kind 0: a doubling step)
     LSA_HD void entry(int kind, int e) {
@@ -699,31 +757,6 @@ LSA_HD void wt_make_desc(unsigned lane, uint32_t *d) {
         d[1] = (uint32_t)WT_ZERO | (uint32_t)WT_ZERO << 8 | (uint32_t)(WT_P + 4 * k + 3) << 16 | 1u << 25;
     }
 }
-// component c of xi * t for t = (t_c, t_o) < 2p tight: c = 0: 9 t0 - t1 + 2p, c = 1: 9 t1 + t0   [< 20; tight]
-LSA_HD F29 wt_xi_comp(unsigned c, const F29 &tc, const F29 &to) {
-    F29 t8;
-#pragma unroll
-    for (int l = 0; l < 9; l++) t8.l[l] = tc.l[l] << 3;
-    const uint32_t pm = w12_mask(0u - c);
-    const F29 neg = sub_k<2>(F29::zero(), to);
-    F29 sel;
-#pragma unroll
-    for (int l = 0; l < 9; l++) sel.l[l] = (to.l[l] & pm) | (neg.l[l] & ~pm);
-    return w12_norm_u(add_lazy(add_lazy(w12_norm_u(t8), tc), sel));
-}
-// the value of the lane next door (2i <-> 2i + 1): one DPP move per limb
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ F29 wt_swap(const F29 &a) {
-    F29 r;
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], 0xB1, 0xf, 0xf, false);   // quad_perm:[1,0,3,2]
-        asm volatile("" : "+v"(r.l[i]));       // opaque: GCNDPPCombine must not fold the move into its consumer (quad29.h)
-    }
-    return r;
-}
-#endif
-
 template <class X>
 struct WTabMiller {
     X &x;

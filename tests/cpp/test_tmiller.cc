@@ -159,6 +159,70 @@ int main() {
             CHECK(same, "table emitted by the fused engine");
         }
     }
+    // ---- the fused shape over the SIGNED digits of the loop count (88 entries, additions of Q and of -Q): not libff's Miller
+    // value -- it differs by vertical lines, elements of Fq6 -- but the same reduced pairing
+    {
+        CHECK(tm_naf_entry_kind(0) == 0 && tm_naf_entry_kind(NAF_NUM_ENTRIES - 2) == 2 && tm_naf_entry_kind(NAF_NUM_ENTRIES - 1) == 3, "signed-digit schedule ends");
+        int kinds[5] = {0, 0, 0, 0, 0};
+        for (int e = 0; e < NAF_NUM_ENTRIES; e++) kinds[tm_naf_entry_kind(e)]++;
+        CHECK(kinds[0] == 65 && kinds[1] + kinds[4] == 21 && kinds[2] == 1 && kinds[3] == 1, "signed-digit schedule counts");
+        // the digits are the loop count
+        {
+            unsigned __int128 v = 0;
+            for (int i = 65; i >= 0; --i) v = 2 * v + (unsigned __int128)(__int128)ate_naf_digit(i);
+            CHECK((uint64_t)v == LSA_ATE_LOOP_COUNT_LO && (uint64_t)(v >> 64) == LSA_ATE_LOOP_COUNT_HI, "signed digits sum to 6u + 2");
+            for (int i = 0; i < 65; i++) CHECK(!(ate_naf_digit(i) && ate_naf_digit(i + 1)), "non-adjacent");
+        }
+        constexpr int NP = 5;
+        using TP = TabMillerP<LoopExec, NP>;
+        const unsigned np = 5;
+        std::vector<Fq2S> g2mem(NP * GP_STRIDE), tpmem(TP::LDS_FQ2);
+        Jac<Fq> Ps[NP];
+        Jac<Fq2> Qc[NP];
+        const Jac<Fq> *Pp[NP];
+        const Jac<Fq2> *Qp[NP];
+        uint8_t neg[NP];
+        Fq2S *rows[3][NP];
+        // (the identity holds on the curve -- it is the group law that makes R - Q the point [a - 1]Q: multiples of the generators,
+        // un-normalised Jacobian; the other blocks of this test feed the step formulas arbitrary coordinates)
+        Jac<Fq> g1 = {Fq::one(), Fq::one() + Fq::one(), Fq::one()};
+        Jac<Fq2> g2;
+        for (int i = 0; i < 8; i++) { g2.X.c0.l[i] = LSA_G2_GEN_X[0][i]; g2.X.c1.l[i] = LSA_G2_GEN_X[1][i]; g2.Y.c0.l[i] = LSA_G2_GEN_Y[0][i]; g2.Y.c1.l[i] = LSA_G2_GEN_Y[1][i]; }
+        g2.Z = Fq2::one();
+        auto times = [](auto pt, uint64_t k) {
+            auto acc = pt;
+            bool have = false;
+            for (int b = 63; b >= 0; --b) {
+                if (have) acc = jac_dbl(acc);
+                if ((k >> b) & 1) { acc = have ? jac_add(acc, pt) : pt; have = true; }
+            }
+            return acc;
+        };
+        for (int c = 0; c < NP; c++) {
+            Ps[c] = times(g1, rng() | 1);
+            Qc[c] = times(g2, rng() | 1);
+            Pp[c] = &Ps[c];
+            neg[c] = (uint8_t)(c & 1);
+            Qp[c] = &Qc[c];
+            for (int s = 0; s < 3; s++) rows[s][c] = tpmem.data() + c * TP_STRIDE + TP_RAW + 3 * s;
+        }
+        uint32_t *tout[NP] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        G2Pre<LoopExec, NP> pre{ex, g2mem.data()};
+        TP tp{ex, tpmem.data()};
+        pre.setup(Qp, np, tout);
+        pre.setup_g1(Pp, neg, np);
+        tp.setup();
+        for (int e = -1; e < NAF_NUM_ENTRIES; e++) {
+            if (e + 1 < NAF_NUM_ENTRIES) pre.entry_rounds(tm_naf_entry_kind(e + 1), e + 1, tout, rows[(e + 1) % 3], true);
+            if (e >= 0) tp.entry(tm_naf_entry_kind(e), e);
+        }
+        for (unsigned c = 0; c < np; c++) {
+            Fq12S f = miller_one(Ps[c], *Qp[c]);
+            if (neg[c]) f = f.unitary_inverse();
+            CHECK(!(tp.result(c) == f), "the signed-digit Miller value is a different representative");
+            CHECK(fq12_final_exponentiation(tp.result(c)) == fq12_final_exponentiation(f), "signed-digit loop: the same reduced pairing");
+        }
+    }
     // ---- one accumulator per wavefront
     for (unsigned cnt = 0; cnt <= (unsigned)TM_MAXM; cnt++) {
         std::vector<Fq2S> lds(WT_LDS_FQ2);

@@ -151,6 +151,42 @@ def test_every_miller_kernel_vs_oracle(kernel):
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("naf", ["1", "0"])
+def test_signed_digit_miller_loop_gives_the_same_gt(naf):
+    """Jobs whose values only leave through a final exponentiation run the fused kernel over the SIGNED digits of 6u + 2
+    (88 table entries instead of 102: csrc/miller.h ate_naf_digit; LSA_MILLER_NAF=0 keeps libff's binary loop).  The
+    Miller values differ from libff's by vertical lines, which the final exponent kills: every GT value -- one product, a
+    verifier's segments, terms with -P, P at infinity -- byte for byte the oracle's either way; a workgroup that holds a G2
+    point at infinity keeps the binary loop (libff's (0, 1) convention is not a point: only its own formulas define the
+    result), so that case is bit-exact too.  Raw Miller values (no final exponentiation) always come from the binary loop."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import legosnark_amd as lsa, oracle_lib as o\n"
+        "lsa.init(0)\n"
+        "n = 43\n"
+        "ps = o.arith_bases('g1', 1234, 11, n); qs = o.arith_bases('g2', 4321, 3, n)\n"
+        "ps[3] = 0\n"
+        "assert np.array_equal(lsa.pairing_product(ps, qs), o.pairing_product(ps, qs))\n"
+        "assert np.array_equal(lsa.miller_loop_product(ps, qs), o.fq12_product(o.miller_loop_batch(ps, qs)))\n"
+        "offs = np.array([0, 5, 5, 12, 30, n], dtype=np.uint64)\n"
+        "got = lsa.pairing_product_segments(ps, qs, offs)\n"
+        "for j in range(5):\n"
+        "    lo, hi = int(offs[j]), int(offs[j + 1])\n"
+        "    assert np.array_equal(got[j], o.pairing_product(ps[lo:hi], qs[lo:hi]) if hi > lo else o.fq12_one()), j\n"
+        "qs2 = qs.copy(); qs2[17] = 0\n"
+        "assert np.array_equal(lsa.pairing_product(ps, qs2), o.pairing_product(ps, qs2))\n"
+        "print('OK')\n"
+    ) % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, LSA_MILLER_KERNEL="6", LSA_MILLER_NAF=naf)
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:]
+
+
 def test_large_batch_takes_the_grouped_kernel_and_matches(lsa):
     """2000 pairs (above the one-wavefront-per-pairing range): product of the Miller values
     against the oracle on a sample, and the planted relation prod e(a_i G1, b_i G2) = 1 with
