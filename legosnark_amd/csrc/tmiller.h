@@ -655,27 +655,40 @@ struct TabMillerP {
                 }
                 res = dotn<6>(xa, yb);
             } else {
-                // the 4 (k even) or 3 unordered pairs of a square, reduced one by one, summed with their weights (6 in
-                // all) and brought back under 2p by a Montgomery product with 1
-                F29 sum = F29::zero();
-#pragma unroll 1
-                for (int j = 0; j < 4; j++) {
-                    int ao = ZERO, bo = ZERO;
-                    uint32_t w2 = 0;
-                    if (j < sqr_pair_count(k)) {
-                        int ti, ui;
-                        bool wrap;
-                        sqr_pair(k, j, ti, ui, wrap);
-                        ao = base + (wrap ? TP_XF : TP_F) + ti;
-                        bo = base + TP_F + ui;
-                        w2 = ti == ui ? 0u : ~0u;
-                    }
-                    const F29 x1 = g12_comp_mul<2>(part, w12_load(m + ao), w12_load(m + bo));
-                    w2 = w12_mask(w2);
+                // the 4 (k even) or 3 unordered pairs of a square in TWO fused reductions of two pairs each (round 6; one
+                // reduction per pair and a product by 1 before: 9 products' worth of multiply-adds and 5 reductions, now 8 and 2).
+                // An off-diagonal pair counts twice: its a-operand is doubled (< 40p when it is xi * f).  A group's integer
+                // sum may then exceed the 169 p^2 that guarantee a result below 2p -- worst case two doubled wrapped pairs,
+                // 2 * 2 * 40p * 2p = 320 p^2 -- which only loosens the result's bound: T / 2^261 + p < 2.9p, the 64-bit
+                // columns hold 9 * 4 + 9 products of tight limbs whatever the values.  Both groups: < 4.9p, two conditional
+                // subtractions bring the coefficient back under 2p.
+                F29 grp[2];
 #pragma unroll
-                    for (int l = 0; l < 9; l++) sum.l[l] += x1.l[l] + (x1.l[l] & w2);
+                for (int g = 0; g < 2; g++) {
+                    F29 xa[4], yb[4];
+#pragma unroll
+                    for (int jj = 0; jj < 2; jj++) {
+                        const int j = 2 * g + jj;
+                        int ao = ZERO, bo = ZERO;
+                        uint32_t w2 = 0;
+                        if (j < sqr_pair_count(k)) {
+                            int ti, ui;
+                            bool wrap;
+                            sqr_pair(k, j, ti, ui, wrap);
+                            ao = base + (wrap ? TP_XF : TP_F) + ti;
+                            bo = base + TP_F + ui;
+                            w2 = ti == ui ? 0u : ~0u;
+                        }
+                        tm_comp_operands<2>(part, w12_load(m + ao), w12_load(m + bo), xa[2 * jj], yb[2 * jj], xa[2 * jj + 1], yb[2 * jj + 1]);
+                        w2 = w12_mask(w2);
+#pragma unroll
+                        for (int l = 0; l < 9; l++) { xa[2 * jj].l[l] += xa[2 * jj].l[l] & w2; xa[2 * jj + 1].l[l] += xa[2 * jj + 1].l[l] & w2; }
+                        xa[2 * jj] = w12_norm_u(xa[2 * jj]);
+                        xa[2 * jj + 1] = w12_norm_u(xa[2 * jj + 1]);
+                    }
+                    grp[g] = dotn<4>(xa, yb);
                 }
-                res = mul(w12_norm_u(sum), F29::one());
+                res = condsub2(condsub4(w12_norm_u(add_lazy(grp[0], grp[1]))));
             }
 #if defined(__HIP_DEVICE_COMPILE__)
             const F29 other = wt_swap(res);
