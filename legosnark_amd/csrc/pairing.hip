@@ -192,14 +192,15 @@ static constexpr int FU_PAIRS = 5;                                     // pairs 
 // tabs (optional): tabs[i] non-null -> the table of g2[i] is also written there (a point seen for the first time: its
 // table goes into the cache while its first Miller loop runs).
 __global__ __launch_bounds__(128) void k_miller_fused(const Jac<Fq> *__restrict__ g1, const Jac<Fq2> *__restrict__ g2, const uint8_t *__restrict__ flags,
-                                                      uint32_t *const *__restrict__ tabs, size_t n, Fq12 *__restrict__ out, int naf) {
+                                                      uint32_t *const *__restrict__ tabs, size_t n, Fq12 *__restrict__ out, int naf, int decouple) {
     using TP = TabMillerP<WaveLocalExec, FU_PAIRS>;
     __shared__ Fq2S g2mem[FU_PAIRS * GP_STRIDE];
     __shared__ Fq2S tpmem[TP::LDS_FQ2];
     __shared__ const Jac<Fq2> *qp[FU_PAIRS];
     __shared__ const Jac<Fq> *pp[FU_PAIRS];
     __shared__ uint8_t ng[FU_PAIRS];
-    __shared__ Fq2S *rows[3][FU_PAIRS];
+    __shared__ Fq2S *rows[TP_RING][FU_PAIRS];
+    __shared__ int s_produced, s_consumed;
     __shared__ uint32_t *tout[FU_PAIRS];
     __shared__ uint8_t kinds[ATE_NUM_COEFFS];
     const size_t lo = (size_t)blockIdx.x * FU_PAIRS;
@@ -215,6 +216,8 @@ __global__ __launch_bounds__(128) void k_miller_fused(const Jac<Fq> *__restrict_
         int ok = naf;
         for (unsigned c = 0; c < count; c++) if (g2[lo + c].Z.is_zero()) ok = 0;
         s_naf = ok;
+        s_produced = 0;
+        s_consumed = 0;
     }
     __syncthreads();
     const int use_naf = s_naf;
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(128) void k_miller_fused(const Jac<Fq> *__restrict_
         pp[tid] = g1 + lo + (have ? tid : 0);
         ng[tid] = have && flags ? (uint8_t)(flags[lo + tid] & 1) : (uint8_t)0;
         tout[tid] = have && tabs ? tabs[lo + tid] : nullptr;
-        for (int s = 0; s < 3; s++) rows[s][tid] = tpmem + tid * TP_STRIDE + TP_RAW + 3 * s;
+        for (int s = 0; s < TP_RING; s++) rows[s][tid] = tpmem + tid * TP_STRIDE + TP_RAW + 3 * s;
     }
     __syncthreads();
     WaveLocalExec ex;
@@ -239,16 +242,38 @@ __global__ __launch_bounds__(128) void k_miller_fused(const Jac<Fq> *__restrict_
         tp.setup();
     }
     __syncthreads();
+    if (decouple) {
+        // The two wavefronts as producer and consumer of a ring of TP_RING rows, ordered by two counters in LDS instead of a
+        // workgroup barrier per entry (round 6).  In lockstep an entry costs the LONGER of the two sides -- the Fq12 chain on a
+        // doubling entry (a squaring and a line product against three G2 rounds), the G2 side on an addition entry (four G2
+        // rounds against one line product) -- so the kernel ran the sum of the maxima; decoupled it runs the maximum of the sums.
+        if (wave == 0) {
+#pragma unroll 1
+            for (int e = 0; e < entries; e++) {
+                while (__hip_atomic_load(&s_consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) + TP_RING <= e) __builtin_amdgcn_s_sleep(1);   // slot e % TP_RING is free
+                pre.entry_rounds(kinds[e], e, tout, rows[e % TP_RING], true);
+                __hip_atomic_store(&s_produced, e + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+#pragma unroll 1
+            for (int e = 0; e < entries; e++) {
+                while (__hip_atomic_load(&s_produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= e) __builtin_amdgcn_s_sleep(1);
+                tp.entry(kinds[e], e);
+                __hip_atomic_store(&s_consumed, e + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    } else {
     // step e: the G2 wavefront computes entry e + 1 (scaled by the pair's (px, py)) while the Fq12 wavefront consumes
     // entry e (one call site each)
 #pragma unroll 1
     for (int e = -1; e < entries; e++) {
         if (wave == 0) {
-            if (e + 1 < entries) pre.entry_rounds(kinds[e + 1], e + 1, tout, rows[(e + 1) % 3], true);
+            if (e + 1 < entries) pre.entry_rounds(kinds[e + 1], e + 1, tout, rows[(e + 1) % TP_RING], true);
         } else if (e >= 0) {
             tp.entry(kinds[e], e);
         }
         __syncthreads();
+    }
     }
     if (wave == 1 && lane < 12u * FU_PAIRS) {
         const unsigned c = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
@@ -487,8 +512,10 @@ int miller_fused_device(const void *d_g1, const void *d_g2, const uint8_t *d_fla
     // values that only ever leave through a final exponentiation take the signed-digit loop (LSA_MILLER_NAF=0: libff's binary one)
     static const bool allow_naf = getenv("LSA_MILLER_NAF") == nullptr || getenv("LSA_MILLER_NAF")[0] != '0';
     const int naf = gt_only && allow_naf && d_tabs == nullptr ? 1 : 0;
+    // LSA_FUSED_LOCKSTEP=1: one workgroup barrier per table entry, as before round 6
+    static const int decouple = getenv("LSA_FUSED_LOCKSTEP") && getenv("LSA_FUSED_LOCKSTEP")[0] == '1' ? 0 : 1;
     hipLaunchKernelGGL(k_miller_fused, dim3((unsigned)((n + FU_PAIRS - 1) / FU_PAIRS)), dim3(128), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, d_flags,
-                       d_tabs, n, (Fq12 *)d_out, naf);
+                       d_tabs, n, (Fq12 *)d_out, naf, decouple);
     HIPCHK(hipGetLastError());
     return LSA_OK;
 }

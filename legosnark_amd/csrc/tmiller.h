@@ -581,7 +581,7 @@ struct TabMiller {
 
 // ------------------------------------------------------------------------------------
 // The Fq12 chain of the fused kernel: NC accumulators per wavefront, ONE pair each, every line delivered READY TO USE
-// ({ell_0, ell_VW * py, ell_VV * px}, by the G2 wavefront of the workgroup) into slot entry % 3 of the accumulator's row
+// ({ell_0, ell_VW * py, ell_VV * px}, by the G2 wavefront of the workgroup) into slot entry % TP_RING of the accumulator's row
 // ring.  No helper lanes, no scaling rounds, no global loads: five accumulators fill sixty lanes.
 // ------------------------------------------------------------------------------------
 // component c of xi * t for t = (t_c, t_o) < 2p tight: c = 0: 9 t0 - t1 + 2p, c = 1: 9 t1 + t0   [< 20; tight]
@@ -609,7 +609,9 @@ __device__ __forceinline__ F29 wt_swap(const F29 &a) {
 }
 #endif
 
-enum { TP_F = 0, TP_XF = 6, TP_T = 12, TP_RAW = 18, TP_STRIDE = 27 };
+// (TP_RING rows of three Fq2S: the G2 wavefront may run that many entries ahead of the chain)
+static constexpr int TP_RING = 6;
+enum { TP_F = 0, TP_XF = 6, TP_T = 12, TP_RAW = 18, TP_STRIDE = TP_RAW + 3 * TP_RING };
 template <class X, int NC>
 struct TabMillerP {
     static_assert(12 * NC <= 64, "one wavefront");
@@ -650,7 +652,7 @@ struct TabMillerP {
                     int ai = k - (j == 0 ? 0 : j + 2);                      // line coefficients sit at w^0, w^3, w^4
                     const bool wrap = ai < 0;
                     if (wrap) ai += 6;
-                    tm_comp_operands<2>(part, w12_load(m + base + (wrap ? TP_XF : TP_F) + ai), w12_load(m + base + TP_RAW + 3 * (entry % 3) + j),
+                    tm_comp_operands<2>(part, w12_load(m + base + (wrap ? TP_XF : TP_F) + ai), w12_load(m + base + TP_RAW + 3 * (entry % TP_RING) + j),
                                         xa[2 * j], yb[2 * j], xa[2 * j + 1], yb[2 * j + 1]);
                 }
                 res = dotn<6>(xa, yb);

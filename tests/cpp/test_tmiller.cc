@@ -128,14 +128,14 @@ int main() {
         const Jac<Fq> *Pp[NP];
         const Jac<Fq2> *Qp[NP];
         uint8_t neg[NP];
-        Fq2S *rows[3][NP];
+        Fq2S *rows[TP_RING][NP];
         for (int c = 0; c < NP; c++) {
             Ps[c] = {rand_fq(), rand_fq(), c == 1 ? Fq::one() : rand_fq()};
             if (c == 2) Ps[c].Z = Fq::zero();
             Pp[c] = &Ps[c];
             neg[c] = (uint8_t)(c & 1);
             Qp[c] = &Qs[c % (int)nq];
-            for (int s = 0; s < 3; s++) rows[s][c] = tpmem.data() + c * TP_STRIDE + TP_RAW + 3 * s;
+            for (int s = 0; s < TP_RING; s++) rows[s][c] = tpmem.data() + c * TP_STRIDE + TP_RAW + 3 * s;
         }
         std::vector<std::vector<uint32_t>> tabs2(np, std::vector<uint32_t>(TM_TAB_WORDS, 0xdeadbeefu));
         uint32_t *tout[NP];
@@ -146,7 +146,7 @@ int main() {
         pre.setup_g1(Pp, neg, np);
         tp.setup();
         for (int e = -1; e < ATE_NUM_COEFFS; e++) {
-            if (e + 1 < ATE_NUM_COEFFS) pre.entry_rounds(tm_entry_kind(e + 1), e + 1, tout, rows[(e + 1) % 3], true);
+            if (e + 1 < ATE_NUM_COEFFS) pre.entry_rounds(tm_entry_kind(e + 1), e + 1, tout, rows[(e + 1) % TP_RING], true);
             if (e >= 0) tp.entry(tm_entry_kind(e), e);
         }
         for (unsigned c = 0; c < np; c++) {
@@ -182,7 +182,7 @@ int main() {
         const Jac<Fq> *Pp[NP];
         const Jac<Fq2> *Qp[NP];
         uint8_t neg[NP];
-        Fq2S *rows[3][NP];
+        Fq2S *rows[TP_RING][NP];
         // (the identity holds on the curve -- it is the group law that makes R - Q the point [a - 1]Q: multiples of the generators,
         // un-normalised Jacobian; the other blocks of this test feed the step formulas arbitrary coordinates)
         Jac<Fq> g1 = {Fq::one(), Fq::one() + Fq::one(), Fq::one()};
@@ -204,7 +204,7 @@ int main() {
             Pp[c] = &Ps[c];
             neg[c] = (uint8_t)(c & 1);
             Qp[c] = &Qc[c];
-            for (int s = 0; s < 3; s++) rows[s][c] = tpmem.data() + c * TP_STRIDE + TP_RAW + 3 * s;
+            for (int s = 0; s < TP_RING; s++) rows[s][c] = tpmem.data() + c * TP_STRIDE + TP_RAW + 3 * s;
         }
         uint32_t *tout[NP] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         G2Pre<LoopExec, NP> pre{ex, g2mem.data()};
@@ -213,7 +213,7 @@ int main() {
         pre.setup_g1(Pp, neg, np);
         tp.setup();
         for (int e = -1; e < NAF_NUM_ENTRIES; e++) {
-            if (e + 1 < NAF_NUM_ENTRIES) pre.entry_rounds(tm_naf_entry_kind(e + 1), e + 1, tout, rows[(e + 1) % 3], true);
+            if (e + 1 < NAF_NUM_ENTRIES) pre.entry_rounds(tm_naf_entry_kind(e + 1), e + 1, tout, rows[(e + 1) % TP_RING], true);
             if (e >= 0) tp.entry(tm_naf_entry_kind(e), e);
         }
         for (unsigned c = 0; c < np; c++) {
