@@ -300,8 +300,9 @@ int lsa_fr_eq_table(const void *r_mont, size_t d, int variant, void *out_mont, i
  * with coset_g, *= g^-k (iFFT / icosetFFT).  coset_g: HOST, one Fr, or NULL.
  * on_device != 0: a is a device pointer; else a host pointer.  log_n <= 28.
  * At most three passes over the data (csrc/ntt.hip); the twiddle tables of the last eight domains (log_n, omega,
- * direction; each up to one vector's size while that is at most LSA_NTT_T1_MB = 512 MB) and of the last four coset
- * generators stay on the device; a second vector of the same size is kept as scratch. */
+ * direction; each up to one vector's size while that is at most LSA_NTT_T1_MB = 512 MB) and of the last eight coset
+ * generators stay on the device, least recently used first out once they hold more than LSA_NTT_CACHE_MB (default
+ * 2048) together; a second vector of the same size is kept as scratch. */
 int lsa_fr_ntt(void *a_mont, size_t log_n, const void *omega_mont, int inverse, const void *coset_g_mont, int on_device);
 
 /* The same four transforms on libfqfft's step_radix2_domain<Fr> of m = 2^big_log + 2^small_log points, small_log <

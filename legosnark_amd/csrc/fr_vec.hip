@@ -27,6 +27,7 @@
 #include "fp.h"
 #include "fr29.h"
 #include "msm.h"
+#include "capi_internal.h"
 
 namespace lsa {
 
@@ -633,10 +634,24 @@ struct FoldGraph {
 constexpr int FOLD_GRAPHS = 6;
 FoldGraph g_fold_graphs[FOLD_GRAPHS];
 uint64_t g_fold_tick = 0;
-bool g_fold_graphs_broken = false;
+// A failed capture / instantiation / launch (a caller with a capture of its own open on this thread, a runtime that is out
+// of graph memory) sends the next FOLD_GRAPH_RETRY_AFTER recursions through plain launches -- ~0.1 ms more host time each at
+// d = 24 -- and is then tried again; the first fallback of a run of them is reported under LSA_TRACE.
+constexpr unsigned FOLD_GRAPH_RETRY_AFTER = 64;
+unsigned g_fold_graph_skip = 0;
+bool g_fold_graph_reported = false;
+void fold_graphs_give_up(const char *what) {
+    (void)hipGetLastError();
+    g_fold_graph_skip = FOLD_GRAPH_RETRY_AFTER;
+    if (!g_fold_graph_reported && trace_on())
+        fprintf(stderr, "[lsa]   fr recursion: %s failed, the next %u recursions are issued as plain launches (no hipGraph)\n", what, FOLD_GRAPH_RETRY_AFTER);
+    g_fold_graph_reported = true;
+}
 bool fold_graphs_on() {
     static const bool on = !(getenv("LSA_FR_GRAPHS") && getenv("LSA_FR_GRAPHS")[0] == '0');
-    return on && !g_fold_graphs_broken;
+    if (!on) return false;
+    if (g_fold_graph_skip) { if (--g_fold_graph_skip == 0) g_fold_graph_reported = false; return false; }
+    return true;
 }
 // issue(st) queues the sequence on st; returns an LSA code.  The first call with a new argument set captures it.
 template <class Issue>
@@ -647,39 +662,37 @@ int fold_run(int kind, size_t d, const void *a0, const void *a1, const void *a2,
         if (g.exec && g.kind == kind && g.d == d && g.a0 == a0 && g.a1 == a1 && g.a2 == a2 && g.a3 == a3 && g.a4 == a4) {
             g.tick = ++g_fold_tick;
             if (hipGraphLaunch(g.exec, st) == hipSuccess) return LSA_OK;
-            (void)hipGetLastError();
-            g_fold_graphs_broken = true;
+            fold_graphs_give_up("hipGraphLaunch");
             return issue(st);
         }
         if (g.tick < victim->tick) victim = &g;
     }
-    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); g_fold_graphs_broken = true; return issue(st); }
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { fold_graphs_give_up("hipStreamBeginCapture"); return issue(st); }
     const int rc = issue(st);
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(st, &graph);
     if (rc != LSA_OK || e != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
-        (void)hipGetLastError();
-        g_fold_graphs_broken = true;                     // (nothing was executed during the capture: run it plainly)
+        fold_graphs_give_up("hipStreamEndCapture");      // (nothing was executed during the capture: run it plainly)
         return rc != LSA_OK ? rc : issue(st);
     }
     hipGraphExec_t exec = nullptr;
     if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
         (void)hipGraphDestroy(graph);
-        (void)hipGetLastError();
-        g_fold_graphs_broken = true;
+        fold_graphs_give_up("hipGraphInstantiate");
         return issue(st);
     }
     (void)hipGraphDestroy(graph);
     if (victim->exec) (void)hipGraphExecDestroy(victim->exec);
     *victim = FoldGraph{kind, d, a0, a1, a2, a3, a4, exec, ++g_fold_tick};
-    if (hipGraphLaunch(exec, st) != hipSuccess) { (void)hipGetLastError(); g_fold_graphs_broken = true; return issue(st); }
+    if (hipGraphLaunch(exec, st) != hipSuccess) { fold_graphs_give_up("hipGraphLaunch"); return issue(st); }
     return LSA_OK;
 }
 }  // namespace
 void fr_vec_release() {
     for (auto &g : g_fold_graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); g = FoldGraph(); }
-    g_fold_graphs_broken = false;
+    g_fold_graph_skip = 0;
+    g_fold_graph_reported = false;
 }
 
 // CPPoly::prove witness coefficients: d_v (2^d, untouched), d_r (d), d_w (2^d; the first

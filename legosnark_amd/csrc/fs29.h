@@ -17,6 +17,51 @@ namespace lsa {
 LSA_HD F29 f29_sqr(const F29 &a) { return sqr(a); }
 LSA_HD F29 f29_mul(const F29 &a, const F29 &b) { return mul(a, b); }
 
+// sum_{t < N} a[t] * b[t] / 2^261 mod p with ONE reduction, written COLUMN-WISE (round 6): the 17 column sums of the
+// schoolbook products are accumulated apart -- consecutive multiply-adds go to different 64-bit accumulators -- and the
+// Montgomery factor m_k of column k is added into the eight later columns as soon as it is known.  fp29.h's mul / dot2 /
+// dot4 run one accumulator through all columns: every multiply-add waits for the one before it, and a dependent
+// v_mad_u64_u32 issues every 11 cycles on gfx950 (tools/ubench_clock.hip) -- invisible with four wavefronts per SIMD to hide
+// it, but the pairing kernels run one or two (236 VGPRs), where the chain, not the issue rate, set the time.
+// Needs tight limbs everywhere and 9 N + 9 <= 64 products of < 2^58 per column; the result is < T / 2^261 + p for the
+// integer sum T (< 2p for T < 169 p^2; callers with more state their bound).  Same value as the serial forms.  [tight]
+template <int N>
+LSA_HD F29 f29_dot_cols(const F29 (&a)[N], const F29 (&b)[N]) {
+    static_assert(9 * N + 9 <= 64, "64-bit columns hold 64 products of 29-bit limbs");
+    uint64_t col[17];
+#pragma unroll
+    for (int k = 0; k < 17; k++) col[k] = 0;
+#pragma unroll
+    for (int t = 0; t < N; t++)
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+#pragma unroll
+            for (int j = 0; j < 9; j++) col[i + j] += (uint64_t)a[t].l[i] * b[t].l[j];
+    uint64_t carry = 0;
+    F29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        uint64_t acc = col[k] + carry;
+        const uint32_t m = ((uint32_t)acc * F29::PINV) & F29::MASK;
+        acc += (uint64_t)m * F29::p(0);
+        carry = acc >> 29;
+#pragma unroll
+        for (int j = 1; j < 9; j++) col[k + j] += (uint64_t)m * F29::p(j);
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+        const uint64_t acc = col[k] + carry;
+        r.l[k - 9] = (uint32_t)acc & F29::MASK;
+        carry = acc >> 29;
+    }
+    r.l[8] = (uint32_t)carry;
+    return r;
+}
+LSA_HD F29 f29_dot2_cols(const F29 &a0, const F29 &b0, const F29 &a1, const F29 &b1) {
+    const F29 a[2] = {a0, a1}, b[2] = {b0, b1};
+    return f29_dot_cols<2>(a, b);
+}
+
 // tight value < 4p -> same residue, < 2p
 LSA_HD F29 condsub2(const F29 &t) {
     F29 d;

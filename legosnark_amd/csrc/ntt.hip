@@ -132,6 +132,7 @@ struct DomainTables {
     Fr *Tlo = nullptr, *Thi = nullptr, *T2 = nullptr, *T1 = nullptr;
     uint32_t *W9 = nullptr;        // W as limbs
     uint64_t tick = 0;
+    size_t bytes = 0;
 };
 struct CosetTables {
     unsigned L = 0;
@@ -140,11 +141,37 @@ struct CosetTables {
     void *mem = nullptr;
     Fr *Glo = nullptr, *Ghi = nullptr, *Gfull = nullptr;
     uint64_t tick = 0;
+    size_t bytes = 0;
 };
 constexpr int NTT_CACHE = 8;          // a step domain keeps two sub-domains, each in both directions
 DomainTables g_dom[NTT_CACHE];
 CosetTables g_cos[NTT_CACHE];
 uint64_t g_ntt_tick = 0;
+// The tables are kept by BYTES as well as by count: a cached domain can be as large as its data (T1: 512 MB at 2^24), so eight
+// of them -- a prover cycling through sizes, step domains in both directions -- could pin 4-5 GB.  Before a table is built the
+// least recently used ones (of either kind, older than the transform in progress) go until the total fits LSA_NTT_CACHE_MB
+// (default 2048).  hipFree waits for the device: a table a queued transform still reads is safe.
+size_t g_ntt_bytes = 0;
+size_t ntt_cache_budget() {
+    static const size_t b = (size_t)(getenv("LSA_NTT_CACHE_MB") ? atol(getenv("LSA_NTT_CACHE_MB")) : 2048) << 20;
+    return b;
+}
+template <class T> void ntt_drop(T &d) {
+    if (d.mem) { (void)hipFree(d.mem); g_ntt_bytes -= d.bytes; }
+    d = T();
+}
+void ntt_make_room(size_t need, uint64_t protect) {
+    while (g_ntt_bytes + need > ntt_cache_budget()) {
+        DomainTables *vd = nullptr;
+        CosetTables *vc = nullptr;
+        uint64_t oldest = ~0ull;
+        for (auto &d : g_dom) if (d.mem && d.tick <= protect && d.tick < oldest) { oldest = d.tick; vd = &d; vc = nullptr; }
+        for (auto &d : g_cos) if (d.mem && d.tick <= protect && d.tick < oldest) { oldest = d.tick; vc = &d; vd = nullptr; }
+        if (vd) ntt_drop(*vd);
+        else if (vc) ntt_drop(*vc);
+        else return;                  // only this transform's own tables are left: they stay, whatever the budget
+    }
+}
 
 int launch_pow_table(const Fr &base, const Fr &c0, size_t count, Fr *out, hipStream_t st) {
     const unsigned blocks = (unsigned)(((count + NTT_RUN - 1) / NTT_RUN + 255) / 256);
@@ -154,21 +181,25 @@ int launch_pow_table(const Fr &base, const Fr &c0, size_t count, Fr *out, hipStr
 }
 // a table about to be replaced may still be read by a transform queued on `st`: everything here is ordered on `st`,
 // and hipFree waits for the device
-int domain_tables(const NttPlan &p, const Fr &omega, bool inverse, hipStream_t st, DomainTables **out) {
+int domain_tables(const NttPlan &p, const Fr &omega, bool inverse, hipStream_t st, uint64_t protect, DomainTables **out) {
     DomainTables *victim = &g_dom[0];
     for (auto &d : g_dom) {
         if (d.mem && d.L == p.L && d.inverse == inverse && memcmp(&d.omega, &omega, sizeof(Fr)) == 0) { d.tick = ++g_ntt_tick; *out = &d; return LSA_OK; }
         if (d.tick < victim->tick) victim = &d;
     }
     DomainTables &d = *victim;
-    if (d.mem) { (void)hipFree(d.mem); d.mem = nullptr; }
+    ntt_drop(d);
     const size_t nW = (size_t)1 << (p.lmax - 1), nlo = (size_t)1 << p.h, nhi = (size_t)1 << (p.L - p.h);
     const size_t n2t = p.l2 ? (size_t)1 << (p.l2 + p.l3) : 0;
     // pass 1's twiddles as one table of n entries (a product per element less) while n * 32 B stays within LSA_NTT_T1_MB
     // (default 512: up to 2^24 elements); beyond, and for rows shorter than a lane's run, the two-level look-up
     static const size_t t1_budget = (size_t)(getenv("LSA_NTT_T1_MB") ? atol(getenv("LSA_NTT_T1_MB")) : 512) << 20;
     const size_t n1t = (p.l1 && p.L - p.l1 >= 4 && (((size_t)1 << p.L) * sizeof(Fr)) <= t1_budget) ? (size_t)1 << p.L : 0;
-    if (hipMalloc(&d.mem, (nW + nlo + nhi + n2t + n1t) * sizeof(Fr) + nW * 36) != hipSuccess) { (void)hipGetLastError(); d.mem = nullptr; set_error("fr_ntt: twiddle allocation failed"); return LSA_ERR_NOMEM; }
+    const size_t dbytes = (nW + nlo + nhi + n2t + n1t) * sizeof(Fr) + nW * 36;
+    ntt_make_room(dbytes, protect);
+    if (hipMalloc(&d.mem, dbytes) != hipSuccess) { (void)hipGetLastError(); d.mem = nullptr; set_error("fr_ntt: twiddle allocation failed"); return LSA_ERR_NOMEM; }
+    d.bytes = dbytes;
+    g_ntt_bytes += dbytes;
     Fr *Wp = (Fr *)d.mem;           // W as words: the source of W9
     d.Tlo = Wp + nW;
     d.Thi = d.Tlo + nlo;
@@ -193,25 +224,29 @@ int domain_tables(const NttPlan &p, const Fr &omega, bool inverse, hipStream_t s
         hipLaunchKernelGGL(k_ntt_t1_table, dim3((unsigned)((n1t / 16 + 255) / 256)), dim3(256), 0, st, w, c32, p.l1, p.L - p.l1, d.T1);
         if (hipGetLastError() != hipSuccess) { set_error("fr_ntt: table kernel launch failed"); rc = LSA_ERR_HIP; }
     }
-    if (rc) { (void)hipFree(d.mem); d.mem = nullptr; return rc; }
+    if (rc) { ntt_drop(d); return rc; }
     *out = &d;
     return LSA_OK;
 }
-int coset_tables(const NttPlan &p, const Fr &g, bool inverse, hipStream_t st, CosetTables **out) {
+int coset_tables(const NttPlan &p, const Fr &g, bool inverse, hipStream_t st, uint64_t protect, CosetTables **out) {
     CosetTables *victim = &g_cos[0];
     for (auto &d : g_cos) {
         if (d.mem && d.L == p.L && d.inverse == inverse && memcmp(&d.g, &g, sizeof(Fr)) == 0) { d.tick = ++g_ntt_tick; *out = &d; return LSA_OK; }
         if (d.tick < victim->tick) victim = &d;
     }
     CosetTables &d = *victim;
-    if (d.mem) { (void)hipFree(d.mem); d.mem = nullptr; }
+    ntt_drop(d);
     const size_t nlo = (size_t)1 << p.h, nhi = (size_t)1 << (p.L - p.h);
     // the powers as one table of n entries (a product per element less) up to a quarter of the budget of pass 1's twiddles:
     // 128 MB, 2^22 elements -- at 2^24 the second 512-MB stream costs what the product saved (icosetFFT 2.52 -> 2.54 ms;
     // 2^20: 0.187 -> 0.172)
     static const size_t full_budget = ((size_t)(getenv("LSA_NTT_T1_MB") ? atol(getenv("LSA_NTT_T1_MB")) : 512) << 20) / 4;
     const size_t nfull = (p.L > NTT_TILE_LOG && (((size_t)1 << p.L) * sizeof(Fr)) <= full_budget) ? (size_t)1 << p.L : 0;
-    if (hipMalloc(&d.mem, (nlo + nhi + nfull) * sizeof(Fr)) != hipSuccess) { (void)hipGetLastError(); d.mem = nullptr; set_error("fr_ntt: coset table allocation failed"); return LSA_ERR_NOMEM; }
+    const size_t cbytes = (nlo + nhi + nfull) * sizeof(Fr);
+    ntt_make_room(cbytes, protect);
+    if (hipMalloc(&d.mem, cbytes) != hipSuccess) { (void)hipGetLastError(); d.mem = nullptr; set_error("fr_ntt: coset table allocation failed"); return LSA_ERR_NOMEM; }
+    d.bytes = cbytes;
+    g_ntt_bytes += cbytes;
     d.Glo = (Fr *)d.mem;
     d.Ghi = d.Glo + nlo;
     d.Gfull = nfull ? d.Ghi + nhi : nullptr;
@@ -223,15 +258,15 @@ int coset_tables(const NttPlan &p, const Fr &g, bool inverse, hipStream_t st, Co
     int rc = launch_pow_table(base, c32, nlo, d.Glo, st);
     if (!rc) rc = launch_pow_table(host_pow(base, (uint64_t)1 << p.h), hi0, nhi, d.Ghi, st);
     if (!rc && nfull) rc = launch_pow_table(base, hi0, nfull, d.Gfull, st);
-    if (rc) { (void)hipFree(d.mem); d.mem = nullptr; return rc; }
+    if (rc) { ntt_drop(d); return rc; }
     *out = &d;
     return LSA_OK;
 }
 }  // namespace
 
 void ntt_release() {
-    for (auto &d : g_dom) { if (d.mem) (void)hipFree(d.mem); d = DomainTables(); }
-    for (auto &d : g_cos) { if (d.mem) (void)hipFree(d.mem); d = CosetTables(); }
+    for (auto &d : g_dom) ntt_drop(d);
+    for (auto &d : g_cos) ntt_drop(d);
 }
 
 // d_a: 2^log_n elements, transformed in place (the result is in d_a when the call returns to the stream); d_tmp: scratch
@@ -247,11 +282,12 @@ int fr_ntt_device(Fr *d_a, unsigned log_n, const Fr &omega, bool inverse, const 
     (void)attr_set;
     const NttPlan p = ntt_plan(log_n);
     DomainTables *dt = nullptr;
-    int rc = domain_tables(p, omega, inverse, st, &dt);
+    const uint64_t protect = g_ntt_tick;                  // tables touched from here on belong to this transform
+    int rc = domain_tables(p, omega, inverse, st, protect, &dt);
     if (rc) return rc;
     CosetTables *ct = nullptr;
     if (coset) {
-        rc = coset_tables(p, *coset, inverse, st, &ct);
+        rc = coset_tables(p, *coset, inverse, st, protect, &ct);
         if (rc) return rc;
     }
     unsigned kinds[3], nk = 0;

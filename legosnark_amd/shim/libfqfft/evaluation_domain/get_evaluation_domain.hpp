@@ -189,7 +189,8 @@ public:
 // big + rounded_small.  The extended and sequence domains are not provided: refused, never silently replaced.
 template <typename FieldT>
 std::shared_ptr<evaluation_domain<FieldT>> get_evaluation_domain(const size_t min_size) {
-    if (min_size == 0) throw std::invalid_argument("get_evaluation_domain: no matching domain (size 0)");
+    // (sizes 0 and 1: every libfqfft domain constructor requires m > 1, upstream ends in DomainSizeException)
+    if (min_size <= 1) throw std::invalid_argument("get_evaluation_domain: no matching domain (libfqfft's domains need m > 1)");
     const auto pow2 = [](size_t v) { return v && (v & (v - 1)) == 0; };
     if (min_size > (size_t(1) << 28))
         throw std::invalid_argument("get_evaluation_domain: size exceeds the 2-adicity of Fr (2^28); libfqfft's extended radix-2 and sequence domains are not provided");
