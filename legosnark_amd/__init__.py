@@ -17,7 +17,10 @@ import numpy as np
 _PKG = os.path.dirname(os.path.abspath(__file__))
 # LSA_LIB_VARIANT=loopback: the TEST build whose comm.hip carries the one-GPU stand-in for a multi-rank collective
 # (csrc/Makefile); the product library is the default and does not contain it
-LIB_PATH = os.path.join(_PKG, "liblegosnark_amd_loopback.so" if os.environ.get("LSA_LIB_VARIANT") == "loopback" else "liblegosnark_amd.so")
+# LSA_LIB_VARIANT=<name> loads liblegosnark_amd_<name>.so: "loopback" (csrc/Makefile: comm.hip's one-GPU stand-in for a collective,
+# tests only) or an experiment build made by hand (e.g. an A/B of a compile-time switch)
+_VARIANT = os.environ.get("LSA_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_PKG, "liblegosnark_amd_%s.so" % _VARIANT if _VARIANT else "liblegosnark_amd.so")
 _lib = None
 
 MSM_STAGES = 8

@@ -97,7 +97,42 @@ struct F29 {
 
     // Montgomery product a*b/2^261 mod p.  Requires limb products a_i*b_j <= 2^60 (both
     // operands "loose" < 2^30 is fine) and a*b < 121 p^2.  [< 2p; tight]
+    // (-DLSA_FP29_COLS: mul, sqr and dot2 column-wise -- independent column accumulators, as fs29.h: f29_dot_cols.  An A/B
+    // switch of round 6; the serial forms stay the default.)
+    static LSA_HD F29 redc_cols(uint64_t (&col)[17]) {
+        uint64_t carry = 0;
+        F29 r;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            uint64_t acc = col[k] + carry;
+            const uint32_t m = ((uint32_t)acc * PINV) & MASK;
+            acc += (uint64_t)m * p(0);
+            carry = acc >> 29;
+#pragma unroll
+            for (int j = 1; j < 9; j++) col[k + j] += (uint64_t)m * p(j);
+        }
+#pragma unroll
+        for (int k = 9; k < 17; k++) {
+            const uint64_t acc = col[k] + carry;
+            r.l[k - 9] = (uint32_t)acc & MASK;
+            carry = acc >> 29;
+        }
+        r.l[8] = (uint32_t)carry;
+        return r;
+    }
     friend LSA_HD F29 mul(const F29 &a, const F29 &b) {
+#if defined(LSA_FP29_COLS)
+        {
+            uint64_t col[17];
+#pragma unroll
+            for (int k = 0; k < 17; k++) col[k] = 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++)
+#pragma unroll
+                for (int j = 0; j < 9; j++) col[i + j] += (uint64_t)a.l[i] * b.l[j];
+            return redc_cols(col);
+        }
+#endif
         uint64_t acc = 0;
         uint32_t m[9];
         F29 r;
@@ -129,6 +164,20 @@ struct F29 {
         uint32_t d[9];
 #pragma unroll
         for (int i = 0; i < 9; i++) d[i] = a.l[i] << 1;
+#if defined(LSA_FP29_COLS)
+        {
+            uint64_t col[17];
+#pragma unroll
+            for (int k = 0; k < 17; k++) col[k] = 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                col[2 * i] += (uint64_t)a.l[i] * a.l[i];
+#pragma unroll
+                for (int j = i + 1; j < 9; j++) col[i + j] += (uint64_t)a.l[i] * d[j];
+            }
+            return redc_cols(col);
+        }
+#endif
         uint64_t acc = 0;
         uint32_t m[9];
         F29 r;
@@ -159,6 +208,18 @@ struct F29 {
     // 64-bit columns.  Needs a0*b0 + a1*b1 < 169 p^2 and at most one loose operand per
     // product (18*2^59 + 9*2^58 < 2^64).  [< 2p; tight]
     friend LSA_HD F29 dot2(const F29 &a0, const F29 &b0, const F29 &a1, const F29 &b1) {
+#if defined(LSA_FP29_COLS)
+        {
+            uint64_t col[17];
+#pragma unroll
+            for (int k = 0; k < 17; k++) col[k] = 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++)
+#pragma unroll
+                for (int j = 0; j < 9; j++) { col[i + j] += (uint64_t)a0.l[i] * b0.l[j]; col[i + j] += (uint64_t)a1.l[i] * b1.l[j]; }
+            return redc_cols(col);
+        }
+#endif
         uint64_t acc = 0;
         uint32_t m[9];
         F29 r;

@@ -20,9 +20,11 @@ LSA_HD F29 f29_mul(const F29 &a, const F29 &b) { return mul(a, b); }
 // sum_{t < N} a[t] * b[t] / 2^261 mod p with ONE reduction, written COLUMN-WISE (round 6): the 17 column sums of the
 // schoolbook products are accumulated apart -- consecutive multiply-adds go to different 64-bit accumulators -- and the
 // Montgomery factor m_k of column k is added into the eight later columns as soon as it is known.  fp29.h's mul / dot2 /
-// dot4 run one accumulator through all columns: every multiply-add waits for the one before it, and a dependent
-// v_mad_u64_u32 issues every 11 cycles on gfx950 (tools/ubench_clock.hip) -- invisible with four wavefronts per SIMD to hide
-// it, but the pairing kernels run one or two (236 VGPRs), where the chain, not the issue rate, set the time.
+// dot4 run one accumulator through all columns, every multiply-add waiting for the one before it (a dependent
+// v_mad_u64_u32 issues every 11 cycles in tools/ubench_clock.hip): the suspicion was that the pairing kernels, at one or two
+// wavefronts per SIMD, ran at the speed of that chain.  MEASURED (-DLSA_F29_COLS, profiles/r06_v5_*): no -- the fused Miller
+// kernel 1.03 -> 1.05 ms, k_g2_precomp 0.66 -> 0.66 ms, config 5 1.54 -> 1.58 ms; likewise the Fr kernels (fr29.h) and
+// the MSM's accumulate kernel (fp29.h).  The serial forms stay; this one is kept behind the switch and in the host tests.
 // Needs tight limbs everywhere and 9 N + 9 <= 64 products of < 2^58 per column; the result is < T / 2^261 + p for the
 // integer sum T (< 2p for T < 169 p^2; callers with more state their bound).  Same value as the serial forms.  [tight]
 template <int N>

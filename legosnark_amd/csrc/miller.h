@@ -410,7 +410,10 @@ LSA_HD F29 g12_comp_mul(unsigned part, const Fq2S &a, const Fq2S &b) {
         y0.l[l] = (b.c1.v.l[l] & pm) | (b.c0.v.l[l] & ~pm);
         y1.l[l] = (b.c0.v.l[l] & pm) | (nb1.l[l] & ~pm);
     }
+#if defined(LSA_F29_COLS)
     return f29_dot2_cols(a.c0.v, y0, a.c1.v, y1);
+#endif
+    return dot2(a.c0.v, y0, a.c1.v, y1);
 }
 LSA_HD Fs &g12_part(Fq2S &v, unsigned part) { return part ? v.c1 : v.c0; }
 

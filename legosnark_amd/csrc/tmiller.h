@@ -358,7 +358,40 @@ struct TMTerm { int a, b; uint32_t w2; };
 // sum_{t < N} a[t] * b[t] / 2^261 mod p with ONE reduction.  Needs sum a_t b_t < 169 p^2, tight limbs
 // everywhere and 9 N + 9 <= 64 limb products per column (N <= 6).  [< 2p; tight]
 template <int N>
-LSA_HD F29 dotn(const F29 (&a)[N], const F29 (&b)[N]) { return f29_dot_cols<N>(a, b); }     // (fs29.h: column-wise, no serial accumulator)
+LSA_HD F29 dotn(const F29 (&a)[N], const F29 (&b)[N]) {
+#if defined(LSA_F29_COLS)
+    return f29_dot_cols<N>(a, b);     // (fs29.h: an A/B switch of round 6 -- measured equal, the serial form stays)
+#endif
+    static_assert(9 * N + 9 <= 64, "64-bit columns hold 64 products of 29-bit limbs");
+    uint64_t acc = 0;
+    uint32_t m[9];
+    F29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++)
+#pragma unroll
+            for (int t = 0; t < N; t++) acc += (uint64_t)a[t].l[i] * b[t].l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F29::p(k - i);
+        m[k] = ((uint32_t)acc * F29::PINV) & F29::MASK;
+        acc += (uint64_t)m[k] * F29::p(0);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++)
+#pragma unroll
+            for (int t = 0; t < N; t++) acc += (uint64_t)a[t].l[i] * b[t].l[k - i];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * F29::p(k - i);
+        r.l[k - 9] = (uint32_t)acc & F29::MASK;
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
 // the two limb-level operand pairs behind component `part` of a*b (b's components < KB p): part 0:
 // a0*b0 + a1*(KB p - b1), part 1: a0*b1 + a1*b0
 template <int KB>

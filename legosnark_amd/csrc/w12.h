@@ -141,7 +141,10 @@ LSA_HD F29 w12_comp_mul(unsigned part, const Fq2S &a, const Fq2S &b) {
         y0.l[l] = (b.c1.v.l[l] & pm) | (b.c0.v.l[l] & ~pm);
         y1.l[l] = (b.c0.v.l[l] & pm) | (nb1.l[l] & ~pm);
     }
+#if defined(LSA_F29_COLS)
     return f29_dot2_cols(a.c0.v, y0, a.c1.v, y1);
+#endif
+    return dot2(a.c0.v, y0, a.c1.v, y1);
 }
 
 // tower <-> polynomial basis: poly index k -> (which Fq6 half, which coefficient)
