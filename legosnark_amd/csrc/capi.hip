@@ -713,8 +713,12 @@ static int stage_jac_ensure(size_t bytes, void **p) {
 static void warm_stage_buffers() {
     const char *w = getenv("LSA_WARM");
     if (w && w[0] == '0') return;
-    (void)g_stage_scalars.ensure((size_t)34 << 20);
-    (void)g_stage_jac.ensure((size_t)202 << 20);
+    // (LSA_WARM_MB scales these with the MSM workspaces: 400 is the default there)
+    const char *mb = getenv("LSA_WARM_MB");
+    const size_t scale = mb ? (size_t)atoll(mb) : 400;
+    if (scale == 0) return;
+    const int e1 = g_stage_scalars.ensure(((size_t)34 << 20) * scale / 400), e2 = g_stage_jac.ensure(((size_t)202 << 20) * scale / 400);
+    if ((e1 || e2) && trace_on()) fprintf(stderr, "[lsa]   warm-up: staging buffers not allocated\n");
     (void)hipGetLastError();
 }
 static void release_stage_buffers() {

@@ -1656,7 +1656,10 @@ static int msm_func_attrs() {
 // What the first MSM of a process used to pay inside its own call (17-20 ms whatever its size: the library's code object
 // loaded on the first kernel launch, eight streams and their events, the function attributes, the first workspace
 // allocations) is paid by lsa_init instead -- a prover's init_public_params(), not its first multiExpMA.  The workspaces
-// are sized for one G1 MSM of 2^20 pairs (192 MB + 8 x 96 MB of the 288 GB); LSA_WARM=0 skips all of it, LSA_WARM_MB sets the size.
+// are sized for the first G1 and G2 MSMs of 2^20 pairs: 400 MB of front workspace + 360 MB for tail slot 0 here, 34 + 202 MB of
+// staging in capi.hip (warm_stage_buffers) -- about 1 GB of the 288 GB per process; LSA_WARM=0 skips all of it (everything
+// is then allocated by the first call that needs it), LSA_WARM_MB sets the size for processes that share a GPU or never see
+// 2^20 pairs (a verifier, a check program: LSA_WARM_MB=16).
 int msm_warmup(hipStream_t st) {
     const char *w = getenv("LSA_WARM");
     if (w && w[0] == '0') return LSA_OK;
@@ -1673,8 +1676,9 @@ int msm_warmup(hipStream_t st) {
     const char *mb = getenv("LSA_WARM_MB");
     const size_t front = (mb ? (size_t)atoll(mb) : 400) << 20, tailb = front / 10 * 9;
     if (front) {
-        if (g_ws.ensure(front) != 0) (void)hipGetLastError();          // (no memory: the first call will say so)
-        if (g_tail[0].ws.ensure(tailb) != 0) (void)hipGetLastError();
+        // (no memory: the first call that needs the workspace will say so; LSA_TRACE reports it here)
+        if (g_ws.ensure(front) != 0) { (void)hipGetLastError(); if (getenv("LSA_TRACE")) fprintf(stderr, "[lsa]   warm-up: front workspace of %zu MB not allocated\n", front >> 20); }
+        if (g_tail[0].ws.ensure(tailb) != 0) { (void)hipGetLastError(); if (getenv("LSA_TRACE")) fprintf(stderr, "[lsa]   warm-up: tail workspace of %zu MB not allocated\n", tailb >> 20); }
     }
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, st, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u);      // loads the code object
     for (auto &t : g_tail) if (t.stream) hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, t.stream, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u);
