@@ -1936,6 +1936,8 @@ static int msm_pipeline(const void *d_bases_v, size_t first, const Fr *d_scalars
     const uint32_t split = wide ? (wide_split == 2 ? 2u : 1u) : 2u;        // lanes per bucket in k_accumulate
     // first reduction level: quads over L buckets (latency) or, for 2^19+ buckets, lanes over L buckets (throughput)
     // (a quad-shared first level over 2^19 buckets was measured too: 0.69 - 1.27 ms against 0.63 ms)
+    // (G2, measured in round 6 with 32768 / 16384 / 8192 first-level lanes instead of 65536 -- longer lane-private chains, a half
+    // to an eighth of the quad level's work behind them: pipelined 2^20-pair G2 MSMs 4.75-5.07 -> 4.80 / 5.41 / 6.78 ms.  65536 stays.)
     const uint32_t L = big ? std::max<uint32_t>(1, B / 65536) : (B > 4096 ? B / 4096 : 1);
     uint32_t logL = 0;
     while ((1u << logL) < L) logL++;

@@ -710,6 +710,35 @@ public:
     // lsa_mtxmultiexp / lsa_scalar_mul_batch).  The same point as libff's double-and-add, by the cheapest route: plain
     // double-and-add for scalars below 2^16, the fixed-base table for the generator, a GLV (G1) / Galbraith-Scott (G2)
     // ladder for any other base (csrc/fixed_base.h, csrc/smul_host.h).
+    // the 4-bit window ladder: correct for ANY point of the curve (the endomorphism ladders below need the order-r subgroup)
+    static Jac window_ladder(const Jac &base, const uint64_t e[4], long top) {
+        Jac res = Jac::inf();
+        Jac tbl[16];
+        tbl[0] = Jac::inf();
+        tbl[1] = base;
+        for (int i = 2; i < 16; i++) tbl[i] = (i & 1) ? lsa::jac_add(tbl[i - 1], base) : lsa::jac_dbl(tbl[i / 2]);
+        for (long nib = top / 4; nib >= 0; --nib) {
+            if (nib != top / 4) for (int j = 0; j < 4; j++) res = lsa::jac_dbl(res);
+            const unsigned d = (unsigned)((e[nib / 16] >> (4 * (nib % 16))) & 15u);
+            if (d) res = lsa::jac_add(res, tbl[d]);
+        }
+        return res;
+    }
+    // G2 is a proper subgroup of the twist's points (cofactor 2p - r), and psi / the cube root of unity act as scalars on it
+    // ONLY: the Galbraith-Scott and GLV ladders return [k]P for P in G2, something else outside.  libff's double-and-add is
+    // right for any point, and its operator>> checks neither the curve's subgroup nor -- with compression -- more than
+    // solvability of y^2 = x^3 + b'.  Every point the shim hands out itself lies in G2; a point that ARRIVES as bytes is
+    // tested once ([r]P = O, one window ladder), and the first one found outside G2 switches every later host product on a
+    // G2 base to the window ladder for the rest of the process (a value cannot carry a tag: the 192-byte layout is libff's).
+    static std::atomic<bool> &outside_subgroup_seen() { static std::atomic<bool> f{false}; return f; }
+    static void note_external_point(const G_shim &p) {
+        if constexpr (GROUP == 2) {
+            if (p.is_zero() || outside_subgroup_seen().load(std::memory_order_relaxed)) return;
+            uint64_t r[4];
+            for (int i = 0; i < 4; i++) r[i] = (uint64_t)lsa::FrParams::MOD[2 * i] | ((uint64_t)lsa::FrParams::MOD[2 * i + 1] << 32);
+            if (!window_ladder(p.jac(), r, 253).Z.is_zero()) outside_subgroup_seen().store(true, std::memory_order_relaxed);
+        }
+    }
     friend G_shim operator*(const alt_bn128_Fr &k, const G_shim &p) {
         lsa_shim::StatScope scope(lsa_shim::ST_SCALAR_MUL_HOST, 1);
         lsa_shim::SmulScope route(GROUP);
@@ -758,19 +787,11 @@ public:
             // (Both use endomorphisms that act as scalars on the prime-order subgroup G2 only -- where every point libff
             // hands out lies; a point of the twist outside G2 must go through LSA_SHIM_GLV=0.)
             static const bool gls_on = !(getenv("LSA_SHIM_GLS4") && getenv("LSA_SHIM_GLS4")[0] == '0');
+            if (outside_subgroup_seen().load(std::memory_order_relaxed)) return G_shim(window_ladder(base, e.data, top));   // (see note_external_point)
             if (glv_on && gls_on) return G_shim(lsa::gls4_mul_host(base, e.data));
         }
         if (glv_on) return G_shim(lsa::glv_mul_host(base, e.data));
-        Jac tbl[16];
-        tbl[0] = Jac::inf();
-        tbl[1] = base;
-        for (int i = 2; i < 16; i++) tbl[i] = (i & 1) ? lsa::jac_add(tbl[i - 1], base) : lsa::jac_dbl(tbl[i / 2]);
-        for (long nib = top / 4; nib >= 0; --nib) {
-            if (nib != top / 4) for (int j = 0; j < 4; j++) res = lsa::jac_dbl(res);
-            const unsigned d = (unsigned)((e.data[nib / 16] >> (4 * (nib % 16))) & 15u);
-            if (d) res = lsa::jac_add(res, tbl[d]);
-        }
-        return G_shim(res);
+        return G_shim(window_ladder(base, e.data, top));
     }
     // libff alt_bn128_G1 / alt_bn128_G2 operator<< / operator>> (alt_bn128_g1.cpp, alt_bn128_g2.cpp)
     // [upstream, recalled]: affine coordinates after to_affine_coordinates();
@@ -820,6 +841,7 @@ public:
 #endif
         if (!is_zero) p = G_shim(tX.v, tY.v, F::one());
         else p = zero();
+        if (is) note_external_point(p);
         return is;
     }
     // curve coefficient: b = 3 (G1), b' = 3 / (9 + u) (G2, the sextic twist)
