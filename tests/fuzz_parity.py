@@ -147,6 +147,9 @@ def case_sumcheck(rng):
     m = rng.randrange(1, 5)
     half = rng.choice([1, rng.randrange(1, 50), rng.randrange(50, 6000)])
     tabs = [o.random_scalars(2 * half, seed=rng.randrange(1 << 30))[0] for _ in range(m)]
+    for t in tabs:                                             # the values at the edges of the kernels' lazy bounds
+        for _ in range(rng.choice([0, 0, 2, half])):
+            t[rng.randrange(2 * half)] = o.fr_mont(rng.choice([0, 1, R - 1, R - 2, (R - 1) // 2]))
     beta = rng.random() < 0.6
     suff = o.random_scalars(half, seed=rng.randrange(1 << 30))[0] if (beta and rng.random() < 0.8) else None
     pre = o.random_scalars(1, seed=rng.randrange(1 << 30))[0][0] if beta else None
@@ -156,7 +159,20 @@ def case_sumcheck(rng):
     return np.array_equal(got, want), "m=%d half=%d beta=%d suff=%d" % (m, half, beta, suff is not None)
 
 
-CASES = [("msm", case_msm, 5), ("batch_exp", case_batch_exp, 2), ("scalar_mul_batch", case_smul, 2), ("pairing_terms", case_pairing, 3),
+def case_eq_table(rng):
+    d = rng.randrange(1, 15)
+    r, _ = o.random_scalars(d, seed=rng.randrange(1 << 30))
+    for i in range(d):
+        if rng.random() < 0.15:
+            r[i] = o.fr_mont(rng.choice([0, 1, R - 1]))
+    ok = np.array_equal(lsa.fr_eq_table(r, 0), o.fr_eq_table(r))          # DPBeta::compute_eq_tbl as the reference's loop computes it
+    v, _ = o.random_scalars(1 << d, seed=rng.randrange(1 << 30))
+    rinv = pow(o.MONT, -1, R)
+    ok = ok and o.fr_dot(v, lsa.fr_eq_table(r, 1)) == o.limbs_to_int(o.fr_eval_mle(v, r)) * rinv % R   # the eq monomials: <v, eq> = evalMLE(v, r)
+    return ok, "eq_table d=%d" % d
+
+
+CASES = [("eq_table", case_eq_table, 1), ("msm", case_msm, 5), ("batch_exp", case_batch_exp, 2), ("scalar_mul_batch", case_smul, 2), ("pairing_terms", case_pairing, 3),
          ("ntt", case_ntt, 2), ("ntt_step", case_ntt_step, 2), ("fr_fold", case_fold, 3), ("sumcheck_round", case_sumcheck, 2)]
 
 
