@@ -151,6 +151,22 @@ struct Fr29 {
         }
         return o;
     }
+    // a - b + 4r for b < 4r, carry-normalised.  [a + 4r; tight]
+    friend LSA_HD Fr29 sub4r(const Fr29 &a, const Fr29 &b) {
+        Fr29 o;
+        int32_t c = 0;
+        uint32_t rc = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            rc += r(i) * 4u;
+            const uint32_t rl = (i < 8) ? (rc & MASK) : rc;
+            rc >>= 29;
+            const int32_t v = (int32_t)a.l[i] - (int32_t)b.l[i] + (int32_t)rl + c;
+            if (i < 8) { o.l[i] = (uint32_t)v & MASK; c = v >> 29; }
+            else o.l[i] = (uint32_t)v;
+        }
+        return o;
+    }
     // the representative in [0, r) of a tight value < 2r
     LSA_HD Fr29 canonical2() const {
         Fr29 d;

@@ -183,9 +183,18 @@ LSA_HD void ntt_tile_stage2(const NttArgs &a, unsigned s, unsigned gidx, uint32_
     const Fr29 y0 = add(x0, x1), y1 = sub2r(x0, x1), y2 = add(x2, x3), y3 = sub2r(x2, x3);
     // stage s + 1: (y0, y2) at position pos, (y1, y3) at position pos + 2^s of a 2^(s+2)-point butterfly
     const unsigned shw = a.plan.lmax - 2 - s;
-    const Fr29 t2 = mul(y2, ntt_lds_get(a.W, pos << shw)), t3 = mul(y3, ntt_lds_get(a.W, (pos + h) << shw));
-    ntt_lds_put(lds, i0, add(y0, t2));
-    ntt_lds_put(lds, i2, sub2r(y0, t2));
+    const Fr29 t3 = mul(y3, ntt_lds_get(a.W, (pos + h) << shw));
+    if (s == 0) {
+        // the first pair of stages of a pass: pos = 0 in every group, the twiddle of (y0, y2) is 1 -- no product (round 6: one of
+        // the group's three).  y2 < 4r then instead of < 2r: values grow to < 8r here and by 4r per later pair of stages, < 24r
+        // after five pairs, far below the 121 r the next product by a twiddle < r allows.
+        ntt_lds_put(lds, i0, add(y0, y2));
+        ntt_lds_put(lds, i2, sub4r(y0, y2));
+    } else {
+        const Fr29 t2 = mul(y2, ntt_lds_get(a.W, pos << shw));
+        ntt_lds_put(lds, i0, add(y0, t2));
+        ntt_lds_put(lds, i2, sub2r(y0, t2));
+    }
     ntt_lds_put(lds, i1, add(y1, t3));
     ntt_lds_put(lds, i3, sub2r(y1, t3));
 }

@@ -73,7 +73,7 @@ LSA_HD void tm_setup_g1(bool valid, const Jac<Fq> *P, bool neg, Fq2S *pxy) {
 }
 
 enum G2PVar {                                  // Fq2S slots of one point
-    GP_X, GP_Y, GP_Z, GP_S,                    // R = (X, Y, Z) < 2p, S = Y + Z < 4p
+    GP_X, GP_Y, GP_Z, GP_S,                    // R = (X, Y, Z): X, Z < 2p, Y < 4p (round 6; GP_S: unused since H = 2 Y Z)
     GP_QX, GP_QY, GP_Q1X, GP_Q1Y, GP_Q2X, GP_Q2Y, GP_TWB, GP_ONE,
     GP_A, GP_B, GP_D, GP_H, GP_E, GP_G, GP_BMF, GP_XIT,           // doubling step
     GP_DD, GP_EE, GP_F, GP_GG, GP_HH, GP_I, GP_J, GP_IMJ,         // addition step
@@ -136,90 +136,103 @@ struct G2Pre {
     Fq2S *mem;          // NG * GP_STRIDE elements
     // the <= 5 products of a round as packed slot lists (byte k = operand of product k): a lane picks its operand with
     // a shift -- an int8 array indexed by the lane lives in scratch, two dependent scratch loads per round
-    struct Prod { uint64_t a, b; int n; };
+    // kb: byte k = a bound K_k (in units of p) of product k's b-operand -- its c1 is negated as K_k p - b1.  Round 6: bounds are
+    // kept PER PRODUCT (2 * bound(a) * K_k < 169 for each, listed beside the table) instead of one "a < 4p, b < 20p" for all of
+    // them, which is what forced a conditional subtraction onto most of the values a step formula produces.
+    struct Prod { uint64_t a, b, kb; int n; };
     static constexpr uint64_t pack5(int v0, int v1 = 0, int v2 = 0, int v3 = 0, int v4 = 0, int v5 = 0) {
         return (uint64_t)v0 | (uint64_t)v1 << 8 | (uint64_t)v2 << 16 | (uint64_t)v3 << 24 | (uint64_t)v4 << 32 | (uint64_t)v5 << 40;
     }
 
     // ops 0-2: the rounds of a doubling step, 3-6: of an addition step with the point at slots (x2, x2 + 1).
     // scaled (the fused kernel): the round after the one that fixes ell_VW and ell_VV also multiplies them by (py, px) on
-    // lanes that are free there, so that the consumer gets its line ready to use
+    // lanes that are free there, so that the consumer gets its line ready to use.
+    // Bounds (units of p; a x b -> 2 a K):  X, Z, every product < 2;  Y < 4;  (px, 0), (py, 0), the point's coordinates < 2.
+    //   0: X Y  2x4=16   Y Y  4x4=32   Z Z  2x2   Y Z  4x2=16   X X  2x2
+    //   1: b' D  1x6=12   B H  2x4=16   ell_VW py  4x2=16   ell_VV px  6x2=24
+    //   2: E E  2x2   A (B-F)  1.5x8=24   G G  4.5x5=45   1 * xi(E-B)  1x40=80
+    //   3: x2 Z, y2 Z  2x2
+    //   4: D D  4x4=32   E E  6x6=72   E x2  6x2=24   D y2  4x2=16   ell_VW py  4x2   ell_VV px  6x2
+    //   5: D F  4x2   X F  2x2   Z G  2x2   1 * xi(E x2 - D y2)  1x40=80
+    //   6: D J  4x8=64   E (I-J)  6x10=120   H Y  2x4=16   Z H  2x2
     static LSA_HD Prod products_of(int op, int x2, bool scaled) {
         const int X2 = x2, Y2 = x2 + 1;
         switch (op) {
-        case 0: return {pack5(GP_X, GP_Y, GP_Z, GP_S, GP_X), pack5(GP_Y, GP_Y, GP_Z, GP_S, GP_X), 5};
-        case 1: return {pack5(GP_TWB, GP_B, GP_L1, GP_L2), pack5(GP_D, GP_H, GP_PY, GP_PX), scaled ? 4 : 2};
-        case 2: return {pack5(GP_E, GP_A, GP_G, GP_ONE), pack5(GP_E, GP_BMF, GP_G, GP_XIT), 4};
-        case 3: return {pack5(X2, Y2), pack5(GP_Z, GP_Z), 2};
-        case 4: return {pack5(GP_DD, GP_EE, GP_EE, GP_DD, GP_L1, GP_L2), pack5(GP_DD, GP_EE, X2, Y2, GP_PY, GP_PX), scaled ? 6 : 4};
-        case 5: return {pack5(GP_DD, GP_X, GP_Z, GP_ONE), pack5(GP_F, GP_F, GP_GG, GP_XIT), 4};
-        default: return {pack5(GP_DD, GP_EE, GP_HH, GP_Z), pack5(GP_J, GP_IMJ, GP_Y, GP_HH), 4};
+        case 0: return {pack5(GP_X, GP_Y, GP_Z, GP_Y, GP_X), pack5(GP_Y, GP_Y, GP_Z, GP_Z, GP_X), pack5(4, 4, 2, 2, 2), 5};
+        case 1: return {pack5(GP_TWB, GP_B, GP_L1, GP_L2), pack5(GP_D, GP_H, GP_PY, GP_PX), pack5(6, 4, 2, 2), scaled ? 4 : 2};
+        case 2: return {pack5(GP_E, GP_A, GP_G, GP_ONE), pack5(GP_E, GP_BMF, GP_G, GP_XIT), pack5(2, 8, 5, 40), 4};
+        case 3: return {pack5(X2, Y2), pack5(GP_Z, GP_Z), pack5(2, 2), 2};
+        case 4: return {pack5(GP_DD, GP_EE, GP_EE, GP_DD, GP_L1, GP_L2), pack5(GP_DD, GP_EE, X2, Y2, GP_PY, GP_PX), pack5(4, 6, 2, 2, 2, 2), scaled ? 6 : 4};
+        case 5: return {pack5(GP_DD, GP_X, GP_Z, GP_ONE), pack5(GP_F, GP_F, GP_GG, GP_XIT), pack5(2, 2, 2, 40), 4};
+        default: return {pack5(GP_DD, GP_EE, GP_HH, GP_Z), pack5(GP_J, GP_IMJ, GP_Y, GP_HH), pack5(8, 10, 4, 2), 4};
         }
     }
     // component c of slot v
     static LSA_HD F29 ld(const Fq2S *V, int v, unsigned c) { return w12_load(&w12_comp(const_cast<Fq2S &>(V[v]), c)).v; }
     static LSA_HD void st(Fq2S *V, int v, unsigned c, const F29 &val) { w12_store(&w12_comp(V[v], c), Fs{val}); }
     static LSA_HD F29 triple(const F29 &a) { return add_lazy(add_lazy(a, a), a).norm(); }
-    // component c of xi * t for t = (t_c, t_o) < 2p tight: c = 0: 9 t0 - t1 + 2p, c = 1: 9 t1 + t0   [< 20; tight]
+    // component c of xi * t for t = (t_c, t_o) < 4p tight: c = 0: 9 t0 - t1 + 4p, c = 1: 9 t1 + t0   [< 40; tight]
     static LSA_HD F29 xi_comp(unsigned c, const F29 &tc, const F29 &to) {
         F29 t8;
 #pragma unroll
         for (int l = 0; l < 9; l++) t8.l[l] = tc.l[l] << 3;
         const uint32_t pm = w12_mask(0u - c);
-        const F29 neg = sub_k<2>(F29::zero(), to);
+        const F29 neg = sub_k<4>(F29::zero(), to);
         F29 sel;
 #pragma unroll
         for (int l = 0; l < 9; l++) sel.l[l] = (to.l[l] & pm) | (neg.l[l] & ~pm);
         return w12_norm_u(add_lazy(add_lazy(w12_norm_u(t8), tc), sel));
     }
     // the additions after the products of round `op`, on component c (one lane each)
-    static LSA_HD void combine(int op, unsigned c, Fq2S *V) {
+    // tab: a table is being written -- its rows must be below 4p (256-bit packing, the table kernels' operand bound), which only
+    // ell_VV of a doubling step is not by itself
+    static LSA_HD void combine(int op, unsigned c, Fq2S *V, bool tab) {
         const unsigned o = c ^ 1u;
         switch (op) {
         case 0: {
-            const F29 B = ld(V, GP_P1, c), C = ld(V, GP_P2, c);
-            const F29 H = sub_k<4>(ld(V, GP_P3, c), add_lazy(B, C));               // (Y+Z)^2 - (B+C) + 4p   [<6]
+            const F29 B = ld(V, GP_P1, c), C = ld(V, GP_P2, c), YZ = ld(V, GP_P3, c);
+            const F29 H = add_lazy(YZ, YZ).norm();                                  // (Y+Z)^2 - (B+C) = 2 Y Z       [<4]
             st(V, GP_A, c, f29_halve(ld(V, GP_P0, c)));                             // X Y / 2                [<1.5]
             st(V, GP_B, c, B);
             st(V, GP_D, c, triple(C));                                              // 3C                     [<6]
             st(V, GP_H, c, H);
-            st(V, GP_L1, c, condsub4(sub_k<6>(F29::zero(), H)));                    // ell_VW = -H   [<=6] -> [<4]
-            st(V, GP_L2, c, condsub4(triple(ld(V, GP_P4, c))));                     // ell_VV = 3 X^2  [<6] -> [<4]
+            st(V, GP_L1, c, sub_k<4>(F29::zero(), H));                              // ell_VW = -H            [<=4]
+            const F29 L2 = triple(ld(V, GP_P4, c));                                 // ell_VV = 3 X^2         [<6]
+            st(V, GP_L2, c, tab ? condsub4(L2) : L2);
         } break;
         case 1: {
             const F29 E = ld(V, GP_P0, c), B = ld(V, GP_B, c);
             const F29 F = triple(E);                                                // 3E                     [<6]
             st(V, GP_E, c, E);
-            st(V, GP_G, c, condsub4(f29_halve(add_lazy(B, F).norm())));             // (B+F)/2  [<4.5] -> [<4]
+            st(V, GP_G, c, f29_halve(add_lazy(B, F).norm()));                       // (B+F)/2                [<4.5]
             st(V, GP_BMF, c, sub_k<6>(B, F));                                       // B - F + 6p             [<8]
             st(V, GP_Z, c, ld(V, GP_P1, c));                                        // Z3 = B H               [<2]
-            const F29 tc = condsub2(sub_k<2>(E, B));                                // E - B  [<4] -> [<2]
-            const F29 to = condsub2(sub_k<2>(ld(V, GP_P0, o), ld(V, GP_B, o)));     // the other component of the same
-            st(V, GP_XIT, c, xi_comp(c, tc, to));                                   // xi (E - B)             [<20]
+            const F29 tc = sub_k<2>(E, B);                                          // E - B + 2p             [<4]
+            const F29 to = sub_k<2>(ld(V, GP_P0, o), ld(V, GP_B, o));               // the other component of the same
+            st(V, GP_XIT, c, xi_comp(c, tc, to));                                   // xi (E - B)             [<40]
             st(V, GP_S1, c, ld(V, GP_P2, c));                                       // (scaled mode: ell_VW * py, ell_VV * px; else unused)
             st(V, GP_S2, c, ld(V, GP_P3, c));
         } break;
         case 2: {
-            const F29 Y3 = condsub2(condsub4(sub_k<6>(ld(V, GP_P2, c), triple(ld(V, GP_P0, c)))));   // G^2 - 3E^2 + 6p [<8] -> [<2]
             st(V, GP_X, c, ld(V, GP_P1, c));
-            st(V, GP_Y, c, Y3);
-            st(V, GP_S, c, add_lazy(Y3, ld(V, GP_Z, c)).norm());                    // [<4]
+            st(V, GP_Y, c, condsub4(sub_k<6>(ld(V, GP_P2, c), triple(ld(V, GP_P0, c)))));   // G^2 - 3E^2 + 6p [<8] -> [<4]
             st(V, GP_L0, c, ld(V, GP_P3, c));                                       // ell_0 = xi (E - B), reduced  [<2]
         } break;
         case 3: {
-            const F29 E = sub_k<2>(ld(V, GP_Y, c), ld(V, GP_P1, c));                // Y1 - y2 Z1 + 2p        [<4]
+            const F29 E = sub_k<2>(ld(V, GP_Y, c), ld(V, GP_P1, c));                // Y1 - y2 Z1 + 2p        [<6]
             const F29 D = sub_k<2>(ld(V, GP_X, c), ld(V, GP_P0, c));                // X1 - x2 Z1 + 2p        [<4]
             st(V, GP_DD, c, D);
             st(V, GP_EE, c, E);
             st(V, GP_L1, c, D);                                                     // ell_VW = D             [<4]
-            st(V, GP_L2, c, sub_k<4>(F29::zero(), E));                              // ell_VV = -E            [<=4]
+            const F29 L2 = sub_k<6>(F29::zero(), E);                                // ell_VV = -E            [<=6]
+            st(V, GP_L2, c, tab ? condsub4(L2) : L2);
         } break;
         case 4: {
             st(V, GP_F, c, ld(V, GP_P0, c));
             st(V, GP_GG, c, ld(V, GP_P1, c));
-            const F29 tc = condsub2(sub_k<2>(ld(V, GP_P2, c), ld(V, GP_P3, c)));    // E x2 - D y2  [<4] -> [<2]
-            const F29 to = condsub2(sub_k<2>(ld(V, GP_P2, o), ld(V, GP_P3, o)));
-            st(V, GP_XIT, c, xi_comp(c, tc, to));
+            const F29 tc = sub_k<2>(ld(V, GP_P2, c), ld(V, GP_P3, c));              // E x2 - D y2 + 2p       [<4]
+            const F29 to = sub_k<2>(ld(V, GP_P2, o), ld(V, GP_P3, o));
+            st(V, GP_XIT, c, xi_comp(c, tc, to));                                   //                        [<40]
             st(V, GP_S1, c, ld(V, GP_P4, c));
             st(V, GP_S2, c, ld(V, GP_P5, c));
         } break;
@@ -232,12 +245,9 @@ struct G2Pre {
             st(V, GP_L0, c, ld(V, GP_P3, c));                                       // ell_0, reduced         [<2]
         } break;
         default: {
-            const F29 Y3 = condsub2(sub_k<2>(ld(V, GP_P1, c), ld(V, GP_P2, c)));    // [<4] -> [<2]
-            const F29 Z3 = ld(V, GP_P3, c);
             st(V, GP_X, c, ld(V, GP_P0, c));
-            st(V, GP_Y, c, Y3);
-            st(V, GP_Z, c, Z3);
-            st(V, GP_S, c, add_lazy(Y3, Z3).norm());                                // [<4]
+            st(V, GP_Y, c, sub_k<2>(ld(V, GP_P1, c), ld(V, GP_P2, c)));             // E (I - J) - H Y1 + 2p  [<4]
+            st(V, GP_Z, c, ld(V, GP_P3, c));
         } break;
         }
     }
@@ -247,18 +257,20 @@ struct G2Pre {
     LSA_HD void round(int op, int x2, uint32_t *const *out, int entry, Fq2S *const *rows = nullptr, bool scaled = false) {
         Fq2S *m = mem;
         const Prod pr = products_of(op, x2, scaled);
+        const bool tab = out != nullptr;
         x.par([=](unsigned lane) {
             const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
             if (g >= (unsigned)NG || (int)k >= pr.n) return;
             Fq2S *V = m + g * GP_STRIDE;
-            // a < 4p, b < 20p: 2 * 4 * 20 = 160 < 169
-            const Fs r = {w12_comp_mul<20>(part, w12_load(V + (unsigned)((pr.a >> (8 * k)) & 0xffu)), w12_load(V + (unsigned)((pr.b >> (8 * k)) & 0xffu)))};
+            // (bounds per product: products_of)
+            const Fs r = {w12_comp_mul_k(part, w12_load(V + (unsigned)((pr.a >> (8 * k)) & 0xffu)), w12_load(V + (unsigned)((pr.b >> (8 * k)) & 0xffu)),
+                                         (int)((pr.kb >> (8 * k)) & 0xffu))};
             w12_store(&w12_comp(V[GP_P0 + k], part), r);
         });
         x.par([=](unsigned lane) {
             const unsigned g = lane / 12, k = (lane % 12) >> 1, part = lane & 1;
             if (g >= (unsigned)NG || k) return;
-            combine(op, part, m + g * GP_STRIDE);
+            combine(op, part, m + g * GP_STRIDE, tab);
         });
         if (op == 2 || op == 5) {
             x.par([=](unsigned lane) {

@@ -147,6 +147,19 @@ LSA_HD F29 w12_comp_mul(unsigned part, const Fq2S &a, const Fq2S &b) {
     return dot2(a.c0.v, y0, a.c1.v, y1);
 }
 
+// the same with the bound of b's components, K p, chosen at run time (tmiller.h: G2Pre keeps bounds per product)
+LSA_HD F29 w12_comp_mul_k(unsigned part, const Fq2S &a, const Fq2S &b, int K) {
+    const uint32_t pm = w12_mask(0u - part);
+    const F29 nb1 = lin2(b.c1.v, -1, F29::zero(), 0, K);
+    F29 y0, y1;
+#pragma unroll
+    for (int l = 0; l < 9; l++) {
+        y0.l[l] = (b.c1.v.l[l] & pm) | (b.c0.v.l[l] & ~pm);
+        y1.l[l] = (b.c0.v.l[l] & pm) | (nb1.l[l] & ~pm);
+    }
+    return dot2(a.c0.v, y0, a.c1.v, y1);
+}
+
 // tower <-> polynomial basis: poly index k -> (which Fq6 half, which coefficient)
 LSA_HD Fq2S &w12_tower_ref(Fq12S &t, int k) {
     Fq6T<Fs> &h = (k & 1) ? t.c1 : t.c0;
