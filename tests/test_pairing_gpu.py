@@ -151,8 +151,8 @@ def test_every_miller_kernel_vs_oracle(kernel):
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:]
 
 
-@pytest.mark.parametrize("naf", ["1", "0"])
-def test_signed_digit_miller_loop_gives_the_same_gt(naf):
+@pytest.mark.parametrize("naf,lockstep", [("1", "0"), ("0", "0"), ("1", "1"), ("0", "1")])
+def test_signed_digit_miller_loop_gives_the_same_gt(naf, lockstep):
     """Jobs whose values only leave through a final exponentiation run the fused kernel over the SIGNED digits of 6u + 2
     (88 table entries instead of 102: csrc/miller.h ate_naf_digit; LSA_MILLER_NAF=0 keeps libff's binary loop).  The
     Miller values differ from libff's by vertical lines, which the final exponent kills: every GT value -- one product, a
@@ -182,7 +182,7 @@ def test_signed_digit_miller_loop_gives_the_same_gt(naf):
         "assert np.array_equal(lsa.pairing_product(ps, qs2), o.pairing_product(ps, qs2))\n"
         "print('OK')\n"
     ) % (root, os.path.join(root, "tests"))
-    env = dict(os.environ, LSA_MILLER_KERNEL="6", LSA_MILLER_NAF=naf)
+    env = dict(os.environ, LSA_MILLER_KERNEL="6", LSA_MILLER_NAF=naf, LSA_FUSED_LOCKSTEP=lockstep)
     r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:]
 
