@@ -333,7 +333,14 @@ int lsa_fq12_product(const void *in_fq12, size_t n, void *out_fq12);
 int lsa_final_exponentiation(const void *in_fq12, size_t n, void *out_fq12, int on_device);
 /* out = final_exponentiation(prod_i miller_loop(P_i, Q_i)) (one GT element, HOST).  n = 1 is
  * reduced_pairing (src/gadgets/subspace.cc:88-102,123-124); the batched form is the CPhad /
- * CPsc verifier shape (BASELINE.json configs[4]).  Host pointers. */
+ * CPsc verifier shape (BASELINE.json configs[4]).  Host pointers.
+ * Wherever a final exponentiation follows inside the library (this call, lsa_pairing_terms / _segments / _sharded with
+ * final_exp) the Miller loops of pairs without a resident line table may walk the SIGNED digits of 6u + 2 (65 doubling and
+ * 21 addition steps instead of 64 and 36): their Miller values differ from libff's by vertical lines, which the final
+ * exponent kills, so every GT value returned is libff's bit for bit -- for every input: workgroups that hold a point at
+ * infinity in G2 or a pair off its curve (where libff's loop is still defined, as the value of its formulas, and the identity
+ * is not) keep libff's binary loop.  Raw Miller values (lsa_miller_loop*, final_exp == 0) always come from the binary loop.
+ * Env LSA_MILLER_NAF=0 switches the signed-digit loop off. */
 int lsa_pairing_product(const void *g1_jac, const void *g2_jac, size_t n, void *out_gt);
 
 /* ---- G2 precomputation (libff G2_precomp) ------------------------------------------------- */

@@ -210,15 +210,39 @@ __global__ __launch_bounds__(128) void k_miller_fused(const Jac<Fq> *__restrict_
     // naf: the signed-digit loop (88 entries instead of 102; miller.h: ate_naf_digit) -- values equal to libff's up to factors the
     // final exponentiation kills; never together with table output (the tables are libff's, row for row).  The identity is the
     // group law's: a workgroup that holds a G2 point at infinity -- libff feeds its step formulas the non-point (0, 1) then, and
-    // what comes out is defined by those formulas alone -- keeps libff's binary loop.
+    // what comes out is defined by those formulas alone -- keeps libff's binary loop ...
+    // ... and the identity holds for points ON the curves only (modulo the curve equations the two loops' functions agree up to
+    // vertical lines; off the curves they are different polynomials).  libff's Miller loop is defined for any coordinates -- it
+    // just evaluates its formulas -- so a workgroup that holds a pair with P off E or Q off the twist keeps the binary loop too:
+    // the values this library returns are then libff's for EVERY input, valid or not.  One lane per pair tests
+    // Y^2 = X^3 + b Z^6 in Jacobian coordinates (a dozen products, once per workgroup).
     __shared__ int s_naf;
+    __shared__ int s_off_curve;
     if (tid == 0) {
-        int ok = naf;
-        for (unsigned c = 0; c < count; c++) if (g2[lo + c].Z.is_zero()) ok = 0;
-        s_naf = ok;
+        s_off_curve = 0;
         s_produced = 0;
         s_consumed = 0;
     }
+    __syncthreads();
+    if (naf && tid < count) {
+        const Jac<Fq2> &Q = g2[lo + tid];
+        const Jac<Fq> &P = g1[lo + tid];
+        bool bad = Q.Z.is_zero();
+        if (!bad) {
+            const P2 X = load2(Q.X), Y = load2(Q.Y), Z = load2(Q.Z);
+            const P2 z2 = Z.sqr(), z6 = z2.sqr() * z2;
+            bad = !(Y.sqr() == X.sqr() * X + fq2_constT<PB>(LSA_TWIST_B) * z6);
+        }
+        if (!bad && !P.Z.is_zero()) {                      // (P at infinity: both loops give an element of Fq4, which the final exponent kills)
+            const PB x = PB::from_mont256(P.X), y = PB::from_mont256(P.Y), z = PB::from_mont256(P.Z);
+            const PB z2 = z.sqr(), z6 = z2.sqr() * z2;
+            const PB three = PB::one() + PB::one() + PB::one();
+            bad = !(y.sqr() == x.sqr() * x + three * z6);
+        }
+        if (bad) atomicOr(&s_off_curve, 1);
+    }
+    __syncthreads();
+    if (tid == 0) s_naf = naf && !s_off_curve;
     __syncthreads();
     const int use_naf = s_naf;
     const int entries = use_naf ? NAF_NUM_ENTRIES : ATE_NUM_COEFFS;

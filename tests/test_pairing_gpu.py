@@ -180,6 +180,10 @@ def test_signed_digit_miller_loop_gives_the_same_gt(naf, lockstep):
         "    assert np.array_equal(got[j], o.pairing_product(ps[lo:hi], qs[lo:hi]) if hi > lo else o.fq12_one()), j\n"
         "qs2 = qs.copy(); qs2[17] = 0\n"
         "assert np.array_equal(lsa.pairing_product(ps, qs2), o.pairing_product(ps, qs2))\n"
+        "ps3 = ps.copy(); ps3[5, 4:8] = o.fq_mont(12345)\n"          # P off the curve: libff's formulas still define a value
+        "assert np.array_equal(lsa.pairing_product(ps3, qs), o.pairing_product(ps3, qs))\n"
+        "qs3 = qs.copy(); qs3[9, 8:12] = o.fq_mont(777)\n"           # Q off the twist
+        "assert np.array_equal(lsa.pairing_product(ps, qs3), o.pairing_product(ps, qs3))\n"
         "print('OK')\n"
     ) % (root, os.path.join(root, "tests"))
     env = dict(os.environ, LSA_MILLER_KERNEL="6", LSA_MILLER_NAF=naf, LSA_FUSED_LOCKSTEP=lockstep)
