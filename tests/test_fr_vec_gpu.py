@@ -145,6 +145,14 @@ def test_eq_table_both_variants(lsa, d):
         assert [fr_int(x) for x in eq1] == want
 
 
+def test_eq_table_rejects_bad_arguments(lsa):
+    r, _ = o.random_scalars(3, seed=1)
+    with pytest.raises(lsa.LsaError):
+        lsa.fr_eq_table(r, 2)                      # variants are 0 (the reference's loop) and 1 (the eq monomials)
+    with pytest.raises(lsa.LsaError):
+        lsa.fr_eq_table(r[:0], 0)                  # the reference's loop writes dst[1]: d >= 1
+
+
 def test_sumcheck_prover_inner_loop_on_device(lsa):
     """The per-round device work of CPSumcheck::prove at d = 8 (two MLE tables + the beta suffix
     table, all resident): round polynomial, then pushRandomness on every table and the suffix
