@@ -726,18 +726,14 @@ public:
     }
     // G2 is a proper subgroup of the twist's points (cofactor 2p - r), and psi / the cube root of unity act as scalars on it
     // ONLY: the Galbraith-Scott and GLV ladders return [k]P for P in G2, something else outside.  libff's double-and-add is
-    // right for any point, and its operator>> checks neither the curve's subgroup nor -- with compression -- more than
-    // solvability of y^2 = x^3 + b'.  Every point the shim hands out itself lies in G2; a point that ARRIVES as bytes is
-    // tested once ([r]P = O, one window ladder), and the first one found outside G2 switches every later host product on a
-    // G2 base to the window ladder for the rest of the process (a value cannot carry a tag: the 192-byte layout is libff's).
-    static std::atomic<bool> &outside_subgroup_seen() { static std::atomic<bool> f{false}; return f; }
+    // right for any point, and its operator>> checks neither the subgroup nor -- with compression -- more than solvability of
+    // y^2 = x^3 + b'.  Every point the shim hands out itself lies in G2; a value cannot carry a tag (the 192-byte layout is
+    // libff's), and testing every point that arrives as bytes would cost a key file of 2^20 points minutes.  So: once a
+    // process has READ a G2 point, its host products on G2 bases other than the generator take the window ladder (275 us
+    // instead of 76) for the rest of its life -- none of the reference's programs reads one; a verifier that does is correct.
+    static std::atomic<bool> &external_point_seen() { static std::atomic<bool> f{false}; return f; }
     static void note_external_point(const G_shim &p) {
-        if constexpr (GROUP == 2) {
-            if (p.is_zero() || outside_subgroup_seen().load(std::memory_order_relaxed)) return;
-            uint64_t r[4];
-            for (int i = 0; i < 4; i++) r[i] = (uint64_t)lsa::FrParams::MOD[2 * i] | ((uint64_t)lsa::FrParams::MOD[2 * i + 1] << 32);
-            if (!window_ladder(p.jac(), r, 253).Z.is_zero()) outside_subgroup_seen().store(true, std::memory_order_relaxed);
-        }
+        if constexpr (GROUP == 2) { if (!p.is_zero()) external_point_seen().store(true, std::memory_order_relaxed); }
     }
     friend G_shim operator*(const alt_bn128_Fr &k, const G_shim &p) {
         lsa_shim::StatScope scope(lsa_shim::ST_SCALAR_MUL_HOST, 1);
@@ -787,7 +783,7 @@ public:
             // (Both use endomorphisms that act as scalars on the prime-order subgroup G2 only -- where every point libff
             // hands out lies; a point of the twist outside G2 must go through LSA_SHIM_GLV=0.)
             static const bool gls_on = !(getenv("LSA_SHIM_GLS4") && getenv("LSA_SHIM_GLS4")[0] == '0');
-            if (outside_subgroup_seen().load(std::memory_order_relaxed)) return G_shim(window_ladder(base, e.data, top));   // (see note_external_point)
+            if (external_point_seen().load(std::memory_order_relaxed)) return G_shim(window_ladder(base, e.data, top));   // (see note_external_point)
             if (glv_on && gls_on) return G_shim(lsa::gls4_mul_host(base, e.data));
         }
         if (glv_on) return G_shim(lsa::glv_mul_host(base, e.data));
