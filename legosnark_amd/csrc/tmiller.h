@@ -500,18 +500,26 @@ struct TabMiller {
                 const Fs r = {dotn<6>(xa, yb)};
                 if (dst) w12_store(dst, r);
             } else {
-                // four (three, one) products reduced one by one, summed with their weights (6 in all) and
-                // brought back under 2p by a Montgomery product with 1
-                F29 sum = F29::zero();
-#pragma unroll 1
-                for (int j = 0; j < 4; j++) {
-                    const TMTerm t = term(mode, lane, j, M, u, scale);
-                    const F29 x1 = g12_comp_mul<2>(part, w12_load(m + t.a), w12_load(m + t.b));
-                    const uint32_t w2 = w12_mask(t.w2);
+                // four (three, one) products in TWO fused reductions of two each, an off-diagonal pair's a-operand doubled: as
+                // TabMillerP::round below (round 6: 8 products' multiply-adds + 2 reductions instead of 9 + 5; a group's sum may
+                // reach 320 p^2 -- result < 2.9p --, both groups < 4.9p, two conditional subtractions restore < 2p)
+                F29 grp[2];
 #pragma unroll
-                    for (int l = 0; l < 9; l++) sum.l[l] += x1.l[l] + (x1.l[l] & w2);
+                for (int g = 0; g < 2; g++) {
+                    F29 xa[4], yb[4];
+#pragma unroll
+                    for (int jj = 0; jj < 2; jj++) {
+                        const TMTerm t = term(mode, lane, 2 * g + jj, M, u, scale);
+                        tm_comp_operands<2>(part, w12_load(m + t.a), w12_load(m + t.b), xa[2 * jj], yb[2 * jj], xa[2 * jj + 1], yb[2 * jj + 1]);
+                        const uint32_t w2 = w12_mask(t.w2);
+#pragma unroll
+                        for (int l = 0; l < 9; l++) { xa[2 * jj].l[l] += xa[2 * jj].l[l] & w2; xa[2 * jj + 1].l[l] += xa[2 * jj + 1].l[l] & w2; }
+                        xa[2 * jj] = w12_norm_u(xa[2 * jj]);
+                        xa[2 * jj + 1] = w12_norm_u(xa[2 * jj + 1]);
+                    }
+                    grp[g] = dotn<4>(xa, yb);
                 }
-                const Fs r = {mul(w12_norm_u(sum), F29::one())};
+                const Fs r = {condsub2(condsub4(w12_norm_u(add_lazy(grp[0], grp[1]))))};
                 if (dst) w12_store(dst, r);
             }
             if (load >= 0) {

@@ -213,10 +213,10 @@ def test_a_failed_call_leaves_no_half_built_table_behind(lsa):
         lsa.g2_table_cache(4096)
 
 
-@pytest.mark.parametrize("switch", ["LSA_MILLER_ROWS=0", "LSA_MILLER_SPLIT=1"])
+@pytest.mark.parametrize("switch", ["LSA_MILLER_ROWS=0", "LSA_MILLER_SPLIT=1", "LSA_MILLER_TAB=4"])
 def test_the_older_kernels_behind_their_switches_give_the_same_bytes(lsa, switch):
-    """k_miller_wtab (two-phase rounds), the row-engine Miller loop on ONE workgroup instead of eight, and the
-    two-wavefront final exponentiation stay in the library behind A/B
+    """k_miller_wtab (two-phase rounds), the row-engine Miller loop on ONE workgroup instead of eight, k_miller_tab (four
+    accumulators per wavefront: what table-resident batches of more than 2048 accumulators take) stay in the library behind A/B
     switches that are read once per process: a child process under the switch must return the bytes this process does
     (a two-term check with a conjugated term, and the Miller values alone)."""
     import subprocess
