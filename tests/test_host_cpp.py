@@ -20,6 +20,19 @@ def test_host_cpp(name, tmp_path):
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("name", ["test_fp29", "test_fp29x2", "test_tmiller", "test_w12", "test_ntt_core"])
+def test_host_cpp_with_the_column_wise_products(name, tmp_path):
+    """-DLSA_FP29_COLS / -DLSA_F29_COLS / -DLSA_FR29_COLS select the column-wise forms of the 29-bit-limb products (17
+    independent column accumulators instead of one serial multiply-add chain: fs29.h f29_dot_cols, fp29.h redc_cols,
+    fr29.h mul).  Round 6 measured them equal to the serial forms on the GPU and left them behind these switches; they must
+    stay the same functions: every host test of the field, tower, Miller and NTT code passes with them too."""
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cc")
+    exe = str(tmp_path / (name + "_cols"))
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-DLSA_FP29_COLS", "-DLSA_F29_COLS", "-DLSA_FR29_COLS", "-I", os.path.join(ROOT, "legosnark_amd", "csrc"), src, "-o", exe])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-2000:]
+
+
 @pytest.mark.parametrize("name", ["test_fp29", "test_glv", "test_tower29"])
 def test_host_cpp_with_the_32_bit_limb_product(name, tmp_path):
     """On the host Fp's Montgomery product runs on four 64-bit limbs; the device compiles the
