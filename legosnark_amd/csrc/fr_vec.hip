@@ -354,6 +354,9 @@ __global__ __launch_bounds__(256) void k_fold_halves(const Fr *old, size_t half,
 // the linear factor.  Fr values are canonical, so the coefficients equal the reference's
 // whatever the summation order.  Streams 32*(2m+1) bytes per p.
 // ------------------------------------------------------------------------------------
+#ifndef LSA_SC_TOUCH_AHEAD
+#define LSA_SC_TOUCH_AHEAD false
+#endif
 static constexpr int SC_MAX_M = 4;
 struct ScTables { const Fr *t[SC_MAX_M]; };
 // x / 2 mod r on a canonical representative (the fixed factor 2^256 of libff's words commutes with the halving)
@@ -388,7 +391,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const Fr29 one = Fr29::one();
     unsigned since = 0, wide_n = 0;
     Fr29Wide w0 = fr29_wide_zero(), w2 = fr29_wide_zero(), wm = fr29_wide_zero(), wn = fr29_wide_zero();      // (M == 2, 3 only)
+    const bool touch_ahead = LSA_SC_TOUCH_AHEAD;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < half; p += (size_t)gridDim.x * blockDim.x) {
+        // (an experiment of round 6, off: one dword of every line the NEXT index will read is loaded now and only waited for at
+        // the end of this iteration -- the kernel holds two wavefronts per SIMD, too few to hide HBM's latency behind the other)
+        uint32_t touched = 0;
+        if (touch_ahead) {
+            const size_t pn = p + (size_t)gridDim.x * blockDim.x;
+            if (pn < half) {
+                if (suff) touched ^= *reinterpret_cast<const volatile uint32_t *>(&suff[pn]);
+#pragma unroll
+                for (int t = 0; t < M; t++) {
+                    touched ^= *reinterpret_cast<const volatile uint32_t *>(&tabs.t[t][pn]);
+                    touched ^= *reinterpret_cast<const volatile uint32_t *>(&tabs.t[t][pn + half]);
+                }
+            }
+        }
+        struct TouchGuard { uint32_t &v; __device__ ~TouchGuard() { asm volatile("" ::"v"(v)); } } touch_guard{touched};
         Fr29 q[M + 1];
         q[0] = suff ? Fr29::from_words(suff[p]) : one;
         if constexpr (M == 2) {

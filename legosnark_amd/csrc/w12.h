@@ -303,13 +303,58 @@ __device__ __forceinline__ F29 w12_redc18(const W12Limbs18 &t, const W12Limbs18 
 __device__ __forceinline__ void w12_pin(F29 &v) {
     asm volatile("" : "+v"(v.l[0]), "+v"(v.l[1]), "+v"(v.l[2]), "+v"(v.l[3]), "+v"(v.l[4]), "+v"(v.l[5]), "+v"(v.l[6]), "+v"(v.l[7]), "+v"(v.l[8]));
 }
-enum { W12_MUL = 0, W12_FROB = 1, W12_LINE = 2 };
-template <int MODE>
-__device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, const uint32_t *frob) {
+enum { W12_MUL = 0, W12_FROB = 1, W12_LINE = 2, W12_SCALE = 3 };
+// ------------------------------------------------------------------------------------------------------------------
+// A FOURTH wavefront beside the chain (HLP; round 6, second session).  The lone final exponentiation inverted one Fq value on
+// its critical path -- the binary GCD of inv29.h, ~20 000 instructions on every lane, 75 us of a 0.39-ms kernel whose other
+// ~265 chain links are one row product each.  tools/gen_fe_scalar_exponent.py: leave the division by n1 (the norm of f f^(q^6)
+// down to Fq) out and the chain ends in FE(f) * n1^(2K) for a constant K -- n1 lies in Fq, Frobenius maps and conjugations fix
+// it -- so the correction n1^e, e = -2K mod (q - 1), is ONE exponentiation in Fq by a fixed 254-bit exponent that does not
+// depend on the chain.  Rows 12 and 13 of a 256-lane workgroup (a wavefront of their own, on the CU's fourth SIMD) run it
+// right to left in the same instruction stream as the chain's rows: per chain link row 12 squares the running power
+// n1^(2^i), row 13 multiplies the accumulator by it where bit i of e is set; 254 of the 264 links that follow the norm, then
+// one link (W12_SCALE) multiplies the twelve components by the accumulator.  Same field element as libff's, so the same
+// bytes (tests: every final exponentiation of the GPU suite goes through it).  LSA_FE_HELPER=0: the 192-lane kernel.
+// State, in the 36 partial-product slots the row engine does not use (LDS words at H):
+//   0..8 the running power, 9..17 the accumulator, 18..26 zero, 27 the state -- 4 * (links done) + 2 * (row 13 multiplies by the
+//   power in THIS link) + (row 12 squares it; zero: both multiply by one) --, 28..35 the exponent's words.
+// ------------------------------------------------------------------------------------------------------------------
+// generated by tools/gen_fe_scalar_exponent.py: e = -2 K mod (q - 1), 254 bits
+static constexpr uint32_t W12_FE_SCALAR_EXP[8] = {0x8d10a36eu, 0xfa9264cdu, 0xc9df5cd9u, 0x2f1120f5u, 0x4317591cu, 0x4bdc2634u, 0xe131a027u, 0x30644e72u};
+static constexpr int W12_FE_SCALAR_EXP_BITS = 254;
+enum { W12_H_PW = 0, W12_H_ACC = 9, W12_H_ZERO = 18, W12_H_STATE = 27, W12_H_EXP = 28 };
+static constexpr uint32_t W12_H_IDLE = 0xffffu << 2;
+template <int MODE, bool HLP = false>
+__device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, const uint32_t *frob, Fq2S *H = nullptr) {
     const unsigned lane = threadIdx.x, row = lane >> 4, r = lane & 15;
     const unsigned k = row >> 1, part = row & 1, i = r >> 1, h = r & 1;
     F29 L, Rv;
-    if (MODE == W12_FROB) {
+    Fs *dst = &w12_comp(D[k < 6 ? k : 0], part);
+    bool store = r == 0;
+    uint32_t hst = 0;
+    if (HLP && row >= 12) {                            // (the whole fourth wavefront)
+        // one LDS round trip in front of the barrier, as the chain's rows have: the state word, the power (every lane: row 12's
+        // second factor, row 13's when the bit is set) and lane 0's first factor by ADDRESS (row 12: the power, rows 13..15: the
+        // accumulator, lanes 1..15 of a row: the zero kept beside them)
+        w12_lds_u32 *hw = w12_lds(H);
+        hst = hw[W12_H_STATE];
+        const Fs *hs = reinterpret_cast<const Fs *>(H);
+        const Fs pw = w12_load(hs);
+        L = w12_load(hs + (r != 0 ? 2 : (row == 12 ? 0 : 1))).v;
+        const F29 one = F29::one();
+        const uint32_t act = w12_mask(0u - (hst & 1u)), sel = w12_mask(0u - ((hst >> 1) & 1u)), sq = w12_mask(0u - (uint32_t)(row == 12));
+        const uint32_t m = (act & sq) | (sel & ~sq);
+#pragma unroll
+        for (int q = 0; q < 9; q++) Rv.l[q] = (pw.v.l[q] & m) | (one.l[q] & ~m);
+        dst = const_cast<Fs *>(hs) + (row == 12 ? 0 : 1);
+        store = r == 0 && row <= 13;
+    } else if (MODE == W12_SCALE) {                    // D_k <- A_k * (the helper's accumulator): lane 0 of a row, the others add nothing
+        const uint32_t lm = w12_mask(0u - (uint32_t)(r == 0));
+        L = w12_load(&w12_comp(A[k], part)).v;
+        const Fs acc = w12_load(reinterpret_cast<const Fs *>(H) + 1);
+#pragma unroll
+        for (int q = 0; q < 9; q++) Rv.l[q] = acc.v.l[q] & lm;
+    } else if (MODE == W12_FROB) {
         static constexpr uint32_t ZERO9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         L = w12_load(&w12_comp(A[k], h)).v;
         const uint32_t *c = r < 2 ? frob + ((k * 2 + part) * 2 + h) * 9 : ZERO9;      // lanes 2..15 of a row add nothing
@@ -343,7 +388,14 @@ __device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, 
     W12_DPP18_MOV(u, t, "row_mirror row_mask:0xf bank_mask:0xf");           // the other half of the row: added inside the reduction
     Fs res = {condsub2(w12_redc18(t, u))};
     w12_pin(res.v);                                    // (dense: see w12_pin)
-    if (r == 0) w12_store(&w12_comp(D[k], part), res);
+    if (store) w12_store(dst, res);
+    if (HLP && row >= 12) {                            // the state of the next link: links done, this link's two bits
+        w12_lds_u32 *hw = w12_lds(H);
+        const uint32_t act = hst & 1u, c2 = (hst >> 2) + act;
+        const uint32_t word = hw[W12_H_EXP + ((c2 >> 5) & 7u)];
+        const uint32_t a2 = act & (uint32_t)(c2 < (uint32_t)W12_FE_SCALAR_EXP_BITS);
+        if (lane == 192) hw[W12_H_STATE] = (c2 << 2) | ((a2 & (word >> (c2 & 31u))) << 1) | a2;
+    }
     __syncthreads();
 }
 // LEAF functions (no calls inside, so no return address to park in a spilled VGPR: a product that calls a product
@@ -355,7 +407,9 @@ __device__ __noinline__ void w12_frob_rows(Fq2S *D, const Fq2S *A, const uint32_
 // number, no calls in the 62 trips.  A free function of the register file's base R (slot s = R + 6 s), NOT a member:
 // a member that is not inlined takes `this`, the W12 object then lives in scratch memory, and every slot address in the
 // caller and here becomes a load from it -- a round trip to L2 in front of each chain link.
-__device__ __noinline__ void w12_exp_by_neg_z_rows(Fq2S *R, int d, int a, int tmp) {
+template <bool HLP>
+__device__ __forceinline__ void w12_exp_by_neg_z_rows_t(Fq2S *R, int d, int a, int tmp) {
+    Fq2S *const H = R + 6 * W12_SLOTS;                  // (the helper's state, HLP only)
     constexpr uint64_t D_P1 = 0x4800120040011001ull, D_P3 = 0x0000804004000000ull, D_M1 = 0x0000000000000010ull, D_M3 = 0x0108000400880200ull;
     const unsigned lane = threadIdx.x;
     auto slot = [R](int s) { return R + 6 * s; };
@@ -365,21 +419,103 @@ __device__ __noinline__ void w12_exp_by_neg_z_rows(Fq2S *R, int d, int a, int tm
     };
     int acc = tmp, alt = tmp + 3;
     const int a3 = tmp + 1, na = tmp + 2, na3 = tmp + 4, sq = tmp + 5;
-    w12_rows<W12_MUL>(slot(sq), slot(a), slot(a), nullptr);
-    w12_rows<W12_MUL>(slot(a3), slot(sq), slot(a), nullptr);        // a^3
+    w12_rows<W12_MUL, HLP>(slot(sq), slot(a), slot(a), nullptr, H);
+    w12_rows<W12_MUL, HLP>(slot(a3), slot(sq), slot(a), nullptr, H);        // a^3
     conj(na, a);
     conj(na3, a3);
 #pragma unroll 1
     for (int i = 61; i >= 0; --i) {
-        w12_rows<W12_MUL>(slot(alt), slot(i == 61 ? a : acc), slot(i == 61 ? a : acc), nullptr);
+        w12_rows<W12_MUL, HLP>(slot(alt), slot(i == 61 ? a : acc), slot(i == 61 ? a : acc), nullptr, H);
         const unsigned p1 = (unsigned)(D_P1 >> i) & 1u, p3 = (unsigned)(D_P3 >> i) & 1u, m1 = (unsigned)(D_M1 >> i) & 1u, m3 = (unsigned)(D_M3 >> i) & 1u;
         if (p1 | p3 | m1 | m3) {
             const int f = p1 ? a : (p3 ? a3 : (m1 ? na : na3));
-            w12_rows<W12_MUL>(slot(acc), slot(alt), slot(f), nullptr);
+            w12_rows<W12_MUL, HLP>(slot(acc), slot(alt), slot(f), nullptr, H);
         } else { const int t = acc; acc = alt; alt = t; }
     }
     conj(d, acc);
 }
+__device__ __noinline__ void w12_exp_by_neg_z_rows(Fq2S *R, int d, int a, int tmp) { w12_exp_by_neg_z_rows_t<false>(R, d, a, tmp); }
+// (the 256-lane forms: the chain's rows and the helper's, see w12_rows)
+__device__ __noinline__ void w12_exp_by_neg_z_rows_h(Fq2S *R, int d, int a, int tmp) { w12_exp_by_neg_z_rows_t<true>(R, d, a, tmp); }
+__device__ __noinline__ void w12_mul_rows_h(Fq2S *D, const Fq2S *A, const Fq2S *B, Fq2S *H) { w12_rows<W12_MUL, true>(D, A, B, nullptr, H); }
+__device__ __noinline__ void w12_frob_rows_h(Fq2S *D, const Fq2S *A, const uint32_t *frob, Fq2S *H) { w12_rows<W12_FROB, true>(D, A, nullptr, frob, H); }
+__device__ __noinline__ void w12_scale_rows_h(Fq2S *D, const Fq2S *A, Fq2S *H) { w12_rows<W12_SCALE, true>(D, A, nullptr, nullptr, H); }
+
+// libff alt_bn128_final_exponentiation on slot 0 -> slot 0, 256 lanes: W12::final_exponentiation's chain with the one
+// inversion replaced by the helper's exponentiation (see w12_rows).  R: the W12_SLOTS registers, followed by the 36 slots of
+// the two-phase product that hold the helper's state here.
+__device__ __forceinline__ void w12_final_exponentiation_h(Fq2S *R) {
+    enum { ELT = 0, FIRST, A, B, C, D, E, F, G, T0, T1, T2, T3, T4, T5 };
+    Fq2S *const H = R + 6 * W12_SLOTS;
+    const unsigned lane = threadIdx.x;
+    auto slot = [R](int s) { return R + 6 * s; };
+    auto conj = [&](int d, int a) {
+        if (lane < 6) { const Fq2S v = slot(a)[lane]; slot(d)[lane] = (lane & 1) ? v.neg() : v; }
+        __syncthreads();
+    };
+    auto mul = [&](int d, int a, int b) { w12_mul_rows_h(slot(d), slot(a), slot(b), H); };
+    auto frob = [&](int power, int d, int a) { w12_frob_rows_h(slot(d), slot(a), &LSA_FROB_ROWS[power - 1][0][0][0][0], H); };
+    {                                                   // the helper idles (times one) until the norm is there
+        w12_lds_u32 *hw = w12_lds(H);
+        if (lane < 27) hw[lane] = 0;
+        if (lane == 27) hw[W12_H_STATE] = W12_H_IDLE;
+        if (lane >= 28 && lane < 36) hw[lane] = W12_FE_SCALAR_EXP[lane - 28];
+    }
+    conj(A, ELT);             // conj(f): f^(q^6)
+    mul(C, ELT, A);           // f * conj(f), an element of Fq6
+    // (f conj f)^-1 * n1: a^(q^2) a^(q^4) * conj(n2), n2 = a a^(q^2) a^(q^4) the norm down to Fq2, n1 = n2 conj(n2) the norm down to Fq
+    frob(2, T0, C);
+    frob(2, T1, T0);
+    mul(T0, T0, T1);
+    mul(T1, C, T0);           // n2 (odd and higher coefficients are 0 mod p)
+    {
+        const Fq2S n2 = w12_load(&slot(T1)[0]);
+        Fs n1 = n2.c0.sqr() + n2.c1.sqr();              // every lane the same arithmetic: no sparse EXEC mask (w12_pin)
+        Fs nc1 = n2.c1.neg();
+        w12_pin(n1.v);
+        w12_pin(nc1.v);
+        __syncthreads();                                // (every lane has read n2)
+        if (lane == 0) slot(T1)[0] = Fq2S{n2.c0, nc1};
+        else if (lane < 6) slot(T1)[lane] = Fq2S::zero();
+        if (lane == 64) {                               // the helper starts: power = n1, accumulator = 1, bit 0 of the exponent
+            w12_store(reinterpret_cast<Fs *>(H), n1);
+            w12_store(reinterpret_cast<Fs *>(H) + 1, Fs::one());
+            w12_lds(H)[W12_H_STATE] = ((W12_FE_SCALAR_EXP[0] & 1u) << 1) | 1u;
+        }
+        __syncthreads();
+    }
+    mul(D, T0, T1);
+    mul(B, A, D);             // f^-1 * n1
+    mul(C, A, B);             // f^(q^6 - 1) * n1
+    frob(2, D, C);
+    mul(FIRST, D, C);         // the easy part * n1^2
+    w12_exp_by_neg_z_rows_h(R, A, FIRST, T0);
+    mul(B, A, A);
+    mul(C, B, B);
+    mul(D, C, B);
+    w12_exp_by_neg_z_rows_h(R, E, D, T0);
+    mul(F, E, E);
+    w12_exp_by_neg_z_rows_h(R, G, F, T0);
+    conj(T2, D);              // H
+    conj(G, G);               // I
+    mul(G, G, E);             // J = I * E
+    mul(G, G, T2);            // K = J * H
+    mul(T2, G, B);            // L = K * B
+    mul(T0, G, E);            // M = K * E
+    mul(T0, T0, FIRST);       // N = M * first
+    frob(1, T1, T2);          // O = frob1(L)
+    mul(T0, T1, T0);          // P = O * N
+    frob(2, T1, G);           // Q = frob2(K)
+    mul(T0, T1, T0);          // R = Q * P
+    conj(T1, FIRST);          // S
+    mul(T1, T1, T2);          // T = S * L
+    frob(3, T1, T1);          // U
+    mul(ELT, T1, T0);         // U * R = FE(f) * n1^(2K)
+    // (264 links since the norm, 254 needed; the loop is for a chain someone shortens)
+    while (w12_lds(H)[W12_H_STATE] & 1u) mul(T5, T5, T5);
+    w12_scale_rows_h(slot(ELT), slot(ELT), H);
+}
+
 #endif
 
 template <class X>

@@ -191,6 +191,44 @@ def test_signed_digit_miller_loop_gives_the_same_gt(naf, lockstep):
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("helper", ["1", "0"])
+def test_final_exponentiation_of_arbitrary_elements(helper):
+    """lsa_final_exponentiation on elements that are NOT Miller values: random Fq12 elements, elements of the subfields
+    Fq6 / Fq2 / Fq, one, sparse ones -- byte for byte the oracle's libff chain.  LSA_FE_HELPER=1 (default): the 256-lane
+    kernel whose fourth wavefront replaces the chain's one inversion by a power of the norm (csrc/w12.h: w12_rows, HLP;
+    tools/gen_fe_scalar_exponent.py); 0: the 192-lane kernel with the inversion.  Zero has no inverse: both kernels
+    return zero for it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, random, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import legosnark_amd as lsa, oracle_lib as o\n"
+        "lsa.init(0)\n"
+        "rng = random.Random(99)\n"
+        "def elt(mask):\n"
+        "    f = np.zeros(48, dtype=np.uint64)\n"
+        "    for c in range(12):\n"
+        "        if (mask >> c) & 1: f[4 * c:4 * c + 4] = o.fq_mont(rng.randrange(o.P))\n"
+        "    return f\n"
+        "masks = [0xfff] * 12 + [0x03f, 0x003, 0x001, 0xfc0, 0x555, 0xaaa, 0x800, 0x041, 0x3cf]\n"
+        "fs = np.stack([elt(m) for m in masks] + [o.fq12_one().reshape(48)])\n"
+        "got = lsa.final_exponentiation(fs)\n"
+        "for i in range(len(fs)):\n"
+        "    assert np.array_equal(got[i].reshape(-1), o.final_exponentiation(fs[i]).reshape(-1)), (i, hex(masks[i]) if i < len(masks) else 'one')\n"
+        "one = lsa.final_exponentiation(fs[:1])\n"              # a lone element: the same kernel, one workgroup
+        "assert np.array_equal(one[0].reshape(-1), got[0].reshape(-1))\n"
+        "z = lsa.final_exponentiation(np.zeros((1, 48), dtype=np.uint64))\n"
+        "assert not z.any()\n"
+        "print('OK')\n"
+    ) % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, LSA_FE_HELPER=helper)
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:]
+
+
 def test_large_batch_takes_the_grouped_kernel_and_matches(lsa):
     """2000 pairs (above the one-wavefront-per-pairing range): product of the Miller values
     against the oracle on a sample, and the planted relation prod e(a_i G1, b_i G2) = 1 with
