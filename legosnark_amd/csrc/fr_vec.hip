@@ -354,9 +354,6 @@ __global__ __launch_bounds__(256) void k_fold_halves(const Fr *old, size_t half,
 // the linear factor.  Fr values are canonical, so the coefficients equal the reference's
 // whatever the summation order.  Streams 32*(2m+1) bytes per p.
 // ------------------------------------------------------------------------------------
-#ifndef LSA_SC_TOUCH_AHEAD
-#define LSA_SC_TOUCH_AHEAD false
-#endif
 static constexpr int SC_MAX_M = 4;
 struct ScTables { const Fr *t[SC_MAX_M]; };
 // x / 2 mod r on a canonical representative (the fixed factor 2^256 of libff's words commutes with the halving)
@@ -382,32 +379,23 @@ __device__ __forceinline__ Fr fr_half(const Fr &x) {
 // (fr29.h: libff's words of x are the 2^261 form of x / 32), so every product loses a factor 32 -- the same number of times
 // in every term of every coefficient (each term is suff times one factor per table: M products, M - 1 without suff, whose
 // place the 2^261 form of 1 takes) -- and the factor comes back with the constant that makes the lane's sums canonical.
-template <int M>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sumcheck_partial(const Fr *__restrict__ suff, ScTables tabs, size_t half, Fr *__restrict__ partial) {
-    __shared__ Fr lds[256];
+// RED3 (M == 3 only): every product of an index reduced on its own -- nine reductions instead of five and four shared ones,
+// ~ 15 % more instructions, but no 64-bit column accumulators (4 x 34 registers, which lived in AGPRs and were moved in
+// and out around every multiply-add): the kernel fits three wavefronts per SIMD instead of two, and at two a SIMD runs
+// at the pace of the products' dependent multiply-add chains (one every 11 cycles per wavefront, 0.64-0.72 of the issue
+// slots by the SQ counters: profiles/r06_w2_sumcheck_sq_pmc.txt).
+template <int M, bool RED3>
+__device__ __forceinline__ void sumcheck_partial_body(const Fr *__restrict__ suff, const ScTables &tabs, size_t half, Fr *__restrict__ partial, Fr *lds) {
     Fr29 c[M + 1];
 #pragma unroll
     for (int i = 0; i <= M; i++) c[i] = Fr29::zero();
     const Fr29 one = Fr29::one();
     unsigned since = 0, wide_n = 0;
     Fr29Wide w0 = fr29_wide_zero(), w2 = fr29_wide_zero(), wm = fr29_wide_zero(), wn = fr29_wide_zero();      // (M == 2, 3 only)
-    const bool touch_ahead = LSA_SC_TOUCH_AHEAD;
     for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < half; p += (size_t)gridDim.x * blockDim.x) {
-        // (an experiment of round 6, off: one dword of every line the NEXT index will read is loaded now and only waited for at
-        // the end of this iteration -- the kernel holds two wavefronts per SIMD, too few to hide HBM's latency behind the other)
-        uint32_t touched = 0;
-        if (touch_ahead) {
-            const size_t pn = p + (size_t)gridDim.x * blockDim.x;
-            if (pn < half) {
-                if (suff) touched ^= *reinterpret_cast<const volatile uint32_t *>(&suff[pn]);
-#pragma unroll
-                for (int t = 0; t < M; t++) {
-                    touched ^= *reinterpret_cast<const volatile uint32_t *>(&tabs.t[t][pn]);
-                    touched ^= *reinterpret_cast<const volatile uint32_t *>(&tabs.t[t][pn + half]);
-                }
-            }
-        }
-        struct TouchGuard { uint32_t &v; __device__ ~TouchGuard() { asm volatile("" ::"v"(v)); } } touch_guard{touched};
+        // (round 6, measured and withdrawn: one dword of every line the NEXT index reads, loaded an iteration ahead -- the kernel holds
+        // two wavefronts per SIMD -- made it slower: 0.47 -> 0.56 ms for two tables, 0.85 -> 1.25 ms for three at half = 2^23;
+        // profiles/r06_w1_sumcheck_touch_ahead.txt)
         Fr29 q[M + 1];
         q[0] = suff ? Fr29::from_words(suff[p]) : one;
         if constexpr (M == 2) {
@@ -448,6 +436,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const Fr29 da = sub2r(a1, a0), db = sub2r(b1, b0), dc = sub2r(c1, c0);          // < 3r
             Fr29 sa0 = a0, sda = da, sa1 = a1;
             if (suff) { sa0 = mul(q[0], a0); sda = mul(q[0], da); sa1 = add(sa0, sda); }    // < 2r, < 2r, < 4r
+            if constexpr (RED3) {
+                const Fr29 e0 = mul(sa0, b0), e2 = mul(sda, db), em = mul(sa1, b1);         // < 2r each
+                const Fr29 t = add(e0, e2), em1 = sub2r(add(t, t), em);                     // E(-1) + 2r < 10r
+                const Fr29 cm = sub2r(add(c0, c0), c1);                                     // C(-1) + 2r < 4r
+                c[0] = add(c[0], mul(e0, c0));                                              // every product < 2r; operands: 2 r^2, 6 r^2, 2 r^2, 40 r^2 < 121 r^2
+                c[1] = add(c[1], mul(em, c1));
+                c[2] = add(c[2], mul(em1, cm));
+                c[3] = add(c[3], mul(e2, dc));
+                if (++since == 16) {                                                    // 16 * 2r + 2r < 121 r
+#pragma unroll
+                    for (int i = 0; i <= M; i++) c[i] = mul(c[i], one);
+                    since = 0;
+                }
+                continue;
+            }
             const Fr29 e0 = mul(sa0, b0).canonical2(), e2 = mul(sda, db).canonical2(), em = mul(sa1, b1);   // < r, < r, < 2r
             const Fr29 t = add(e0, e2), em1 = sub2r(add(t, t), em);                         // E(-1) + 2r < 6r
             const Fr29 cm = sub2r(add(c0, c0), c1);                                         // C(-1) + 2r < 4r
@@ -529,6 +532,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i <= M; i++) partial[(size_t)blockIdx.x * (SC_MAX_M + 1) + i] = tot[i];
     }
+}
+template <int M>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sumcheck_partial(const Fr *__restrict__ suff, ScTables tabs, size_t half, Fr *__restrict__ partial) {
+    __shared__ Fr lds[256];
+    sumcheck_partial_body<M, false>(suff, tabs, half, partial, lds);
+}
+#ifndef LSA_SC3_WAVES
+#define LSA_SC3_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LSA_SC3_WAVES, LSA_SC3_WAVES))) void k_sumcheck_partial3r(const Fr *__restrict__ suff, ScTables tabs, size_t half, Fr *__restrict__ partial) {
+    __shared__ Fr lds[256];
+    sumcheck_partial_body<3, true>(suff, tabs, half, partial, lds);
 }
 
 // out[0..m(+1)] = (have_beta ? ((1-rho) + (2rho-1) X) * pre : 1) * sum of the block partials (one workgroup: the partials of a
@@ -822,9 +837,14 @@ int fr_sumcheck_round_device(const Fr *d_suff, const Fr *const *d_tables, size_t
     ScTables tabs;
     for (int t = 0; t < SC_MAX_M; t++) tabs.t[t] = t < (int)m ? d_tables[t] : nullptr;
     size_t b = (half + 255) / 256;
-    const unsigned blocks = (unsigned)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+    // three tables: LSA_SC3=wide keeps the shared-reduction kernel (two wavefronts per SIMD: 1024 workgroups are two full rounds); the
+    // default reduces every product and holds three per SIMD (768 workgroups are one round)
+    static const bool sc3_reduced = [] { const char *e = getenv("LSA_SC3"); return !(e && *e == 'w'); }();
+    const size_t cap = (m == 3 && sc3_reduced) ? 256 * LSA_SC3_WAVES : 1024;
+    const unsigned blocks = (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
     if (m == 1) hipLaunchKernelGGL((k_sumcheck_partial<1>), dim3(blocks), dim3(256), 0, st, d_suff, tabs, half, d_partial);
     else if (m == 2) hipLaunchKernelGGL((k_sumcheck_partial<2>), dim3(blocks), dim3(256), 0, st, d_suff, tabs, half, d_partial);
+    else if (m == 3 && sc3_reduced) hipLaunchKernelGGL(k_sumcheck_partial3r, dim3(blocks), dim3(256), 0, st, d_suff, tabs, half, d_partial);
     else if (m == 3) hipLaunchKernelGGL((k_sumcheck_partial<3>), dim3(blocks), dim3(256), 0, st, d_suff, tabs, half, d_partial);
     else hipLaunchKernelGGL((k_sumcheck_partial<4>), dim3(blocks), dim3(256), 0, st, d_suff, tabs, half, d_partial);
     hipLaunchKernelGGL(k_sumcheck_finish, dim3(1), dim3(256), 0, st, d_partial, blocks, (unsigned)m, rho ? 1 : 0,

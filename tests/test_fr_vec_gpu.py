@@ -121,6 +121,38 @@ def test_sumcheck_round_vs_oracle(lsa, m, half, beta, suff):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("kernel", ["reduced", "wide"])
+def test_sumcheck_three_tables_both_kernels(kernel):
+    """Three tables: the default kernel reduces every product (k_sumcheck_partial3r, three wavefronts per SIMD, 768
+    workgroups), LSA_SC3=wide keeps the one with four shared reductions per four indices (k_sumcheck_partial<3>).  Both
+    against the oracle: with and without the suffix table and the beta factor, a ragged size, and 3.4 M indices -- seventeen
+    and eighteen per lane, so that the lane's lazy sums are brought back below 2r (every sixteen additions) and the shared
+    reductions meet a remainder of one and two."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import legosnark_amd as lsa, oracle_lib as o\n"
+        "lsa.init(0)\n"
+        "rng = np.random.default_rng(5000)\n"
+        "def residues(n):\n"                                  # any 256-bit value below r is a Montgomery residue: top limb below 2^60
+        "    a = rng.integers(0, 1 << 64, (n, 4), dtype=np.uint64); a[:, 3] &= np.uint64((1 << 60) - 1); return a\n"
+        "for half, beta, suff in ((1, True, True), (1000, True, False), (777, False, False), (70001, True, True), (3400000 + 5, True, True)):\n"
+        "    tabs = [residues(2 * half) for t in range(3)]\n"
+        "    s = residues(half) if suff else None\n"
+        "    pr = o.random_scalars(2, seed=78)[0]\n"
+        "    kw = dict(suff=s, pre=pr[0], rho_j=pr[1]) if beta else {}\n"
+        "    assert np.array_equal(lsa.sumcheck_round(tabs, **kw), o.fr_sumcheck_round(tabs, **kw)), (half, beta, suff)\n"
+        "print('OK')\n"
+    ) % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, LSA_SC3=kernel)
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:]
+
+
 @pytest.mark.parametrize("d", [1, 2, 3, 7, 8, 9, 13, 16])
 def test_eq_table_both_variants(lsa, d):
     """DPBeta::compute_eq_tbl (mle.h:93-105).  Variant 0 = the reference's loop as written (restated literally in the
