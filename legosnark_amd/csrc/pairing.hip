@@ -113,22 +113,22 @@ __global__ __launch_bounds__(256) void k_final_exp_wave_h(const Fq12 *__restrict
     if (lane < 12) reinterpret_cast<Fq *>(&out[e])[lane] = w12_fq_ref(lds, lane)->to_mont256();
 }
 
-// out[b] = prod in[8b .. 8b+7], one wavefront per group of 8 (W12 products)
-__global__ __launch_bounds__(192) void k_fq12_prod8_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
+// out[b] = prod in[G b .. G b + G - 1] (G <= 8), one workgroup per group (W12 products)
+__global__ __launch_bounds__(192) void k_fq12_prod8_wave(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out, unsigned G) {
     __shared__ Fq2S lds[W12_LDS_FQ2];
-    const size_t lo = (size_t)blockIdx.x * 8;
+    const size_t lo = (size_t)blockIdx.x * G;
     if (lo >= n) return;
     const unsigned lane = threadIdx.x;
     WaveExec192 ex;
     W12<WaveExec192> w{ex, lds, lds + 6 * W12_SLOTS};
-    for (unsigned x = lane; x < 96; x += 192) {  // 8 elements x 12 Fq
+    for (unsigned x = lane; x < 12 * G; x += 192) {  // G elements x 12 Fq
         const unsigned e = x / 12, l = x % 12;
         Fs v = (l == 0) ? Fs::one() : Fs::zero();       // missing inputs = 1
         if (lo + e < n) v = Fs::from_mont256(reinterpret_cast<const Fq *>(&in[lo + e])[l]);
         *w12_fq_ref(w.slot((int)e), l) = v;
     }
     __syncthreads();
-    for (int s = 1; s < 8; s++) w.mul(0, 0, s);
+    for (int s = 1; s < (int)G; s++) w.mul(0, 0, s);
     if (lane < 12) reinterpret_cast<Fq *>(&out[blockIdx.x])[lane] = w12_fq_ref(w.slot(0), lane)->to_mont256();
 }
 
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(64) void k_miller_wtab(const Jac<Fq> *__restrict__ 
 // K > 1: K workgroups per accumulator (blockIdx = a * K + r), out[a * K + r] = the factor of the steps r mod K
 __global__ __launch_bounds__(192) void k_miller_rtab(const Jac<Fq> *__restrict__ g1, const uint32_t *const *__restrict__ tabs,
                                                      const uint8_t *__restrict__ flags, const uint32_t *__restrict__ acc_off, size_t nacc,
-                                                     unsigned M, const uint32_t *__restrict__ ident, Fq12 *__restrict__ out, unsigned K) {
+                                                     unsigned M, const uint32_t *__restrict__ ident, Fq12 *__restrict__ out, unsigned K, RtSplit split) {
     __shared__ Fq2S lds[RT_LDS_FQ2];
     __shared__ const uint32_t *tp[RT_MAXM];
     __shared__ const Jac<Fq> *pp[RT_MAXM];
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(192) void k_miller_rtab(const Jac<Fq> *__restrict__
     }
     __syncthreads();
 #if defined(__HIP_DEVICE_COMPILE__)
-    rt_miller_run(lds, tp, pp, ng, len, M, K, r, own);
+    rt_miller_run(lds, tp, pp, ng, len, M, split.start[r], split.start[r + 1], own);
 #endif
     if (lane < 12) {
         const unsigned k = lane >> 1, part = lane & 1, t = (k & 1) * 3 + (k >> 1);
@@ -472,6 +472,18 @@ __global__ __launch_bounds__(192) void k_miller_rtab(const Jac<Fq> *__restrict__
 // the family (LSA_MILLER_KERNEL=3) beside the fused kernel (k_miller_fused), which every fresh pair takes by default.
 // (Rounds 1-2 also had one pairing per wavefront, six and twelve lanes per pairing -- k_miller_wave / _g6 / _g12; they
 // lost every shape to the fused kernel in rounds 3 and 4 and were removed in round 5.)
+// the K ranges of rt_split per number of pairs per accumulator (K = 1, 2, 4, 8), made once
+static RtSplit rt_split_for(unsigned M, unsigned K) {
+    static const std::vector<RtSplit> tab = [] {
+        std::vector<RtSplit> t;
+        for (unsigned k = 0; k < 4; k++)
+            for (unsigned m = 0; m <= (unsigned)RT_MAXM; m++) t.push_back(rt_split(m ? m : 1u, 1u << k));
+        return t;
+    }();
+    const unsigned k = K >= 8 ? 3u : (K >= 4 ? 2u : (K >= 2 ? 1u : 0u));
+    return tab[k * ((unsigned)RT_MAXM + 1) + (M <= (unsigned)RT_MAXM ? M : (unsigned)RT_MAXM)];
+}
+
 int miller_device(const void *d_g1, const void *d_g2, size_t n, void *d_out, hipStream_t st) {
     if (n == 0) return LSA_OK;
     hipLaunchKernelGGL(k_miller, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const Jac<Fq> *)d_g1, (const Jac<Fq2> *)d_g2, n,
@@ -503,7 +515,7 @@ int fq12_product_device(void *d_buf, void *d_scratch, size_t n, void **result, h
     Fq12 *a = (Fq12 *)d_buf, *b = (Fq12 *)d_scratch;
     while (n > 1) {
         size_t m = (n + 7) / 8;
-        if (m < 16384) hipLaunchKernelGGL(k_fq12_prod8_wave, dim3((unsigned)m), dim3(192), 0, st, a, n, b);      // three wavefronts: the one-phase row product (w12.h)
+        if (m < 16384) hipLaunchKernelGGL(k_fq12_prod8_wave, dim3((unsigned)m), dim3(192), 0, st, a, n, b, 8u);      // three wavefronts: the one-phase row product (w12.h)
         else hipLaunchKernelGGL(k_fq12_prod8, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, st, a, n, b);
         Fq12 *t = a; a = b; b = t;
         n = m;
@@ -575,17 +587,19 @@ int miller_tab_device(const void *d_g1, const uint32_t *const *d_tabs, const uin
     // few accumulators of one or two pairs (the verifiers' lone checks): the row engine, 0.2 ms against 0.35 (LSA_MILLER_ROWS=0: off)
     static const bool rows = getenv("LSA_MILLER_ROWS") == nullptr || atoi(getenv("LSA_MILLER_ROWS")) != 0;
     if (wave && rows && M <= (unsigned)RT_MAXM && nacc <= 512) {
-        // a handful of accumulators: eight workgroups share each loop's line products (rt_miller_run), k_fq12_prod8_wave
-        // multiplies their eight factors -- 64 + 102 M / 8 chain links instead of 64 + 102 M (LSA_MILLER_SPLIT=1: off)
+        // up to 128 accumulators: K = 8, 4 or 2 workgroups (at most one per CU in all) share each loop's line products (rt_miller_run:
+        // contiguous ranges of steps, cut even by rt_split), k_fq12_prod8_wave multiplies their K factors -- 65 / 73 chain links
+        // (one / two pairs per accumulator) with K = 8 instead of 63 + 102 M (LSA_MILLER_SPLIT=1: off)
         static const unsigned split = getenv("LSA_MILLER_SPLIT") ? (unsigned)atoi(getenv("LSA_MILLER_SPLIT")) : 8u;
-        if (split == 8 && nacc <= 32) {
-            if (!g_rt_parts && hipMalloc(&g_rt_parts, 32 * 8 * sizeof(Fq12)) != hipSuccess) { g_rt_parts = nullptr; set_error("miller_tab: hipMalloc failed"); return LSA_ERR_NOMEM; }
-            hipLaunchKernelGGL(k_miller_rtab, dim3((unsigned)nacc * 8), dim3(192), 0, st, (const Jac<Fq> *)d_g1, d_tabs, d_flags, d_acc_off, nacc, M, d_ident,
-                               (Fq12 *)g_rt_parts, 8u);
-            hipLaunchKernelGGL(k_fq12_prod8_wave, dim3((unsigned)nacc), dim3(192), 0, st, (const Fq12 *)g_rt_parts, nacc * 8, (Fq12 *)d_out);
+        const unsigned K = split == 1 ? 1u : (nacc <= 32 ? 8u : (nacc <= 64 ? 4u : (nacc <= 128 ? 2u : 1u)));
+        if (K > 1) {
+            if (!g_rt_parts && hipMalloc(&g_rt_parts, 256 * sizeof(Fq12)) != hipSuccess) { g_rt_parts = nullptr; set_error("miller_tab: hipMalloc failed"); return LSA_ERR_NOMEM; }
+            hipLaunchKernelGGL(k_miller_rtab, dim3((unsigned)nacc * K), dim3(192), 0, st, (const Jac<Fq> *)d_g1, d_tabs, d_flags, d_acc_off, nacc, M, d_ident,
+                               (Fq12 *)g_rt_parts, K, rt_split_for((unsigned)M, K));
+            hipLaunchKernelGGL(k_fq12_prod8_wave, dim3((unsigned)nacc), dim3(192), 0, st, (const Fq12 *)g_rt_parts, nacc * K, (Fq12 *)d_out, K);
         } else
             hipLaunchKernelGGL(k_miller_rtab, dim3((unsigned)nacc), dim3(192), 0, st, (const Jac<Fq> *)d_g1, d_tabs, d_flags, d_acc_off, nacc, M, d_ident,
-                               (Fq12 *)d_out, 1u);
+                               (Fq12 *)d_out, 1u, rt_split_for((unsigned)M, 1u));
     } else if (wave)
         hipLaunchKernelGGL(k_miller_wtab, dim3((unsigned)nacc), dim3(64), 0, st, (const Jac<Fq> *)d_g1, d_tabs, d_flags, d_acc_off, nacc, M, d_ident,
                            (Fq12 *)d_out);

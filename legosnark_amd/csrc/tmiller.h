@@ -922,6 +922,42 @@ struct WTabMiller {
 
 static constexpr int RT_MAXM = 2;
 enum { RT_F = 0, RT_PXY = 6, RT_LINES = RT_PXY + RT_MAXM, RT_LDS_FQ2 = RT_LINES + RT_MAXM * ATE_NUM_COEFFS * 3 };
+// The 66 steps of a Miller loop over a table (64 doubling steps with one or two lines each, two closing lines) cut into K <= 8
+// contiguous ranges for the K workgroups that share one accumulator (rt_miller_run): range [start[r], start[r + 1]) costs its
+// workgroup 63 - start[r] squarings (none from step 64 on) + M line products per line; the smallest bound T that K ranges
+// cover the loop with, ranges grown from the end.
+struct RtSplit { uint8_t start[9]; };
+inline RtSplit rt_split(unsigned M, unsigned K) {
+    auto lines = [](int ph) { return ph < 64 ? 1 + ate_bit(63 - ph) : 1; };
+    RtSplit best{};
+    for (int T = 1; T < 1024; T++) {
+        int b = 66, starts[9], n = 0;
+        starts[0] = 66;
+        for (unsigned r = 0; r < K && b > 0; r++) {
+            int a = b, ln = 0;
+            while (a > 0) {
+                const int na = a - 1, sq = na < 64 ? 63 - na : 0;
+                if (sq + (int)M * (ln + lines(na)) > T) break;
+                ln += lines(na);
+                a = na;
+            }
+            if (a == b) break;
+            starts[++n] = a;
+            b = a;
+        }
+        if (b != 0) continue;
+        // n ranges (n <= K) from the end; workgroups beyond n get empty ranges at the front
+        for (unsigned r = 0; r <= K; r++) {
+            const int back = (int)K - (int)r;              // start[r] = the start of the range `back` places from the end
+            best.start[r] = (uint8_t)(back <= n ? starts[back] : 0);
+        }
+        best.start[K] = 66;
+        return best;
+    }
+    for (unsigned r = 0; r <= K; r++) best.start[r] = (uint8_t)(r == 0 ? 0 : 66);      // (not reached: T = 64 + 102 M always covers)
+    return best;
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // ------------------------------------------------------------------------------------------------------------------
 // The same job on the row engine of w12.h (192 lanes, up to RT_MAXM pairs per accumulator): the latency shape for the
@@ -935,19 +971,23 @@ enum { RT_F = 0, RT_PXY = 6, RT_LINES = RT_PXY + RT_MAXM, RT_LDS_FQ2 = RT_LINES 
 // Same field elements as WTabMiller's (products commute, values leave canonical), 64 + 102 M rounds.
 // ------------------------------------------------------------------------------------------------------------------
 // m: RT_LDS_FQ2 values in LDS; tab, P, neg: RT_MAXM entries each (pairs >= cnt: the identity table); result in m[RT_F .. RT_F + 5].
-// K > 1: ONE OF K workgroups that share the loop.  With F_s the product of the lines of step s, the loop computes
-// f = prod_s F_s^(2^(63 - s)) (times the two closing lines) by f <- f^2 * F_s; the factors of the steps s = r mod K alone
+// [lo, hi) != [0, 66): ONE OF K workgroups that share the loop.  With F_s the product of the lines of step s, the loop computes
+// f = prod_s F_s^(2^(63 - s)) (times the two closing lines) by f <- f^2 * F_s; the factors of a SUBSET of the steps alone
 // obey the same recurrence -- g <- g^2 every step, g <- g * F_s on the workgroup's own steps -- and the K results
-// multiply to f.  The 64 squarings stay (they are the chain), the 102 M line products are shared out: 64 + 102 M / K
-// links instead of 64 + 102 M, on K otherwise idle CUs; `own` (104 bytes of LDS) marks the entries of the own steps.
+// multiply to f.  The squarings are the chain, the 102 M line products are shared out, on K otherwise idle CUs; `own`
+// (104 bytes of LDS) marks the entries of the own steps.
+// (round 6, second session) WHICH steps a workgroup takes: a contiguous range [lo, hi) of the 66, not a residue class.  A
+// workgroup's accumulator is 1 until its first own step, so its chain starts THERE -- 63 - lo squarings instead of 64 for
+// everybody -- and the ranges are cut (rt_split, on the host) so that squarings + line products come out even: 65 links
+// instead of 77 for one pair per accumulator, 73 instead of 90 for two.
 __device__ __forceinline__ void rt_miller_run(Fq2S *m, const uint32_t *const *tab, const Jac<Fq> *const *P, const uint8_t *neg, unsigned cnt, unsigned M,
-                                              unsigned K, unsigned r, uint8_t *own) {
+                                              unsigned lo, unsigned hi, uint8_t *own) {
     const unsigned lane = threadIdx.x;
     if (lane < 66) {                                      // lane = step: its entries are [first, first + lines)
         unsigned first = 0;
         for (unsigned s = 0; s < lane; s++) first += s < 64 ? 1u + (unsigned)ate_bit(63 - (int)s) : 1u;
         const unsigned lines = lane < 64 ? 1u + (unsigned)ate_bit(63 - (int)lane) : 1u;
-        for (unsigned l = 0; l < lines; l++) own[first + l] = (uint8_t)(lane % K == r);
+        for (unsigned l = 0; l < lines; l++) own[first + l] = (uint8_t)(lane >= lo && lane < hi);
     }
     {   // (px, py) of every pair, computed by every lane (no sparse EXEC mask: w12_pin), stored by one
         const unsigned i = lane & (RT_MAXM - 1);
@@ -980,8 +1020,8 @@ __device__ __forceinline__ void rt_miller_run(Fq2S *m, const uint32_t *const *ta
     for (int ph = 0; ph < 66; ph++) {
         const bool dbl = ph < 64;
         const int lines = dbl ? 1 + ate_bit(63 - ph) : 1;
-        if (dbl) w12_rows<W12_MUL>(m + RT_F, m + RT_F, m + RT_F, nullptr);
-        const bool mine = (unsigned)ph % K == r;
+        if (dbl && (unsigned)ph > lo) w12_rows<W12_MUL>(m + RT_F, m + RT_F, m + RT_F, nullptr);       // (up to its first own step the accumulator is 1)
+        const bool mine = (unsigned)ph >= lo && (unsigned)ph < hi;
 #pragma unroll 1
         for (int li = 0; li < lines; li++, u++) {
             if (!mine) continue;

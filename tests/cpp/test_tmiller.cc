@@ -51,8 +51,32 @@ static std::vector<Line> expected_lines(const Jac<Fq2> &Q, P2 &qx, P2 &qy) {
     out.push_back(addition_step(q2x, q2y, R));
     return out;
 }
+// rt_split: K contiguous ranges of the 66 steps that cover the loop, cost per range (63 - start squarings + M per line) even
+static void check_rt_split() {
+    auto lines = [](int ph) { return ph < 64 ? 1 + ate_bit(63 - ph) : 1; };
+    int total = 0;
+    for (int ph = 0; ph < 66; ph++) total += lines(ph);
+    CHECK(total == ATE_NUM_COEFFS, "66 steps hold the 102 table entries");
+    for (unsigned M = 1; M <= (unsigned)RT_MAXM; M++)
+        for (unsigned K : {1u, 2u, 8u}) {
+            const RtSplit s = rt_split(M, K);
+            bool ok = s.start[0] == 0 && s.start[K] == 66;
+            int worst = 0;
+            for (unsigned r = 0; r < K; r++) {
+                ok = ok && s.start[r] <= s.start[r + 1];
+                int ln = 0;
+                for (int ph = s.start[r]; ph < s.start[r + 1]; ph++) ln += lines(ph);
+                const int sq = s.start[r] < 64 && s.start[r + 1] > s.start[r] ? 63 - s.start[r] : 0;
+                if (sq + (int)M * ln > worst) worst = sq + (int)M * ln;
+            }
+            CHECK(ok, "rt_split covers the loop with ordered ranges");
+            if (K == 1) CHECK(worst == 63 + (int)M * ATE_NUM_COEFFS, "one workgroup: the whole loop");
+            if (K == 8) CHECK(worst <= (M == 1 ? 65 : 73), "eight workgroups: 65 links for one pair per accumulator, 73 for two");
+        }
+}
 int main() {
     LoopExec ex;
+    check_rt_split();
     // ---- line tables
     const unsigned nq = 5;
     Jac<Fq2> Qs[GP_GROUPS];

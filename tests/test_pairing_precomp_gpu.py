@@ -37,7 +37,7 @@ def test_g2_precompute_matches_the_oracle(lsa):
             assert np.array_equal(got[i], o.precompute_g2(qs[i])), (n, i)
 
 
-@pytest.mark.parametrize("n", [1, 3, 4, 5, 17, 70])
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 17, 33, 64, 70, 128, 129])
 def test_miller_loop_over_tables(lsa, n):
     ps = o.arith_bases("g1", 900 + n, 13, n)
     if n >= 3:
@@ -94,6 +94,29 @@ def test_products_with_conjugated_terms_and_shared_accumulators(lsa, chunk):
         assert np.array_equal(lsa.pairing_product_segments(ps, qs, off), _oracle_terms(ps, qs, np.zeros(n, np.uint8), off, True))
     finally:
         lsa.pairing_set_chunk(0)
+
+
+@pytest.mark.parametrize("nseg,per", [(20, 2), (33, 2), (45, 3), (64, 2), (100, 2), (128, 1), (140, 2)])
+def test_split_miller_loops_every_group_size(lsa, nseg, per):
+    """Miller loops over resident tables on the row engine: up to 32 / 64 / 128 accumulators are shared out over 8 / 4 / 2
+    workgroups each -- contiguous ranges of the loop's steps, cut even by rt_split (csrc/tmiller.h) -- and beyond that one
+    workgroup runs the whole loop.  Products of `per` terms (accumulators of two pairs and of one), conjugated terms, raw
+    Miller products and GT values against the oracle."""
+    rng = random.Random(1000 + nseg)
+    n = nseg * per
+    ps = o.arith_bases("g1", 4242 + nseg, 17, n)
+    qs_distinct = _g2_points(5, 21)
+    idx = [rng.randrange(5) for _ in range(n)]
+    qs = qs_distinct[idx]
+    tabs = lsa.g2_precompute(qs_distinct)
+    flags = np.array([rng.randrange(2) for _ in range(n)], dtype=np.uint8)
+    off = np.arange(0, n + 1, per, dtype=np.uint64)
+    want = _oracle_terms(ps, qs, flags, off, False)
+    got = lsa.pairing_terms(ps, off, tables=tabs, index=idx, flags=flags, final_exp=False)
+    assert np.array_equal(got, want)
+    gt = lsa.pairing_terms(ps, off, tables=tabs, index=idx, flags=flags, final_exp=True)
+    for j in range(0, nseg, max(1, nseg // 6)):
+        assert np.array_equal(gt[j], o.final_exponentiation(want[j])), j
 
 
 def test_a_verifier_check_is_one_product(lsa):
