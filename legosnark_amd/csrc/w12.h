@@ -316,14 +316,15 @@ enum { W12_MUL = 0, W12_FROB = 1, W12_LINE = 2, W12_SCALE = 3 };
 // one link (W12_SCALE) multiplies the twelve components by the accumulator.  Same field element as libff's, so the same
 // bytes (tests: every final exponentiation of the GPU suite goes through it).  LSA_FE_HELPER=0: the 192-lane kernel.
 // State, in the 36 partial-product slots the row engine does not use (LDS words at H):
-//   0..8 the running power, 9..17 the accumulator, 18..26 zero, 27 the state -- 4 * (links done) + 2 * (row 13 multiplies by the
-//   power in THIS link) + (row 12 squares it; zero: both multiply by one) --, 28..35 the exponent's words.
+//   0..8 the running power, 9..17 the accumulator, 18..26 zero, 28..35 the exponent's words, 36 the state -- 2 * (links done) + (the
+//   exponentiation is running: row 12 squares the power; zero: both rows multiply by one) --, 37 the exponent's bits from this
+//   link's on (bit 0: row 13 multiplies by the power in THIS link), refilled from 28..35 every 32 links.
 // ------------------------------------------------------------------------------------------------------------------
 // generated by tools/gen_fe_scalar_exponent.py: e = -2 K mod (q - 1), 254 bits
 static constexpr uint32_t W12_FE_SCALAR_EXP[8] = {0x8d10a36eu, 0xfa9264cdu, 0xc9df5cd9u, 0x2f1120f5u, 0x4317591cu, 0x4bdc2634u, 0xe131a027u, 0x30644e72u};
 static constexpr int W12_FE_SCALAR_EXP_BITS = 254;
-enum { W12_H_PW = 0, W12_H_ACC = 9, W12_H_ZERO = 18, W12_H_STATE = 27, W12_H_EXP = 28 };
-static constexpr uint32_t W12_H_IDLE = 0xffffu << 2;
+enum { W12_H_PW = 0, W12_H_ACC = 9, W12_H_ZERO = 18, W12_H_EXP = 28, W12_H_STATE = 36, W12_H_BITS = 37 };
+static constexpr uint32_t W12_H_IDLE = 0xffffu << 1;
 template <int MODE, bool HLP = false>
 __device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, const uint32_t *frob, Fq2S *H = nullptr) {
     const unsigned lane = threadIdx.x, row = lane >> 4, r = lane & 15;
@@ -331,21 +332,26 @@ __device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, 
     F29 L, Rv;
     Fs *dst = &w12_comp(D[k < 6 ? k : 0], part);
     bool store = r == 0;
-    uint32_t hst = 0;
+    uint32_t hst2 = 0, hbits2 = 0;
     if (HLP && row >= 12) {                            // (the whole fourth wavefront)
-        // one LDS round trip in front of the barrier, as the chain's rows have: the state word, the power (every lane: row 12's
+        // one LDS round trip in front of the barrier, as the chain's rows have: the state words, the power (every lane: row 12's
         // second factor, row 13's when the bit is set) and lane 0's first factor by ADDRESS (row 12: the power, rows 13..15: the
-        // accumulator, lanes 1..15 of a row: the zero kept beside them)
+        // accumulator, lanes 1..15 of a row: the zero kept beside them).  The next link's state is worked out HERE, where this
+        // wavefront waits for the chain's rows anyway, and stored behind the barrier.
         w12_lds_u32 *hw = w12_lds(H);
-        hst = hw[W12_H_STATE];
+        const uint32_t hst = hw[W12_H_STATE], hbits = hw[W12_H_BITS];
         const Fs *hs = reinterpret_cast<const Fs *>(H);
         const Fs pw = w12_load(hs);
         L = w12_load(hs + (r != 0 ? 2 : (row == 12 ? 0 : 1))).v;
         const F29 one = F29::one();
-        const uint32_t act = w12_mask(0u - (hst & 1u)), sel = w12_mask(0u - ((hst >> 1) & 1u)), sq = w12_mask(0u - (uint32_t)(row == 12));
+        const uint32_t act = w12_mask(0u - (hst & 1u)), sel = act & w12_mask(0u - (hbits & 1u)), sq = w12_mask(0u - (uint32_t)(row == 12));
         const uint32_t m = (act & sq) | (sel & ~sq);
 #pragma unroll
         for (int q = 0; q < 9; q++) Rv.l[q] = (pw.v.l[q] & m) | (one.l[q] & ~m);
+        const uint32_t c2 = (hst >> 1) + (hst & 1u);
+        hbits2 = hbits >> 1;
+        if ((c2 & 31u) == 0u) hbits2 = hw[W12_H_EXP + ((c2 >> 5) & 7u)];          // (every 32nd link)
+        hst2 = (c2 << 1) | ((hst & 1u) & (uint32_t)(c2 < (uint32_t)W12_FE_SCALAR_EXP_BITS));
         dst = const_cast<Fs *>(hs) + (row == 12 ? 0 : 1);
         store = r == 0 && row <= 13;
     } else if (MODE == W12_SCALE) {                    // D_k <- A_k * (the helper's accumulator): lane 0 of a row, the others add nothing
@@ -381,6 +387,7 @@ __device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, 
         Rv = lin2(bj.c0.v, c0, bj.c1.v, c1, K);
     }
     __syncthreads();                                   // every lane holds its operands: D may alias A or B from here on
+    if (HLP && lane == 192) { w12_lds(H)[W12_H_STATE] = hst2; w12_lds(H)[W12_H_BITS] = hbits2; }
     W12Limbs18 t = w12_wide_mul(L, Rv), u;
     W12_DPP18(t, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
     W12_DPP18(t, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");         // sums of four (< 2^31)
@@ -389,13 +396,6 @@ __device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, 
     Fs res = {condsub2(w12_redc18(t, u))};
     w12_pin(res.v);                                    // (dense: see w12_pin)
     if (store) w12_store(dst, res);
-    if (HLP && row >= 12) {                            // the state of the next link: links done, this link's two bits
-        w12_lds_u32 *hw = w12_lds(H);
-        const uint32_t act = hst & 1u, c2 = (hst >> 2) + act;
-        const uint32_t word = hw[W12_H_EXP + ((c2 >> 5) & 7u)];
-        const uint32_t a2 = act & (uint32_t)(c2 < (uint32_t)W12_FE_SCALAR_EXP_BITS);
-        if (lane == 192) hw[W12_H_STATE] = (c2 << 2) | ((a2 & (word >> (c2 & 31u))) << 1) | a2;
-    }
     __syncthreads();
 }
 // LEAF functions (no calls inside, so no return address to park in a spilled VGPR: a product that calls a product
@@ -457,9 +457,9 @@ __device__ __forceinline__ void w12_final_exponentiation_h(Fq2S *R) {
     auto frob = [&](int power, int d, int a) { w12_frob_rows_h(slot(d), slot(a), &LSA_FROB_ROWS[power - 1][0][0][0][0], H); };
     {                                                   // the helper idles (times one) until the norm is there
         w12_lds_u32 *hw = w12_lds(H);
-        if (lane < 27) hw[lane] = 0;
-        if (lane == 27) hw[W12_H_STATE] = W12_H_IDLE;
+        if (lane < 28) hw[lane] = 0;
         if (lane >= 28 && lane < 36) hw[lane] = W12_FE_SCALAR_EXP[lane - 28];
+        if (lane == 36) { hw[W12_H_STATE] = W12_H_IDLE; hw[W12_H_BITS] = 0; }
     }
     conj(A, ELT);             // conj(f): f^(q^6)
     mul(C, ELT, A);           // f * conj(f), an element of Fq6
@@ -480,7 +480,8 @@ __device__ __forceinline__ void w12_final_exponentiation_h(Fq2S *R) {
         if (lane == 64) {                               // the helper starts: power = n1, accumulator = 1, bit 0 of the exponent
             w12_store(reinterpret_cast<Fs *>(H), n1);
             w12_store(reinterpret_cast<Fs *>(H) + 1, Fs::one());
-            w12_lds(H)[W12_H_STATE] = ((W12_FE_SCALAR_EXP[0] & 1u) << 1) | 1u;
+            w12_lds(H)[W12_H_STATE] = 1u;
+            w12_lds(H)[W12_H_BITS] = W12_FE_SCALAR_EXP[0];
         }
         __syncthreads();
     }
