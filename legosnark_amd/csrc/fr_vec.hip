@@ -538,11 +538,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __shared__ Fr lds[256];
     sumcheck_partial_body<M, false>(suff, tabs, half, partial, lds);
 }
-// (two tables at three wavefronts per SIMD: 168 VGPRs + 112 B of scratch; LSA_SC2=3 -- an A/B of round 6)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_sumcheck_partial2_occ3(const Fr *__restrict__ suff, ScTables tabs, size_t half, Fr *__restrict__ partial) {
-    __shared__ Fr lds[256];
-    sumcheck_partial_body<2, false>(suff, tabs, half, partial, lds);
-}
+// (two tables at three wavefronts per SIMD -- 168 VGPRs + 112 B of scratch -- measured and withdrawn: 0.475 -> 0.51-0.52 ms at half =
+// 2^23; profiles/r06_w6_sumcheck_two_tables_three_wavefronts.txt)
 #ifndef LSA_SC3_WAVES
 #define LSA_SC3_WAVES 3
 #endif
@@ -845,11 +842,9 @@ int fr_sumcheck_round_device(const Fr *d_suff, const Fr *const *d_tables, size_t
     // three tables: LSA_SC3=wide keeps the shared-reduction kernel (two wavefronts per SIMD: 1024 workgroups are two full rounds); the
     // default reduces every product and holds three per SIMD (768 workgroups are one round)
     static const bool sc3_reduced = [] { const char *e = getenv("LSA_SC3"); return !(e && *e == 'w'); }();
-    static const bool sc2_occ3 = [] { const char *e = getenv("LSA_SC2"); return e && *e == '3'; }();
-    const size_t cap = (m == 3 && sc3_reduced) ? 256 * LSA_SC3_WAVES : ((m == 2 && sc2_occ3) ? 768 : 1024);
+    const size_t cap = (m == 3 && sc3_reduced) ? 256 * LSA_SC3_WAVES : 1024;
     const unsigned blocks = (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
     if (m == 1) hipLaunchKernelGGL((k_sumcheck_partial<1>), dim3(blocks), dim3(256), 0, st, d_suff, tabs, half, d_partial);
-    else if (m == 2 && sc2_occ3) hipLaunchKernelGGL(k_sumcheck_partial2_occ3, dim3(blocks), dim3(256), 0, st, d_suff, tabs, half, d_partial);
     else if (m == 2) hipLaunchKernelGGL((k_sumcheck_partial<2>), dim3(blocks), dim3(256), 0, st, d_suff, tabs, half, d_partial);
     else if (m == 3 && sc3_reduced) hipLaunchKernelGGL(k_sumcheck_partial3r, dim3(blocks), dim3(256), 0, st, d_suff, tabs, half, d_partial);
     else if (m == 3) hipLaunchKernelGGL((k_sumcheck_partial<3>), dim3(blocks), dim3(256), 0, st, d_suff, tabs, half, d_partial);
