@@ -81,3 +81,25 @@ def test_frobenius_row_constants_are_the_generators_output():
     base = ((1 * 6 + 0) * 2 + 0) * 2 * 9                      # [power - 1 = 1][k = 0][part 0][h 0]
     assert sum(l << (29 * i) for i, l in enumerate(limbs[base:base + 9])) == one
     assert all(l == 0 for l in limbs[base + 9:base + 18])       # -g1 = 0
+
+
+def test_final_exponentiation_scalar_exponent_is_the_generators_output():
+    """csrc/w12.h: W12_FE_SCALAR_EXP is generated (tools/gen_fe_scalar_exponent.py walks libff's final-exponentiation chain
+    symbolically, with conjugations NOT changing the sign of a stray Fq factor, and checks on the big-int model that the
+    chain without its inversion, times n1^e, is f^(libff's exponent)); the committed words must be what the script prints."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_fe_scalar_exponent.py")], cwd=root, capture_output=True, text=True, check=True).stdout
+    header = open(os.path.join(root, "legosnark_amd", "csrc", "w12.h")).read()
+    want = re.search(r"W12_FE_SCALAR_EXP\[8\] = \{([^}]*)\}", out).group(1)
+    got = re.search(r"W12_FE_SCALAR_EXP\[8\] = \{([^}]*)\}", header).group(1)
+    assert got == want
+    bits = re.search(r"W12_FE_SCALAR_EXP_BITS = (\d+)", out).group(1)
+    assert re.search(r"W12_FE_SCALAR_EXP_BITS = (\d+)", header).group(1) == bits == "254"
+    # e < q - 1, and the chain has the links to run it: 264 row products follow the norm (w12.h: w12_final_exponentiation_h)
+    words = [int(x.strip()[:-1], 16) for x in want.split(",")]
+    e = sum(w << (32 * i) for i, w in enumerate(words))
+    q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+    assert 0 < e < q - 1 and e.bit_length() == 254
