@@ -167,6 +167,48 @@ struct Fr29 {
         }
         return o;
     }
+    // ---- sums without carries (round 6, second session: the NTT's first stage of a stage pair).  A value whose limbs 0..7 may
+    // exceed 29 bits ("loose") is still a valid operand of mul as long as they stay below 2^31 and the OTHER operand is tight:
+    // a column is at most 9 * 2^31 * 2^29 + 9 * 2^58 + a carry < 2^64.
+    // a + b limb by limb.  [a + b; limbs < 2^29 + those of a]
+    friend LSA_HD Fr29 add_loose(const Fr29 &a, const Fr29 &b) {
+        Fr29 o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.l[i] = a.l[i] + b.l[i];
+        return o;
+    }
+    // limb i of 3r "lifted": 3r written with limbs 0..7 >= 2^29 - 1 (limb 0: >= 2^29) and the top limb one less than its
+    // normalised value -- the same integer (the borrowed 2^29 (i+1) of every limb is the lower neighbour's 2^29 more), so that
+    // a_i + lift_i - b_i is non-negative for any tight b < 3r - 2^232 (a product's < 2r is) and NO borrow runs between limbs
+    static LSA_HD uint32_t lift3r(int i) {
+        uint64_t c = 0;
+        uint32_t n = 0;
+        for (int k = 0; k <= i; k++) {
+            c += (uint64_t)r(k) * 3u;
+            n = k < 8 ? (uint32_t)c & MASK : (uint32_t)c;
+            c >>= 29;
+        }
+        return i == 0 ? n + (1u << 29) : (i < 8 ? n + MASK : n - 1u);
+    }
+    // a - b + 3r limb by limb, b tight and < 2r.  [a + 3r; limbs < 2^30 + those of a]
+    friend LSA_HD Fr29 sub3r_loose(const Fr29 &a, const Fr29 &b) {
+        Fr29 o;
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.l[i] = a.l[i] + lift3r(i) - b.l[i];
+        return o;
+    }
+    // the same, carry-normalised (unsigned carries: a's limbs may be loose, up to 3 * 2^29).  [a + 3r; tight]
+    friend LSA_HD Fr29 sub3r_norm(const Fr29 &a, const Fr29 &b) {
+        Fr29 o;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const uint32_t v = a.l[i] + lift3r(i) - b.l[i] + c;
+            if (i < 8) { o.l[i] = v & MASK; c = v >> 29; }
+            else o.l[i] = v;
+        }
+        return o;
+    }
     // the representative in [0, r) of a tight value < 2r
     LSA_HD Fr29 canonical2() const {
         Fr29 d;

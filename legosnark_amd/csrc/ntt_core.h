@@ -94,9 +94,13 @@ struct NttArgs {
 };
 
 LSA_HD unsigned ntt_brev(unsigned x, unsigned bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits ? __builtin_bitreverse32(x) >> (32u - bits) : 0u;      // v_bfrev_b32 (the loop below: ~5 instructions per bit and element)
+#else
     unsigned r = 0;
     for (unsigned i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
     return r;
+#endif
 }
 LSA_HD Fr29 ntt_lds_get(const uint32_t *lds, unsigned idx) {
     Fr29 v;
@@ -180,21 +184,29 @@ LSA_HD void ntt_tile_stage2(const NttArgs &a, unsigned s, unsigned gidx, uint32_
         x1 = mul(x1, w);
         x3 = mul(x3, w);
     }
-    const Fr29 y0 = add(x0, x1), y1 = sub2r(x0, x1), y2 = add(x2, x3), y3 = sub2r(x2, x3);
     // stage s + 1: (y0, y2) at position pos, (y1, y3) at position pos + 2^s of a 2^(s+2)-point butterfly
     const unsigned shw = a.plan.lmax - 2 - s;
-    const Fr29 t3 = mul(y3, ntt_lds_get(a.W, (pos + h) << shw));
-    if (s == 0) {
-        // the first pair of stages of a pass: pos = 0 in every group, the twiddle of (y0, y2) is 1 -- no product (round 6: one of
-        // the group's three).  y2 < 4r then instead of < 2r: values grow to < 8r here and by 4r per later pair of stages, < 24r
-        // after five pairs, far below the 121 r the next product by a twiddle < r allows.
-        ntt_lds_put(lds, i0, add(y0, y2));
-        ntt_lds_put(lds, i2, sub4r(y0, y2));
-    } else {
+    if (s != 0) {
+        // the first stage's sums WITHOUT carries (fr29.h: add_loose / sub3r_loose, 9 and 18 instructions instead of 27 and 36):
+        // x1, x3 are fresh products (tight, < 2r), x0, x2 tight values out of LDS; the sums' limbs stay below 3 * 2^29, which
+        // the products by the (tight) twiddles and the carry-normalising second stage accept.  Values: an output is below
+        // (its x0 or x2) + 6r -- 8r after the pass's first pair, + 6r per later pair, < 32r after five, far below the 121 r a
+        // product allows.
+        const Fr29 y0 = add_loose(x0, x1), y1 = sub3r_loose(x0, x1), y2 = add_loose(x2, x3), y3 = sub3r_loose(x2, x3);
+        const Fr29 t3 = mul(y3, ntt_lds_get(a.W, (pos + h) << shw));
         const Fr29 t2 = mul(y2, ntt_lds_get(a.W, pos << shw));
         ntt_lds_put(lds, i0, add(y0, t2));
         ntt_lds_put(lds, i2, sub2r(y0, t2));
+        ntt_lds_put(lds, i1, add(y1, t3));
+        ntt_lds_put(lds, i3, sub3r_norm(y1, t3));
+        return;
     }
+    // s == 0, the first pair of stages of a pass: no twiddle in stage 0, pos = 0 in every group, the twiddle of (y0, y2) is 1 -- one
+    // product instead of four.  y2 < 4r then instead of < 2r: values grow to < 8r here.
+    const Fr29 y0 = add(x0, x1), y1 = sub2r(x0, x1), y2 = add(x2, x3), y3 = sub2r(x2, x3);
+    const Fr29 t3 = mul(y3, ntt_lds_get(a.W, (pos + h) << shw));
+    ntt_lds_put(lds, i0, add(y0, y2));
+    ntt_lds_put(lds, i2, sub4r(y0, y2));
     ntt_lds_put(lds, i1, add(y1, t3));
     ntt_lds_put(lds, i3, sub2r(y1, t3));
 }

@@ -4,7 +4,8 @@
 The parametrised tests under tests/ pin chosen shapes; this draws shapes and contents at random for a time budget and
 compares every result with the oracle's restatement of the reference algorithm: MSMs (G1 / G2; bases with random Z,
 points at infinity, repeated bases; scalars of 254 / 128 / 64 / 31 / 16 bits with 0, 1 and r - 1 planted), batch_exp,
-batched scalar multiplication, pairing products with conjugated terms and several segments, the radix-2 and the step
+batched scalar multiplication, pairing products with conjugated terms and several segments, final exponentiations of
+arbitrary Fq12 elements, the radix-2 and the step
 NTT in all four modes, the witness recursion, evalMLE, pushRandomness and the sumcheck round polynomial.  One JSON line
 per operation kind at the end (cases, failures, the seeds of failures); exit status 1 on any mismatch.  A script, not a
 pytest module (its run time is a budget, not a property): the oracle is the checker here as in the tests beside it."""
@@ -172,7 +173,21 @@ def case_eq_table(rng):
     return ok, "eq_table d=%d" % d
 
 
-CASES = [("eq_table", case_eq_table, 1), ("msm", case_msm, 5), ("batch_exp", case_batch_exp, 2), ("scalar_mul_batch", case_smul, 2), ("pairing_terms", case_pairing, 3),
+def case_final_exp(rng):
+    """lsa_final_exponentiation on arbitrary Fq12 elements (not Miller values): random components, random subsets of them zero"""
+    n = rng.choice([1, 1, 2, 5, 17])
+    fs = np.zeros((n, 48), dtype=np.uint64)
+    for i in range(n):
+        mask = rng.choice([0xfff, 0xfff, 0xfff, rng.randrange(1, 0x1000)])
+        for c in range(12):
+            if (mask >> c) & 1:
+                fs[i, 4 * c:4 * c + 4] = o.fq_mont(rng.randrange(P))
+    got = lsa.final_exponentiation(fs)
+    ok = all(np.array_equal(got[i].reshape(-1), o.final_exponentiation(fs[i]).reshape(-1)) for i in range(n))
+    return ok, "final_exp n=%d" % n
+
+
+CASES = [("final_exp", case_final_exp, 1), ("eq_table", case_eq_table, 1), ("msm", case_msm, 5), ("batch_exp", case_batch_exp, 2), ("scalar_mul_batch", case_smul, 2), ("pairing_terms", case_pairing, 3),
          ("ntt", case_ntt, 2), ("ntt_step", case_ntt_step, 2), ("fr_fold", case_fold, 3), ("sumcheck_round", case_sumcheck, 2)]
 
 

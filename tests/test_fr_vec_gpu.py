@@ -235,6 +235,28 @@ def test_ntt_vs_oracle(lsa, log_n):
             assert np.array_equal(got, want), (inverse, coset is not None)
 
 
+@pytest.mark.parametrize("log_n", [10, 13, 16, 19])
+def test_ntt_extreme_values(lsa, log_n):
+    """Inputs that push the lazy sums of the butterflies to their bounds (csrc/ntt_core.h: the first stage of a stage pair adds
+    without carries, values grow by up to 6r per pair): every element r - 1, alternating 0 / r - 1, blocks of r - 1 and of
+    small values -- all four modes against the oracle."""
+    n = 1 << log_n
+    top = o.fr_mont(o.R - 1)
+    rng = np.random.default_rng(log_n)
+    pats = []
+    a = np.tile(top, (n, 1)); pats.append(a)
+    b = np.zeros((n, 4), dtype=np.uint64); b[::2] = top; pats.append(b)
+    c = np.tile(top, (n, 1)); c[n // 2:] = o.fr_mont(1); c[rng.integers(0, n, 8)] = o.fr_mont(2); pats.append(c)
+    d = rng.integers(0, 1 << 64, (n, 4), dtype=np.uint64); d[:, 3] = np.uint64(0x30644E72E131A028)      # top limb just below r's: values close to r
+    pats.append(d)
+    w = o.fr_mont(o.fr_root_of_unity(log_n))
+    g = o.fr_mont(o.FR_GENERATOR)
+    for k, a in enumerate(pats):
+        for inverse, coset in ((False, None), (True, g)) if k else ((False, None), (True, None), (False, g), (True, g)):
+            got = lsa.fr_ntt(a, w, inverse=inverse, coset=coset)
+            assert np.array_equal(got, o.fr_domain_transform(a, w, inverse=inverse, coset=coset)), (k, inverse, coset is not None)
+
+
 def test_ntt_round_trip_full_size_on_device(lsa):
     """n = 2^20 on a device-resident vector: icosetFFT(cosetFFT(a)) == a, and the transform of a
     delta at position 1 is the geometric sequence omega^k (checked at sampled positions)."""
