@@ -403,7 +403,7 @@ __device__ __forceinline__ void sumcheck_partial_body(const Fr *__restrict__ suf
             // product with (b0 + db X) by Karatsuba: the middle coefficient is (sa0 + sda)(b0 + db) - sa0 b0 - sda db --
             // and the three last products only ever enter sums over p, so four indices share ONE reduction each
             // (fr29.h: fr29_wide_*): 2 * 162 + 3 * 81 + 3 * 81 / 4 multiply-adds per index instead of 5 * 162
-            const Fr29 a0 = Fr29::from_words(tabs.t[0][p]), da = sub2r(Fr29::from_words(tabs.t[0][p + half]), a0);
+            const Fr29 a0 = Fr29::from_words(tabs.t[0][p]), da = sub3r_loose(Fr29::from_words(tabs.t[0][p + half]), a0);    // (loose: only ever times the tight q[0])
             const Fr29 b0 = Fr29::from_words(tabs.t[1][p]), db = sub2r(Fr29::from_words(tabs.t[1][p + half]), b0);
             const Fr29 sa0 = mul(q[0], a0), sda = mul(q[0], da);                      // < 2r each
             fr29_wide_mac(w0, sa0, b0);
@@ -433,14 +433,16 @@ __device__ __forceinline__ void sumcheck_partial_body(const Fr *__restrict__ suf
             const Fr29 a0 = Fr29::from_words(tabs.t[0][p]), a1 = Fr29::from_words(tabs.t[0][p + half]);
             const Fr29 b0 = Fr29::from_words(tabs.t[1][p]), b1 = Fr29::from_words(tabs.t[1][p + half]);
             const Fr29 c0 = Fr29::from_words(tabs.t[2][p]), c1 = Fr29::from_words(tabs.t[2][p + half]);
-            const Fr29 da = sub2r(a1, a0), db = sub2r(b1, b0), dc = sub2r(c1, c0);          // < 3r
+            // (RED3: sums that only ever meet a TIGHT factor in a product are taken without carries -- fr29.h: add_loose, sub3r_loose)
+            const Fr29 db = sub2r(b1, b0);                                                  // < 3r
+            const Fr29 da = RED3 ? sub3r_loose(a1, a0) : sub2r(a1, a0), dc = RED3 ? sub3r_loose(c1, c0) : sub2r(c1, c0);   // < 3r (RED3: < 4r, loose)
             Fr29 sa0 = a0, sda = da, sa1 = a1;
-            if (suff) { sa0 = mul(q[0], a0); sda = mul(q[0], da); sa1 = add(sa0, sda); }    // < 2r, < 2r, < 4r
+            if (suff) { sa0 = mul(q[0], a0); sda = mul(q[0], da); sa1 = RED3 ? add_loose(sa0, sda) : add(sa0, sda); }    // < 2r, < 2r, < 4r
             if constexpr (RED3) {
-                const Fr29 e0 = mul(sa0, b0), e2 = mul(sda, db), em = mul(sa1, b1);         // < 2r each
-                const Fr29 t = add(e0, e2), em1 = sub2r(add(t, t), em);                     // E(-1) + 2r < 10r
-                const Fr29 cm = sub2r(add(c0, c0), c1);                                     // C(-1) + 2r < 4r
-                c[0] = add(c[0], mul(e0, c0));                                              // every product < 2r; operands: 2 r^2, 6 r^2, 2 r^2, 40 r^2 < 121 r^2
+                const Fr29 e0 = mul(sa0, b0), e2 = mul(sda, db), em = mul(sa1, b1);         // < 2r each (a loose factor meets b0 / db / b1: tight)
+                const Fr29 t = add_loose(e0, e2), em1 = sub2r(add(t, t), em);               // E(-1) + 2r < 10r, tight
+                const Fr29 cm = sub3r_loose(add_loose(c0, c0), c1);                         // C(-1) + 3r < 5r, limbs < 2^31
+                c[0] = add(c[0], mul(e0, c0));                                              // every product < 2r; operands: 2 r^2, 8 r^2, 2 r^2, 50 r^2 < 121 r^2
                 c[1] = add(c[1], mul(em, c1));
                 c[2] = add(c[2], mul(em1, cm));
                 c[3] = add(c[3], mul(e2, dc));
