@@ -325,6 +325,29 @@ __device__ __forceinline__ Fr29 block_scalar_261(const Fr &k, uint32_t (&s_k)[9]
     for (int i = 0; i < 9; i++) c.l[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_k[i]);
     return c;
 }
+// (stream kernels: their loads and stores are marked non-temporal -- every byte is touched once; round 6: pushRandomness at half = 2^23
+// 0.181 -> 0.177 ms, the suffix update equal; -DLSA_STREAM_TEMPORAL: plain accesses; profiles/r06_w9_stream_kernels_nontemporal.txt)
+typedef uint32_t lsa_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Fr fr_stream_load(const Fr *p) {
+#if !defined(LSA_STREAM_TEMPORAL)
+    const lsa_u32x4 lo = __builtin_nontemporal_load(reinterpret_cast<const lsa_u32x4 *>(p)), hi = __builtin_nontemporal_load(reinterpret_cast<const lsa_u32x4 *>(p) + 1);
+    Fr x;
+    x.l[0] = lo.x; x.l[1] = lo.y; x.l[2] = lo.z; x.l[3] = lo.w; x.l[4] = hi.x; x.l[5] = hi.y; x.l[6] = hi.z; x.l[7] = hi.w;
+    return x;
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ void fr_stream_store(Fr *p, const Fr &x) {
+#if !defined(LSA_STREAM_TEMPORAL)
+    lsa_u32x4 lo, hi;
+    lo.x = x.l[0]; lo.y = x.l[1]; lo.z = x.l[2]; lo.w = x.l[3]; hi.x = x.l[4]; hi.y = x.l[5]; hi.z = x.l[6]; hi.w = x.l[7];
+    __builtin_nontemporal_store(lo, reinterpret_cast<lsa_u32x4 *>(p));
+    __builtin_nontemporal_store(hi, reinterpret_cast<lsa_u32x4 *>(p) + 1);
+#else
+    *p = x;
+#endif
+}
 __global__ __launch_bounds__(256) void k_fold_halves(const Fr *old, size_t half, const Fr *__restrict__ r_ptr, Fr *cur) {
     __shared__ uint32_t s_k[9];
     const Fr29 r261 = block_scalar_261(*r_ptr, s_k);
@@ -334,12 +357,12 @@ __global__ __launch_bounds__(256) void k_fold_halves(const Fr *old, size_t half,
 #pragma unroll
         for (int u = 0; u < STREAM_UNROLL; u++) {
             const size_t p = p0 + u * stride;
-            if (p < half) { a[u] = old[p]; b[u] = old[p + half]; }
+            if (p < half) { a[u] = fr_stream_load(old + p); b[u] = fr_stream_load(old + p + half); }
         }
 #pragma unroll
         for (int u = 0; u < STREAM_UNROLL; u++) {
             const size_t p = p0 + u * stride;
-            if (p < half) cur[p] = a[u] + fr_mul_261(b[u] - a[u], r261);   // = a (1 - r) + old[p + half] r
+            if (p < half) fr_stream_store(cur + p, a[u] + fr_mul_261(b[u] - a[u], r261));   // = a (1 - r) + old[p + half] r
         }
     }
 }
@@ -593,12 +616,12 @@ __global__ __launch_bounds__(256) void k_scale_upper(const Fr *old, size_t half,
 #pragma unroll
         for (int u = 0; u < STREAM_UNROLL; u++) {
             const size_t p = p0 + u * stride;
-            if (p < half) x[u] = old[p + half];
+            if (p < half) x[u] = fr_stream_load(old + p + half);
         }
 #pragma unroll
         for (int u = 0; u < STREAM_UNROLL; u++) {
             const size_t p = p0 + u * stride;
-            if (p < half) cur[p] = fr_mul_261(x[u], k261);
+            if (p < half) fr_stream_store(cur + p, fr_mul_261(x[u], k261));
         }
     }
 }
