@@ -81,8 +81,13 @@ enum G2PVar {                                  // Fq2S slots of one point
     GP_PX, GP_PY, GP_S1, GP_S2,                // fused kernel: (px, 0), (py, 0) of the pair's G1 point; ell_VW * py, ell_VV * px
     GP_P0, GP_P1, GP_P2, GP_P3, GP_P4, GP_P5,  // the round's products
     GP_NQX, GP_NQY,                            // -Q (the signed-digit loop's subtractions)
+    GP_LIFT0, GP_LIFT1, GP_LIFT2, GP_LIFT3,    // the products' negation offsets K p, lifted (w12.h: w12_comp_mul_lift): 7 rows of nine words
     GP_STRIDE
 };
+// the bounds K (units of p) the products of G2Pre's rounds keep for their b-operands; kb below holds INDICES into this list
+static constexpr int GP_KLIST[7] = {2, 4, 5, 6, 8, 10, 40};
+static constexpr int gp_ki(int K) { return K == 2 ? 0 : K == 4 ? 1 : K == 5 ? 2 : K == 6 ? 3 : K == 8 ? 4 : K == 10 ? 5 : 6; }
+static_assert(GP_KLIST[gp_ki(40)] == 40 && GP_KLIST[gp_ki(5)] == 5 && GP_KLIST[gp_ki(10)] == 10, "index of a bound");
 static constexpr int GP_GROUPS = 5;
 static constexpr int GP_LDS_FQ2 = GP_GROUPS * GP_STRIDE;
 
@@ -158,13 +163,13 @@ struct G2Pre {
     static LSA_HD Prod products_of(int op, int x2, bool scaled) {
         const int X2 = x2, Y2 = x2 + 1;
         switch (op) {
-        case 0: return {pack5(GP_X, GP_Y, GP_Z, GP_Y, GP_X), pack5(GP_Y, GP_Y, GP_Z, GP_Z, GP_X), pack5(4, 4, 2, 2, 2), 5};
-        case 1: return {pack5(GP_TWB, GP_B, GP_L1, GP_L2), pack5(GP_D, GP_H, GP_PY, GP_PX), pack5(6, 4, 2, 2), scaled ? 4 : 2};
-        case 2: return {pack5(GP_E, GP_A, GP_G, GP_ONE), pack5(GP_E, GP_BMF, GP_G, GP_XIT), pack5(2, 8, 5, 40), 4};
-        case 3: return {pack5(X2, Y2), pack5(GP_Z, GP_Z), pack5(2, 2), 2};
-        case 4: return {pack5(GP_DD, GP_EE, GP_EE, GP_DD, GP_L1, GP_L2), pack5(GP_DD, GP_EE, X2, Y2, GP_PY, GP_PX), pack5(4, 6, 2, 2, 2, 2), scaled ? 6 : 4};
-        case 5: return {pack5(GP_DD, GP_X, GP_Z, GP_ONE), pack5(GP_F, GP_F, GP_GG, GP_XIT), pack5(2, 2, 2, 40), 4};
-        default: return {pack5(GP_DD, GP_EE, GP_HH, GP_Z), pack5(GP_J, GP_IMJ, GP_Y, GP_HH), pack5(8, 10, 4, 2), 4};
+        case 0: return {pack5(GP_X, GP_Y, GP_Z, GP_Y, GP_X), pack5(GP_Y, GP_Y, GP_Z, GP_Z, GP_X), pack5(gp_ki(4), gp_ki(4), gp_ki(2), gp_ki(2), gp_ki(2)), 5};
+        case 1: return {pack5(GP_TWB, GP_B, GP_L1, GP_L2), pack5(GP_D, GP_H, GP_PY, GP_PX), pack5(gp_ki(6), gp_ki(4), gp_ki(2), gp_ki(2)), scaled ? 4 : 2};
+        case 2: return {pack5(GP_E, GP_A, GP_G, GP_ONE), pack5(GP_E, GP_BMF, GP_G, GP_XIT), pack5(gp_ki(2), gp_ki(8), gp_ki(5), gp_ki(40)), 4};
+        case 3: return {pack5(X2, Y2), pack5(GP_Z, GP_Z), pack5(gp_ki(2), gp_ki(2)), 2};
+        case 4: return {pack5(GP_DD, GP_EE, GP_EE, GP_DD, GP_L1, GP_L2), pack5(GP_DD, GP_EE, X2, Y2, GP_PY, GP_PX), pack5(gp_ki(4), gp_ki(6), gp_ki(2), gp_ki(2), gp_ki(2), gp_ki(2)), scaled ? 6 : 4};
+        case 5: return {pack5(GP_DD, GP_X, GP_Z, GP_ONE), pack5(GP_F, GP_F, GP_GG, GP_XIT), pack5(gp_ki(2), gp_ki(2), gp_ki(2), gp_ki(40)), 4};
+        default: return {pack5(GP_DD, GP_EE, GP_HH, GP_Z), pack5(GP_J, GP_IMJ, GP_Y, GP_HH), pack5(gp_ki(8), gp_ki(10), gp_ki(4), gp_ki(2)), 4};
         }
     }
     // component c of slot v
@@ -263,8 +268,8 @@ struct G2Pre {
             if (g >= (unsigned)NG || (int)k >= pr.n) return;
             Fq2S *V = m + g * GP_STRIDE;
             // (bounds per product: products_of)
-            const Fs r = {w12_comp_mul_k(part, w12_load(V + (unsigned)((pr.a >> (8 * k)) & 0xffu)), w12_load(V + (unsigned)((pr.b >> (8 * k)) & 0xffu)),
-                                         (int)((pr.kb >> (8 * k)) & 0xffu))};
+            const Fs r = {w12_comp_mul_lift(part, w12_load(V + (unsigned)((pr.a >> (8 * k)) & 0xffu)), w12_load(V + (unsigned)((pr.b >> (8 * k)) & 0xffu)),
+                                            reinterpret_cast<const uint32_t *>(V + GP_LIFT0) + 9u * (unsigned)((pr.kb >> (8 * k)) & 0xffu))};
             w12_store(&w12_comp(V[GP_P0 + k], part), r);
         });
         x.par([=](unsigned lane) {
@@ -332,6 +337,7 @@ struct G2Pre {
             V[GP_S] = qy + P2::one();
             V[GP_TWB] = fq2_constT<PB>(LSA_TWIST_B);
             V[GP_ONE] = P2::one();
+            for (int t = 0; t < 7; t++) w12_lift_kp(GP_KLIST[t], reinterpret_cast<uint32_t *>(V + GP_LIFT0) + 9 * t);
             if (out && out[g]) {                                   // libff keeps the affine point beside the coefficients
                 uint32_t *d = out[g] + ATE_NUM_COEFFS * TM_ROW_WORDS;
                 qx.c0.v.pack256(d); qx.c1.v.pack256(d + 8); qy.c0.v.pack256(d + 16); qy.c1.v.pack256(d + 24);

@@ -160,6 +160,49 @@ LSA_HD F29 w12_comp_mul_k(unsigned part, const Fq2S &a, const Fq2S &b, int K) {
     return dot2(a.c0.v, y0, a.c1.v, y1);
 }
 
+// The same with K p - b1 taken WITHOUT a carry chain (round 6, second session; lin2 above: three 64-bit multiply-adds, a mask and a
+// 64-bit shift per limb, ~60 instructions; here 12): `lift` holds K p with its limbs 0..6 "lifted" -- limb 0 plus 2^29, limbs 1..6
+// plus 2^29 - 1, limb 7 minus 1: the same integer, each limb lending the 2^29 of its lower neighbour -- so that for a tight b1
+// limbs 0..6 of the difference are lift_i - b1_i >= 0 with no borrow between them (below 2^30: "loose"); only limbs 7 and 8 run
+// a borrow.  The value is K p - b1 exactly, as before; dot2 accepts one loose factor per product (a column: 9 * 2^58 + 9 * 2^59 +
+// 9 * 2^58 < 2^64).  lift: nine words (device: in LDS).
+LSA_HD F29 w12_comp_mul_lift(unsigned part, const Fq2S &a, const Fq2S &b, const uint32_t *lift) {
+    const uint32_t pm = w12_mask(0u - part);
+    uint32_t lw[9];
+#if defined(__HIP_DEVICE_COMPILE__)
+    w12_lds_u32 *lp = w12_lds(lift);
+#pragma unroll
+    for (int l = 0; l < 9; l++) lw[l] = lp[l];
+#else
+    for (int l = 0; l < 9; l++) lw[l] = lift[l];
+#endif
+    F29 nb1;
+#pragma unroll
+    for (int l = 0; l < 7; l++) nb1.l[l] = lw[l] - b.c1.v.l[l];
+    const int32_t v7 = (int32_t)lw[7] - (int32_t)b.c1.v.l[7];
+    nb1.l[7] = (uint32_t)v7 & F29::MASK;
+    nb1.l[8] = (uint32_t)((int32_t)lw[8] - (int32_t)b.c1.v.l[8] + (v7 >> 29));
+    F29 y0, y1;
+#pragma unroll
+    for (int l = 0; l < 9; l++) {
+        y0.l[l] = (b.c1.v.l[l] & pm) | (b.c0.v.l[l] & ~pm);
+        y1.l[l] = (b.c0.v.l[l] & pm) | (nb1.l[l] & ~pm);
+    }
+    return dot2(a.c0.v, y0, a.c1.v, y1);
+}
+// the nine words of K p for w12_comp_mul_lift
+LSA_HD void w12_lift_kp(int K, uint32_t out[9]) {
+    uint64_t c = 0;
+    for (int i = 0; i < 9; i++) {
+        c += (uint64_t)F29::p(i) * (uint32_t)K;
+        out[i] = i < 8 ? (uint32_t)c & F29::MASK : (uint32_t)c;
+        c >>= 29;
+    }
+    out[0] += 1u << 29;
+    for (int i = 1; i < 7; i++) out[i] += F29::MASK;
+    out[7] -= 1u;                                        // (as a signed word: -1 when limb 7 of K p is 0)
+}
+
 // tower <-> polynomial basis: poly index k -> (which Fq6 half, which coefficient)
 LSA_HD Fq2S &w12_tower_ref(Fq12S &t, int k) {
     Fq6T<Fs> &h = (k & 1) ? t.c1 : t.c0;
