@@ -927,7 +927,7 @@ struct WTabMiller {
 };
 
 static constexpr int RT_MAXM = 2;
-enum { RT_F = 0, RT_PXY = 6, RT_LINES = RT_PXY + RT_MAXM, RT_LDS_FQ2 = RT_LINES + RT_MAXM * ATE_NUM_COEFFS * 3 };
+enum { RT_F = 0, RT_PXY = 6, RT_LINES = RT_PXY + RT_MAXM, RT_F2 = RT_LINES + RT_MAXM * ATE_NUM_COEFFS * 3, RT_LDS_FQ2 = RT_F2 + 6 };   // (RT_F2: the accumulator's other home)
 // The 66 steps of a Miller loop over a table (64 doubling steps with one or two lines each, two closing lines) cut into K <= 8
 // contiguous ranges for the K workgroups that share one accumulator (rt_miller_run): range [start[r], start[r + 1]) costs its
 // workgroup 63 - start[r] squarings (none from step 64 on) + M line products per line; the smallest bound T that K ranges
@@ -1021,19 +1021,26 @@ __device__ __forceinline__ void rt_miller_run(Fq2S *m, const uint32_t *const *ta
         w12_store(&w12_comp(m[RT_LINES + (i * ATE_NUM_COEFFS + e) * 3 + (c >> 1)], c & 1u), Fs{v});
     }
     __syncthreads();
-    unsigned u = 0;
+    // the accumulator alternates between two homes (RT_F, RT_F2): a link's result is never written over one of its factors, so a
+    // link needs ONE barrier (w12_rows, NOALIAS); an odd number of links ends with a copy back to RT_F
+    unsigned u = 0, cur = 0;
+    auto home = [m](unsigned which) { return m + (which ? (int)RT_F2 : (int)RT_F); };
 #pragma unroll 1
     for (int ph = 0; ph < 66; ph++) {
         const bool dbl = ph < 64;
         const int lines = dbl ? 1 + ate_bit(63 - ph) : 1;
-        if (dbl && (unsigned)ph > lo) w12_rows<W12_MUL>(m + RT_F, m + RT_F, m + RT_F, nullptr);       // (up to its first own step the accumulator is 1)
+        if (dbl && (unsigned)ph > lo) { w12_rows<W12_MUL, false, true>(home(cur ^ 1u), home(cur), home(cur), nullptr); cur ^= 1u; }   // (up to its first own step the accumulator is 1)
         const bool mine = (unsigned)ph >= lo && (unsigned)ph < hi;
 #pragma unroll 1
         for (int li = 0; li < lines; li++, u++) {
             if (!mine) continue;
 #pragma unroll 1
-            for (unsigned i = 0; i < M; i++) w12_rows<W12_LINE>(m + RT_F, m + RT_F, m + RT_LINES + (i * ATE_NUM_COEFFS + u) * 3, nullptr);
+            for (unsigned i = 0; i < M; i++) { w12_rows<W12_LINE, false, true>(home(cur ^ 1u), home(cur), m + RT_LINES + (i * ATE_NUM_COEFFS + u) * 3, nullptr); cur ^= 1u; }
         }
+    }
+    if (cur) {
+        if (lane < 6) m[RT_F + lane] = m[RT_F2 + lane];
+        __syncthreads();
     }
 }
 #endif

@@ -368,7 +368,9 @@ static constexpr uint32_t W12_FE_SCALAR_EXP[8] = {0x8d10a36eu, 0xfa9264cdu, 0xc9
 static constexpr int W12_FE_SCALAR_EXP_BITS = 254;
 enum { W12_H_PW = 0, W12_H_ACC = 9, W12_H_ZERO = 18, W12_H_EXP = 28, W12_H_STATE = 36, W12_H_BITS = 37 };
 static constexpr uint32_t W12_H_IDLE = 0xffffu << 1;
-template <int MODE, bool HLP = false>
+// NOALIAS: D is neither A nor B -- the barrier between the operand loads and the result's stores (which only keeps a fast
+// wavefront from overwriting what a slow one has not read yet) is not needed then: one barrier per chain link instead of two
+template <int MODE, bool HLP = false, bool NOALIAS = false>
 __device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, const uint32_t *frob, Fq2S *H = nullptr) {
     const unsigned lane = threadIdx.x, row = lane >> 4, r = lane & 15;
     const unsigned k = row >> 1, part = row & 1, i = r >> 1, h = r & 1;
@@ -429,7 +431,7 @@ __device__ __forceinline__ void w12_rows(Fq2S *D, const Fq2S *A, const Fq2S *B, 
         const Fq2S bj = w12_load(&B[jb]);
         Rv = lin2(bj.c0.v, c0, bj.c1.v, c1, K);
     }
-    __syncthreads();                                   // every lane holds its operands: D may alias A or B from here on
+    if (!NOALIAS) __syncthreads();                     // every lane holds its operands: D may alias A or B from here on
     if (HLP && lane == 192) { w12_lds(H)[W12_H_STATE] = hst2; w12_lds(H)[W12_H_BITS] = hbits2; }
     W12Limbs18 t = w12_wide_mul(L, Rv), u;
     W12_DPP18(t, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
@@ -453,6 +455,8 @@ __device__ __noinline__ void w12_frob_rows(Fq2S *D, const Fq2S *A, const uint32_
 template <bool HLP>
 __device__ __forceinline__ void w12_exp_by_neg_z_rows_t(Fq2S *R, int d, int a, int tmp) {
     Fq2S *const H = R + 6 * W12_SLOTS;                  // (the helper's state, HLP only)
+    // (every product of this function writes a slot that is neither of its factors: the 256-lane form drops the first barrier of
+    // a link -- w12_rows, NOALIAS; the 192-lane fallback stays as it was)
     constexpr uint64_t D_P1 = 0x4800120040011001ull, D_P3 = 0x0000804004000000ull, D_M1 = 0x0000000000000010ull, D_M3 = 0x0108000400880200ull;
     const unsigned lane = threadIdx.x;
     auto slot = [R](int s) { return R + 6 * s; };
@@ -462,17 +466,17 @@ __device__ __forceinline__ void w12_exp_by_neg_z_rows_t(Fq2S *R, int d, int a, i
     };
     int acc = tmp, alt = tmp + 3;
     const int a3 = tmp + 1, na = tmp + 2, na3 = tmp + 4, sq = tmp + 5;
-    w12_rows<W12_MUL, HLP>(slot(sq), slot(a), slot(a), nullptr, H);
-    w12_rows<W12_MUL, HLP>(slot(a3), slot(sq), slot(a), nullptr, H);        // a^3
+    w12_rows<W12_MUL, HLP, HLP>(slot(sq), slot(a), slot(a), nullptr, H);
+    w12_rows<W12_MUL, HLP, HLP>(slot(a3), slot(sq), slot(a), nullptr, H);        // a^3
     conj(na, a);
     conj(na3, a3);
 #pragma unroll 1
     for (int i = 61; i >= 0; --i) {
-        w12_rows<W12_MUL, HLP>(slot(alt), slot(i == 61 ? a : acc), slot(i == 61 ? a : acc), nullptr, H);
+        w12_rows<W12_MUL, HLP, HLP>(slot(alt), slot(i == 61 ? a : acc), slot(i == 61 ? a : acc), nullptr, H);
         const unsigned p1 = (unsigned)(D_P1 >> i) & 1u, p3 = (unsigned)(D_P3 >> i) & 1u, m1 = (unsigned)(D_M1 >> i) & 1u, m3 = (unsigned)(D_M3 >> i) & 1u;
         if (p1 | p3 | m1 | m3) {
             const int f = p1 ? a : (p3 ? a3 : (m1 ? na : na3));
-            w12_rows<W12_MUL, HLP>(slot(acc), slot(alt), slot(f), nullptr, H);
+            w12_rows<W12_MUL, HLP, HLP>(slot(acc), slot(alt), slot(f), nullptr, H);
         } else { const int t = acc; acc = alt; alt = t; }
     }
     conj(d, acc);
