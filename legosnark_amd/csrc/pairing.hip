@@ -99,7 +99,7 @@ __global__ __launch_bounds__(LANES) void k_final_exp_wave(const Fq12 *__restrict
 }
 
 // The same with a fourth wavefront that computes, beside the chain, the power of the norm that the chain's one inversion
-// would have divided out (w12.h: w12_rows, HLP): no binary GCD on the critical path, 0.39 -> 0.32 ms for a lone element.
+// would have divided out (w12.h: w12_rows, HLP): no binary GCD on the critical path, 0.39 -> 0.34 ms for a lone element.
 __global__ __launch_bounds__(256) void k_final_exp_wave_h(const Fq12 *__restrict__ in, size_t n, Fq12 *__restrict__ out) {
     __shared__ Fq2S lds[W12_LDS_FQ2];
     const size_t e = blockIdx.x;
