@@ -141,6 +141,23 @@ def test_msm_known_discrete_log_medium():
         assert canon(got) == canon(mul(o.generator(group), o.fr_mont(k)))
 
 
+def test_final_exponentiation_of_arbitrary_elements_vs_model():
+    """The oracle's final exponentiation (libff's chain: easy part with its inversion, three exponentiations by z) on elements
+    that are NOT Miller values -- random Fq12 elements, elements of Fq6 / Fq2 / Fq, sparse ones -- against the independent model's
+    plain power f^(libff's exponent) (oracle/pymodel: square-and-multiply on schoolbook Fp12 arithmetic).  This is the checker of
+    the GPU kernel that replaces the chain's inversion by a power of the norm (csrc/w12.h: w12_final_exponentiation_h)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "pymodel"))
+    import bn254_model as M
+    rng = random.Random(2026)
+    for mask in (0x3f, 0x3f, 0x3f, 0x15, 0x01, 0x2a, 0x09, 0x20):       # which of the six Fp2 coefficients are non-zero
+        g = [(rng.randrange(P), rng.randrange(P)) if (mask >> i) & 1 else (0, 0) for i in range(6)]
+        if mask == 0x01:
+            g[0] = (rng.randrange(1, P), 0)                              # an element of Fq
+        assert o.fq12_to_model(o.final_exponentiation(o.fq12_from_model(g))) == M.final_exponentiation(g), hex(mask)
+
+
 def test_pairing_golden(golden):
     pr = golden["pairing"]
     g1, g2 = o.generator("g1"), o.generator("g2")
